@@ -43,29 +43,38 @@ def test_mse_sgd_step_vs_torch():
 
 
 def test_sparse_ce_adam_vs_torch():
+    """Loss/gradients vs torch autograd at every step; the Adam update vs the
+    float64 closed form of the TF2 ResourceApplyAdam recurrence."""
     rng = np.random.default_rng(1)
     p = M.init_mlp(rng, 10, 20, 5)
     x = rng.normal(size=(50, 10)).astype(np.float32)
     lab = rng.integers(0, 5, size=50)
     w = rng.normal(size=50).astype(np.float32)
-    tp = [torch.tensor(a, requires_grad=True) for a in p]
-    opt = torch.optim.Adam(tp, lr=0.002, betas=(0.9, 0.999), eps=1e-7)
     st = M.AdamState(p, 0.002)
-    for step in range(3):
-        opt.zero_grad()
+    m64 = [np.zeros(a.shape) for a in p]
+    v64 = [np.zeros(a.shape) for a in p]
+    for step in range(1, 4):
+        tp = [torch.tensor(a, requires_grad=True) for a in p]
         logits = _torch_forward(tp, torch.tensor(x))
         ce = torch.nn.functional.cross_entropy(logits, torch.tensor(lab), reduction="none")
         loss_t = (ce * torch.tensor(w)).sum() / 50
         loss_t.backward()
-        opt.step()
         lg, cache = M.forward(p, x, want_cache=True)
         loss, dl = M.sparse_ce_loss_and_dlogits(lg, lab, w)
-        M.adam_apply(p, M.backward(p, cache, dl), st)
-        assert abs(float(loss) - float(loss_t.detach())) < (2e-6 if step == 0 else 1e-4) * max(1, abs(float(loss_t.detach())))
-    # torch's Adam puts eps outside the bias correction slightly differently
-    # (sqrt(v)/sqrt(1-b2^t)+eps); with eps=1e-7 the two forms agree to ~1e-5 relative.
-    for a, t in zip(p, tp):
-        np.testing.assert_allclose(a, t.detach().numpy(), rtol=1e-3, atol=2e-6)
+        grads = M.backward(p, cache, dl)
+        assert abs(float(loss) - float(loss_t.detach())) < 2e-6 * max(1, abs(float(loss_t.detach())))
+        for g, t in zip(grads, tp):
+            np.testing.assert_allclose(g, t.grad.numpy(), rtol=2e-5, atol=1e-7)
+        before = [a.astype(np.float64) for a in p]
+        M.adam_apply(p, grads, st)
+        alpha = 0.002 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        for k, g in enumerate(grads):
+            g = g.astype(np.float64)
+            m64[k] += (g - m64[k]) * 0.1
+            v64[k] += (g * g - v64[k]) * 0.001
+            want = before[k] - alpha * m64[k] / (np.sqrt(v64[k]) + 1e-7)
+            np.testing.assert_allclose(p[k], want, rtol=1e-5, atol=1e-7)
+            m64[k], v64[k] = st.m[k].astype(np.float64), st.v[k].astype(np.float64)
 
 
 @pytest.mark.reference
