@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI declared in include/rcmarl.h.
+
+The product loads ``lib/librcmarl_hip.so`` (built by rcmarl_amd.build for
+gfx950) and FAILS LOUDLY if it is missing -- there is no CPU fallback.  The
+same signature table is used by the tests to bind the hipemu build of the very
+same kernel sources (tests/hipemu), which is test infrastructure only.
+"""
+import ctypes as C
+import os
+
+c_f32p = C.c_void_p      # float*   (device pointer, or host pointer for the hipemu build)
+c_i32p = C.c_void_p      # int*
+c_u8p = C.c_void_p       # unsigned char*
+c_f64p = C.c_void_p      # double*
+c_stream = C.c_void_p    # hipStream_t
+
+# name -> argtypes (every function returns int: 0 ok, see RCMARL_ERR_* in include/rcmarl.h)
+c_long = C.c_long
+c_int = C.c_int
+c_float = C.c_float
+
+# name -> argtypes (every function returns int: 0 ok, see RCMARL_ERR_* in include/rcmarl.h)
+SIGNATURES = {
+    "rcmarl_abi_version": [],
+    "rcmarl_fit_partial_size": [c_int],
+    "rcmarl_actor_partial_size": [c_int, c_int],
+    "rcmarl_rows_per_chunk": [],
+    # msg, theta, nbr, coop, S, N, ldp, P_hid, d, H, lo_dbg, hi_dbg, stream
+    "rcmarl_consensus_params": [c_f32p, c_f32p, c_i32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_f32p, c_f32p, c_stream],
+    # x, x_seed_stride, theta, a1t, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_layer1_forward": [c_f32p, c_long, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_stream],
+    # x, x_seed_stride, dz1t, theta, mask, S, N, B, in_dim, hid, ldp, ldb, lr, stream
+    "rcmarl_layer1_backward_sgd": [c_f32p, c_long, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_float, c_stream],
+    # x, x_seed_stride, dz1t, theta, m, v, mask, S, N, B, in_dim, hid, ldp, ldb, alpha, 1-b1, 1-b2, eps, stream
+    "rcmarl_layer1_backward_adam": [c_f32p, c_long, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_stream],
+    # a1t, theta, y, partials, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_mid_fit": [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
+    "rcmarl_small_sgd": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
+    # a1t, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_mid_value": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_stream],
+    # a1t, theta, msg, nbr, coop, partials, agg_out, S, N, B, in_dim, hid, ldp, ldb, d, H, stream
+    "rcmarl_consensus_head": [c_f32p, c_f32p, c_f32p, c_i32p, c_u8p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_int, c_int, c_int, c_stream],
+    # partials, theta, coop, S, N, B, in_dim, hid, ldp, stream
+    "rcmarl_head_apply": [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # a1t, theta, act_t, delta, partials, S, N, B, in_dim, hid, n_actions, ldp, ldb, stream
+    "rcmarl_mid_actor": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_int, c_stream],
+    # partials, theta, m, v, mask, loss_out, S, N, B, in_dim, hid, n_actions, ldp, alpha, 1-b1, 1-b2, eps, stream
+    "rcmarl_small_adam": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_float, c_float, c_float, c_float, c_stream],
+    # r, seed_stride, coop, n_coop, rcoop, S, N, B, ldb, stream
+    "rcmarl_team_reward": [c_f32p, c_long, c_u8p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_stream],
+    # src, seed_stride, rcoop, mode, out, S, N, B, ldb, stream
+    "rcmarl_gather_agent_major": [c_f32p, c_long, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_stream],
+    # r_team, v_next, v_cur, gamma, delta, n_total, stream
+    "rcmarl_td_error": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_long, c_stream],
+}
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk"}
+
+ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",
+          3: "RCMARL_ERR_UNSUPPORTED (shape outside the compiled kernels)"}
+
+
+class RcmarlError(RuntimeError):
+    pass
+
+
+class CLib:
+    """Thin checked wrapper: ``lib.rcmarl_xxx(...)`` raises on a non-zero status."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RcmarlError(
+                "rcmarl HIP library not found at %s -- build it with `python -m rcmarl_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        self.path = path
+        self._dll = C.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(self._dll, name)      # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+            setattr(self, name, fn if name in UNCHECKED else self._checked(name, fn))
+
+    @staticmethod
+    def _checked(name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise RcmarlError("%s failed: %s" % (name, ERRORS.get(rc, rc)))
+            return 0
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def load():
+    """The product library (HIP, gfx950).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        from . import build
+        _lib = CLib(build.lib_path())
+    return _lib

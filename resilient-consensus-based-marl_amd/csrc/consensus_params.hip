@@ -1,0 +1,162 @@
+// K1 -- resilient consensus over the hidden-layer parameters of all agents.
+//
+// Replaces the reference's per-agent / per-layer Python loop
+//   RPBCAC_agent.resilient_consensus_critic_hidden / _TR_hidden
+//   (agents/resilient_CAC_agents.py:142-166) and the aggregation rule
+//   RPBCAC_agent._resilient_aggregation (agents/resilient_CAC_agents.py:42-58)
+// as called from training/train_agents.py:129-135.
+//
+// For every seed s, cooperative agent i and hidden parameter p < P_hid:
+//   v_k   = msg[s][nbr[i][k]][p],  k = 0..d-1   (v_0 = the agent's own message)
+//   lower = min(sorted(v)[H], v_0),  upper = max(sorted(v)[d-H-1], v_0)
+//   theta[s][i][p] = (sum_k clamp(v_k, lower, upper)) / d
+// Columns >= P_hid (output layer) and rows of non-cooperative agents are not
+// written (the aggregated W3,b3 are discarded by the reference, :150-153).
+//
+// MI355X mapping: one workgroup owns one (seed, 64-column tile).  The tile of
+// ALL N message rows is staged once into LDS with 16-B coalesced loads (each
+// message row is read from HBM exactly once: compulsory traffic), then every
+// lane owns one column and walks the agents; the neighbour list of an agent is
+// wave-uniform (scalar loads), the d candidate values sit in VGPRs and the two
+// order statistics come from a pruned min/max network (selnet_generated.inc).
+// HBM roofline: 4*(P read + P_hid written) bytes per (seed, agent).
+#include "rcmarl_common.h"
+#include "selnet_generated.inc"
+
+namespace {
+
+template <int D, int H>
+__device__ __forceinline__ float aggregate_regs(const float (&v)[D], float& lower, float& upper) {
+  float lo, hi;
+  SelNet<D, H>::run(v, lo, hi);
+  lower = fminf(lo, v[0]);
+  upper = fmaxf(hi, v[0]);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[k], lower, upper);  // clamp
+  return sum / (float)D;
+}
+
+// stage msg[s][0..N)[c0..c0+TC) -> tile[N][TC] with float4 loads (ldp % 64 == 0, c0 % TC == 0)
+__device__ __forceinline__ void stage_tile(const float* __restrict__ m, float* tile, int N, int ldp, int c0, int log2tc) {
+  const int TC = 1 << log2tc;
+  const int q_per_row = TC >> 2;
+  const int total = N * q_per_row;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int row = idx / q_per_row, q = idx - row * q_per_row;
+    const float4 x = *reinterpret_cast<const float4*>(m + (size_t)row * ldp + c0 + 4 * q);
+    *reinterpret_cast<float4*>(tile + (row << log2tc) + 4 * q) = x;
+  }
+}
+
+template <int D, int H>
+__global__ __launch_bounds__(256) void k_consensus_params(const float* __restrict__ msg, float* __restrict__ theta,
+                                                          const int* __restrict__ nbr,
+                                                          const unsigned char* __restrict__ coop, int N, int ldp,
+                                                          int P_hid, int log2tc, float* __restrict__ lo_dbg,
+                                                          float* __restrict__ hi_dbg) {
+  RCMARL_DYN_SMEM(float, tile);
+  const int TC = 1 << log2tc;
+  const int s = blockIdx.y;
+  const int c0 = blockIdx.x << log2tc;
+  stage_tile(msg + (size_t)s * N * ldp, tile, N, ldp, c0, log2tc);
+  __syncthreads();
+  const int c = threadIdx.x & (TC - 1);
+  const int rows_per_pass = blockDim.x >> log2tc;
+  const bool col_ok = (c0 + c) < P_hid;
+  auto one_agent = [&](const int i) {
+    if (!coop[i]) return;
+    float v[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) v[k] = tile[(nbr[i * D + k] << log2tc) + c];
+    float lower, upper;
+    const float out = aggregate_regs<D, H>(v, lower, upper);
+    if (col_ok) {
+      const size_t o = ((size_t)s * N + i) * ldp + c0 + c;
+      theta[o] = out;
+      if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+    }
+  };
+  if (log2tc == 6) {
+    // one wavefront = one agent: make the agent index an SGPR so the neighbour
+    // list and the cooperation flag come through the scalar cache
+    for (int i = threadIdx.x >> 6; i < N; i += rows_per_pass) one_agent(__builtin_amdgcn_readfirstlane(i));
+  } else {
+    for (int i = threadIdx.x >> log2tc; i < N; i += rows_per_pass) one_agent(i);
+  }
+}
+
+// Any (d, H) without a generated network: order statistics by rank counting
+// out of the LDS tile (O(d^2) LDS reads).  Correct for every d >= 2H+1; slow.
+__global__ __launch_bounds__(256) void k_consensus_params_generic(const float* __restrict__ msg,
+                                                                  float* __restrict__ theta,
+                                                                  const int* __restrict__ nbr,
+                                                                  const unsigned char* __restrict__ coop, int N,
+                                                                  int ldp, int P_hid, int log2tc, int d, int H,
+                                                                  float* __restrict__ lo_dbg,
+                                                                  float* __restrict__ hi_dbg) {
+  RCMARL_DYN_SMEM(float, tile);
+  const int TC = 1 << log2tc;
+  const int s = blockIdx.y;
+  const int c0 = blockIdx.x << log2tc;
+  stage_tile(msg + (size_t)s * N * ldp, tile, N, ldp, c0, log2tc);
+  __syncthreads();
+  const int c = threadIdx.x & (TC - 1);
+  const int rows_per_pass = blockDim.x >> log2tc;
+  const bool col_ok = (c0 + c) < P_hid;
+  for (int i = threadIdx.x >> log2tc; i < N; i += rows_per_pass) {
+    if (!coop[i]) continue;
+    const int* nb = nbr + i * d;
+    const float own = tile[(nb[0] << log2tc) + c];
+    float lo = own, hi = own;
+    for (int k = 0; k < d; ++k) {
+      const float x = tile[(nb[k] << log2tc) + c];
+      int rank = 0;
+      for (int m = 0; m < d; ++m) {
+        const float y = tile[(nb[m] << log2tc) + c];
+        rank += (y < x || (y == x && m < k)) ? 1 : 0;
+      }
+      if (rank == H) lo = x;
+      if (rank == d - H - 1) hi = x;
+    }
+    const float lower = fminf(lo, own), upper = fmaxf(hi, own);
+    float sum = 0.f;
+    for (int k = 0; k < d; ++k) sum += __builtin_amdgcn_fmed3f(tile[(nb[k] << log2tc) + c], lower, upper);
+    if (col_ok) {
+      const size_t o = ((size_t)s * N + i) * ldp + c0 + c;
+      theta[o] = sum / (float)d;
+      if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+    }
+  }
+}
+
+}  // namespace
+
+// C-ABI: see include/rcmarl.h
+RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const unsigned char* coop,
+                                          int S, int N, int ldp, int P_hid, int d, int H, float* lo_dbg,
+                                          float* hi_dbg, void* stream) {
+  if (!msg || !theta || !nbr || !coop || S <= 0 || N <= 0 || d <= 0 || H < 0 || d < 2 * H + 1 || (ldp & 63) ||
+      P_hid <= 0 || P_hid > ldp || (!!lo_dbg != !!hi_dbg))
+    return RCMARL_ERR_ARG;
+  // widest column tile whose [N][TC] fp32 image fits 64 KiB of LDS (two workgroups per CU)
+  int log2tc = 6;
+  while (log2tc > 2 && ((size_t)N << log2tc) * sizeof(float) > 64 * 1024) --log2tc;
+  if (((size_t)N << log2tc) * sizeof(float) > 64 * 1024) return RCMARL_ERR_UNSUPPORTED;
+  const int TC = 1 << log2tc;
+  const dim3 grid(rc_ceil_div(P_hid, TC), S), block(256);
+  const size_t smem = ((size_t)N << log2tc) * sizeof(float);
+  bool done = false;
+#define RC_CASE(DD, HH)                                                                                              \
+  if (!done && d == DD && H == HH) {                                                                                 \
+    RCMARL_LAUNCH((k_consensus_params<DD, HH>), grid, block, smem, stream, msg, theta, nbr, coop, N, ldp, P_hid,     \
+                  log2tc, lo_dbg, hi_dbg);                                                                           \
+    done = true;                                                                                                     \
+  }
+  RCMARL_SELNET_COMBOS(RC_CASE)
+#undef RC_CASE
+  if (!done)
+    RCMARL_LAUNCH(k_consensus_params_generic, grid, block, smem, stream, msg, theta, nbr, coop, N, ldp, P_hid, log2tc,
+                  d, H, lo_dbg, hi_dbg);
+  return rcmarl_check_launch();
+}

@@ -1,0 +1,609 @@
+// K4/K5 (layers 2-3), K2+K3, K6, K7 -- everything between the two layer-1 GEMMs.
+//
+// After rcmarl_layer1_forward the first-layer activations of every agent are
+// FEATURE-MAJOR: a1t[S][N*HID][ldb].  In all kernels below one lane owns one
+// replay row b of one (seed, agent); a workgroup = 256 consecutive rows, so the
+// agent's weights W2,b2,W3,b3 are workgroup-uniform (scalar loads, SGPR
+// operands) and every a1t access is a fully coalesced 256-B wave load.
+//
+//   k_mid_fit         one full-batch SGD step of critic.fit / TR.fit, layers 2-3
+//                     forward + MSE + backward      (agents/resilient_CAC_agents.py:118,136)
+//   k_mid_value       V(s) / r(s,a) forward, optional TD target r + gamma*V(ns)   (:114-115)
+//   k_consensus_head  estimate consensus + projection residual                    (:168-206, :60-84)
+//   k_mid_actor       softmax / TD-weighted sparse CE forward+backward            (:86-101)
+//   k_small_sgd / k_small_adam / k_head_apply   reduce partials, apply updates
+#include "rcmarl_common.h"
+#include "selnet_generated.inc"
+
+namespace {
+
+constexpr int ROWS = 256;          // replay rows per workgroup
+constexpr int LDR = ROWS + 1;      // LDS row stride: (k*LDR + r) % 32 distinct over k
+
+template <int HID> struct FitPart {  // layout of one partial-gradient record
+  static constexpr int gW2 = 0, gb2 = HID * HID, gW3 = gb2 + HID, gb3 = gW3 + HID, gb1 = gb3 + 1, loss = gb1 + HID,
+                       SIZE = loss + 1, NSMALL = SIZE - gb2;
+};
+template <int HID, int A> struct ActorPart {
+  static constexpr int gW2 = 0, gW3 = HID * HID, gb2 = gW3 + HID * A, gb3 = gb2 + HID, gb1 = gb3 + A,
+                       loss = gb1 + HID, SIZE = loss + 1, NSMALL = SIZE - gb2;
+};
+
+template <int HID>
+__device__ __forceinline__ void load_a1(const float* __restrict__ a1t, long row0, int ldb, int b, bool valid,
+                                        float (&a1)[HID]) {
+#pragma unroll
+  for (int j = 0; j < HID; ++j) a1[j] = valid ? a1t[(row0 + j) * ldb + b] : 0.f;
+}
+
+// z2 = a1 @ W2 + b2 ; a2 = lrelu(z2)
+template <int HID>
+__device__ __forceinline__ void layer2(const float* __restrict__ th, const NetGeom& g, const float (&a1)[HID],
+                                       float (&a2)[HID]) {
+#pragma unroll
+  for (int k = 0; k < HID; ++k) a2[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < HID; ++j)
+#pragma unroll
+    for (int k = 0; k < HID; ++k) a2[k] = fmaf(a1[j], th[g.o_W2 + j * HID + k], a2[k]);
+#pragma unroll
+  for (int k = 0; k < HID; ++k) a2[k] = rc_lrelu(a2[k] + th[g.o_b2 + k]);
+}
+
+template <int HID>
+__device__ __forceinline__ float head1(const float* __restrict__ w3, float b3, const float (&a2)[HID]) {
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) v = fmaf(a2[k], w3[k], v);
+  return v + b3;
+}
+
+// Sum K per-lane values over the 256 lanes (4 wavefronts) of the workgroup and store the K
+// totals to out[0..K).  red: >= 4*K floats of LDS.  Two barriers per call.
+template <int K>
+__device__ __forceinline__ void block_reduce_store(float (&vals)[K], float* red, float* __restrict__ out) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) vals[k] = rc_wave_sum(vals[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[w * K + k] = vals[k];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += ROWS) out[k] = (red[k] + red[K + k]) + (red[2 * K + k] + red[3 * K + k]);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int HID>
+__global__ __launch_bounds__(256) void k_mid_fit(float* __restrict__ a1t, const float* __restrict__ theta,
+                                                 const float* __restrict__ y, float* __restrict__ partials, int N,
+                                                 int B, int in_dim, int ldp, int ldb, int nchunk) {
+  typedef FitPart<HID> PT;
+  __shared__ float sA[HID * LDR];
+  __shared__ float sD[HID * LDR];
+  __shared__ float red[4 * PT::NSMALL];
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  const int r = threadIdx.x, b = chunk * ROWS + r;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  float a1[HID], a2[HID], dz2[HID];
+  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, a2);
+  const float v = head1<HID>(th + g.o_W3, th[g.o_b3], a2);
+  const float diff = valid ? v - y[((long)s * N + i) * ldb + b] : 0.f;
+  const float dv = (2.0f * diff) / (float)B;
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
+  float small[PT::NSMALL];                     // [gb2 | gW3 | gb3 | gb1 | loss] as in FitPart
+  // backward through layers 3 and 2
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    dz2[k] = dv * th[g.o_W3 + k] * rc_lrelu_grad_from_act(a2[k]);
+    small[PT::gb2 - PT::gb2 + k] = dz2[k];
+    small[PT::gW3 - PT::gb2 + k] = a2[k] * dv;
+  }
+  small[PT::gb3 - PT::gb2] = dv;
+  small[PT::loss - PT::gb2] = diff * diff;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    sA[k * LDR + r] = a1[k];
+    sD[k * LDR + r] = dz2[k];
+  }
+  // dz1 = (dz2 @ W2^T) * lrelu'(z1); overwrite a1t in place (feature-major, coalesced)
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    float da1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) da1 = fmaf(dz2[k], th[g.o_W2 + j * HID + k], da1);
+    const float dz1 = da1 * rc_lrelu_grad_from_act(a1[j]);
+    small[PT::gb1 - PT::gb2 + j] = dz1;
+    if (valid) a1t[(row0 + j) * ldb + b] = dz1;
+  }
+  block_reduce_store<PT::NSMALL>(small, red, out + PT::gb2);   // (its barriers also publish sA/sD)
+  // gW2[j][k] = sum_r a1[r][j] * dz2[r][k]
+  for (int e = r; e < HID * HID; e += ROWS) {
+    const int j = e / HID, k = e - j * HID;
+    float acc = 0.f;
+    for (int q = 0; q < ROWS; ++q) acc = fmaf(sA[j * LDR + q], sD[k * LDR + q], acc);
+    out[PT::gW2 + e] = acc;
+  }
+}
+
+// theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B
+template <int HID>
+__global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ partials, float* __restrict__ theta,
+                                                   const unsigned char* __restrict__ mask,
+                                                   float* __restrict__ loss_out, int N, int B, int in_dim, int ldp,
+                                                   int nchunk, float lr) {
+  typedef FitPart<HID> PT;
+  const int s = blockIdx.y, i = blockIdx.x;
+  if (mask && !mask[i]) return;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  float* th = theta + ((long)s * N + i) * ldp;
+  const float* pp = partials + ((long)s * N + i) * nchunk * PT::SIZE;
+  for (int e = threadIdx.x; e < PT::SIZE; e += blockDim.x) {
+    float sum = 0.f;
+    for (int c = 0; c < nchunk; ++c) sum += pp[(long)c * PT::SIZE + e];
+    if (e == PT::loss) {
+      if (loss_out) loss_out[(long)s * N + i] = sum / (float)B;
+      continue;
+    }
+    int o;
+    if (e < PT::gb2) o = g.o_W2 + e;
+    else if (e < PT::gW3) o = g.o_b2 + (e - PT::gb2);
+    else if (e < PT::gb3) o = g.o_W3 + (e - PT::gW3);
+    else if (e < PT::gb1) o = g.o_b3;
+    else o = g.o_b1 + (e - PT::gb1);
+    th[o] = th[o] - lr * sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[s][n][b] = head(a1)                    (r_applied == nullptr)
+//             = r_applied[s][n][b] + gamma*v (TD target, agents/resilient_CAC_agents.py:115)
+template <int HID>
+__global__ __launch_bounds__(256) void k_mid_value(const float* __restrict__ a1t, const float* __restrict__ theta,
+                                                   const float* __restrict__ r_applied, float gamma,
+                                                   float* __restrict__ out, int N, int B, int in_dim, int ldp,
+                                                   int ldb) {
+  const int s = blockIdx.z, i = blockIdx.y;
+  const int b = blockIdx.x * ROWS + threadIdx.x;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  float a1[HID], a2[HID];
+  load_a1<HID>(a1t, ((long)s * N + i) * HID, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, a2);
+  const float v = head1<HID>(th + g.o_W3, th[g.o_b3], a2);
+  if (valid) {
+    const long o = ((long)s * N + i) * ldb + b;
+    out[o] = r_applied ? r_applied[o] + gamma * v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2+K3.  For cooperative agent i: phi = features_{theta_i}(x); V_k = phi . W3(msg[nbr[i][k]]) + b3;
+// agg = resilient aggregate over k; residual e = (agg - V_live)/(|phi|^2+1);
+// partial[chunk] = [sum_b e*phi (HID) | sum_b e]
+template <int HID, int D, int H>
+__device__ __forceinline__ float select_agg(const float (&v)[D]) {
+  float lo, hi;
+  SelNet<D, H>::run(v, lo, hi);
+  const float lower = fminf(lo, v[0]), upper = fmaxf(hi, v[0]);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[k], lower, upper);
+  return sum / (float)D;
+}
+
+template <int HID, int D, int H>
+__global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict__ a1t, const float* __restrict__ theta,
+                                                        const float* __restrict__ msg, const int* __restrict__ nbr,
+                                                        const unsigned char* __restrict__ coop,
+                                                        float* __restrict__ partials, float* __restrict__ agg_out,
+                                                        int N, int B, int in_dim, int ldp, int ldb, int nchunk) {
+  __shared__ float red[4 * (HID + 1)];
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  if (!coop[i]) return;                       // workgroup-uniform
+  const int b = chunk * ROWS + threadIdx.x;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  float a1[HID], phi[HID];
+  load_a1<HID>(a1t, ((long)s * N + i) * HID, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, phi);
+  float nrm = 0.f;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) nrm = fmaf(phi[k], phi[k], nrm);
+  nrm += 1.0f;
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const float* mh = msg + ((long)s * N + nbr[i * D + k]) * ldp;
+    v[k] = head1<HID>(mh + g.o_W3, mh[g.o_b3], phi);
+  }
+  const float agg = select_agg<HID, D, H>(v);
+  const float v_live = head1<HID>(th + g.o_W3, th[g.o_b3], phi);
+  const float e = valid ? (agg - v_live) / nrm : 0.f;
+  if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (HID + 1);
+  float proj[HID + 1];
+#pragma unroll
+  for (int k = 0; k < HID; ++k) proj[k] = e * phi[k];
+  proj[HID] = e;
+  block_reduce_store<HID + 1>(proj, red, out);
+}
+
+// runtime (d, H) fallback: neighbour estimates staged in LDS, order statistics by rank counting
+template <int HID>
+__global__ __launch_bounds__(256) void k_consensus_head_generic(
+    const float* __restrict__ a1t, const float* __restrict__ theta, const float* __restrict__ msg,
+    const int* __restrict__ nbr, const unsigned char* __restrict__ coop, float* __restrict__ partials,
+    float* __restrict__ agg_out, int N, int B, int in_dim, int ldp, int ldb, int nchunk, int d, int H) {
+  __shared__ float red[4 * (HID + 1)];
+  RCMARL_DYN_SMEM(float, est);                // [d][ROWS]
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  if (!coop[i]) return;
+  const int r = threadIdx.x, b = chunk * ROWS + r;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  float a1[HID], phi[HID];
+  load_a1<HID>(a1t, ((long)s * N + i) * HID, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, phi);
+  float nrm = 0.f;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) nrm = fmaf(phi[k], phi[k], nrm);
+  nrm += 1.0f;
+  for (int k = 0; k < d; ++k) {
+    const float* mh = msg + ((long)s * N + nbr[i * d + k]) * ldp;
+    est[k * ROWS + r] = head1<HID>(mh + g.o_W3, mh[g.o_b3], phi);
+  }
+  const float own = est[r];
+  float lo = own, hi = own;
+  for (int k = 0; k < d; ++k) {
+    const float x = est[k * ROWS + r];
+    int rank = 0;
+    for (int m = 0; m < d; ++m) {
+      const float yv = est[m * ROWS + r];
+      rank += (yv < x || (yv == x && m < k)) ? 1 : 0;
+    }
+    if (rank == H) lo = x;
+    if (rank == d - H - 1) hi = x;
+  }
+  const float lower = fminf(lo, own), upper = fmaxf(hi, own);
+  float sum = 0.f;
+  for (int k = 0; k < d; ++k) sum += __builtin_amdgcn_fmed3f(est[k * ROWS + r], lower, upper);
+  const float agg = sum / (float)d;
+  const float v_live = head1<HID>(th + g.o_W3, th[g.o_b3], phi);
+  const float e = valid ? (agg - v_live) / nrm : 0.f;
+  if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (HID + 1);
+  float proj[HID + 1];
+#pragma unroll
+  for (int k = 0; k < HID; ++k) proj[k] = e * phi[k];
+  proj[HID] = e;
+  block_reduce_store<HID + 1>(proj, red, out);
+}
+
+// W3 += (1/B) sum_chunks partial[0..HID) ; b3 += (1/B) sum partial[HID]     (cooperative agents)
+template <int HID>
+__global__ __launch_bounds__(64) void k_head_apply(const float* __restrict__ partials, float* __restrict__ theta,
+                                                   const unsigned char* __restrict__ coop, int N, int B, int in_dim,
+                                                   int ldp, int nchunk) {
+  const int s = blockIdx.y, i = blockIdx.x;
+  if (!coop[i]) return;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  float* th = theta + ((long)s * N + i) * ldp;
+  const float* pp = partials + ((long)s * N + i) * nchunk * (HID + 1);
+  const int e = threadIdx.x;
+  if (e <= HID) {
+    float sum = 0.f;
+    for (int c = 0; c < nchunk; ++c) sum += pp[c * (HID + 1) + e];
+    const int o = (e < HID) ? g.o_W3 + e : g.o_b3;
+    th[o] = th[o] + sum / (float)B;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7 actor: softmax + TD-weighted sparse cross-entropy, backward through layers 3-2.
+template <int HID, int A>
+__global__ __launch_bounds__(256) void k_mid_actor(float* __restrict__ a1t, const float* __restrict__ theta,
+                                                   const float* __restrict__ act_t /*[S][N][ldb] labels*/,
+                                                   const float* __restrict__ delta /*[S][N][ldb] sample weights*/,
+                                                   float* __restrict__ partials, int N, int B, int in_dim, int ldp,
+                                                   int ldb, int nchunk) {
+  typedef ActorPart<HID, A> PT;
+  __shared__ float sA[HID * LDR];
+  __shared__ float sD[HID * LDR];
+  __shared__ float red[4 * PT::NSMALL];
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  const int r = threadIdx.x, b = chunk * ROWS + r;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, A);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  float a1[HID], a2[HID], dz2[HID], dl[A];
+  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, a2);
+  float logit[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) acc = fmaf(a2[k], th[g.o_W3 + k * A + a], acc);
+    logit[a] = acc + th[g.o_b3 + a];
+  }
+  float mx = logit[0];
+#pragma unroll
+  for (int a = 1; a < A; ++a) mx = fmaxf(mx, logit[a]);
+  float se = 0.f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) se += expf(logit[a] - mx);
+  const float lse = logf(se);
+  const long o = ((long)s * N + i) * ldb + b;
+  const int label = valid ? (int)act_t[o] : 0;
+  const float w = valid ? delta[o] : 0.f;
+  float nll = 0.f;
+  const float wB = w / (float)B;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    const float logp = (logit[a] - mx) - lse;
+    if (a == label) nll = -logp;
+    dl[a] = (expf(logp) - (a == label ? 1.f : 0.f)) * wB;
+  }
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
+  float small[PT::NSMALL];                     // [gb2 | gb3 | gb1 | loss] as in ActorPart
+#pragma unroll
+  for (int a = 0; a < A; ++a) small[PT::gb3 - PT::gb2 + a] = dl[a];
+  small[PT::loss - PT::gb2] = nll * w;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    float da2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) da2 = fmaf(dl[a], th[g.o_W3 + k * A + a], da2);
+    dz2[k] = da2 * rc_lrelu_grad_from_act(a2[k]);
+    small[k] = dz2[k];
+  }
+  // phase 1: gW3[k][a] = sum_r a2[r][k]*dl[r][a]
+#pragma unroll
+  for (int k = 0; k < HID; ++k) sA[k * LDR + r] = a2[k];
+#pragma unroll
+  for (int a = 0; a < A; ++a) sD[a * LDR + r] = dl[a];
+  __syncthreads();
+  for (int e = r; e < HID * A; e += ROWS) {
+    const int k = e / A, a = e - k * A;
+    float acc = 0.f;
+    for (int q = 0; q < ROWS; ++q) acc = fmaf(sA[k * LDR + q], sD[a * LDR + q], acc);
+    out[PT::gW3 + e] = acc;
+  }
+  __syncthreads();
+  // phase 2: gW2 and dz1
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    sA[k * LDR + r] = a1[k];
+    sD[k * LDR + r] = dz2[k];
+  }
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    float da1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) da1 = fmaf(dz2[k], th[g.o_W2 + j * HID + k], da1);
+    const float dz1 = da1 * rc_lrelu_grad_from_act(a1[j]);
+    small[PT::gb1 - PT::gb2 + j] = dz1;
+    if (valid) a1t[(row0 + j) * ldb + b] = dz1;
+  }
+  block_reduce_store<PT::NSMALL>(small, red, out + PT::gb2);
+  for (int e = r; e < HID * HID; e += ROWS) {
+    const int j = e / HID, k = e - j * HID;
+    float acc = 0.f;
+    for (int q = 0; q < ROWS; ++q) acc = fmaf(sA[j * LDR + q], sD[k * LDR + q], acc);
+    out[PT::gW2 + e] = acc;
+  }
+}
+
+template <int HID, int A>
+__global__ __launch_bounds__(256) void k_small_adam(const float* __restrict__ partials, float* __restrict__ theta,
+                                                    float* __restrict__ adam_m, float* __restrict__ adam_v,
+                                                    const unsigned char* __restrict__ mask,
+                                                    float* __restrict__ loss_out, int N, int B, int in_dim, int ldp,
+                                                    int nchunk, float alpha, float one_m_b1, float one_m_b2,
+                                                    float eps) {
+  typedef ActorPart<HID, A> PT;
+  const int s = blockIdx.y, i = blockIdx.x;
+  if (mask && !mask[i]) return;
+  const NetGeom g = make_geom(in_dim, HID, A);
+  const long ro = ((long)s * N + i) * ldp;
+  const float* pp = partials + ((long)s * N + i) * nchunk * PT::SIZE;
+  for (int e = threadIdx.x; e < PT::SIZE; e += blockDim.x) {
+    float sum = 0.f;
+    for (int c = 0; c < nchunk; ++c) sum += pp[(long)c * PT::SIZE + e];
+    if (e == PT::loss) {
+      if (loss_out) loss_out[(long)s * N + i] = sum / (float)B;
+      continue;
+    }
+    int o;
+    if (e < PT::gW3) o = g.o_W2 + e;
+    else if (e < PT::gb2) o = g.o_W3 + (e - PT::gW3);
+    else if (e < PT::gb3) o = g.o_b2 + (e - PT::gb2);
+    else if (e < PT::gb1) o = g.o_b3 + (e - PT::gb3);
+    else o = g.o_b1 + (e - PT::gb1);
+    float mm = adam_m[ro + o], vv = adam_v[ro + o];
+    mm += (sum - mm) * one_m_b1;
+    vv += (sum * sum - vv) * one_m_b2;
+    adam_m[ro + o] = mm; adam_v[ro + o] = vv;
+    theta[ro + o] = theta[ro + o] - (mm * alpha) / (sqrtf(vv) + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 helpers
+// r_coop[s][b] = sum over cooperative agents (in index order) of r[s][b][n]/n_coop   (train_agents.py:96-98)
+__global__ __launch_bounds__(256) void k_team_reward(const float* __restrict__ r, long seed_stride,
+                                                     const unsigned char* __restrict__ coop, int n_coop,
+                                                     float* __restrict__ rcoop, int N, int B, int ldb) {
+  const int s = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* row = r + (long)s * seed_stride + (long)b * N;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n)
+    if (coop[n]) acc += row[n] / (float)n_coop;
+  rcoop[(long)s * ldb + b] = acc;
+}
+
+// agent-major gather: out[s][n][b] = mode[n]==0 ? src[s][b][n] : (mode[n]==1 ? rcoop[s][b] : -rcoop[s][b])
+__global__ __launch_bounds__(256) void k_gather_agent_major(const float* __restrict__ src, long seed_stride,
+                                                            const float* __restrict__ rcoop,
+                                                            const int* __restrict__ mode, float* __restrict__ out,
+                                                            int N, int B, int ldb) {
+  const int s = blockIdx.z, n = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int m = mode ? mode[n] : 0;
+  float v;
+  if (m == 0) v = src[(long)s * seed_stride + (long)b * N + n];
+  else v = (m == 1) ? rcoop[(long)s * ldb + b] : -rcoop[(long)s * ldb + b];
+  out[((long)s * N + n) * ldb + b] = v;
+}
+
+// delta = r_team + gamma*V(ns) - V(s)            (agents/resilient_CAC_agents.py:98)
+__global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_team, const float* __restrict__ v_next,
+                                                  const float* __restrict__ v_cur, float gamma,
+                                                  float* __restrict__ delta, long n_total) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_total) delta[t] = r_team[t] + gamma * v_next[t] - v_cur[t];
+}
+
+bool bad_mid(const void* a, const void* b, int S, int N, int B, int in_dim, int hid, int ldp, int ldb) {
+  return !a || !b || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) || ldb < B;
+}
+
+}  // namespace
+
+#define RC_HID_SWITCH(hid, STMT)               \
+  switch (hid) {                               \
+    case 20: { constexpr int HID_ = 20; STMT; } break; \
+    default: return RCMARL_ERR_UNSUPPORTED;    \
+  }
+
+RCMARL_EXPORT int rcmarl_fit_partial_size(int hid) { return hid * hid + 3 * hid + 2; }
+RCMARL_EXPORT int rcmarl_actor_partial_size(int hid, int n_actions) {
+  return hid * hid + 2 * hid + hid * n_actions + n_actions + 1;
+}
+RCMARL_EXPORT int rcmarl_rows_per_chunk(void) { return ROWS; }
+
+RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B,
+                                 int in_dim, int hid, int ldp, int ldb, void* stream) {
+  if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(nchunk, N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
+                                   ldp, ldb, nchunk));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const unsigned char* mask, float* loss_out,
+                                   int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream) {
+  if (!partials || !theta || S <= 0 || N <= 0 || B <= 0) return RCMARL_ERR_ARG;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(N, S), block(256);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
+                                   in_dim, ldp, nchunk, lr));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma,
+                                   float* out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                                   void* stream) {
+  if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !out) return RCMARL_ERR_ARG;
+  const dim3 grid(rc_ceil_div(B, ROWS), N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_value<HID_>), grid, block, 0, stream, a1t, theta, r_applied, gamma, out, N,
+                                   B, in_dim, ldp, ldb));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, const float* msg, const int* nbr,
+                                        const unsigned char* coop, float* partials, float* agg_out, int S, int N,
+                                        int B, int in_dim, int hid, int ldp, int ldb, int d, int H, void* stream) {
+  if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !msg || !nbr || !coop || !partials || d <= 0 || H < 0 ||
+      d < 2 * H + 1)
+    return RCMARL_ERR_ARG;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(nchunk, N, S), block(ROWS);
+  bool done = false;
+#define RC_CASE(DD, HH)                                                                                          \
+  if (!done && d == DD && H == HH) {                                                                             \
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_consensus_head<HID_, DD, HH>), grid, block, 0, stream, a1t, theta, msg,  \
+                                     nbr, coop, partials, agg_out, N, B, in_dim, ldp, ldb, nchunk));            \
+    done = true;                                                                                                 \
+  }
+  RCMARL_SELNET_COMBOS(RC_CASE)
+#undef RC_CASE
+  if (!done) {
+    const size_t smem = (size_t)d * ROWS * sizeof(float);
+    if (smem > 60 * 1024) return RCMARL_ERR_UNSUPPORTED;
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_consensus_head_generic<HID_>), grid, block, smem, stream, a1t, theta, msg, nbr,
+                                     coop, partials, agg_out, N, B, in_dim, ldp, ldb, nchunk, d, H));
+  }
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_head_apply(const float* partials, float* theta, const unsigned char* coop, int S, int N,
+                                    int B, int in_dim, int hid, int ldp, void* stream) {
+  if (!partials || !theta || !coop || S <= 0 || N <= 0 || B <= 0 || hid >= 64) return RCMARL_ERR_ARG;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(N, S), block(64);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_head_apply<HID_>), grid, block, 0, stream, partials, theta, coop, N, B, in_dim,
+                                   ldp, nchunk));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_mid_actor(float* a1t, const float* theta, const float* act_t, const float* delta,
+                                   float* partials, int S, int N, int B, int in_dim, int hid, int n_actions, int ldp,
+                                   int ldb, void* stream) {
+  if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !act_t || !delta || !partials) return RCMARL_ERR_ARG;
+  if (n_actions != 5) return RCMARL_ERR_UNSUPPORTED;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(nchunk, N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_actor<HID_, 5>), grid, block, 0, stream, a1t, theta, act_t, delta, partials,
+                                   N, B, in_dim, ldp, ldb, nchunk));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v,
+                                    const unsigned char* mask, float* loss_out, int S, int N, int B, int in_dim,
+                                    int hid, int n_actions, int ldp, float alpha, float one_m_b1, float one_m_b2,
+                                    float eps, void* stream) {
+  if (!partials || !theta || !adam_m || !adam_v || S <= 0 || N <= 0 || B <= 0) return RCMARL_ERR_ARG;
+  if (n_actions != 5) return RCMARL_ERR_UNSUPPORTED;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(N, S), block(256);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_adam<HID_, 5>), grid, block, 0, stream, partials, theta, adam_m, adam_v,
+                                   mask, loss_out, N, B, in_dim, ldp, nchunk, alpha, one_m_b1, one_m_b2, eps));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_team_reward(const float* r, long seed_stride, const unsigned char* coop, int n_coop,
+                                     float* rcoop, int S, int N, int B, int ldb, void* stream) {
+  if (!r || !coop || !rcoop || S <= 0 || N <= 0 || B <= 0 || n_coop <= 0 || ldb < B) return RCMARL_ERR_ARG;
+  const dim3 grid(rc_ceil_div(B, 256), S), block(256);
+  RCMARL_LAUNCH(k_team_reward, grid, block, 0, stream, r, seed_stride, coop, n_coop, rcoop, N, B, ldb);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_gather_agent_major(const float* src, long seed_stride, const float* rcoop, const int* mode,
+                                            float* out, int S, int N, int B, int ldb, void* stream) {
+  if (!src || !out || S <= 0 || N <= 0 || B <= 0 || ldb < B || (mode && !rcoop)) return RCMARL_ERR_ARG;
+  const dim3 grid(rc_ceil_div(B, 256), N, S), block(256);
+  RCMARL_LAUNCH(k_gather_agent_major, grid, block, 0, stream, src, seed_stride, rcoop, mode, out, N, B, ldb);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_td_error(const float* r_team, const float* v_next, const float* v_cur, float gamma,
+                                  float* delta, long n_total, void* stream) {
+  if (!r_team || !v_next || !v_cur || !delta || n_total <= 0) return RCMARL_ERR_ARG;
+  const dim3 grid((unsigned)((n_total + 255) / 256)), block(256);
+  RCMARL_LAUNCH(k_td_error, grid, block, 0, stream, r_team, v_next, v_cur, gamma, delta, n_total);
+  return rcmarl_check_launch();
+}

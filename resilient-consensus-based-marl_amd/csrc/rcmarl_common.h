@@ -1,0 +1,70 @@
+// Shared device/host helpers for the rcmarl HIP kernels (gfx950 / MI355X).
+//
+// Data layout conventions (see DESIGN.md "Data layout in HBM"):
+//   * every network family (actor / critic / team-reward) of every agent of every
+//     seed is one row of a stacked parameter matrix  theta[S][N][ldp]  (fp32),
+//     row = [W1(in x hid) | b1 | W2(hid x hid) | b2 | W3(hid x out) | b3 | pad]
+//     in Keras order (reference main.py:59-82, SURVEY.md 8b "weight exchange
+//     format"); ldp = P rounded up to 64 floats so every row is 256-B aligned.
+//   * activations of the batched layer-1 GEMM are FEATURE-MAJOR:
+//     a1t[S][N*hid][ldb]  (row = one hidden unit of one agent, contiguous over
+//     the replay batch index b) so that a wavefront's lanes map to consecutive b.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RCMARL_OK 0
+#define RCMARL_ERR_ARG 1
+#define RCMARL_ERR_LAUNCH 2
+#define RCMARL_ERR_UNSUPPORTED 3
+
+#ifdef RCMARL_EMU
+#define RCMARL_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define RCMARL_DYN_SMEM(type, name) HIPEMU_DYN_SMEM(type, name)
+#define RCMARL_EXPORT extern "C"
+typedef floatx16 rc_f32x16;
+#else
+#define RCMARL_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define RCMARL_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
+  type* name = reinterpret_cast<type*>(name##_raw)
+#define RCMARL_EXPORT extern "C" __attribute__((visibility("default")))
+typedef float rc_f32x16 __attribute__((ext_vector_type(16)));
+#endif
+
+static inline int rcmarl_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? RCMARL_OK : RCMARL_ERR_LAUNCH;
+}
+
+// Offsets of the six Keras arrays inside one parameter row.
+struct NetGeom {
+  int in_dim, hid, out_dim;
+  int o_b1, o_W2, o_b2, o_W3, o_b3, P, P_hid;
+};
+__host__ __device__ static inline NetGeom make_geom(int in_dim, int hid, int out_dim) {
+  NetGeom g;
+  g.in_dim = in_dim; g.hid = hid; g.out_dim = out_dim;
+  g.o_b1 = in_dim * hid;
+  g.o_W2 = g.o_b1 + hid;
+  g.o_b2 = g.o_W2 + hid * hid;
+  g.o_W3 = g.o_b2 + hid;
+  g.o_b3 = g.o_W3 + hid * out_dim;
+  g.P = g.o_b3 + out_dim;
+  g.P_hid = g.o_W3;
+  return g;
+}
+
+#define RC_LEAK 0.1f
+__device__ __forceinline__ float rc_lrelu(float z) { return z > 0.f ? z : RC_LEAK * z; }
+// LeakyReLU keeps the sign, so the derivative can be recovered from the activation.
+__device__ __forceinline__ float rc_lrelu_grad_from_act(float a) { return a > 0.f ? 1.f : RC_LEAK; }
+
+__device__ __forceinline__ float rc_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+static inline int rc_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,162 @@
+// hipemu -- a tiny CPU stand-in for the slice of the HIP runtime the rcmarl
+// kernels use.  TEST INFRASTRUCTURE ONLY: it lets the *same* kernel sources be
+// compiled with g++ and executed on the CPU (one workgroup at a time, one
+// ucontext fiber per work-item, 64-lane wavefronts, emulated f32 MFMA) so
+// indexing / LDS / barrier logic is exercised by the `-m "not gpu"` tests in a
+// container without a GPU.  It is never linked into the product library and
+// never loaded by the product package.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __shared__ static
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int2 { int x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+namespace hipemu {
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  bool done = false;
+  unsigned long long wait_gen = 0;   // barrier generation the fiber waits to pass
+  int wait_kind = 0;                 // 0 none, 1 block barrier, 2 wave barrier
+};
+struct State {
+  dim3 grid, block, bidx, tidx;
+  int cur = 0, nthreads = 0;
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  std::function<void()> body;
+  // barriers
+  int blk_arrived = 0; unsigned long long blk_gen = 0;
+  std::vector<int> wave_arrived; std::vector<unsigned long long> wave_gen;
+  // wave exchange scratch: [wave][lane][slot]
+  std::vector<float> xch_f; std::vector<unsigned long long> xch_u;
+  std::vector<char> dyn_smem;
+};
+State& st();
+void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body);
+void block_barrier();
+void wave_barrier();
+inline int lane() { return st().cur & 63; }
+inline int wave() { return st().cur >> 6; }
+inline int wave_size_here() {   // lanes present in this (possibly partial) wave
+  int base = (st().cur >> 6) << 6;
+  int n = st().nthreads - base;
+  return n > 64 ? 64 : n;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::st().tidx)
+#define blockIdx (hipemu::st().bidx)
+#define blockDim (hipemu::st().block)
+#define gridDim (hipemu::st().grid)
+#define warpSize 64
+
+inline void __syncthreads() { hipemu::block_barrier(); }
+
+// ---- cross-lane ----------------------------------------------------------------
+template <typename T> inline T __hipemu_xch(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "xch");
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  unsigned long long bits = 0; memcpy(&bits, &v, sizeof(T));
+  s.xch_u[(size_t)w * 64 + l] = bits;
+  hipemu::wave_barrier();
+  unsigned long long got = s.xch_u[(size_t)w * 64 + (src_lane & 63)];
+  hipemu::wave_barrier();
+  T r; memcpy(&r, &got, sizeof(T));
+  return r;
+}
+template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return __hipemu_xch(v, hipemu::lane() ^ mask); }
+template <typename T> inline T __shfl(T v, int src, int width = 64) { (void)width; return __hipemu_xch(v, src); }
+template <typename T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  (void)width; int l = hipemu::lane(); int src = l + (int)delta; if (src > 63) src = l; return __hipemu_xch(v, src);
+}
+inline int __builtin_amdgcn_readfirstlane(int v) { return __hipemu_xch(v, 0); }
+
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
+  return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+
+// ---- f32 MFMA (layout: cdna_hip_programming.md section 3) -----------------------
+struct floatx16 { float v[16]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+struct floatx4 { float v[4]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+inline floatx16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, floatx16 c, int, int, int) {
+  // lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+  // holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] in register r.
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  s.xch_f[((size_t)w * 64 + l) * 2 + 0] = a;
+  s.xch_f[((size_t)w * 64 + l) * 2 + 1] = b;
+  hipemu::wave_barrier();
+  floatx16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 2; ++k) {
+      float av = s.xch_f[((size_t)w * 64 + row + 32 * k) * 2 + 0];
+      float bv = s.xch_f[((size_t)w * 64 + col + 32 * k) * 2 + 1];
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
+inline floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, floatx4 c, int, int, int) {
+  // lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=(l>>4)*4+r][col=l&15]
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  s.xch_f[((size_t)w * 64 + l) * 2 + 0] = a;
+  s.xch_f[((size_t)w * 64 + l) * 2 + 1] = b;
+  hipemu::wave_barrier();
+  floatx4 d = c;
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = (l >> 4) * 4 + r;
+    float acc = d[r];
+    for (int k = 0; k < 4; ++k) {
+      float av = s.xch_f[((size_t)w * 64 + row + 16 * k) * 2 + 0];
+      float bv = s.xch_f[((size_t)w * 64 + col + 16 * k) * 2 + 1];
+      acc = fmaf(av, bv, acc);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
+
+// dynamic LDS
+#define HIPEMU_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::st().dyn_smem.data())
+
+inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline float __fdividef(float a, float b) { return a / b; }

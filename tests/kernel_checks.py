@@ -1,0 +1,313 @@
+"""Kernel-vs-oracle parity checks shared by the hipemu (CPU) tests and the
+GPU tests.  A *backend* supplies memory + the bound C-ABI library:
+
+    bk.lib              CLib (emu build or the product librcmarl_hip.so)
+    bk.dev(np_array)    -> device handle holding a copy
+    bk.ptr(handle)      -> raw pointer for the C-ABI
+    bk.host(handle)     -> numpy copy (synchronises)
+    bk.stream           -> hipStream_t or None
+"""
+import numpy as np
+
+from oracle import mlp_np as M
+from oracle import rpbcac_oracle as O
+
+HID = 20
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def geom(in_dim, out_dim, hid=HID):
+    P = in_dim * hid + hid + hid * hid + hid + hid * out_dim + out_dim
+    return P, P - (hid * out_dim + out_dim)
+
+
+def pack_rows(params_sn, ldp):
+    """params_sn[s][n] = [W1..b3] -> theta[S][N][ldp] fp32 (padding = 0)."""
+    S, N = len(params_sn), len(params_sn[0])
+    th = np.zeros((S, N, ldp), np.float32)
+    for s in range(S):
+        for n in range(N):
+            v = np.concatenate([np.asarray(a, np.float32).ravel() for a in params_sn[s][n]])
+            th[s, n, :len(v)] = v
+    return th
+
+
+def unpack_row(row, in_dim, out_dim, hid=HID):
+    shapes = [(in_dim, hid), (hid,), (hid, hid), (hid,), (hid, out_dim), (out_dim,)]
+    out, o = [], 0
+    for sh in shapes:
+        n = int(np.prod(sh))
+        out.append(row[o:o + n].reshape(sh).copy())
+        o += n
+    return out
+
+
+def random_params(rng, S, N, in_dim, out_dim, bias_scale=0.1):
+    out = []
+    for s in range(S):
+        row = []
+        for n in range(N):
+            p = M.init_mlp(rng, in_dim, HID, out_dim)
+            for k in (1, 3, 5):
+                p[k] += (bias_scale * rng.normal(size=p[k].shape)).astype(np.float32)
+            row.append(p)
+        out.append(row)
+    return out
+
+
+def circulant(N, d):
+    return np.array([[(i + k) % N for k in range(d)] for i in range(N)], dtype=np.int32)
+
+
+def random_regular(N, d, rng):
+    nbr = np.zeros((N, d), np.int32)
+    for i in range(N):
+        others = rng.permutation([j for j in range(N) if j != i])[:d - 1]
+        nbr[i] = [i] + list(others)
+    return nbr
+
+
+def rel_close(got, want, rtol, what=""):
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= rtol * scale, "%s: max abs err %.3e > %.1e * %.3g" % (what, err, rtol, scale)
+
+
+# ------------------------------------------------------------------------------------------
+def check_consensus_params(bk, N, d, H, P, P_hid, graph, S=2):
+    rng = np.random.default_rng(N * 100 + d)
+    ldp = pad64(P)
+    nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
+    coop = np.ones(N, np.uint8)
+    coop[N - 1] = 0
+    base = rng.normal(size=(S, 1, ldp)).astype(np.float32)
+    msg = (base + 0.01 * rng.normal(size=(S, N, ldp))).astype(np.float32)
+    msg[:, N - 1] = 1e3                       # adversarial row
+    msg[:, :, 5] = msg[:, :1, 5]              # ties
+    theta0 = rng.normal(size=(S, N, ldp)).astype(np.float32)
+    d_msg, d_theta, d_nbr, d_coop = bk.dev(msg), bk.dev(theta0), bk.dev(nbr), bk.dev(coop)
+    d_lo, d_hi = bk.dev(np.zeros_like(theta0)), bk.dev(np.zeros_like(theta0))
+    bk.lib.rcmarl_consensus_params(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_nbr), bk.ptr(d_coop), S, N, ldp, P_hid, d,
+                                   H, bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+    theta, lo, hi = bk.host(d_theta), bk.host(d_lo), bk.host(d_hi)
+    want = theta0.copy()
+    for s in range(S):
+        for i in range(N):
+            if not coop[i]:
+                continue
+            vals = msg[s, nbr[i], :P_hid]
+            want[s, i, :P_hid] = O.resilient_aggregate(vals, H)
+            wl, wh, _ = O.aggregation_bounds(vals, H)
+            # order-statistic bounds: bit-exact
+            np.testing.assert_array_equal(lo[s, i, :P_hid], wl)
+            np.testing.assert_array_equal(hi[s, i, :P_hid], wh)
+    # means: fp32 summation order only (|x| up to 1e3 in the adversarial columns)
+    np.testing.assert_allclose(theta, want, rtol=2e-6, atol=2e-6)
+    # untouched: output-layer columns, padding, non-cooperative rows
+    np.testing.assert_array_equal(theta[:, :, P_hid:], theta0[:, :, P_hid:])
+    np.testing.assert_array_equal(theta[:, N - 1], theta0[:, N - 1])
+
+
+# ------------------------------------------------------------------------------------------
+def _layer1(bk, d_x, x_stride, d_theta, d_a1t, S, N, B, in_dim, ldp, ldb):
+    bk.lib.rcmarl_layer1_forward(bk.ptr(d_x), x_stride, bk.ptr(d_theta), bk.ptr(d_a1t), S, N, B, in_dim, HID, ldp, ldb,
+                                 bk.stream)
+
+
+def check_layer1_forward(bk, S, N, B, in_dim):
+    rng = np.random.default_rng(B + in_dim)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    d_x, d_th = bk.dev(x), bk.dev(theta)
+    d_a = bk.dev(np.full((S, N * HID, ldb), np.nan, np.float32))
+    _layer1(bk, d_x, B * in_dim, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    a1t = bk.host(d_a)
+    for s in range(S):
+        for n in range(N):
+            want = M.lrelu(x[s] @ params[s][n][0] + params[s][n][1])          # [B, HID]
+            rel_close(a1t[s, n * HID:(n + 1) * HID, :B].T, want, 2e-6, "a1")
+
+
+def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent=None):
+    """`steps` full-batch SGD steps of the local fit (layer1_forward -> mid_fit ->
+    small_sgd -> layer1_backward_sgd) incl. the TD target (mid_value) vs the oracle."""
+    rng = np.random.default_rng(S * 1000 + N * 100 + B + in_dim)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    nx = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    r_applied = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.uint8)
+    if masked_agent is not None:
+        mask[masked_agent] = 0
+    nchunk = (B + 255) // 256
+    psz = bk.lib.rcmarl_fit_partial_size(HID)
+    d_x, d_nx, d_th, d_r, d_mask = bk.dev(x), bk.dev(nx), bk.dev(theta), bk.dev(r_applied), bk.dev(mask)
+    d_msg = bk.dev(theta.copy())
+    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+    d_y = bk.dev(np.zeros((S, N, ldb), np.float32))
+    d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    L = bk.lib
+    # target from the pre-fit weights (agents/resilient_CAC_agents.py:114-115)
+    _layer1(bk, d_nx, B * in_dim, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    L.rcmarl_mid_value(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_r), gamma, bk.ptr(d_y), S, N, B, in_dim, HID, ldp, ldb,
+                       bk.stream)
+    for st in range(steps):
+        _layer1(bk, d_x, B * in_dim, d_msg, d_a, S, N, B, in_dim, ldp, ldb)
+        L.rcmarl_mid_fit(bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part), S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+        L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
+                           in_dim, HID, ldp, lr, bk.stream)
+        L.rcmarl_layer1_backward_sgd(bk.ptr(d_x), B * in_dim, bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim,
+                                     HID, ldp, ldb, lr, bk.stream)
+    msg, y, loss = bk.host(d_msg), bk.host(d_y), bk.host(d_loss)
+    for s in range(S):
+        for n in range(N):
+            p0 = params[s][n]
+            target = r_applied[s, n, :B, None] + np.float32(gamma) * M.forward(p0, nx[s])
+            rel_close(y[s, n, :B], target[:, 0], 3e-6, "td target")
+            if not mask[n]:
+                np.testing.assert_array_equal(msg[s, n], theta[s, n])
+                continue
+            pw = M.copy_params(p0)
+            hist = M.fit_mse(pw, x[s], target, lr, epochs=steps)
+            got = unpack_row(msg[s, n], in_dim, 1)
+            for k in range(6):
+                rel_close(got[k], pw[k], 1e-5, "fit param %d" % k)
+            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+    np.testing.assert_array_equal(bk.host(d_th), theta)           # live weights untouched (rollback)
+
+
+def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
+    """K2+K3: estimate consensus + projection step of the output layer."""
+    rng = np.random.default_rng(S + N * 10 + B + d * 7 + H)
+    P, P_hid = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    live = random_params(rng, S, N, in_dim, 1)
+    msgp = random_params(rng, S, N, in_dim, 1)
+    theta, msg = pack_rows(live, ldp), pack_rows(msgp, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
+    coop = np.ones(N, np.uint8)
+    coop[0] = 0
+    for s in range(S):                              # an outlier head among the messages
+        msg[s, 1, P_hid:P] *= 50.0
+        msgp[s][1][4] = msgp[s][1][4] * np.float32(50.0)
+        msgp[s][1][5] = msgp[s][1][5] * np.float32(50.0)
+    nchunk = (B + 255) // 256
+    d_x, d_th, d_msg, d_nbr, d_coop = bk.dev(x), bk.dev(theta), bk.dev(msg), bk.dev(nbr), bk.dev(coop)
+    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+    d_part = bk.dev(np.zeros((S, N, nchunk, HID + 1), np.float32))
+    d_agg = bk.dev(np.zeros((S, N, ldb), np.float32))
+    L = bk.lib
+    _layer1(bk, d_x, B * in_dim, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    L.rcmarl_consensus_head(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_msg), bk.ptr(d_nbr), bk.ptr(d_coop), bk.ptr(d_part),
+                            bk.ptr(d_agg), S, N, B, in_dim, HID, ldp, ldb, d, H, bk.stream)
+    L.rcmarl_head_apply(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_coop), S, N, B, in_dim, HID, ldp, bk.stream)
+    th_new, agg = bk.host(d_th), bk.host(d_agg)
+    for s in range(S):
+        for i in range(N):
+            if not coop[i]:
+                np.testing.assert_array_equal(th_new[s, i], theta[s, i])
+                continue
+            ag = O.CoopAgent(M.init_mlp(rng, in_dim, HID, 5), live[s][i], live[s][i], 0.002, 0.01, 0.9, H)
+            want_agg = ag.consensus_estimates_critic(x[s], [msgp[s][j] for j in nbr[i]])
+            rel_close(agg[s, i, :B], want_agg[:, 0], 5e-6, "estimate aggregate")
+            ag.projection_step_critic(x[s], want_agg)
+            got = unpack_row(th_new[s, i], in_dim, 1)
+            for k in range(4):
+                np.testing.assert_array_equal(got[k], live[s][i][k])          # hidden layers frozen
+            rel_close(got[4], ag.critic[4], 2e-5, "W3 after projection")
+            rel_close(got[5], ag.critic[5], 2e-5, "b3 after projection")
+
+
+def check_actor_step(bk, S, N, B, in_dim, steps=2, lr=0.002):
+    rng = np.random.default_rng(S + N + B + in_dim)
+    A = 5
+    P, _ = geom(in_dim, A)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, A)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    act = rng.integers(0, A, size=(S, N, ldb)).astype(np.float32)
+    delta = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.uint8)
+    mask[N - 1] = 0
+    nchunk = (B + 255) // 256
+    psz = bk.lib.rcmarl_actor_partial_size(HID, A)
+    d_x, d_th, d_act, d_delta, d_mask = bk.dev(x), bk.dev(theta), bk.dev(act), bk.dev(delta), bk.dev(mask)
+    d_m, d_v = bk.dev(np.zeros_like(theta)), bk.dev(np.zeros_like(theta))
+    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+    d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    L = bk.lib
+    b1, b2, eps = 0.9, 0.999, 1e-7
+    losses = []
+    for t in range(1, steps + 1):
+        alpha = np.float32(lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t))
+        _layer1(bk, d_x, B * in_dim, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+        L.rcmarl_mid_actor(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_act), bk.ptr(d_delta), bk.ptr(d_part), S, N, B, in_dim, HID,
+                           A, ldp, ldb, bk.stream)
+        L.rcmarl_small_adam(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_m), bk.ptr(d_v), bk.ptr(d_mask), bk.ptr(d_loss), S, N, B,
+                            in_dim, HID, A, ldp, float(alpha), float(np.float32(1 - b1)), float(np.float32(1 - b2)),
+                            float(np.float32(eps)), bk.stream)
+        L.rcmarl_layer1_backward_adam(bk.ptr(d_x), B * in_dim, bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_m), bk.ptr(d_v),
+                                      bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, ldb, float(alpha),
+                                      float(np.float32(1 - b1)), float(np.float32(1 - b2)), float(np.float32(eps)),
+                                      bk.stream)
+        losses.append(bk.host(d_loss).copy())
+    th_new = bk.host(d_th)
+    for s in range(S):
+        for n in range(N):
+            if not mask[n]:
+                np.testing.assert_array_equal(th_new[s, n], theta[s, n])
+                continue
+            pw = M.copy_params(params[s][n])
+            st = M.AdamState(pw, lr)
+            for t in range(steps):
+                l = M.fit_actor_ce(pw, st, x[s], act[s, n, :B], delta[s, n, :B], epochs=1)[0]
+                assert abs(losses[t][s, n] - l) <= 2e-5 * max(1.0, abs(l)), (t, losses[t][s, n], l)
+            got = unpack_row(th_new[s, n], in_dim, A)
+            for k in range(6):
+                # Adam normalises tiny gradients to +-lr steps: compare in units of lr
+                assert np.abs(got[k] - pw[k]).max() <= 0.02 * lr * steps + 1e-6, ("actor param", k, np.abs(got[k] - pw[k]).max())
+
+
+def check_reward_helpers(bk, S, N, B):
+    rng = np.random.default_rng(S + N + B)
+    ldb = pad64(B)
+    cap = B + 7
+    r = rng.normal(size=(S, cap, N)).astype(np.float32)
+    coop = np.ones(N, np.uint8)
+    coop[N // 2] = 0
+    n_coop = int(coop.sum())
+    mode = np.zeros(N, np.int32)
+    mode[0], mode[N // 2] = 1, 2
+    d_r, d_coop, d_mode = bk.dev(r), bk.dev(coop), bk.dev(mode)
+    d_rc = bk.dev(np.zeros((S, ldb), np.float32))
+    d_out = bk.dev(np.zeros((S, N, ldb), np.float32))
+    L = bk.lib
+    L.rcmarl_team_reward(bk.ptr(d_r), cap * N, bk.ptr(d_coop), n_coop, bk.ptr(d_rc), S, N, B, ldb, bk.stream)
+    L.rcmarl_gather_agent_major(bk.ptr(d_r), cap * N, bk.ptr(d_rc), bk.ptr(d_mode), bk.ptr(d_out), S, N, B, ldb, bk.stream)
+    rc, out = bk.host(d_rc), bk.host(d_out)
+    for s in range(S):
+        want = np.zeros(B, np.float32)
+        for n in range(N):
+            if coop[n]:
+                want += r[s, :B, n] / n_coop                          # train_agents.py:96-98
+        np.testing.assert_array_equal(rc[s, :B], want)
+        for n in range(N):
+            w = r[s, :B, n] if mode[n] == 0 else (want if mode[n] == 1 else -want)
+            np.testing.assert_array_equal(out[s, n, :B], w)
+    a, b, c = (rng.normal(size=1000).astype(np.float32) for _ in range(3))
+    d_o, d_a, d_b, d_c = bk.dev(np.zeros(1000, np.float32)), bk.dev(a), bk.dev(b), bk.dev(c)
+    L.rcmarl_td_error(bk.ptr(d_a), bk.ptr(d_b), bk.ptr(d_c), 0.9, bk.ptr(d_o), 1000, bk.stream)
+    np.testing.assert_allclose(bk.host(d_o), a + np.float32(0.9) * b - c, rtol=1e-6, atol=1e-7)

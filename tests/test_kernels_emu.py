@@ -1,0 +1,64 @@
+"""Kernel-vs-oracle parity on the hipemu (CPU) build of the HIP sources.
+Exercises indexing / LDS staging / barrier / MFMA-layout logic without a GPU.
+The real parity tests (same checks, real hardware, product C-ABI) are in
+test_kernels_gpu.py."""
+import numpy as np
+import pytest
+
+import kernel_checks as KC
+from emu_util import emu_lib, p
+
+
+class EmuBackend:
+    stream = None
+
+    def __init__(self):
+        self.lib = emu_lib()
+
+    def dev(self, arr):
+        return np.ascontiguousarray(arr).copy()
+
+    def ptr(self, h):
+        return p(h)
+
+    def host(self, h):
+        return h
+
+
+@pytest.fixture(scope="module")
+def bk():
+    return EmuBackend()
+
+
+@pytest.mark.parametrize("N,d,H,P,P_hid,graph", [
+    (5, 4, 1, 661, 640, "circ"), (5, 4, 0, 661, 640, "circ"), (12, 10, 4, 200, 150, "rand"),
+    (7, 3, 1, 70, 64, "circ"), (20, 18, 8, 130, 128, "circ"), (9, 7, 2, 100, 90, "rand"),
+    (30, 23, 5, 90, 77, "rand"),   # no generated network for (23,5): rank-counting fallback
+])
+def test_consensus_params(bk, N, d, H, P, P_hid, graph):
+    KC.check_consensus_params(bk, N, d, H, P, P_hid, graph)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 150, 6), (1, 7, 130, 21), (1, 2, 260, 136)])
+def test_layer1_forward(bk, S, N, B, in_dim):
+    KC.check_layer1_forward(bk, S, N, B, in_dim)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 3, 300, 6, None), (1, 7, 130, 21, 2), (1, 2, 70, 140, None)])
+def test_sgd_fit(bk, S, N, B, in_dim, masked):
+    KC.check_sgd_fit(bk, S, N, B, in_dim, steps=2, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,d,H,graph", [(2, 5, 300, 10, 4, 1, "circ"), (1, 6, 100, 18, 3, 0, "rand"),
+                                                    (1, 12, 70, 24, 11, 2, "rand")])
+def test_consensus_head(bk, S, N, B, in_dim, d, H, graph):
+    KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 300, 6), (1, 5, 100, 10)])
+def test_actor_step(bk, S, N, B, in_dim):
+    KC.check_actor_step(bk, S, N, B, in_dim)
+
+
+def test_reward_helpers(bk):
+    KC.check_reward_helpers(bk, 2, 5, 300)
