@@ -61,6 +61,22 @@ SIGNATURES = {
     "rcmarl_gather_agent_major": [c_f32p, c_long, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_stream],
     # r_team, v_next, v_cur, gamma, delta, n_total, stream
     "rcmarl_td_error": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_long, c_stream],
+    # xs, theta, probs, S, N, in_dim, hid, n_actions, ldp, stream
+    "rcmarl_policy_probs": [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # xs, theta, out, S, N, in_dim, hid, ldp, stream
+    "rcmarl_value_rows": [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # xs, pos, goal, theta, seeds, nrow, ncol, scale, rp_s, rp_ns, rp_sa, rp_a, rp_r, cap, row, pos_next, xs_next,
+    # ret, gpow, episode, step, mu, S, N, hid, n_actions, ldp, act_out, stream
+    "rcmarl_rollout_step": [c_f32p, c_i32p, c_i32p, c_f32p, C.c_void_p, c_int, c_int, c_f64p, c_f32p, c_f32p, c_f32p,
+                            c_f32p, c_f32p, c_long, c_long, c_i32p, c_f32p, c_f64p, C.c_double, c_int, c_int, c_float,
+                            c_int, c_int, c_int, c_int, c_int, c_i32p, c_stream],
+    # pos, goal, actions, nrow, ncol, scale, rp_s, rp_ns, rp_sa, rp_a, rp_r, cap, row, pos_next, xs_next, ret, gpow,
+    # S, N, stream
+    "rcmarl_env_apply": [c_i32p, c_i32p, c_i32p, c_int, c_int, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_long,
+                         c_long, c_i32p, c_f32p, c_f64p, C.c_double, c_int, c_int, c_stream],
+    # pos_in, seeds, nrow, ncol, scale, episode, pos, xs, ret, S, N, stream
+    "rcmarl_env_reset": [c_i32p, C.c_void_p, c_int, c_int, c_f64p, c_int, c_i32p, c_f32p, c_f64p, c_int, c_int,
+                         c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk"}
 

@@ -160,3 +160,5 @@ inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; 
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline int max(int a, int b) { return a > b ? a : b; }

@@ -311,3 +311,91 @@ def check_reward_helpers(bk, S, N, B):
     d_o, d_a, d_b, d_c = bk.dev(np.zeros(1000, np.float32)), bk.dev(a), bk.dev(b), bk.dev(c)
     L.rcmarl_td_error(bk.ptr(d_a), bk.ptr(d_b), bk.ptr(d_c), 0.9, bk.ptr(d_o), 1000, bk.stream)
     np.testing.assert_allclose(bk.host(d_o), a + np.float32(0.9) * b - c, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------
+def check_rollout(bk, S, N, nrow, ncol, steps=6, mode="device"):
+    """Rollout kernels vs the oracle env + agents: policy probabilities, start-state
+    values, Philox sampling, transitions, rewards, replay rows, discounted returns."""
+    from oracle import philox_np as PX
+    rng = np.random.default_rng(S * 7 + N)
+    A = 5
+    in_a = 2 * N
+    Pa, _ = geom(in_a, A)
+    Pc, _ = geom(in_a, 1)
+    ldpa, ldpc = pad64(Pa), pad64(Pc)
+    actors = random_params(rng, S, N, in_a, A, bias_scale=0.3)
+    critics = random_params(rng, S, N, in_a, 1)
+    th_a, th_c = pack_rows(actors, ldpa), pack_rows(critics, ldpc)
+    goal = rng.integers(0, min(5, nrow), size=(S, N, 2)).astype(np.int32)
+    seeds = np.array([1000 + 17 * s for s in range(S)], dtype=np.uint64)
+    scale = np.array([np.mean(np.arange(nrow)), np.mean(np.arange(ncol)), np.std(np.arange(nrow)), np.std(np.arange(ncol))])
+    cap = steps + 3
+    gamma, mu, episode = 0.9, 0.1, 5
+    L = bk.lib
+    d_tha, d_thc, d_goal, d_seeds, d_scale = bk.dev(th_a), bk.dev(th_c), bk.dev(goal), bk.dev(seeds), bk.dev(scale)
+    d_pos = [bk.dev(np.zeros((S, N, 2), np.int32)) for _ in range(2)]
+    d_xs = [bk.dev(np.zeros((S, 2 * N), np.float32)) for _ in range(2)]
+    d_ret = bk.dev(np.zeros((S, N), np.float64))
+    rp = {k: bk.dev(np.zeros((S, cap, w * N), np.float32)) for k, w in (("s", 2), ("ns", 2), ("sa", 3), ("a", 1), ("r", 1))}
+    d_probs = bk.dev(np.zeros((S, N, A), np.float32))
+    d_val = bk.dev(np.zeros((S, N), np.float32))
+    d_act = bk.dev(np.zeros((S, N), np.int32))
+    L.rcmarl_env_reset(None, bk.ptr(d_seeds), nrow, ncol, bk.ptr(d_scale), episode, bk.ptr(d_pos[0]), bk.ptr(d_xs[0]),
+                       bk.ptr(d_ret), S, N, bk.stream)
+    envs = []
+    for s in range(S):
+        env = O.GridWorldOracle(nrow, ncol, N, goal[s], None, True, True, rng_mode="device", seed=int(seeds[s]))
+        env.reset(episode=episode)
+        envs.append(env)
+    np.testing.assert_array_equal(bk.host(d_pos[0]), np.stack([e.state for e in envs]))
+    L.rcmarl_value_rows(bk.ptr(d_xs[0]), bk.ptr(d_thc), bk.ptr(d_val), S, N, in_a, HID, ldpc, bk.stream)
+    val = bk.host(d_val)
+    for s in range(S):
+        st, _ = envs[s].get_data()
+        np.testing.assert_array_equal(bk.host(d_xs[0])[s], st.astype(np.float32).ravel())
+        for i in range(N):
+            want = M.forward(critics[s][i], st.astype(np.float32).reshape(1, -1))[0, 0]
+            assert abs(val[s, i] - want) <= 3e-6 * max(1.0, abs(want))
+    want_ret = np.zeros((S, N))
+    cur = 0
+    n_flip = 0
+    for j in range(steps):
+        L.rcmarl_policy_probs(bk.ptr(d_xs[cur]), bk.ptr(d_tha), bk.ptr(d_probs), S, N, in_a, HID, A, ldpa, bk.stream)
+        probs = bk.host(d_probs)
+        oracle_act = np.zeros((S, N), np.int64)
+        for s in range(S):
+            st, _ = envs[s].get_data()
+            op = np.stack([M.softmax(M.forward(actors[s][i], st.astype(np.float32).reshape(1, -1)))[0] for i in range(N)])
+            rel_close(probs[s], op, 3e-6, "policy probs")
+            oracle_act[s] = PX.sample_actions(op, int(seeds[s]), episode, j, mu)
+        if mode == "device":
+            L.rcmarl_rollout_step(bk.ptr(d_xs[cur]), bk.ptr(d_pos[cur]), bk.ptr(d_goal), bk.ptr(d_tha), bk.ptr(d_seeds),
+                                  nrow, ncol, bk.ptr(d_scale), bk.ptr(rp["s"]), bk.ptr(rp["ns"]), bk.ptr(rp["sa"]),
+                                  bk.ptr(rp["a"]), bk.ptr(rp["r"]), cap, j, bk.ptr(d_pos[1 - cur]), bk.ptr(d_xs[1 - cur]),
+                                  bk.ptr(d_ret), float(gamma ** j), episode, j, mu, S, N, HID, A, ldpa, bk.ptr(d_act),
+                                  bk.stream)
+            act = bk.host(d_act).astype(np.int64)
+            n_flip += int((act != oracle_act).sum())     # only possible through last-ulp cdf differences
+        else:
+            act = oracle_act
+            d_a = bk.dev(act.astype(np.int32))
+            L.rcmarl_env_apply(bk.ptr(d_pos[cur]), bk.ptr(d_goal), bk.ptr(d_a), nrow, ncol, bk.ptr(d_scale), bk.ptr(rp["s"]),
+                               bk.ptr(rp["ns"]), bk.ptr(rp["sa"]), bk.ptr(rp["a"]), bk.ptr(rp["r"]), cap, j,
+                               bk.ptr(d_pos[1 - cur]), bk.ptr(d_xs[1 - cur]), bk.ptr(d_ret), float(gamma ** j), S, N,
+                               bk.stream)
+        cur = 1 - cur
+        H = {k: bk.host(v) for k, v in rp.items()}
+        for s in range(S):
+            st, _ = envs[s].get_data()
+            envs[s].step(act[s].astype(np.float64))
+            nst, rew = envs[s].get_data()
+            want_ret[s] += rew * (gamma ** j)
+            np.testing.assert_array_equal(bk.host(d_pos[cur])[s], envs[s].state)
+            np.testing.assert_array_equal(H["s"][s, j], st.astype(np.float32).ravel())
+            np.testing.assert_array_equal(H["ns"][s, j], nst.astype(np.float32).ravel())
+            np.testing.assert_array_equal(H["a"][s, j], act[s].astype(np.float32))
+            np.testing.assert_array_equal(H["r"][s, j], rew.astype(np.float32))
+            np.testing.assert_array_equal(H["sa"][s, j], np.concatenate([st.astype(np.float32), act[s].astype(np.float32)[:, None]], axis=1).ravel())
+    np.testing.assert_array_equal(bk.host(d_ret), want_ret)      # float64, same operation order
+    assert n_flip == 0, "%d sampled actions differ from the oracle's Philox stream" % n_flip

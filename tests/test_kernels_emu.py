@@ -62,3 +62,8 @@ def test_actor_step(bk, S, N, B, in_dim):
 
 def test_reward_helpers(bk):
     KC.check_reward_helpers(bk, 2, 5, 300)
+
+
+@pytest.mark.parametrize("S,N,nrow,ncol,mode", [(2, 5, 5, 5, "device"), (1, 70, 16, 16, "device"), (2, 5, 5, 5, "host")])
+def test_rollout(bk, S, N, nrow, ncol, mode):
+    KC.check_rollout(bk, S, N, nrow, ncol, steps=5, mode=mode)
