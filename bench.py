@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""bench.py -- RPBCAC training throughput on MI355X (driver contract).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one training block of the reference loop (training/train_agents.py:
+46-163): n_ep_fixed=50 episodes x max_ep_len=20 environment steps of rollout for
+every seed and agent, followed by the full update block (10 epochs of local
+fits + resilient consensus, the actor step, the replay trim).  Nothing is
+skipped inside the timed region.  Data: synthetic (random goals, Glorot-init
+networks, on-device grid-world); arithmetic fp32 like the reference.
+
+Prints ONE JSON line (rank 0): metric = agent-steps/s (whole loop), plus
+consensus-updates/s, the per-kernel breakdown, `roofline` for the dominant
+kernel, `roofline_consensus` for the consensus kernel and `cpu_baseline`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3      # MI355X dense fp32 (vector == fp32-input MFMA), MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0         # spec; ~6290 GB/s measured copy ceiling
+
+WORKLOADS = {
+    # BASELINE.json configs[3] sharded over the node: 128 seeds / 8 GPUs = 16 seeds per GPU (weak scaling)
+    "cfg4_shard": dict(N=256, nrow=32, ncol=32, H=8, d=18, S=16, graph="circulant",
+                       desc="BASELINE configs[3] per-GPU shard: 256 agents, 32x32 grid, H=8, circulant in-degree d=18 "
+                            "(=2H+2), 16 independent seeds per GPU, all cooperative"),
+    # the configuration the north-star targets are quoted on
+    "target_N256_H1": dict(N=256, nrow=5, ncol=5, H=1, d=4, S=16, graph="circulant",
+                           desc="north_star target: 256 agents, 5x5 grid, H=1, circulant d=4, 16 seeds per GPU"),
+    "cfg3": dict(N=64, nrow=16, ncol=16, H=4, d=10, S=32, graph="regular",
+                 desc="BASELINE configs[2]: 64 agents, 16x16 grid, random 9-regular in-graph + self (d=10), H=4, 32 seeds per GPU"),
+    "cfg1_batched": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=512, graph="circulant",
+                         desc="5 cooperative agents, 5x5 grid, H=1, 512 seeds per GPU"),
+}
+
+
+def build_graph(kind, N, d, seed=0):
+    if kind == "circulant":
+        return [[(i + k) % N for k in range(d)] for i in range(N)]
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(N):
+        others = [j for j in range(N) if j != i]
+        out.append([i] + [int(x) for x in rng.permutation(others)[:d - 1]])
+    return out
+
+
+def make_engine(w, S, seeds, lib):
+    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+    N = w["N"]
+    cfg = EngineConfig(N, ["Cooperative"] * N, build_graph(w["graph"], N, w["d"]), H=w["H"], gamma=0.9, slow_lr=0.002,
+                       fast_lr=0.01, max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000, nrow=w["nrow"],
+                       ncol=w["ncol"], n_seeds=S, rng_mode="device")
+    eng = RPBCACEngine(cfg, seeds=seeds, device="cuda", lib=lib)
+    eng.init_glorot(base_seed=1)
+    goals = np.stack([np.random.RandomState(int(s)).randint(0, 5, size=(N, 2)) for s in seeds])   # main.py:48 draws goals in [0,5)
+    eng.set_goals(goals)
+    return eng
+
+
+# --------------------------------------------------------------------------------------------
+def cpu_baseline(w, budget_s=25.0):
+    """The reference's loop structure (per agent -> per neighbour -> per layer; oracle/
+    rpbcac_oracle.py) timed on this host on a bounded sample of the same workload and
+    extrapolated linearly to one training block of one seed."""
+    from oracle import rpbcac_oracle as O
+    from oracle import mlp_np as M
+    N, d, H = w["N"], w["d"], w["H"]
+    B, n_last, n_epochs, steps_per_block = 3000, 1000, 10, 1000
+    rng = np.random.default_rng(0)
+    in_nodes = build_graph(w["graph"], N, d)
+    agents = [O.CoopAgent(M.init_mlp(rng, 2 * N, 20, 5), M.init_mlp(rng, 2 * N, 20, 1), M.init_mlp(rng, 3 * N, 20, 1),
+                          0.002, 0.01, 0.9, H) for _ in range(N)]
+    goals = rng.integers(0, 5, size=(N, 2))
+    env = O.GridWorldOracle(w["nrow"], w["ncol"], N, goals, None, True, True, rng_mode="device", seed=1)
+    # (a) rollout: per-agent batch-of-one policy forward + numpy RNG draws + python env step
+    env.reset(episode=0)
+    state, _ = env.get_data()
+    n_steps = 3
+    t0 = time.perf_counter()
+    for j in range(n_steps):
+        action = np.zeros(N)
+        for i in range(N):
+            action[i] = agents[i].act_numpy(state[None])
+        env.step(action)
+        state, _ = env.get_data()
+    t_step = (time.perf_counter() - t0) / n_steps
+    # (b) phases I-III on a sample of agents
+    s = rng.normal(size=(B, N, 2)).astype(np.float32)
+    ns = rng.normal(size=(B, N, 2)).astype(np.float32)
+    a = rng.integers(0, 5, size=(B, N, 1)).astype(np.float32)
+    r = -rng.integers(0, 9, size=(B, N, 1)).astype(np.float32) / 5
+    sa = np.concatenate([s, a], axis=-1)
+    k = 4 if N >= 64 else min(N, 5)
+    sample = list(range(k))
+    t0 = time.perf_counter()
+    msgs_c, msgs_t = [], []
+    for i in sample:
+        x, _ = agents[i].local_fit_tr(sa, r[:, i])
+        y, _ = agents[i].local_fit_critic(s, ns, r[:, i])
+        msgs_t.append(x)
+        msgs_c.append(y)
+    t_fit = (time.perf_counter() - t0) / k
+    t0 = time.perf_counter()
+    for i in sample:
+        c_in = [msgs_c[j % k] for j in range(d)]
+        t_in = [msgs_t[j % k] for j in range(d)]
+        ag = agents[i]
+        ag.consensus_hidden_critic(c_in)
+        ag.consensus_hidden_tr(t_in)
+        c_agg = ag.consensus_estimates_critic(s, c_in)
+        t_agg = ag.consensus_estimates_tr(sa, t_in)
+        ag.projection_step_critic(s, c_agg)
+        ag.projection_step_tr(sa, t_agg)
+    t_cons = (time.perf_counter() - t0) / k
+    t0 = time.perf_counter()
+    for i in sample:
+        agents[i].actor_step(s[-n_last:], ns[-n_last:], sa[-n_last:], a[-n_last:, i])
+    t_actor = (time.perf_counter() - t0) / k
+    block = steps_per_block * t_step + n_epochs * N * (t_fit + t_cons) + N * t_actor
+    return {
+        "value": N * steps_per_block / block, "unit": "agent-steps/s", "cores": int(torch.get_num_threads()),
+        "host_cpus": os.cpu_count(), "kind": "port",
+        "consensus_updates_per_s": 1.0 / t_cons,
+        "sample": "oracle/rpbcac_oracle.py (reference loop structure, numpy fp32), one seed: %d env steps with all %d agents; "
+                  "local fits, consensus b/c/d and actor step of %d sample agents at B=%d; extrapolated linearly to one "
+                  "block (1000 env steps + 10 epochs x %d agents + actor step)" % (n_steps, N, k, B, N),
+        "seconds": {"env_step_all_agents": t_step, "local_fit_per_agent_epoch": t_fit,
+                    "consensus_per_agent_epoch": t_cons, "actor_per_agent": t_actor, "block_extrapolated": block},
+    }
+
+
+# --------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg4_shard", choices=sorted(WORKLOADS))
+    ap.add_argument("--seeds-per-gpu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from rcmarl_amd import capi
+    from rcmarl_amd.timing import TimedLib
+    from rcmarl_amd.parallel import allreduce_curves
+    w = WORKLOADS[args.workload]
+    S = args.seeds_per_gpu or w["S"]
+    seeds = [1000 + rank * S + k for k in range(S)]                # disjoint seed shards per rank
+    tlib = TimedLib(capi.load())
+    eng = make_engine(w, S, seeds, tlib)
+    N = w["N"]
+    c = eng.cfg
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run_block()
+    barrier()
+    tlib.enabled = not args.no_kernel_timing
+    tlib.reset()
+    curves = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        team, adv, est = eng.run_block()
+        curves.append(np.stack([team.sum(1), adv.sum(1), est.sum(1)], axis=1))   # per-episode sums over local seeds
+    curve = allreduce_curves(np.concatenate(curves, 0), S, device=torch.device("cuda", local_rank))  # C1: RCCL all-reduce
+    barrier()
+    dt = time.perf_counter() - t0
+    tlib.enabled = False
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    B_steady = eng.cap if args.warmup >= 2 else None
+
+    # per-kernel breakdown of the timed region (HIP events on the launch stream)
+    ksum = tlib.summary()
+    # one extra, untimed block with phase synchronisation for the phase split
+    eng.profile_phases = True
+    for k in eng.timers:
+        eng.timers[k] = 0.0
+    eng.run_block()
+    ph = dict(eng.timers)
+    eng.profile_phases = False
+
+    if rank == 0:
+        env_steps = c.n_ep_fixed * c.max_ep_len
+        agent_steps = world * S * N * env_steps * args.steps
+        cons_updates = world * S * eng.n_coop * c.n_epochs * args.steps
+        ph_total = ph["rollout"] + ph["phase1"] + ph["phase2"] + ph["phase3"]
+        out = {
+            "metric": "agent-steps/sec (whole RPBCAC training loop; + consensus-updates/sec)",
+            "value": agent_steps / dt, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
+                       "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady,
+                       "env_steps_per_block": env_steps, "n_epochs": c.n_epochs, "hidden": 20,
+                       "parallelism": "seed-sharded, %d seeds/GPU x %d GPU, one all-reduce of return curves" % (S, world)},
+            "consensus_updates_per_s": cons_updates / dt,
+            "consensus_updates_per_s_phase2_only": (S * eng.n_coop * c.n_epochs) / ph["phase2"] if ph["phase2"] > 0 else None,
+            "phase_seconds_per_block": {k: ph[k] for k in ("rollout", "phase1", "phase2", "phase3")},
+            "phase_fraction": {k: ph[k] / ph_total for k in ("rollout", "phase1", "phase2", "phase3")} if ph_total > 0 else None,
+            "mean_team_return_last_block": float(curve[-c.n_ep_fixed:, 0].mean()),
+        }
+        if ksum:
+            tot_ms = sum(v[1] for v in ksum.values())
+            out["kernels"] = {k.replace("rcmarl_", ""): {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[2], 2),
+                                                        "frac": round(v[1] / tot_ms, 4)} for k, v in
+                              sorted(ksum.items(), key=lambda kv: -kv[1][1])}
+            out["roofline"], out["roofline_consensus"] = rooflines(tlib, ksum)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(w)
+                out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:                                     # the baseline must never kill the bench line
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rooflines(tlib, ksum):
+    """roofline objects for the time-dominant kernel and for the consensus kernel (K1)."""
+    work = tlib.work
+    dom = max(ksum.items(), key=lambda kv: kv[1][1])[0]
+
+    def obj(name):
+        n, tot_ms, avg_us = ksum[name]
+        flops, byts = work.get(name, (0.0, 0.0))
+        if name == "rcmarl_consensus_params":
+            ach = byts / (tot_ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": n, "avg_us": avg_us,
+                    "algorithmic_bytes_per_launch": byts / n,
+                    "note": "compulsory bytes 8*P_hid per (seed, agent) (SURVEY 8d); VALU-bound selection network at d=18 (128 min/max per element)"}
+        ach = flops / (tot_ms * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP32_PEAK_TFLOPS, "traffic": None, "launches": n, "avg_us": avg_us,
+                "algorithmic_flops_per_launch": flops / n,
+                "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
+    return obj(dom), (obj("rcmarl_consensus_params") if "rcmarl_consensus_params" in ksum else None)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/* rcmarl.h -- C-ABI of the MI355X-native RPBCAC hot path (librcmarl_hip.so).
+ *
+ * The reference (mfigura/Resilient-consensus-based-MARL) has NO native/FFI
+ * boundary: its hot path is Python calling TensorFlow/Keras.  This header is
+ * the boundary a maintainer would bind instead (ctypes stub in
+ * INTEGRATION.md; rcmarl_amd/capi.py is that binding).  Each entry point
+ * names the reference code it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no framework types.  All pointers are DEVICE
+ *     pointers unless stated; `stream` is a hipStream_t (NULL = default).
+ *   - every function only enqueues work on `stream`: no allocation, no
+ *     synchronisation.  Returns 0 or an RCMARL_ERR_* code; never throws.
+ *   - parameter matrices theta[S][N][ldp] (fp32): one row per (seed, agent),
+ *     row = [W1(in x hid) | b1 | W2(hid x hid) | b2 | W3(hid x out) | b3 | pad]
+ *     in Keras order (main.py:59-82), ldp % 64 == 0.
+ *   - replay tensors X[S][rows][width] fp32 row-major; `x` may point at a row
+ *     window, `x_seed_stride` (elements) is the distance between seeds.
+ *   - feature-major activations a1t[S][N*hid][ldb], ldb % 64 == 0, ldb >= B.
+ *   - agent-major per-sample vectors y[S][N][ldb].
+ *   - S seeds, N agents, B replay rows, d in-neighbourhood size incl. self,
+ *     H trim parameter, hid hidden width (compiled: 20), out = 1 or n_actions.
+ */
+#ifndef RCMARL_H
+#define RCMARL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCMARL_OK 0
+#define RCMARL_ERR_ARG 1          /* bad argument (null pointer, misaligned ld, d < 2H+1, ...) */
+#define RCMARL_ERR_LAUNCH 2       /* hipGetLastError() != hipSuccess after the launch */
+#define RCMARL_ERR_UNSUPPORTED 3  /* shape outside the compiled kernels (hid != 20, n_actions != 5, ...) */
+
+int rcmarl_abi_version(void);
+int rcmarl_fit_partial_size(int hid);                  /* floats per partial record of rcmarl_mid_fit */
+int rcmarl_actor_partial_size(int hid, int n_actions); /* floats per partial record of rcmarl_mid_actor */
+int rcmarl_rows_per_chunk(void);                       /* replay rows per workgroup (256); nchunk = ceil(B/256) */
+
+/* K1: resilient consensus over hidden-layer parameters.
+ * Replaces RPBCAC_agent.resilient_consensus_critic_hidden/_TR_hidden
+ * (agents/resilient_CAC_agents.py:142-166) + _resilient_aggregation (:42-58) for ALL
+ * cooperative agents of all seeds (loop at training/train_agents.py:125-135).
+ * theta[s][i][p] <- mean_k clamp(msg[s][nbr[i][k]][p], lower, upper), p < P_hid, coop[i] != 0.
+ * nbr: int[N][d] with nbr[i][0] == i; coop: uint8[N].  lo_dbg/hi_dbg (both or neither,
+ * [S][N][ldp]) receive the clip window for bit-exact tests. */
+int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const unsigned char* coop, int S, int N,
+                            int ldp, int P_hid, int d, int H, float* lo_dbg, float* hi_dbg, void* stream);
+
+/* K4 layer 1 forward (shared input => one GEMM per seed), Keras Dense + LeakyReLU(0.1):
+ * a1t[s][n*hid+j][b] = lrelu(sum_k x[s][b][k]*W1[s][n][k][j] + b1[s][n][j]).
+ * Replaces the first Dense of every model call at agents/resilient_CAC_agents.py:66,79,95-97,114,181,201. */
+int rcmarl_layer1_forward(const float* x, long x_seed_stride, const float* theta, float* a1t, int S, int N, int B,
+                          int in_dim, int hid, int ldp, int ldb, void* stream);
+
+/* K5 layer 1 backward + optimizer: W1[s][n][k][j] -= lr * sum_b x[s][b][k]*dz1t[s][n*hid+j][b]
+ * (inside critic.fit / TR.fit, agents/resilient_CAC_agents.py:118,136); mask: uint8[N] or NULL. */
+int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride, const float* dz1t, float* theta,
+                               const unsigned char* mask, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                               float lr, void* stream);
+/* same with the Adam rule of actor.train_on_batch (agents/resilient_CAC_agents.py:38,99):
+ * m += (g-m)(1-b1); v += (g*g-v)(1-b2); w -= alpha*m/(sqrt(v)+eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t). */
+int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride, const float* dz1t, float* theta, float* adam_m,
+                                float* adam_v, const unsigned char* mask, int S, int N, int B, int in_dim, int hid,
+                                int ldp, int ldb, float alpha, float one_m_b1, float one_m_b2, float eps, void* stream);
+
+/* K4/K5 layers 2-3 of one full-batch SGD step of critic.fit / TR.fit with MSE loss
+ * (agents/resilient_CAC_agents.py:116-118,134-136): forward, loss vs y[s][n][b], backward.
+ * a1t is overwritten IN PLACE by dz1 (feature-major); per-chunk partial gradients go to
+ * partials[S][N][nchunk][rcmarl_fit_partial_size(hid)] = [gW2|gb2|gW3|gb3|gb1|sum (v-y)^2]. */
+int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B, int in_dim,
+                   int hid, int ldp, int ldb, void* stream);
+/* reduce the partials over chunks and apply SGD to b1,W2,b2,W3,b3; loss_out[S][N] (or NULL) = MSE. */
+int rcmarl_small_sgd(const float* partials, float* theta, const unsigned char* mask, float* loss_out, int S, int N,
+                     int B, int in_dim, int hid, int ldp, float lr, void* stream);
+
+/* K6: out[s][n][b] = head(a1t) (r_applied NULL), or the TD target r_applied + gamma*V
+ * (local_TD_target, agents/resilient_CAC_agents.py:114-115).  Also serves r_team, V, nV of :95-97. */
+int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma, float* out, int S,
+                     int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+
+/* K2+K3: consensus over estimates + projection residual.
+ * Replaces resilient_consensus_critic/_TR (agents/resilient_CAC_agents.py:168-206) and the
+ * gradient of critic_update_team/TR_update_team (:60-84) for all cooperative agents:
+ *   phi = features_{theta_i}(x); V_k = phi . W3(msg[nbr[i][k]]) + b3(msg[...]); agg = aggregate_H(V)
+ *   e = (agg - V_{theta_i}) / (|phi|^2 + 1); partials[S][N][nchunk][hid+1] = [sum_b e*phi | sum_b e].
+ * a1t must hold layer-1 activations of theta (the freshly aggregated hidden layers).
+ * agg_out[S][N][ldb] optional (tests). */
+int rcmarl_consensus_head(const float* a1t, const float* theta, const float* msg, const int* nbr,
+                          const unsigned char* coop, float* partials, float* agg_out, int S, int N, int B, int in_dim,
+                          int hid, int ldp, int ldb, int d, int H, void* stream);
+/* W3 += sum/B, b3 += sum/B: the normalised projection step (fast_lr cancels, :67-71). */
+int rcmarl_head_apply(const float* partials, float* theta, const unsigned char* coop, int S, int N, int B, int in_dim,
+                      int hid, int ldp, void* stream);
+
+/* K7 actor: softmax + sample-weighted sparse CE forward/backward through layers 3-2
+ * (actor.train_on_batch(s, a_local, sample_weight=TD), agents/resilient_CAC_agents.py:99).
+ * act_t, delta: [S][N][ldb] labels (as floats) and sample weights; a1t overwritten by dz1. */
+int rcmarl_mid_actor(float* a1t, const float* theta, const float* act_t, const float* delta, float* partials, int S,
+                     int N, int B, int in_dim, int hid, int n_actions, int ldp, int ldb, void* stream);
+int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v, const unsigned char* mask,
+                      float* loss_out, int S, int N, int B, int in_dim, int hid, int n_actions, int ldp, float alpha,
+                      float one_m_b1, float one_m_b2, float eps, void* stream);
+
+/* r_coop[s][b] = sum_{coop n, index order} r[s][b][n]/n_coop   (training/train_agents.py:96-98) */
+int rcmarl_team_reward(const float* r, long seed_stride, const unsigned char* coop, int n_coop, float* rcoop, int S,
+                       int N, int B, int ldb, void* stream);
+/* out[s][n][b] = src[s][b][n] (mode NULL or mode[n]==0), rcoop[s][b] (1), -rcoop[s][b] (2):
+ * the r_applied selection of training/train_agents.py:106-116 and the a[:,node] slices of :151-153 */
+int rcmarl_gather_agent_major(const float* src, long seed_stride, const float* rcoop, const int* mode, float* out,
+                              int S, int N, int B, int ldb, void* stream);
+/* delta = r_team + gamma*nV - V   (global_TD_error, agents/resilient_CAC_agents.py:98) */
+int rcmarl_td_error(const float* r_team, const float* v_next, const float* v_cur, float gamma, float* delta,
+                    long n_total, void* stream);
+
+/* Rollout.  xs[S][2N]: scaled global state vector; pos/goal: int[S][N][2]; scale: DEVICE double[4] =
+ * {mean_x, mean_y, std_x, std_y} (environments/grid_world.py:29-33); seeds: DEVICE uint64[S].
+ * probs[s][n][:] = actor_n(xs[s])                    (actor.predict, agents/resilient_CAC_agents.py:215) */
+int rcmarl_policy_probs(const float* xs, const float* theta, float* probs, int S, int N, int in_dim, int hid,
+                        int n_actions, int ldp, void* stream);
+/* out[s][n] = critic_n(xs[s])                        (training/train_agents.py:60-62) */
+int rcmarl_value_rows(const float* xs, const float* theta, float* out, int S, int N, int in_dim, int hid, int ldp,
+                      void* stream);
+/* fused environment step with the on-device Philox stream (rng_mode 'device'): actor forward,
+ * get_action's three draws (agents/resilient_CAC_agents.py:208-219), Grid_World.step
+ * (environments/grid_world.py:47-64), replay append and discounted-return accumulation
+ * (training/train_agents.py:69-80).  Writes row `row` of the five replay tensors [S][cap][.]. */
+int rcmarl_rollout_step(const float* xs, const int* pos, const int* goal, const float* theta,
+                        const unsigned long long* seeds, int nrow, int ncol, const double* scale, float* rp_s,
+                        float* rp_ns, float* rp_sa, float* rp_a, float* rp_r, long cap, long row, int* pos_next,
+                        float* xs_next, double* ret, double gpow, int episode, int step, float mu, int S, int N,
+                        int hid, int n_actions, int ldp, int* act_out, void* stream);
+/* same transition for host-sampled actions int[S][N] (rng_mode 'numpy': NumPy legacy stream parity) */
+int rcmarl_env_apply(const int* pos, const int* goal, const int* actions, int nrow, int ncol, const double* scale,
+                     float* rp_s, float* rp_ns, float* rp_sa, float* rp_a, float* rp_r, long cap, long row,
+                     int* pos_next, float* xs_next, double* ret, double gpow, int S, int N, void* stream);
+/* Grid_World.reset (environments/grid_world.py:37-45): positions from pos_in (int[S][N][2]) or, if NULL,
+ * from the Philox stream; also zeroes the per-episode return accumulator ret[S][N] (double). */
+int rcmarl_env_reset(const int* pos_in, const unsigned long long* seeds, int nrow, int ncol, const double* scale,
+                     int episode, int* pos, float* xs, double* ret, int S, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCMARL_H */

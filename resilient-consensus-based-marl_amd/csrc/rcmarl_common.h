@@ -62,9 +62,21 @@ __device__ __forceinline__ float rc_lrelu(float z) { return z > 0.f ? z : RC_LEA
 __device__ __forceinline__ float rc_lrelu_grad_from_act(float a) { return a > 0.f ? 1.f : RC_LEAK; }
 
 __device__ __forceinline__ float rc_wave_sum(float v) {
+#ifdef RCMARL_EMU
+  // same xor-butterfly association order, evaluated locally after ONE lane exchange
+  // (keeps the CPU emulation of shuffle-heavy kernels fast)
+  float all[64], nxt[64];
+  __hipemu_gather64(v, all);
+  for (int m = 32; m >= 1; m >>= 1) {
+    for (int l = 0; l < 64; ++l) nxt[l] = all[l] + all[l ^ m];
+    for (int l = 0; l < 64; ++l) all[l] = nxt[l];
+  }
+  return all[hipemu::lane()];
+#else
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
+#endif
 }
 
 static inline int rc_ceil_div(int a, int b) { return (a + b - 1) / b; }

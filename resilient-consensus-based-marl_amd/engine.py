@@ -1,0 +1,491 @@
+"""Batched RPBCAC training engine (host side).
+
+One engine instance = S independent seeds x N agents resident on ONE GPU.  It
+replaces the body of the reference's ``train_RPBCAC`` (training/train_agents.py:
+15-184): the rollout loop (:46-80), the update block (:86-163: I local fits,
+II resilient consensus, III actor step, IV replay trim) and the episode
+summaries (:168-180) -- with every per-agent Python/Keras loop turned into a
+batched HIP kernel launch through the C-ABI of include/rcmarl.h.
+
+PyTorch is used for device memory, copies and streams only; all arithmetic of
+the hot path runs in csrc/*.hip.  There is no CPU fallback: the constructor
+raises if the HIP library or a GPU is missing (tests inject the hipemu build
+explicitly via ``lib=``/``device='cpu'``).
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import capi
+
+HID = 20
+COOP, FAULTY, GREEDY, MALICIOUS = "Cooperative", "Faulty", "Greedy", "Malicious"
+
+
+def pad64(n):
+    return (int(n) + 63) // 64 * 64
+
+
+def net_numel(in_dim, out_dim, hid=HID):
+    return in_dim * hid + hid + hid * hid + hid + hid * out_dim + out_dim
+
+
+def net_shapes(in_dim, out_dim, hid=HID):
+    return [(in_dim, hid), (hid,), (hid, hid), (hid,), (hid, out_dim), (out_dim,)]
+
+
+def flatten_params(params):
+    return np.concatenate([np.asarray(p, dtype=np.float32).ravel() for p in params])
+
+
+def unflatten_params(vec, in_dim, out_dim, hid=HID):
+    out, o = [], 0
+    for sh in net_shapes(in_dim, out_dim, hid):
+        n = int(np.prod(sh))
+        out.append(np.array(vec[o:o + n], dtype=np.float32).reshape(sh))
+        o += n
+    return out
+
+
+class EngineConfig:
+    """Same keys as the reference's ``args`` dict (main.py:26-44) plus the
+    grid size, seed count and RNG mode."""
+
+    def __init__(self, n_agents, agent_label, in_nodes, H=0, gamma=0.9, slow_lr=0.002, fast_lr=0.01, n_actions=5,
+                 n_states=2, max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000, common_reward=False,
+                 nrow=5, ncol=5, n_seeds=1, rng_mode="device", mu=0.1, scaling=True, randomize_state=True,
+                 local_fit_steps=5):
+        self.n_agents, self.agent_label = int(n_agents), list(agent_label)
+        self.in_nodes = [list(map(int, row)) for row in in_nodes]
+        self.H, self.gamma, self.slow_lr, self.fast_lr = int(H), float(gamma), float(slow_lr), float(fast_lr)
+        self.n_actions, self.n_states = int(n_actions), int(n_states)
+        self.max_ep_len, self.n_ep_fixed, self.n_epochs = int(max_ep_len), int(n_ep_fixed), int(n_epochs)
+        self.buffer_size, self.common_reward = int(buffer_size), bool(common_reward)
+        self.nrow, self.ncol, self.n_seeds = int(nrow), int(ncol), int(n_seeds)
+        self.rng_mode, self.mu, self.scaling, self.randomize_state = rng_mode, float(mu), bool(scaling), bool(randomize_state)
+        self.local_fit_steps = int(local_fit_steps)
+        assert len(self.agent_label) == self.n_agents and len(self.in_nodes) == self.n_agents
+        d = len(self.in_nodes[0])
+        for i, row in enumerate(self.in_nodes):
+            if len(row) != d:
+                raise ValueError("all in-neighbourhoods must have the same size d (got %d and %d)" % (d, len(row)))
+            if row[0] != i:
+                raise ValueError("in_nodes[i][0] must be i (own value first, agents/resilient_CAC_agents.py:49)")
+        if d < 2 * self.H + 1:
+            raise ValueError("need d >= 2H+1")
+        if self.n_states != 2 or self.n_actions != 5:
+            raise ValueError("the grid-world has 2 state dims and 5 actions per agent")
+        if rng_mode not in ("device", "numpy"):
+            raise ValueError("rng_mode must be 'device' or 'numpy'")
+        for lab in self.agent_label:
+            if lab not in (COOP, FAULTY, GREEDY, MALICIOUS):
+                raise ValueError("unknown agent label %r" % lab)
+
+    @property
+    def d(self):
+        return len(self.in_nodes[0])
+
+
+class RPBCACEngine:
+    def __init__(self, cfg, seeds=None, device="cuda", lib=None):
+        self.cfg = cfg
+        if lib is None:
+            lib = capi.load()                      # raises if librcmarl_hip.so is missing
+            if device == "cuda" and not torch.cuda.is_available():
+                raise capi.RcmarlError("rcmarl_amd needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.lib = lib
+        self.dev = torch.device(device)
+        c = cfg
+        S, N = c.n_seeds, c.n_agents
+        self.S, self.N = S, N
+        self.in_c, self.in_r = N * c.n_states, N * (c.n_states + 1)
+        self.P = {"actor": net_numel(self.in_c, c.n_actions), "critic": net_numel(self.in_c, 1), "tr": net_numel(self.in_r, 1)}
+        self.in_dim = {"actor": self.in_c, "critic": self.in_c, "tr": self.in_r}
+        self.out_dim = {"actor": c.n_actions, "critic": 1, "tr": 1}
+        self.ldp = {k: pad64(v) for k, v in self.P.items()}
+        self.n_last = c.max_ep_len * c.n_ep_fixed
+        self.cap = c.buffer_size + self.n_last
+        self.ldb = pad64(self.cap)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.theta = {k: torch.zeros(S, N, self.ldp[k], **f32) for k in ("actor", "critic", "tr")}
+        self.msg = {k: torch.zeros(S, N, self.ldp[k], **f32) for k in ("critic", "tr")}
+        self.adam_m = torch.zeros(S, N, self.ldp["actor"], **f32)
+        self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
+        self.adam_t = 0
+        self.a1t = torch.zeros(S, N * HID, self.ldb, **f32)
+        self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
+        self.rcoop = torch.zeros(S, self.ldb, **f32)
+        nchunk_max = (self.cap + 255) // 256
+        psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
+        self.partials = torch.zeros(S * N * nchunk_max * psz, **f32)
+        self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
+        # replay buffers [S][cap][w*N]
+        self.rp = {k: torch.zeros(S, self.cap, w * N, **f32) for k, w in (("s", 2), ("ns", 2), ("sa", 3), ("a", 1), ("r", 1))}
+        self.B = 0
+        # environment
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.pos = [torch.zeros(S, N, 2, **i32) for _ in range(2)]
+        self.xs = [torch.zeros(S, 2 * N, **f32) for _ in range(2)]
+        self.cur = 0
+        self.goal = torch.zeros(S, N, 2, **i32)
+        self.ret = torch.zeros(S, N, dtype=torch.float64, device=self.dev)
+        self.ret_hist = torch.zeros(c.n_ep_fixed, S, N, dtype=torch.float64, device=self.dev)
+        self.est = torch.zeros(S, N, **f32)
+        self.est_hist = torch.zeros(c.n_ep_fixed, S, N, **f32)
+        self.probs = torch.zeros(S, N, c.n_actions, **f32)
+        self.act_i32 = torch.zeros(S, N, **i32)
+        if c.scaling:
+            xr, yr = np.arange(c.nrow), np.arange(c.ncol)
+            scale = [np.mean(xr), np.mean(yr), np.std(xr), np.std(yr)]     # environments/grid_world.py:29-33
+        else:
+            scale = [0.0, 0.0, 1.0, 1.0]
+        self.scale = torch.tensor(scale, dtype=torch.float64, device=self.dev)
+        seeds = list(range(S)) if seeds is None else [int(x) for x in seeds]
+        assert len(seeds) == S
+        self.seeds = seeds
+        self.seeds_dev = torch.tensor(np.asarray(seeds, dtype=np.uint64).view(np.int64), dtype=torch.int64, device=self.dev)
+        # graph / roles
+        self.nbr = torch.tensor(np.asarray(c.in_nodes, dtype=np.int32), **i32)
+        coop = np.array([1 if l == COOP else 0 for l in c.agent_label], dtype=np.uint8)
+        self.coop_np = coop
+        self.n_coop = int(coop.sum())
+        self.coop = torch.tensor(coop, dtype=torch.uint8, device=self.dev)
+        mode = np.array([(1 if c.common_reward else 0) if l == COOP else 0 for l in c.agent_label], dtype=np.int32)
+        self.fit_mode = torch.tensor(mode, **i32)
+        self.episode = 0                      # global episode counter
+        self.timers = {"rollout": 0.0, "phase1": 0.0, "phase2": 0.0, "phase3": 0.0, "blocks": 0}
+        self.gpow = [float(c.gamma ** j) for j in range(c.max_ep_len)]
+        self.initial_state = None             # used when randomize_state is False
+        self.np_rngs = None                   # rng_mode='numpy': one RandomState-like object per seed
+
+    # ---- plumbing -------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream if self.dev.type == "cuda" else None
+
+    def sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    @staticmethod
+    def _p(t, offset_elems=0):
+        return None if t is None else t.data_ptr() + 4 * int(offset_elems)
+
+    def set_weights(self, seed_idx, agent, net, params):
+        vec = flatten_params(params)
+        assert vec.size == self.P[net], (net, vec.size, self.P[net])
+        self.theta[net][seed_idx, agent, :vec.size] = torch.from_numpy(vec).to(self.dev)
+
+    def get_weights(self, seed_idx, agent, net):
+        vec = self.theta[net][seed_idx, agent, :self.P[net]].detach().cpu().numpy()
+        return unflatten_params(vec, self.in_dim[net], self.out_dim[net])
+
+    def set_all_weights(self, net, array):
+        """array: [S][N][P] fp32."""
+        arr = np.asarray(array, dtype=np.float32)
+        assert arr.shape == (self.S, self.N, self.P[net])
+        self.theta[net][:, :, :self.P[net]] = torch.from_numpy(arr).to(self.dev)
+
+    def get_all_weights(self, net):
+        return self.theta[net][:, :, :self.P[net]].detach().cpu().numpy()
+
+    def init_glorot(self, base_seed=0):
+        """Keras-default initialisation (Glorot-uniform kernels, zero biases; reference
+        main.py:59-82) drawn from a NumPy generator per seed (TensorFlow's own init
+        stream is not reproducible outside TensorFlow -- SURVEY.md section 7)."""
+        for net in ("actor", "critic", "tr"):
+            arr = np.zeros((self.S, self.N, self.P[net]), np.float32)
+            for s in range(self.S):
+                rng = np.random.default_rng([int(base_seed), int(self.seeds[s]) & 0x7FFFFFFF, {"actor": 0, "critic": 1, "tr": 2}[net]])
+                for n in range(self.N):
+                    o = 0
+                    for sh in net_shapes(self.in_dim[net], self.out_dim[net]):
+                        cnt = int(np.prod(sh))
+                        if len(sh) == 2:
+                            lim = math.sqrt(6.0 / (sh[0] + sh[1]))
+                            arr[s, n, o:o + cnt] = rng.uniform(-lim, lim, size=cnt).astype(np.float32)
+                        o += cnt
+            self.set_all_weights(net, arr)
+
+    def set_goals(self, desired):
+        """desired: [S][N][2] (or [N][2], broadcast over seeds) integer goal cells."""
+        d = np.asarray(desired, dtype=np.int32)
+        if d.ndim == 2:
+            d = np.broadcast_to(d, (self.S, self.N, 2))
+        self.goal.copy_(torch.from_numpy(np.ascontiguousarray(d)).to(self.dev))
+
+    def load_replay(self, states, nstates, actions, rewards, seed_idx=0):
+        """exp_buffer of the reference API (train_agents.py:36-40): lists of per-step arrays."""
+        B = len(states)
+        assert B <= self.cap
+        if B == 0:
+            return
+        s = np.asarray(states, np.float32).reshape(B, -1)
+        ns = np.asarray(nstates, np.float32).reshape(B, -1)
+        a = np.asarray(actions, np.float32).reshape(B, -1)
+        r = np.asarray(rewards, np.float32).reshape(B, -1)
+        sa = np.concatenate([s.reshape(B, self.N, 2), a.reshape(B, self.N, 1)], axis=-1).reshape(B, -1)
+        for k, v in (("s", s), ("ns", ns), ("a", a), ("r", r), ("sa", sa)):
+            self.rp[k][seed_idx, :B] = torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
+        self.B = B
+
+    def dump_replay(self, seed_idx=0):
+        B = self.B
+        g = lambda k: self.rp[k][seed_idx, :B].detach().cpu().numpy()
+        s, ns, a, r = g("s"), g("ns"), g("a"), g("r")
+        N = self.N
+        return ([s[b].reshape(N, 2).astype(np.float64) for b in range(B)], [ns[b].reshape(N, 2).astype(np.float64) for b in range(B)],
+                [a[b].reshape(N, 1).astype(np.float64) for b in range(B)], [r[b].reshape(N, 1).astype(np.float64) for b in range(B)])
+
+    # ---- rollout (train_agents.py:46-80) ---------------------------------------------------
+    def _reset(self, host_positions=None):
+        c, L = self.cfg, self.lib
+        pin = None
+        if host_positions is not None:
+            pin = torch.from_numpy(np.ascontiguousarray(np.asarray(host_positions, dtype=np.int32))).to(self.dev)
+        L.rcmarl_env_reset(self._p(pin), self.seeds_dev.data_ptr(), c.nrow, c.ncol, self.scale.data_ptr(), self.episode,
+                           self.pos[self.cur].data_ptr(), self.xs[self.cur].data_ptr(), self.ret.data_ptr(), self.S,
+                           self.N, self.stream)
+
+    def _replay_ptrs(self):
+        return [self.rp[k].data_ptr() for k in ("s", "ns", "sa", "a", "r")]
+
+    def rollout_episode(self, ep_in_block):
+        """One episode for all seeds; appends max_ep_len rows to the replay buffers."""
+        c, L, S, N = self.cfg, self.lib, self.S, self.N
+        if c.rng_mode == "numpy":
+            if c.randomize_state:                                     # env.reset(): grid_world.py:39-40
+                host_pos = np.stack([rng.randint([0, 0], [c.nrow, c.ncol], size=(N, 2)) for rng in self.np_rngs])
+            else:
+                host_pos = np.broadcast_to(np.asarray(self.initial_state), (S, N, 2))
+            self._reset(host_pos)
+        else:
+            self._reset(None if c.randomize_state else np.broadcast_to(np.asarray(self.initial_state), (S, N, 2)))
+        # expected returns at the start state (train_agents.py:60-62)
+        L.rcmarl_value_rows(self.xs[self.cur].data_ptr(), self.theta["critic"].data_ptr(), self.est.data_ptr(), S, N,
+                            self.in_c, HID, self.ldp["critic"], self.stream)
+        self.est_hist[ep_in_block].copy_(self.est)
+        rp = self._replay_ptrs()
+        for j in range(c.max_ep_len):
+            cur, nxt = self.cur, 1 - self.cur
+            row = self.B + j
+            if c.rng_mode == "device":
+                L.rcmarl_rollout_step(self.xs[cur].data_ptr(), self.pos[cur].data_ptr(), self.goal.data_ptr(),
+                                      self.theta["actor"].data_ptr(), self.seeds_dev.data_ptr(), c.nrow, c.ncol,
+                                      self.scale.data_ptr(), rp[0], rp[1], rp[2], rp[3], rp[4], self.cap, row,
+                                      self.pos[nxt].data_ptr(), self.xs[nxt].data_ptr(), self.ret.data_ptr(),
+                                      self.gpow[j], self.episode, j, c.mu, S, N, HID, c.n_actions, self.ldp["actor"],
+                                      None, self.stream)
+            else:
+                L.rcmarl_policy_probs(self.xs[cur].data_ptr(), self.theta["actor"].data_ptr(), self.probs.data_ptr(), S, N,
+                                      self.in_c, HID, c.n_actions, self.ldp["actor"], self.stream)
+                probs = self.probs.detach().cpu().numpy()
+                acts = np.zeros((S, N), np.int32)
+                for s in range(S):                                    # get_action(): agents/...:208-219
+                    rng = self.np_rngs[s]
+                    for i in range(N):
+                        a_rand = rng.choice(c.n_actions)
+                        a_pol = rng.choice(c.n_actions, p=probs[s, i])
+                        acts[s, i] = rng.choice([a_pol, a_rand], p=[1 - c.mu, c.mu])
+                self.act_i32.copy_(torch.from_numpy(acts).to(self.dev))
+                L.rcmarl_env_apply(self.pos[cur].data_ptr(), self.goal.data_ptr(), self.act_i32.data_ptr(), c.nrow, c.ncol,
+                                   self.scale.data_ptr(), rp[0], rp[1], rp[2], rp[3], rp[4], self.cap, row,
+                                   self.pos[nxt].data_ptr(), self.xs[nxt].data_ptr(), self.ret.data_ptr(), self.gpow[j],
+                                   S, N, self.stream)
+            self.cur = nxt
+        self.B += c.max_ep_len
+        self.ret_hist[ep_in_block].copy_(self.ret)
+        self.episode += 1
+
+    # ---- update block (train_agents.py:86-163) ---------------------------------------------
+    def _x(self, key, row0=0):
+        """(pointer, seed_stride) of replay tensor `key` starting at row `row0`."""
+        w = self.rp[key].shape[2]
+        return self.rp[key].data_ptr() + 4 * row0 * w, self.cap * w
+
+    def _layer1(self, xkey, theta, net, B, row0=0):
+        ptr, stride = self._x(xkey, row0)
+        self.lib.rcmarl_layer1_forward(ptr, stride, theta.data_ptr(), self.a1t.data_ptr(), self.S, self.N, B,
+                                       self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+
+    def _local_fit(self, net, xkey, y, B, mask):
+        """5 full-batch SGD steps on the message copy (agents/resilient_CAC_agents.py:118,136)."""
+        L, S, N = self.lib, self.S, self.N
+        msg = self.msg[net]
+        ptr, stride = self._x(xkey)
+        for step in range(self.cfg.local_fit_steps):
+            self._layer1(xkey, msg, net, B)
+            L.rcmarl_mid_fit(self.a1t.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(), S, N, B,
+                             self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+            L.rcmarl_small_sgd(self.partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+                               self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
+                               self.ldp[net], self.cfg.fast_lr, self.stream)
+            L.rcmarl_layer1_backward_sgd(ptr, stride, self.a1t.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
+                                         self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
+
+    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None):
+        self._layer1(xkey, theta, net, B, row0)
+        self.lib.rcmarl_mid_value(self.a1t.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
+                                  self.S, self.N, B, self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+
+    def _consensus(self, net, xkey, B):
+        """Phase II for one network family: hidden-layer consensus (K1), then estimate
+        consensus + projection step of the output layer (K2+K3)."""
+        L, S, N, c = self.lib, self.S, self.N, self.cfg
+        g_hid = self.P[net] - (HID * 1 + 1)
+        L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),
+                                  self.coop.data_ptr(), S, N, self.ldp[net], g_hid, c.d, c.H, None, None, self.stream)
+        self._layer1(xkey, self.theta[net], net, B)
+        L.rcmarl_consensus_head(self.a1t.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
+                                self.nbr.data_ptr(), self.coop.data_ptr(), self.partials.data_ptr(), None, S, N, B,
+                                self.in_dim[net], HID, self.ldp[net], self.ldb, c.d, c.H, self.stream)
+        L.rcmarl_head_apply(self.partials.data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(), S, N, B,
+                            self.in_dim[net], HID, self.ldp[net], self.stream)
+
+    def _timed(self, key, t0):
+        if self.profile_phases:
+            self.sync()
+            t1 = time.perf_counter()
+            self.timers[key] += t1 - t0
+            return t1
+        return t0
+
+    profile_phases = False
+
+    def update_block(self):
+        c, L, S, N, B = self.cfg, self.lib, self.S, self.N, self.B
+        assert B >= self.n_last
+        for lab in c.agent_label:
+            if lab in (GREEDY, MALICIOUS, FAULTY):
+                self._require_adversary_support()
+        t0 = time.perf_counter()
+        if self.profile_phases:
+            self.sync()
+            t0 = time.perf_counter()
+        rptr, rstride = self._x("r")
+        L.rcmarl_team_reward(rptr, rstride, self.coop.data_ptr(), max(self.n_coop, 1), self.rcoop.data_ptr(), S, N, B,
+                             self.ldb, self.stream)
+        L.rcmarl_gather_agent_major(rptr, rstride, self.rcoop.data_ptr(), self.fit_mode.data_ptr(),
+                                    self.ybuf["r_fit"].data_ptr(), S, N, B, self.ldb, self.stream)
+        for _ in range(c.n_epochs):
+            # I) local fits of TR and critic on a copy (= the transmitted message); live nets untouched
+            self.msg["tr"].copy_(self.theta["tr"])
+            self.msg["critic"].copy_(self.theta["critic"])
+            self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+            self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
+            self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+            self._adversary_messages(B)
+            t0 = self._timed("phase1", t0)
+            # II) resilient consensus (cooperative agents)
+            self._consensus("critic", "s", B)
+            self._consensus("tr", "sa", B)
+            t0 = self._timed("phase2", t0)
+        # III) actor update on the last n_ep_fixed episodes
+        self._actor_update(B)
+        self._adversary_actor_updates(B)
+        t0 = self._timed("phase3", t0)
+        # IV) trim the replay buffer (after the update, train_agents.py:158-163)
+        if B > c.buffer_size:
+            q = B - c.buffer_size
+            for k in self.rp:
+                self.rp[k][:, :c.buffer_size] = self.rp[k][:, q:B].clone()
+            self.B = c.buffer_size
+        self.timers["blocks"] += 1
+
+    def _actor_update(self, B):
+        c, L, S, N = self.cfg, self.lib, self.S, self.N
+        nl = self.n_last
+        row0 = B - nl
+        self._value("sa", self.theta["tr"], "tr", self.ybuf["v_tr"], nl, row0)
+        self._value("ns", self.theta["critic"], "critic", self.ybuf["v_next"], nl, row0)
+        self._value("s", self.theta["critic"], "critic", self.ybuf["v_cur"], nl, row0)
+        L.rcmarl_td_error(self.ybuf["v_tr"].data_ptr(), self.ybuf["v_next"].data_ptr(), self.ybuf["v_cur"].data_ptr(),
+                          c.gamma, self.ybuf["delta"].data_ptr(), S * N * self.ldb, self.stream)
+        aptr, astride = self._x("a", row0)
+        L.rcmarl_gather_agent_major(aptr, astride, None, None, self.ybuf["act_t"].data_ptr(), S, N, nl, self.ldb, self.stream)
+        self.adam_t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-7
+        alpha = float(np.float32(c.slow_lr * math.sqrt(1.0 - b2 ** self.adam_t) / (1.0 - b1 ** self.adam_t)))
+        omb1, omb2, epsf = float(np.float32(1 - b1)), float(np.float32(1 - b2)), float(np.float32(eps))
+        self._layer1("s", self.theta["actor"], "actor", nl, row0)
+        L.rcmarl_mid_actor(self.a1t.data_ptr(), self.theta["actor"].data_ptr(), self.ybuf["act_t"].data_ptr(),
+                           self.ybuf["delta"].data_ptr(), self.partials.data_ptr(), S, N, nl, self.in_c, HID, c.n_actions,
+                           self.ldp["actor"], self.ldb, self.stream)
+        L.rcmarl_small_adam(self.partials.data_ptr(), self.theta["actor"].data_ptr(), self.adam_m.data_ptr(),
+                            self.adam_v.data_ptr(), self.coop.data_ptr(), self.loss["actor"].data_ptr(), S, N, nl, self.in_c,
+                            HID, c.n_actions, self.ldp["actor"], alpha, omb1, omb2, epsf, self.stream)
+        sptr, sstride = self._x("s", row0)
+        L.rcmarl_layer1_backward_adam(sptr, sstride, self.a1t.data_ptr(), self.theta["actor"].data_ptr(),
+                                      self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.coop.data_ptr(), S, N, nl,
+                                      self.in_c, HID, self.ldp["actor"], self.ldb, alpha, omb1, omb2, epsf, self.stream)
+
+    # adversaries (agents/adversarial_CAC_agents.py) are handled by engine_adversaries.py
+    def _require_adversary_support(self):
+        if not hasattr(self, "adv"):
+            from . import engine_adversaries
+            engine_adversaries.attach(self)
+
+    def _adversary_messages(self, B):
+        if hasattr(self, "adv"):
+            self.adv.phase1(B)
+
+    def _adversary_actor_updates(self, B):
+        if hasattr(self, "adv"):
+            self.adv.actor_updates(B)
+
+    # ---- whole training loop ----------------------------------------------------------------
+    def run_block(self):
+        """n_ep_fixed episodes of rollout followed by one update block.  Returns the
+        per-episode logs of the block: (team_returns[E][S], adv_returns[E][S], est_returns[E][S])."""
+        c = self.cfg
+        t0 = time.perf_counter()
+        if self.profile_phases:
+            self.sync()
+            t0 = time.perf_counter()
+        for e in range(c.n_ep_fixed):
+            self.rollout_episode(e)
+        self._timed("rollout", t0)
+        self.update_block()
+        return self.episode_logs(c.n_ep_fixed)
+
+    def episode_logs(self, n_eps):
+        """Episode summaries exactly as train_agents.py:168-180 computes them (float64
+        sequential sums over agents; np.mean of the float32 start-state values)."""
+        ret = self.ret_hist[:n_eps].detach().cpu().numpy()
+        est = self.est_hist[:n_eps].detach().cpu().numpy()
+        coop = self.coop_np.astype(bool)
+        E, S, N = ret.shape
+        team, adv, estm = np.zeros((E, S)), np.zeros((E, S)), np.zeros((E, S))
+        n_coop = self.n_coop
+        for e in range(E):
+            for s in range(S):
+                t = a = 0
+                for i in range(N):
+                    if coop[i]:
+                        t += ret[e, s, i] / n_coop
+                    else:
+                        a += ret[e, s, i] / (N - n_coop)
+                team[e, s], adv[e, s] = t, a
+                estm[e, s] = np.mean(est[e, s][coop]) if n_coop else np.nan
+        return team, adv, estm
+
+    def train(self, n_episodes):
+        """Full loop; returns dict of per-episode arrays [n_episodes][S]."""
+        c = self.cfg
+        logs = {"True_team_returns": [], "True_adv_returns": [], "Estimated_team_returns": []}
+        done = 0
+        while done < n_episodes:
+            n = min(c.n_ep_fixed, n_episodes - done)
+            if n == c.n_ep_fixed:
+                team, adv, est = self.run_block()
+            else:                               # trailing episodes without an update (t % n_ep_fixed never hits)
+                for e in range(n):
+                    self.rollout_episode(e)
+                team, adv, est = self.episode_logs(n)
+            logs["True_team_returns"].append(team)
+            logs["True_adv_returns"].append(adv)
+            logs["Estimated_team_returns"].append(est)
+            done += n
+        return {k: np.concatenate(v, axis=0) for k, v in logs.items()}

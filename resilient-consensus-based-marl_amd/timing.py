@@ -1,0 +1,66 @@
+"""Per-kernel HIP-event timing of C-ABI launches (used by bench.py).
+
+Wraps a capi.CLib: every launch is bracketed by two events recorded on the
+stream the kernel is launched on (torch's current stream), so durations can
+be read after the timed region without synchronising inside it."""
+import collections
+
+import torch
+
+from . import capi
+
+
+def _gemm_flops(a, first):          # (..., S, N, B, in_dim, hid, ...) starting at index `first`
+    S, N, B, in_dim, hid = a[first:first + 5]
+    return 2.0 * S * N * hid * B * in_dim, 0.0
+
+
+# algorithmic work per launch: name -> f(args) -> (flops, bytes)   (DESIGN.md "Kernels")
+WORK = {
+    "rcmarl_layer1_forward": lambda a: _gemm_flops(a, 4),
+    "rcmarl_layer1_backward_sgd": lambda a: _gemm_flops(a, 5),
+    "rcmarl_layer1_backward_adam": lambda a: _gemm_flops(a, 7),
+    # msg, theta, nbr, coop, S, N, ldp, P_hid, ...: read P_hid + write P_hid floats per (seed, agent)
+    "rcmarl_consensus_params": lambda a: (0.0, 8.0 * a[4] * a[5] * a[7]),
+    # a1t, theta, y, partials, S, N, B, in_dim, hid: layers 2-3 fwd+bwd ~ (8 h^2 + 12 h) flops per (row, agent)
+    "rcmarl_mid_fit": lambda a: (a[4] * a[5] * a[6] * (8.0 * a[8] ** 2 + 12.0 * a[8]), 8.0 * a[4] * a[5] * a[6] * a[8]),
+}
+
+
+class TimedLib:
+    def __init__(self, lib):
+        self._lib = lib
+        self.enabled = False
+        self._events = collections.defaultdict(list)
+        self.work = {}
+        for name in capi.SIGNATURES:
+            fn = getattr(lib, name)
+            setattr(self, name, fn if name in capi.UNCHECKED else self._wrap(name, fn))
+
+    def _wrap(self, name, fn):
+        def call(*args):
+            if not self.enabled:
+                return fn(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args)
+            e1.record()
+            self._events[name].append((e0, e1))
+            if name in WORK:
+                f, b = WORK[name](args)
+                pf, pb = self.work.get(name, (0.0, 0.0))
+                self.work[name] = (pf + f, pb + b)
+            return r
+        return call
+
+    def reset(self):
+        self._events.clear()
+        self.work = {}
+
+    def summary(self):
+        """name -> (launches, total_ms, avg_us); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, evs in self._events.items():
+            tot = sum(a.elapsed_time(b) for a, b in evs)
+            out[name] = (len(evs), tot, 1e3 * tot / max(len(evs), 1))
+        return out

@@ -1,0 +1,88 @@
+"""Engine-vs-oracle end-to-end checks shared by the hipemu (CPU) and GPU tests."""
+import numpy as np
+
+from oracle import mlp_np as M
+from oracle import rpbcac_oracle as O
+from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+
+CIRC5 = [[0, 1, 2, 3], [1, 2, 3, 4], [2, 3, 4, 0], [3, 4, 0, 1], [4, 0, 1, 2]]
+
+
+def make_args(labels, H, n_episodes, max_ep_len, n_ep_fixed, n_epochs, buffer_size, seed, in_nodes=None,
+              common_reward=False, slow_lr=0.002, fast_lr=0.01, gamma=0.9):
+    n = len(labels)
+    return {"n_agents": n, "agent_label": list(labels), "in_nodes": in_nodes or CIRC5, "n_actions": 5, "n_states": 2,
+            "n_episodes": n_episodes, "max_ep_len": max_ep_len, "n_ep_fixed": n_ep_fixed, "n_epochs": n_epochs,
+            "slow_lr": slow_lr, "fast_lr": fast_lr, "batch_size": 200, "buffer_size": buffer_size, "gamma": gamma, "H": H,
+            "common_reward": common_reward, "summary_dir": "./", "pretrained_agents": False, "random_seed": seed}
+
+
+def init_weights(rng, n_agents):
+    out = []
+    for _ in range(n_agents):
+        out.append({"actor": M.init_mlp(rng, 2 * n_agents, 20, 5), "critic": M.init_mlp(rng, 2 * n_agents, 20, 1),
+                    "tr": M.init_mlp(rng, 3 * n_agents, 20, 1)})
+    return out
+
+
+def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3):
+    """Run the oracle (one run per seed) and the engine (all seeds batched); return both results."""
+    n = args["n_agents"]
+    S = len(seeds)
+    wrng = np.random.default_rng(weight_seed)
+    W = [init_weights(wrng, n) for _ in range(S)]
+    goals = [np.random.default_rng(100 + s).integers(0, min(5, nrow), size=(n, 2)) for s in range(S)]
+    cfg = EngineConfig(n, args["agent_label"], args["in_nodes"], H=args["H"], gamma=args["gamma"], slow_lr=args["slow_lr"],
+                       fast_lr=args["fast_lr"], max_ep_len=args["max_ep_len"], n_ep_fixed=args["n_ep_fixed"],
+                       n_epochs=args["n_epochs"], buffer_size=args["buffer_size"], common_reward=args["common_reward"],
+                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode)
+    eng = RPBCACEngine(cfg, seeds=list(seeds), device=device, lib=lib)
+    for s in range(S):
+        for i in range(n):
+            for net in ("actor", "critic", "tr"):
+                eng.set_weights(s, i, net, W[s][i][net])
+    eng.set_goals(np.stack(goals))
+    # --- oracle
+    o_logs, o_weights = [], []
+    for s in range(S):
+        a = dict(args)
+        a["random_seed"] = int(seeds[s])
+        agents = [O.make_agent(lab, W[s][i]["actor"], W[s][i]["critic"], W[s][i]["tr"], a["slow_lr"], a["fast_lr"], a["gamma"], a["H"])
+                  for i, lab in enumerate(a["agent_label"])]
+        if rng_mode == "numpy":
+            np.random.seed(int(seeds[s]))
+            env = O.GridWorldOracle(nrow, ncol, n, goals[s], None, True, True)
+            w, df = O.train(env, agents, a, rng_mode="numpy")
+        else:
+            env = O.GridWorldOracle(nrow, ncol, n, goals[s], None, True, True, rng_mode="device", seed=int(seeds[s]))
+            w, df = O.train(env, agents, a, rng_mode="device")
+        o_logs.append(df)
+        o_weights.append(w)
+    # --- engine
+    if rng_mode == "numpy":
+        eng.np_rngs = []
+        for s in range(S):
+            r = np.random.RandomState(int(seeds[s]))
+            r.randint([0, 0], [nrow, ncol], size=(n, 2))       # the env constructor's reset() draw (grid_world.py:28)
+            eng.np_rngs.append(r)
+    logs = eng.train(args["n_episodes"])
+    return eng, logs, o_logs, o_weights
+
+
+def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4):
+    S, n = eng.S, eng.N
+    for s in range(S):
+        df = o_logs[s]
+        # identical action streams -> bit-identical float64 returns
+        np.testing.assert_array_equal(logs["True_team_returns"][:, s], df["True_team_returns"].to_numpy(dtype=np.float64))
+        np.testing.assert_array_equal(logs["True_adv_returns"][:, s], df["True_adv_returns"].to_numpy(dtype=np.float64))
+        np.testing.assert_allclose(logs["Estimated_team_returns"][:, s], df["Estimated_team_returns"].to_numpy(dtype=np.float64),
+                                   rtol=1e-4, atol=1e-5)
+        for i in range(n):
+            for k, net in enumerate(("actor", "critic", "tr")):
+                got = eng.get_weights(s, i, net)
+                for a, b in zip(got, o_weights[s][i][k]):
+                    scale = max(1.0, float(np.abs(b).max()))
+                    tol = rtol_w * scale if net != "actor" else 0.05 * eng.cfg.slow_lr * max(1, eng.adam_t) + 1e-5
+                    err = float(np.abs(a - b).max())
+                    assert err <= tol, (s, i, net, err, tol)

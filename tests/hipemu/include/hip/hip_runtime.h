@@ -98,6 +98,15 @@ template <typename T> inline T __shfl(T v, int src, int width = 64) { (void)widt
 template <typename T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
   (void)width; int l = hipemu::lane(); int src = l + (int)delta; if (src > 63) src = l; return __hipemu_xch(v, src);
 }
+inline void __hipemu_gather64(float v, float (&out)[64]) {
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  s.xch_f[((size_t)w * 64 + l) * 2] = v;
+  hipemu::wave_barrier();
+  int n = hipemu::wave_size_here();
+  for (int i = 0; i < 64; ++i) out[i] = i < n ? s.xch_f[((size_t)w * 64 + i) * 2] : 0.f;
+  hipemu::wave_barrier();
+}
 inline int __builtin_amdgcn_readfirstlane(int v) { return __hipemu_xch(v, 0); }
 
 inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {

@@ -1,0 +1,20 @@
+"""End-to-end engine (host logic + every kernel, hipemu build) vs the oracle's
+train() on tiny cooperative scenarios, both RNG modes.  CPU-only."""
+import pytest
+
+import engine_checks as EC
+from emu_util import emu_lib
+
+
+@pytest.mark.parametrize("rng_mode", ["device", "numpy"])
+def test_engine_coop_matches_oracle(rng_mode):
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=5, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=11)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, rng_mode, "cpu", emu_lib(), seeds=(11, 12))
+    EC.compare(eng, logs, o_logs, o_w)
+
+
+def test_engine_common_reward_H0():
+    args = EC.make_args(["Cooperative"] * 5, H=0, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=5,
+                        common_reward=True)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, "device", "cpu", emu_lib(), seeds=(5,))
+    EC.compare(eng, logs, o_logs, o_w)

@@ -1,0 +1,80 @@
+"""Parity tests proper: every HIP kernel, on a real MI355X, through the product
+C-ABI (librcmarl_hip.so), against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import kernel_checks as KC
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuBackend:
+    def __init__(self):
+        from rcmarl_amd import capi
+        self.lib = capi.load()
+        assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def dev(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype == np.uint64:
+            return torch.from_numpy(arr.view(np.int64)).cuda()
+        return torch.from_numpy(arr).cuda()
+
+    def ptr(self, h):
+        return None if h is None else h.data_ptr()
+
+    def host(self, h):
+        torch.cuda.synchronize()
+        return h.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def bk():
+    return GpuBackend()
+
+
+@pytest.mark.parametrize("N,d,H,P,P_hid,graph", [
+    (5, 4, 1, 661, 640, "circ"), (5, 4, 0, 761, 740, "circ"), (64, 10, 4, 3021, 3000, "rand"),
+    (256, 18, 8, 1100, 1070, "circ"), (256, 4, 1, 700, 650, "circ"), (300, 18, 8, 300, 280, "rand"),
+    (30, 23, 5, 90, 77, "rand"), (100, 66, 32, 200, 190, "rand"), (1024, 18, 8, 200, 130, "circ"),
+])
+def test_consensus_params(bk, N, d, H, P, P_hid, graph):
+    KC.check_consensus_params(bk, N, d, H, P, P_hid, graph)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 64, 700, 128), (2, 7, 130, 21), (1, 13, 3000, 39)])
+def test_layer1_forward(bk, S, N, B, in_dim):
+    KC.check_layer1_forward(bk, S, N, B, in_dim)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (2, 5, 3000, 15, 4), (1, 32, 700, 64, 2),
+                                                 (1, 7, 130, 21, None)])
+def test_sgd_fit(bk, S, N, B, in_dim, masked):
+    KC.check_sgd_fit(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,d,H,graph", [(2, 5, 1000, 10, 4, 1, "circ"), (1, 24, 700, 48, 10, 4, "rand"),
+                                                    (1, 20, 300, 40, 18, 8, "circ"), (1, 12, 70, 24, 11, 2, "rand"),
+                                                    (1, 30, 300, 90, 23, 5, "rand")])
+def test_consensus_head(bk, S, N, B, in_dim, d, H, graph):
+    KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 16, 300, 32)])
+def test_actor_step(bk, S, N, B, in_dim):
+    KC.check_actor_step(bk, S, N, B, in_dim, steps=3)
+
+
+def test_reward_helpers(bk):
+    KC.check_reward_helpers(bk, 2, 5, 1000)
+    KC.check_reward_helpers(bk, 1, 64, 3000)
+
+
+@pytest.mark.parametrize("S,N,nrow,ncol,mode", [(3, 5, 5, 5, "device"), (2, 70, 16, 16, "device"), (2, 5, 5, 5, "host")])
+def test_rollout(bk, S, N, nrow, ncol, mode):
+    KC.check_rollout(bk, S, N, nrow, ncol, steps=20, mode=mode)
