@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "librcmarl_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def lib_path():
@@ -34,7 +34,7 @@ def _stamp():
         h.update(p.encode())
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + " -no-hip-rt").encode())
     return h.hexdigest()
 
 
@@ -59,7 +59,7 @@ def build_hip(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(cc, _sources()))
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path()] + objs,
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", lib_path()] + objs,
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])

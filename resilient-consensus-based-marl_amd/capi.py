@@ -88,15 +88,30 @@ class RcmarlError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """librcmarl_hip.so is linked WITHOUT its own HIP runtime (-no-hip-rt): it must run on the very
+    runtime instance PyTorch uses, otherwise streams/pointers handed over from torch belong to a
+    different libamdhip64 and every launch fails.  PyTorch wheels bundle their runtime and load it
+    RTLD_LOCAL; re-open it RTLD_GLOBAL so our undefined hip* symbols bind to it."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    try:
+        C.CDLL(cand if os.path.exists(cand) else "libamdhip64.so.7", mode=C.RTLD_GLOBAL)
+    except OSError as e:                       # pragma: no cover
+        raise RcmarlError("cannot load the HIP runtime (libamdhip64): %s" % e)
+
+
 class CLib:
     """Thin checked wrapper: ``lib.rcmarl_xxx(...)`` raises on a non-zero status."""
 
-    def __init__(self, path):
+    def __init__(self, path, needs_hip=True):
         if not os.path.exists(path):
             raise RcmarlError(
                 "rcmarl HIP library not found at %s -- build it with `python -m rcmarl_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
         self.path = path
+        if needs_hip:
+            _preload_hip_runtime()
         self._dll = C.CDLL(path)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(self._dll, name)      # AttributeError if the symbol is missing

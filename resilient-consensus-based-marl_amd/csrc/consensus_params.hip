@@ -37,52 +37,92 @@ __device__ __forceinline__ float aggregate_regs(const float (&v)[D], float& lowe
   return sum / (float)D;
 }
 
-// stage msg[s][0..N)[c0..c0+TC) -> tile[N][TC] with float4 loads (ldp % 64 == 0, c0 % TC == 0)
-__device__ __forceinline__ void stage_tile(const float* __restrict__ m, float* tile, int N, int ldp, int c0, int log2tc) {
-  const int TC = 1 << log2tc;
-  const int q_per_row = TC >> 2;
-  const int total = N * q_per_row;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const int row = idx / q_per_row, q = idx - row * q_per_row;
-    const float4 x = *reinterpret_cast<const float4*>(m + (size_t)row * ldp + c0 + 4 * q);
-    *reinterpret_cast<float4*>(tile + (row << log2tc) + 4 * q) = x;
+// Software-pipelined tile staging: a workgroup walks a strided sequence of (seed, column-tile)
+// work items.  The [N][TC] image of the NEXT item is fetched into registers (up to PF float4 per
+// thread, all issued back-to-back) while the current item is being aggregated out of LDS, and
+// committed to LDS after the barrier that retires the current item.  ldp % 64 == 0, c0 % TC == 0.
+constexpr int PF = 16;   // 256 threads x 16 float4 = 64 KiB = the largest tile image
+struct TileStager {
+  const float* msg; int N, ldp, log2tc, tiles_per_seed;
+  __device__ __forceinline__ void fetch(int t, float (&pf)[4 * PF]) const {
+    const int lq = log2tc - 2, total = N << lq;
+    const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) << log2tc;
+    const float* m = msg + (size_t)s * N * ldp + c0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      int idx = threadIdx.x + 256 * u;
+      idx = idx < total ? idx : total - 1;     // clamp instead of predicate: keeps pf[] in registers
+      const float4 x = *reinterpret_cast<const float4*>(m + (size_t)(idx >> lq) * ldp + 4 * (idx & ((1 << lq) - 1)));
+      pf[4 * u] = x.x; pf[4 * u + 1] = x.y; pf[4 * u + 2] = x.z; pf[4 * u + 3] = x.w;
+    }
   }
-}
+  __device__ __forceinline__ void commit(const float (&pf)[4 * PF], float* tile) const {
+    const int lq = log2tc - 2, total = N << lq;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = threadIdx.x + 256 * u;
+      if (idx < total) *reinterpret_cast<float4*>(tile + ((idx >> lq) << log2tc) + 4 * (idx & ((1 << lq) - 1))) =
+            make_float4(pf[4 * u], pf[4 * u + 1], pf[4 * u + 2], pf[4 * u + 3]);
+    }
+  }
+};
 
 template <int D, int H>
 __global__ __launch_bounds__(256) void k_consensus_params(const float* __restrict__ msg, float* __restrict__ theta,
                                                           const int* __restrict__ nbr,
                                                           const unsigned char* __restrict__ coop, int N, int ldp,
-                                                          int P_hid, int log2tc, float* __restrict__ lo_dbg,
-                                                          float* __restrict__ hi_dbg) {
+                                                          int P_hid, int log2tc, int tiles_per_seed, int total_tiles,
+                                                          float* __restrict__ lo_dbg, float* __restrict__ hi_dbg) {
   RCMARL_DYN_SMEM(float, tile);
   const int TC = 1 << log2tc;
-  const int s = blockIdx.y;
-  const int c0 = blockIdx.x << log2tc;
-  stage_tile(msg + (size_t)s * N * ldp, tile, N, ldp, c0, log2tc);
-  __syncthreads();
+  const TileStager st{msg, N, ldp, log2tc, tiles_per_seed};
+  float pf[4 * PF];
+  int t = blockIdx.x;
+  if (t < total_tiles) st.fetch(t, pf);
   const int c = threadIdx.x & (TC - 1);
-  const int rows_per_pass = blockDim.x >> log2tc;
-  const bool col_ok = (c0 + c) < P_hid;
-  auto one_agent = [&](const int i) {
-    if (!coop[i]) return;
-    float v[D];
+  const int rows_per_pass = 256 >> log2tc;
+  for (; t < total_tiles; t += gridDim.x) {
+    __syncthreads();                       // every wave is done with the previous tile image
+    st.commit(pf, tile);
+    __syncthreads();
+    if (t + (int)gridDim.x < total_tiles) st.fetch(t + gridDim.x, pf);   // in flight during the aggregation below
+    const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) << log2tc;
+    const bool col_ok = (c0 + c) < P_hid;
+    auto load_vals = [&](const int i, float (&v)[D]) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) v[k] = tile[(nbr[i * D + k] << log2tc) + c];
-    float lower, upper;
-    const float out = aggregate_regs<D, H>(v, lower, upper);
-    if (col_ok) {
-      const size_t o = ((size_t)s * N + i) * ldp + c0 + c;
-      theta[o] = out;
-      if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+      for (int k = 0; k < D; ++k) v[k] = tile[(nbr[i * D + k] << log2tc) + c];
+    };
+    auto finish = [&](const int i, const float (&v)[D]) {
+      float lower, upper;
+      const float out = aggregate_regs<D, H>(v, lower, upper);
+      if (col_ok) {
+        const size_t o = ((size_t)s * N + i) * ldp + c0 + c;
+        theta[o] = out;
+        if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+      }
+    };
+    if (log2tc == 6) {
+      // one wavefront = one agent: the agent index is an SGPR, so the neighbour list and the
+      // cooperation flag come through the scalar cache; two agents per trip for ILP
+      int i = threadIdx.x >> 6;
+      for (; i + 4 < N; i += 8) {
+        const int ia = __builtin_amdgcn_readfirstlane(i), ib = __builtin_amdgcn_readfirstlane(i + 4);
+        const bool ca = coop[ia] != 0, cb = coop[ib] != 0;
+        float va[D], vb[D];
+        if (ca) load_vals(ia, va);
+        if (cb) load_vals(ib, vb);
+        if (ca) finish(ia, va);
+        if (cb) finish(ib, vb);
+      }
+      for (; i < N; i += 4) {
+        const int ia = __builtin_amdgcn_readfirstlane(i);
+        if (coop[ia]) { float va[D]; load_vals(ia, va); finish(ia, va); }
+      }
+    } else {
+      for (int i = threadIdx.x >> log2tc; i < N; i += rows_per_pass) {
+        if (coop[i]) { float va[D]; load_vals(i, va); finish(i, va); }
+      }
     }
-  };
-  if (log2tc == 6) {
-    // one wavefront = one agent: make the agent index an SGPR so the neighbour
-    // list and the cooperation flag come through the scalar cache
-    for (int i = threadIdx.x >> 6; i < N; i += rows_per_pass) one_agent(__builtin_amdgcn_readfirstlane(i));
-  } else {
-    for (int i = threadIdx.x >> log2tc; i < N; i += rows_per_pass) one_agent(i);
   }
 }
 
@@ -99,7 +139,12 @@ __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* _
   const int TC = 1 << log2tc;
   const int s = blockIdx.y;
   const int c0 = blockIdx.x << log2tc;
-  stage_tile(msg + (size_t)s * N * ldp, tile, N, ldp, c0, log2tc);
+  {
+    const TileStager st{msg, N, ldp, log2tc, (int)gridDim.x};
+    float pf[4 * PF];
+    st.fetch(s * gridDim.x + blockIdx.x, pf);
+    st.commit(pf, tile);
+  }
   __syncthreads();
   const int c = threadIdx.x & (TC - 1);
   const int rows_per_pass = blockDim.x >> log2tc;
@@ -144,13 +189,24 @@ RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const 
   while (log2tc > 2 && ((size_t)N << log2tc) * sizeof(float) > 64 * 1024) --log2tc;
   if (((size_t)N << log2tc) * sizeof(float) > 64 * 1024) return RCMARL_ERR_UNSUPPORTED;
   const int TC = 1 << log2tc;
-  const dim3 grid(rc_ceil_div(P_hid, TC), S), block(256);
   const size_t smem = ((size_t)N << log2tc) * sizeof(float);
+  const int tiles_per_seed = rc_ceil_div(P_hid, TC), total_tiles = tiles_per_seed * S;
+  // persistent-style launch: as many workgroups as fit the chip at once (LDS-limited), each
+  // walking total_tiles with stride gridDim.x so that loads of tile t+1 overlap compute of tile t
+  int wg_per_cu = (int)((160 * 1024) / (smem + 512));
+  if (wg_per_cu > 4) wg_per_cu = 4;
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  int nwg = 256 * wg_per_cu;
+#ifdef RCMARL_EMU
+  nwg = 3;                                 // make the CPU emulation exercise the strided tile walk
+#endif
+  if (nwg > total_tiles) nwg = total_tiles;
+  const dim3 grid_p(nwg), grid(tiles_per_seed, S), block(256);
   bool done = false;
 #define RC_CASE(DD, HH)                                                                                              \
   if (!done && d == DD && H == HH) {                                                                                 \
-    RCMARL_LAUNCH((k_consensus_params<DD, HH>), grid, block, smem, stream, msg, theta, nbr, coop, N, ldp, P_hid,     \
-                  log2tc, lo_dbg, hi_dbg);                                                                           \
+    RCMARL_LAUNCH((k_consensus_params<DD, HH>), grid_p, block, smem, stream, msg, theta, nbr, coop, N, ldp, P_hid,   \
+                  log2tc, tiles_per_seed, total_tiles, lo_dbg, hi_dbg);                                              \
     done = true;                                                                                                     \
   }
   RCMARL_SELNET_COMBOS(RC_CASE)

@@ -8,7 +8,7 @@
 // with M x N x K = (N*hid) x B x in  and  in x (N*hid) x B.  They carry ~94 % of the
 // FLOPs of a local fit at N=256.  Both run on the fp32-input MFMA
 // (v_mfma_f32_32x32x2_f32: exact fp32, bit-equal to an fmaf chain), LDS-tiled
-// 128x128x16 per 256-thread workgroup (4 wavefronts, each 64x64 = 2x2 MFMA tiles).
+// 128x128x32 per 256-thread workgroup, next k-tile prefetched into registers (4 wavefronts, each 64x64 = 2x2 MFMA tiles).
 //
 // Layouts: X[S][rows][in] row-major (replay buffer), theta[S][N][ldp] parameter
 // rows, activations FEATURE-MAJOR a1t[S][N*hid][ldb] (contiguous over b).
@@ -16,9 +16,11 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDA = BM + 4;   // A tile [BK][LDA]; +4 keeps 16-B row alignment for ds_write_b128
-constexpr int LDB = BN + 2;   // B tile [BK][LDB]; 4*LDB mod 32 == 8 -> conflict-free transposing writes
+constexpr int LDB = BN + 1;   // B tile [BK][LDB]; 4*LDB mod 32 == 4 -> conflict-free transposing writes
+constexpr int A_REGS = BK * BM / 256;   // 16 floats of the next A tile per thread
+constexpr int B_REGS = BK * BN / 256;   // 16 floats of the next B tile per thread
 
 __device__ __forceinline__ rc_f32x16 zero16() {
   rc_f32x16 z;
@@ -27,59 +29,74 @@ __device__ __forceinline__ rc_f32x16 zero16() {
   return z;
 }
 
-// B-operand loader shared by both GEMMs: source is [n][k] with k contiguous
-// (X[b][k] for the forward, dz1t[col][b] for the backward); tile goes to LDS
-// transposed as Bs[k][n].  256 threads, 128 n x 16 k = 512 float4.
-__device__ __forceinline__ void load_B_kcontig(const float* __restrict__ src, long ld, int n0, int n_lim, int k0,
-                                               int k_lim, bool vec_ok, float* Bs) {
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int idx = threadIdx.x + 256 * r;     // 0..511
-    const int n = idx >> 2, kq = idx & 3;
-    const int gn = n0 + n, gk = k0 + 4 * kq;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gn < n_lim) {
-      const float* p = src + (long)gn * ld + gk;
-      if (vec_ok && gk + 3 < k_lim) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (gk + 0 < k_lim) v.x = p[0];
-        if (gk + 1 < k_lim) v.y = p[1];
-        if (gk + 2 < k_lim) v.z = p[2];
-        if (gk + 3 < k_lim) v.w = p[3];
-      }
-    }
-    float* d = Bs + (4 * kq) * LDB + n;
-    d[0] = v.x; d[LDB] = v.y; d[2 * LDB] = v.z; d[3 * LDB] = v.w;
-  }
-}
+// Every loader is split in two halves so the k-loop can software-pipeline:
+//   fetch(m0|n0, k0, regs)  : global -> registers (issued before the MFMA phase of the previous tile)
+//   commit(regs, tile)      : registers -> LDS     (after the barrier that retires the previous tile)
 
-// forward A operand: A(m = column (n_agent, j), k) = theta[agent][k*hid + j]
+// B operand, shared by both GEMMs: source is [n][k] with k contiguous (X[b][k] for the
+// forward, dz1t[col][b] for the backward); the tile lands transposed as Bs[k][n].
+struct LoadB_KContig {
+  const float* src; long ld; int n_lim, k_lim; bool vec_ok;
+  __device__ __forceinline__ void fetch(int n0, int k0, float (&r)[B_REGS]) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = threadIdx.x + 256 * q;     // 0..1023 : 128 n x 8 float4
+      const int n = idx >> 3, kq = idx & 7;
+      const int gn = n0 + n, gk = k0 + 4 * kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gn < n_lim) {
+        const float* p = src + (long)gn * ld + gk;
+        if (vec_ok && gk + 3 < k_lim) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (gk + 0 < k_lim) v.x = p[0];
+          if (gk + 1 < k_lim) v.y = p[1];
+          if (gk + 2 < k_lim) v.z = p[2];
+          if (gk + 3 < k_lim) v.w = p[3];
+        }
+      }
+      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+  }
+  __device__ __forceinline__ void commit(const float (&r)[B_REGS], float* Bs) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = threadIdx.x + 256 * q;
+      const int n = idx >> 3, kq = idx & 7;
+      float* d = Bs + (4 * kq) * LDB + n;
+      d[0] = r[4 * q]; d[LDB] = r[4 * q + 1]; d[2 * LDB] = r[4 * q + 2]; d[3 * LDB] = r[4 * q + 3];
+    }
+  }
+};
+
+// forward A operand: A(m = column (agent, j), k) = theta[agent][k*hid + j]
 struct LoadA_W1 {
   const float* theta_s; int ldp, hid, ncols, in_dim;
-  __device__ __forceinline__ void operator()(int m0, int k0, float* As) const {
+  __device__ __forceinline__ void fetch(int m0, int k0, float (&r)[A_REGS]) const {
     const int m = threadIdx.x & 127;
     const int col = m0 + m;
     const bool ok = col < ncols;
     const int agent = ok ? col / hid : 0;
     const int j = col - agent * hid;
-    const float* base = theta_s + (long)agent * ldp + j;
+    const float* base = theta_s + (long)agent * ldp + j + (long)(k0 + (threadIdx.x >> 7)) * hid;
+    const int kbase = k0 + (threadIdx.x >> 7);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int k = (threadIdx.x >> 7) + 2 * r;
-      const int gk = k0 + k;
-      As[k * LDA + m] = (ok && gk < in_dim) ? base[(long)gk * hid] : 0.f;
-    }
+    for (int q = 0; q < A_REGS; ++q) r[q] = (ok && kbase + 2 * q < in_dim) ? base[(long)(2 * q) * hid] : 0.f;
+  }
+  __device__ __forceinline__ void commit(const float (&r)[A_REGS], float* As) const {
+    const int m = threadIdx.x & 127;
+#pragma unroll
+    for (int q = 0; q < A_REGS; ++q) As[((threadIdx.x >> 7) + 2 * q) * LDA + m] = r[q];
   }
 };
 
 // backward A operand: A(m = input feature, k = b) = X[b][m]  (m contiguous)
 struct LoadA_XT {
   const float* x_s; int in_dim, B; bool vec_ok;
-  __device__ __forceinline__ void operator()(int m0, int k0, float* As) const {
+  __device__ __forceinline__ void fetch(int m0, int k0, float (&r)[A_REGS]) const {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int idx = threadIdx.x + 256 * r;   // 0..511 : 16 rows x 32 float4
+    for (int q = 0; q < 4; ++q) {
+      const int idx = threadIdx.x + 256 * q;   // 0..1023 : 32 rows x 32 float4
       const int k = idx >> 5, mq = idx & 31;
       const int gb = k0 + k, gm = m0 + 4 * mq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -94,20 +111,21 @@ struct LoadA_XT {
           if (gm + 3 < in_dim) v.w = p[3];
         }
       }
-      *reinterpret_cast<float4*>(As + k * LDA + 4 * mq) = v;
+      r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+  }
+  __device__ __forceinline__ void commit(const float (&r)[A_REGS], float* As) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = threadIdx.x + 256 * q;
+      const int k = idx >> 5, mq = idx & 31;
+      *reinterpret_cast<float4*>(As + k * LDA + 4 * mq) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
     }
   }
 };
 
-struct LoadB_Generic {
-  const float* src; long ld; int n_lim, k_lim; bool vec_ok;
-  __device__ __forceinline__ void operator()(int n0, int k0, float* Bs) const {
-    load_B_kcontig(src, ld, n0, n_lim, k0, k_lim, vec_ok, Bs);
-  }
-};
-
-// 128x128 output tile, K swept in steps of 16.  Calls epi(m, n, value) for every
-// accumulator element (m, n are global indices; the functor bounds-checks).
+// 128x128 output tile, K swept in steps of 32 with register prefetch of the next tile.
+// Calls epi(m, n, value) for every accumulator element (global indices; the functor bounds-checks).
 template <class LA, class LB, class Epi>
 __device__ __forceinline__ void gemm_tile(const LA& la, const LB& lb, const Epi& epi, int m0, int n0, int K) {
   __shared__ __attribute__((aligned(16))) float As[BK * LDA];
@@ -119,11 +137,18 @@ __device__ __forceinline__ void gemm_tile(const LA& la, const LB& lb, const Epi&
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = zero16();
+  float ra[A_REGS], rb[B_REGS];
+  la.fetch(m0, 0, ra);
+  lb.fetch(n0, 0, rb);
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();                 // previous tile fully consumed
-    la(m0, k0, As);
-    lb(n0, k0, Bs);
+    la.commit(ra, As);
+    lb.commit(rb, Bs);
     __syncthreads();
+    if (k0 + BK < K) {               // next tile's HBM/L2 latency hides behind this tile's MFMAs
+      la.fetch(m0, k0 + BK, ra);
+      lb.fetch(n0, k0 + BK, rb);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const int k = kk + (lane >> 5);
@@ -140,24 +165,27 @@ __device__ __forceinline__ void gemm_tile(const LA& la, const LB& lb, const Epi&
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      typename Epi::RowCtx ctx = epi.row(m);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int n = n0 + wn0 + 32 * nt + (lane & 31);
-        epi(m, n, acc[mt][nt][r]);
-      }
+      for (int nt = 0; nt < 2; ++nt) epi(ctx, m, n0 + wn0 + 32 * nt + (lane & 31), acc[mt][nt][r]);
+    }
 }
 
 // ---- forward: a1t[col][b] = lrelu(sum_k W1[k][col] * X[b][k] + b1[col]) ---------------
 struct EpiForward {
   const float* theta_s; float* a1t_s; int ldp, hid, ncols, B, ldb, o_b1;
-  __device__ __forceinline__ void operator()(int m, int n, float v) const {
-    if (m < ncols && n < B) {
-      const int agent = m / hid, j = m - agent * hid;
-      const float z = v + theta_s[(long)agent * ldp + o_b1 + j];
-      a1t_s[(long)m * ldb + n] = rc_lrelu(z);
-    }
+  struct RowCtx { float bias; bool ok; };
+  __device__ __forceinline__ RowCtx row(int m) const {      // m = column (agent, j): one bias per row
+    RowCtx c;
+    c.ok = m < ncols;
+    const int agent = c.ok ? m / hid : 0;
+    c.bias = c.ok ? theta_s[(long)agent * ldp + o_b1 + (m - agent * hid)] : 0.f;
+    return c;
+  }
+  __device__ __forceinline__ void operator()(const RowCtx& c, int m, int n, float v) const {
+    if (c.ok && n < B) a1t_s[(long)m * ldb + n] = rc_lrelu(v + c.bias);
   }
 };
 
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(256) void k_layer1_forward(const float* __restrict_
   float* a1t_s = a1t + (long)s * ncols * ldb;
   const bool vec_ok = (in_dim & 3) == 0 && ((x_seed_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   LoadA_W1 la{theta_s, ldp, hid, ncols, in_dim};
-  LoadB_Generic lb{x_s, (long)in_dim, B, in_dim, vec_ok};
+  LoadB_KContig lb{x_s, (long)in_dim, B, in_dim, vec_ok};
   EpiForward epi{theta_s, a1t_s, ldp, hid, ncols, B, ldb, in_dim * hid};
   gemm_tile(la, lb, epi, blockIdx.y * BM, blockIdx.x * BN, in_dim);
 }
@@ -179,7 +207,9 @@ __global__ __launch_bounds__(256) void k_layer1_forward(const float* __restrict_
 // ---- backward: W1[k][col] <- W1[k][col] - lr * sum_b X[b][k] * dz1t[col][b] ------------
 struct EpiSgd {
   float* theta_s; const unsigned char* mask; int ldp, hid, ncols, in_dim; float lr;
-  __device__ __forceinline__ void operator()(int m, int n, float g) const {
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row(int) const { return RowCtx(); }
+  __device__ __forceinline__ void operator()(const RowCtx&, int m, int n, float g) const {
     if (m < in_dim && n < ncols) {
       const int agent = n / hid, j = n - agent * hid;
       if (mask == nullptr || mask[agent]) {
@@ -194,7 +224,9 @@ struct EpiSgd {
 struct EpiAdam {
   float* theta_s; float* m_s; float* v_s; const unsigned char* mask; int ldp, hid, ncols, in_dim;
   float alpha, one_m_b1, one_m_b2, eps;
-  __device__ __forceinline__ void operator()(int m, int n, float g) const {
+  struct RowCtx {};
+  __device__ __forceinline__ RowCtx row(int) const { return RowCtx(); }
+  __device__ __forceinline__ void operator()(const RowCtx&, int m, int n, float g) const {
     if (m < in_dim && n < ncols) {
       const int agent = n / hid, j = n - agent * hid;
       if (mask == nullptr || mask[agent]) {
@@ -218,7 +250,7 @@ __global__ __launch_bounds__(256) void k_layer1_backward_sgd(const float* __rest
   const float* x_s = x + (long)s * x_seed_stride;
   const bool vec_ok = (in_dim & 3) == 0 && ((x_seed_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   LoadA_XT la{x_s, in_dim, B, vec_ok};
-  LoadB_Generic lb{dz1t + (long)s * ncols * ldb, (long)ldb, ncols, B, true};
+  LoadB_KContig lb{dz1t + (long)s * ncols * ldb, (long)ldb, ncols, B, true};
   EpiSgd epi{theta + (long)s * N * ldp, mask, ldp, hid, ncols, in_dim, lr};
   gemm_tile(la, lb, epi, blockIdx.y * BM, blockIdx.x * BN, B);
 }
@@ -235,7 +267,7 @@ __global__ __launch_bounds__(256) void k_layer1_backward_adam(const float* __res
   const float* x_s = x + (long)s * x_seed_stride;
   const bool vec_ok = (in_dim & 3) == 0 && ((x_seed_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   LoadA_XT la{x_s, in_dim, B, vec_ok};
-  LoadB_Generic lb{dz1t + (long)s * ncols * ldb, (long)ldb, ncols, B, true};
+  LoadB_KContig lb{dz1t + (long)s * ncols * ldb, (long)ldb, ncols, B, true};
   const long so = (long)s * N * ldp;
   EpiAdam epi{theta + so, adam_m + so, adam_v + so, mask, ldp, hid, ncols, in_dim, alpha, one_m_b1, one_m_b2, eps};
   gemm_tile(la, lb, epi, blockIdx.y * BM, blockIdx.x * BN, B);

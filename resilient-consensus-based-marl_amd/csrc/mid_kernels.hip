@@ -63,9 +63,9 @@ __device__ __forceinline__ float head1(const float* __restrict__ w3, float b3, c
 template <int K>
 __device__ __forceinline__ void block_reduce_store(float (&vals)[K], float* red, float* __restrict__ out) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) vals[k] = rc_wave_sum(vals[k]);
+  for (int k = 0; k < K; ++k) vals[k] = rc_wave_sum_lane63(vals[k]);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 63) {
     const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) red[w * K + k] = vals[k];

@@ -25,8 +25,11 @@
 #define RCMARL_EXPORT extern "C"
 typedef floatx16 rc_f32x16;
 #else
+// hipGetLastError() is sticky across the whole runtime (PyTorch's own calls included):
+// drop any stale error first so rcmarl_check_launch() reports THIS launch only.
 #define RCMARL_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+  do { (void)hipGetLastError();                              \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__); } while (0)
 #define RCMARL_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
   type* name = reinterpret_cast<type*>(name##_raw)
 #define RCMARL_EXPORT extern "C" __attribute__((visibility("default")))
@@ -75,6 +78,26 @@ __device__ __forceinline__ float rc_wave_sum(float v) {
 #else
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
+}
+
+// Wave-wide sum whose result is only needed in ONE lane (lane 63): six v_add_f32 with DPP
+// modifiers (quad_perm x2, row_half_mirror, row_mirror, row_bcast15, row_bcast31) instead of
+// six ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ float rc_wave_sum_lane63(float v) {
+#ifdef RCMARL_EMU
+  return rc_wave_sum(v);
+#else
+#define RC_DPP_ADD(ctrl, rmask) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xf, false))
+  RC_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+  RC_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+  RC_DPP_ADD(0x141, 0xf);   // row_half_mirror
+  RC_DPP_ADD(0x140, 0xf);   // row_mirror        -> every lane holds its 16-lane row sum
+  RC_DPP_ADD(0x142, 0xa);   // row_bcast15 into rows 1,3
+  RC_DPP_ADD(0x143, 0xc);   // row_bcast31 into rows 2,3 -> lane 63 holds the wave sum
+#undef RC_DPP_ADD
   return v;
 #endif
 }

@@ -15,7 +15,7 @@ def emu_lib():
     if _emu is None:
         import build_emu
         from rcmarl_amd.capi import CLib
-        _emu = CLib(build_emu.build_emu())
+        _emu = CLib(build_emu.build_emu(), needs_hip=False)
     return _emu
 
 
