@@ -43,9 +43,9 @@ int rcmarl_rows_per_chunk(void);                       /* replay rows per workgr
  * (agents/resilient_CAC_agents.py:142-166) + _resilient_aggregation (:42-58) for ALL
  * cooperative agents of all seeds (loop at training/train_agents.py:125-135).
  * theta[s][i][p] <- mean_k clamp(msg[s][nbr[i][k]][p], lower, upper), p < P_hid, coop[i] != 0.
- * nbr: int[N][d] with nbr[i][0] == i; coop: uint8[N].  lo_dbg/hi_dbg (both or neither,
+ * nbr: int[N][d] with nbr[i][0] == i; coop: int32[N] (0/1 flags).  lo_dbg/hi_dbg (both or neither,
  * [S][N][ldp]) receive the clip window for bit-exact tests. */
-int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const unsigned char* coop, int S, int N,
+int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const int* coop, int S, int N,
                             int ldp, int P_hid, int d, int H, float* lo_dbg, float* hi_dbg, void* stream);
 
 /* K4 layer 1 forward (shared input => one GEMM per seed), Keras Dense + LeakyReLU(0.1):
@@ -55,14 +55,14 @@ int rcmarl_layer1_forward(const float* x, long x_seed_stride, const float* theta
                           int in_dim, int hid, int ldp, int ldb, void* stream);
 
 /* K5 layer 1 backward + optimizer: W1[s][n][k][j] -= lr * sum_b x[s][b][k]*dz1t[s][n*hid+j][b]
- * (inside critic.fit / TR.fit, agents/resilient_CAC_agents.py:118,136); mask: uint8[N] or NULL. */
+ * (inside critic.fit / TR.fit, agents/resilient_CAC_agents.py:118,136); mask: int32[N] flags or NULL. */
 int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride, const float* dz1t, float* theta,
-                               const unsigned char* mask, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                               const int* mask, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
                                float lr, void* stream);
 /* same with the Adam rule of actor.train_on_batch (agents/resilient_CAC_agents.py:38,99):
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); w -= alpha*m/(sqrt(v)+eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t). */
 int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride, const float* dz1t, float* theta, float* adam_m,
-                                float* adam_v, const unsigned char* mask, int S, int N, int B, int in_dim, int hid,
+                                float* adam_v, const int* mask, int S, int N, int B, int in_dim, int hid,
                                 int ldp, int ldb, float alpha, float one_m_b1, float one_m_b2, float eps, void* stream);
 
 /* K4/K5 layers 2-3 of one full-batch SGD step of critic.fit / TR.fit with MSE loss
@@ -72,7 +72,7 @@ int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride, const float*
 int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B, int in_dim,
                    int hid, int ldp, int ldb, void* stream);
 /* reduce the partials over chunks and apply SGD to b1,W2,b2,W3,b3; loss_out[S][N] (or NULL) = MSE. */
-int rcmarl_small_sgd(const float* partials, float* theta, const unsigned char* mask, float* loss_out, int S, int N,
+int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
                      int B, int in_dim, int hid, int ldp, float lr, void* stream);
 
 /* K6: out[s][n][b] = head(a1t) (r_applied NULL), or the TD target r_applied + gamma*V
@@ -88,10 +88,10 @@ int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applie
  * a1t must hold layer-1 activations of theta (the freshly aggregated hidden layers).
  * agg_out[S][N][ldb] optional (tests). */
 int rcmarl_consensus_head(const float* a1t, const float* theta, const float* msg, const int* nbr,
-                          const unsigned char* coop, float* partials, float* agg_out, int S, int N, int B, int in_dim,
+                          const int* coop, float* partials, float* agg_out, int S, int N, int B, int in_dim,
                           int hid, int ldp, int ldb, int d, int H, void* stream);
 /* W3 += sum/B, b3 += sum/B: the normalised projection step (fast_lr cancels, :67-71). */
-int rcmarl_head_apply(const float* partials, float* theta, const unsigned char* coop, int S, int N, int B, int in_dim,
+int rcmarl_head_apply(const float* partials, float* theta, const int* coop, int S, int N, int B, int in_dim,
                       int hid, int ldp, void* stream);
 
 /* K7 actor: softmax + sample-weighted sparse CE forward/backward through layers 3-2
@@ -99,12 +99,12 @@ int rcmarl_head_apply(const float* partials, float* theta, const unsigned char* 
  * act_t, delta: [S][N][ldb] labels (as floats) and sample weights; a1t overwritten by dz1. */
 int rcmarl_mid_actor(float* a1t, const float* theta, const float* act_t, const float* delta, float* partials, int S,
                      int N, int B, int in_dim, int hid, int n_actions, int ldp, int ldb, void* stream);
-int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v, const unsigned char* mask,
+int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v, const int* mask,
                       float* loss_out, int S, int N, int B, int in_dim, int hid, int n_actions, int ldp, float alpha,
                       float one_m_b1, float one_m_b2, float eps, void* stream);
 
 /* r_coop[s][b] = sum_{coop n, index order} r[s][b][n]/n_coop   (training/train_agents.py:96-98) */
-int rcmarl_team_reward(const float* r, long seed_stride, const unsigned char* coop, int n_coop, float* rcoop, int S,
+int rcmarl_team_reward(const float* r, long seed_stride, const int* coop, int n_coop, float* rcoop, int S,
                        int N, int B, int ldb, void* stream);
 /* out[s][n][b] = src[s][b][n] (mode NULL or mode[n]==0), rcoop[s][b] (1), -rcoop[s][b] (2):
  * the r_applied selection of training/train_agents.py:106-116 and the a[:,node] slices of :151-153 */

@@ -70,7 +70,7 @@ struct TileStager {
 template <int D, int H>
 __global__ __launch_bounds__(256) void k_consensus_params(const float* __restrict__ msg, float* __restrict__ theta,
                                                           const int* __restrict__ nbr,
-                                                          const unsigned char* __restrict__ coop, int N, int ldp,
+                                                          const int* __restrict__ coop, int N, int ldp,
                                                           int P_hid, int log2tc, int tiles_per_seed, int total_tiles,
                                                           float* __restrict__ lo_dbg, float* __restrict__ hi_dbg) {
   RCMARL_DYN_SMEM(float, tile);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_consensus_params(const float* __restric
 __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* __restrict__ msg,
                                                                   float* __restrict__ theta,
                                                                   const int* __restrict__ nbr,
-                                                                  const unsigned char* __restrict__ coop, int N,
+                                                                  const int* __restrict__ coop, int N,
                                                                   int ldp, int P_hid, int log2tc, int d, int H,
                                                                   float* __restrict__ lo_dbg,
                                                                   float* __restrict__ hi_dbg) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* _
 }  // namespace
 
 // C-ABI: see include/rcmarl.h
-RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const unsigned char* coop,
+RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const int* coop,
                                           int S, int N, int ldp, int P_hid, int d, int H, float* lo_dbg,
                                           float* hi_dbg, void* stream) {
   if (!msg || !theta || !nbr || !coop || S <= 0 || N <= 0 || d <= 0 || H < 0 || d < 2 * H + 1 || (ldp & 63) ||

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_layer1_forward(const float* __restrict_
 
 // ---- backward: W1[k][col] <- W1[k][col] - lr * sum_b X[b][k] * dz1t[col][b] ------------
 struct EpiSgd {
-  float* theta_s; const unsigned char* mask; int ldp, hid, ncols, in_dim; float lr;
+  float* theta_s; const int* mask; int ldp, hid, ncols, in_dim; float lr;
   struct RowCtx {};
   __device__ __forceinline__ RowCtx row(int) const { return RowCtx(); }
   __device__ __forceinline__ void operator()(const RowCtx&, int m, int n, float g) const {
@@ -222,7 +222,7 @@ struct EpiSgd {
 
 // TF2 ResourceApplyAdam: m += (g-m)(1-b1); v += (g*g-v)(1-b2); w -= alpha*m/(sqrt(v)+eps)
 struct EpiAdam {
-  float* theta_s; float* m_s; float* v_s; const unsigned char* mask; int ldp, hid, ncols, in_dim;
+  float* theta_s; float* m_s; float* v_s; const int* mask; int ldp, hid, ncols, in_dim;
   float alpha, one_m_b1, one_m_b2, eps;
   struct RowCtx {};
   __device__ __forceinline__ RowCtx row(int) const { return RowCtx(); }
@@ -243,7 +243,7 @@ struct EpiAdam {
 
 __global__ __launch_bounds__(256) void k_layer1_backward_sgd(const float* __restrict__ x, long x_seed_stride,
                                                              const float* __restrict__ dz1t, float* __restrict__ theta,
-                                                             const unsigned char* __restrict__ mask, int N, int B,
+                                                             const int* __restrict__ mask, int N, int B,
                                                              int in_dim, int hid, int ldp, int ldb, float lr) {
   const int s = blockIdx.z;
   const int ncols = N * hid;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_layer1_backward_adam(const float* __res
                                                               const float* __restrict__ dz1t,
                                                               float* __restrict__ theta, float* __restrict__ adam_m,
                                                               float* __restrict__ adam_v,
-                                                              const unsigned char* __restrict__ mask, int N, int B,
+                                                              const int* __restrict__ mask, int N, int B,
                                                               int in_dim, int hid, int ldp, int ldb, float alpha,
                                                               float one_m_b1, float one_m_b2, float eps) {
   const int s = blockIdx.z;
@@ -290,7 +290,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward(const float* x, long x_seed_stride, cons
 }
 
 RCMARL_EXPORT int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride, const float* dz1t, float* theta,
-                                             const unsigned char* mask, int S, int N, int B, int in_dim, int hid,
+                                             const int* mask, int S, int N, int B, int in_dim, int hid,
                                              int ldp, int ldb, float lr, void* stream) {
   if (bad_common(x, dz1t, theta, S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
   const dim3 grid(rc_ceil_div(N * hid, BN), rc_ceil_div(in_dim, BM), S), block(256);
@@ -300,7 +300,7 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride,
 }
 
 RCMARL_EXPORT int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride, const float* dz1t, float* theta,
-                                              float* adam_m, float* adam_v, const unsigned char* mask, int S, int N,
+                                              float* adam_m, float* adam_v, const int* mask, int S, int N,
                                               int B, int in_dim, int hid, int ldp, int ldb, float alpha,
                                               float one_m_b1, float one_m_b2, float eps, void* stream) {
   if (bad_common(x, dz1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !adam_m || !adam_v) return RCMARL_ERR_ARG;

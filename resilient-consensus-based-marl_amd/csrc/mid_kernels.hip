@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_mid_fit(float* __restrict__ a1t, const 
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B
 template <int HID>
 __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ partials, float* __restrict__ theta,
-                                                   const unsigned char* __restrict__ mask,
+                                                   const int* __restrict__ mask,
                                                    float* __restrict__ loss_out, int N, int B, int in_dim, int ldp,
                                                    int nchunk, float lr) {
   typedef FitPart<HID> PT;
@@ -201,7 +201,7 @@ __device__ __forceinline__ float select_agg(const float (&v)[D]) {
 template <int HID, int D, int H>
 __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict__ a1t, const float* __restrict__ theta,
                                                         const float* __restrict__ msg, const int* __restrict__ nbr,
-                                                        const unsigned char* __restrict__ coop,
+                                                        const int* __restrict__ coop,
                                                         float* __restrict__ partials, float* __restrict__ agg_out,
                                                         int N, int B, int in_dim, int ldp, int ldb, int nchunk) {
   __shared__ float red[4 * (HID + 1)];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict_
 template <int HID>
 __global__ __launch_bounds__(256) void k_consensus_head_generic(
     const float* __restrict__ a1t, const float* __restrict__ theta, const float* __restrict__ msg,
-    const int* __restrict__ nbr, const unsigned char* __restrict__ coop, float* __restrict__ partials,
+    const int* __restrict__ nbr, const int* __restrict__ coop, float* __restrict__ partials,
     float* __restrict__ agg_out, int N, int B, int in_dim, int ldp, int ldb, int nchunk, int d, int H) {
   __shared__ float red[4 * (HID + 1)];
   RCMARL_DYN_SMEM(float, est);                // [d][ROWS]
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_consensus_head_generic(
 // W3 += (1/B) sum_chunks partial[0..HID) ; b3 += (1/B) sum partial[HID]     (cooperative agents)
 template <int HID>
 __global__ __launch_bounds__(64) void k_head_apply(const float* __restrict__ partials, float* __restrict__ theta,
-                                                   const unsigned char* __restrict__ coop, int N, int B, int in_dim,
+                                                   const int* __restrict__ coop, int N, int B, int in_dim,
                                                    int ldp, int nchunk) {
   const int s = blockIdx.y, i = blockIdx.x;
   if (!coop[i]) return;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_mid_actor(float* __restrict__ a1t, cons
 template <int HID, int A>
 __global__ __launch_bounds__(256) void k_small_adam(const float* __restrict__ partials, float* __restrict__ theta,
                                                     float* __restrict__ adam_m, float* __restrict__ adam_v,
-                                                    const unsigned char* __restrict__ mask,
+                                                    const int* __restrict__ mask,
                                                     float* __restrict__ loss_out, int N, int B, int in_dim, int ldp,
                                                     int nchunk, float alpha, float one_m_b1, float one_m_b2,
                                                     float eps) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_small_adam(const float* __restrict__ pa
 // K6 helpers
 // r_coop[s][b] = sum over cooperative agents (in index order) of r[s][b][n]/n_coop   (train_agents.py:96-98)
 __global__ __launch_bounds__(256) void k_team_reward(const float* __restrict__ r, long seed_stride,
-                                                     const unsigned char* __restrict__ coop, int n_coop,
+                                                     const int* __restrict__ coop, int n_coop,
                                                      float* __restrict__ rcoop, int N, int B, int ldb) {
   const int s = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -503,7 +503,7 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   return rcmarl_check_launch();
 }
 
-RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const unsigned char* mask, float* loss_out,
+RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out,
                                    int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream) {
   if (!partials || !theta || S <= 0 || N <= 0 || B <= 0) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS);
@@ -524,7 +524,7 @@ RCMARL_EXPORT int rcmarl_mid_value(const float* a1t, const float* theta, const f
 }
 
 RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, const float* msg, const int* nbr,
-                                        const unsigned char* coop, float* partials, float* agg_out, int S, int N,
+                                        const int* coop, float* partials, float* agg_out, int S, int N,
                                         int B, int in_dim, int hid, int ldp, int ldb, int d, int H, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !msg || !nbr || !coop || !partials || d <= 0 || H < 0 ||
       d < 2 * H + 1)
@@ -549,7 +549,7 @@ RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, co
   return rcmarl_check_launch();
 }
 
-RCMARL_EXPORT int rcmarl_head_apply(const float* partials, float* theta, const unsigned char* coop, int S, int N,
+RCMARL_EXPORT int rcmarl_head_apply(const float* partials, float* theta, const int* coop, int S, int N,
                                     int B, int in_dim, int hid, int ldp, void* stream) {
   if (!partials || !theta || !coop || S <= 0 || N <= 0 || B <= 0 || hid >= 64) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS);
@@ -572,7 +572,7 @@ RCMARL_EXPORT int rcmarl_mid_actor(float* a1t, const float* theta, const float* 
 }
 
 RCMARL_EXPORT int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v,
-                                    const unsigned char* mask, float* loss_out, int S, int N, int B, int in_dim,
+                                    const int* mask, float* loss_out, int S, int N, int B, int in_dim,
                                     int hid, int n_actions, int ldp, float alpha, float one_m_b1, float one_m_b2,
                                     float eps, void* stream) {
   if (!partials || !theta || !adam_m || !adam_v || S <= 0 || N <= 0 || B <= 0) return RCMARL_ERR_ARG;
@@ -584,7 +584,7 @@ RCMARL_EXPORT int rcmarl_small_adam(const float* partials, float* theta, float* 
   return rcmarl_check_launch();
 }
 
-RCMARL_EXPORT int rcmarl_team_reward(const float* r, long seed_stride, const unsigned char* coop, int n_coop,
+RCMARL_EXPORT int rcmarl_team_reward(const float* r, long seed_stride, const int* coop, int n_coop,
                                      float* rcoop, int S, int N, int B, int ldb, void* stream) {
   if (!r || !coop || !rcoop || S <= 0 || N <= 0 || B <= 0 || n_coop <= 0 || ldb < B) return RCMARL_ERR_ARG;
   const dim3 grid(rc_ceil_div(B, 256), S), block(256);

@@ -148,10 +148,10 @@ class RPBCACEngine:
         self.seeds_dev = torch.tensor(np.asarray(seeds, dtype=np.uint64).view(np.int64), dtype=torch.int64, device=self.dev)
         # graph / roles
         self.nbr = torch.tensor(np.asarray(c.in_nodes, dtype=np.int32), **i32)
-        coop = np.array([1 if l == COOP else 0 for l in c.agent_label], dtype=np.uint8)
+        coop = np.array([1 if l == COOP else 0 for l in c.agent_label], dtype=np.int32)
         self.coop_np = coop
         self.n_coop = int(coop.sum())
-        self.coop = torch.tensor(coop, dtype=torch.uint8, device=self.dev)
+        self.coop = torch.tensor(coop, dtype=torch.int32, device=self.dev)
         mode = np.array([(1 if c.common_reward else 0) if l == COOP else 0 for l in c.agent_label], dtype=np.int32)
         self.fit_mode = torch.tensor(mode, **i32)
         self.episode = 0                      # global episode counter

@@ -81,7 +81,7 @@ def check_consensus_params(bk, N, d, H, P, P_hid, graph, S=2):
     rng = np.random.default_rng(N * 100 + d)
     ldp = pad64(P)
     nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
-    coop = np.ones(N, np.uint8)
+    coop = np.ones(N, np.int32)
     coop[N - 1] = 0
     base = rng.normal(size=(S, 1, ldp)).astype(np.float32)
     msg = (base + 0.01 * rng.normal(size=(S, N, ldp))).astype(np.float32)
@@ -145,7 +145,7 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
     x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
     nx = rng.normal(size=(S, B, in_dim)).astype(np.float32)
     r_applied = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    mask = np.ones(N, np.uint8)
+    mask = np.ones(N, np.int32)
     if masked_agent is not None:
         mask[masked_agent] = 0
     nchunk = (B + 255) // 256
@@ -196,7 +196,7 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
     theta, msg = pack_rows(live, ldp), pack_rows(msgp, ldp)
     x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
     nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
-    coop = np.ones(N, np.uint8)
+    coop = np.ones(N, np.int32)
     coop[0] = 0
     for s in range(S):                              # an outlier head among the messages
         msg[s, 1, P_hid:P] *= 50.0
@@ -239,7 +239,7 @@ def check_actor_step(bk, S, N, B, in_dim, steps=2, lr=0.002):
     x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
     act = rng.integers(0, A, size=(S, N, ldb)).astype(np.float32)
     delta = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    mask = np.ones(N, np.uint8)
+    mask = np.ones(N, np.int32)
     mask[N - 1] = 0
     nchunk = (B + 255) // 256
     psz = bk.lib.rcmarl_actor_partial_size(HID, A)
@@ -286,7 +286,7 @@ def check_reward_helpers(bk, S, N, B):
     ldb = pad64(B)
     cap = B + 7
     r = rng.normal(size=(S, cap, N)).astype(np.float32)
-    coop = np.ones(N, np.uint8)
+    coop = np.ones(N, np.int32)
     coop[N // 2] = 0
     n_coop = int(coop.sum())
     mode = np.zeros(N, np.int32)
