@@ -90,6 +90,11 @@ int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applie
 int rcmarl_consensus_head(const float* a1t, const float* theta, const float* msg, const int* nbr,
                           const int* coop, float* partials, float* agg_out, int S, int N, int B, int in_dim,
                           int hid, int ldp, int ldb, int d, int H, void* stream);
+/* K3 alone: the same projection residual toward a caller-supplied aggregate agg[S][N][ldb]
+ * (critic_update_team(s, agg) / TR_update_team(sa, agg) called on their own, :60-84). */
+int rcmarl_projection_residual(const float* a1t, const float* theta, const float* agg, const int* coop,
+                               float* partials, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                               void* stream);
 /* W3 += sum/B, b3 += sum/B: the normalised projection step (fast_lr cancels, :67-71). */
 int rcmarl_head_apply(const float* partials, float* theta, const int* coop, int S, int N, int B, int in_dim,
                       int hid, int ldp, void* stream);
@@ -102,6 +107,23 @@ int rcmarl_mid_actor(float* a1t, const float* theta, const float* act_t, const f
 int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v, const int* mask,
                       float* loss_out, int S, int N, int B, int in_dim, int hid, int n_actions, int ldp, float alpha,
                       float one_m_b1, float one_m_b2, float eps, void* stream);
+
+/* X1: one whole Keras fit() of the adversaries' networks per launch (one workgroup per (seed, adversary)).
+ * agents: int[n_adv] agent indices; the rows theta[s][agents[k]] are trained IN PLACE.
+ * perm: int[S][n_adv][epochs][B] row permutation per epoch (Keras shuffle; NULL = natural order).
+ * rcmarl_minibatch_fit: SGD + MSE against y[S][N][ldb]  -- Greedy/Malicious critic & TR fits,
+ *   fit(batch_size=32, epochs=10), agents/adversarial_CAC_agents.py:121-165, 228-253.
+ * rcmarl_minibatch_actor: Adam + sample-weighted sparse CE -- the adversaries' actor_update,
+ *   fit(batch_size=200, epochs=1), :38-41, :111-117, :221-225.  t0 = Adam steps taken before this call.
+ * loss_out[S][N] (or NULL): first-epoch loss. */
+int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float* theta, const int* agents, int n_adv,
+                         const float* y, const int* perm, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                         int batch_size, int epochs, float lr, float* loss_out, void* stream);
+int rcmarl_minibatch_actor(const float* x, long x_seed_stride, float* theta, float* adam_m, float* adam_v,
+                           const int* agents, int n_adv, const float* act_t, const float* delta, const int* perm, int S,
+                           int N, int B, int in_dim, int hid, int n_actions, int ldp, int ldb, int batch_size,
+                           int epochs, double lr, double beta1, double beta2, double eps, int t0, float* loss_out,
+                           void* stream);
 
 /* r_coop[s][b] = sum_{coop n, index order} r[s][b][n]/n_coop   (training/train_agents.py:96-98) */
 int rcmarl_team_reward(const float* r, long seed_stride, const int* coop, int n_coop, float* rcoop, int S,

@@ -57,6 +57,18 @@ SIGNATURES = {
                           c_int, c_float, c_float, c_float, c_float, c_stream],
     # r, seed_stride, coop, n_coop, rcoop, S, N, B, ldb, stream
     "rcmarl_team_reward": [c_f32p, c_long, c_u8p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_stream],
+    # a1t, theta, agg, coop, partials, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_projection_residual": [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_stream],
+    # x, x_seed_stride, theta, agents, n_adv, y, perm, S, N, B, in_dim, hid, ldp, ldb, batch_size, epochs, lr,
+    # loss_out, stream
+    "rcmarl_minibatch_fit": [c_f32p, c_long, c_f32p, c_i32p, c_int, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_float, c_f32p, c_stream],
+    # x, x_seed_stride, theta, adam_m, adam_v, agents, n_adv, act_t, delta, perm, S, N, B, in_dim, hid, n_actions,
+    # ldp, ldb, batch_size, epochs, lr, beta1, beta2, eps, t0, loss_out, stream
+    "rcmarl_minibatch_actor": [c_f32p, c_long, c_f32p, c_f32p, c_f32p, c_i32p, c_int, c_f32p, c_f32p, c_i32p, c_int,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, C.c_double, C.c_double,
+                               C.c_double, C.c_double, c_int, c_f32p, c_stream],
     # src, seed_stride, rcoop, mode, out, S, N, B, ldb, stream
     "rcmarl_gather_agent_major": [c_f32p, c_long, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_stream],
     # r_team, v_next, v_cur, gamma, delta, n_total, stream

@@ -288,6 +288,38 @@ __global__ __launch_bounds__(256) void k_consensus_head_generic(
   block_reduce_store<HID + 1>(proj, red, out);
 }
 
+// K3 alone: projection residual toward a caller-supplied aggregate agg_in[S][N][ldb]
+// (critic_update_team(s, agg) / TR_update_team(sa, agg), agents/resilient_CAC_agents.py:60-84);
+// same partial records as k_consensus_head.
+template <int HID>
+__global__ __launch_bounds__(256) void k_projection(const float* __restrict__ a1t, const float* __restrict__ theta,
+                                                    const float* __restrict__ agg_in, const int* __restrict__ coop,
+                                                    float* __restrict__ partials, int N, int B, int in_dim, int ldp,
+                                                    int ldb, int nchunk) {
+  __shared__ float red[4 * (HID + 1)];
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  if (!coop[i]) return;
+  const int b = chunk * ROWS + threadIdx.x;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  float a1[HID], phi[HID];
+  load_a1<HID>(a1t, ((long)s * N + i) * HID, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, phi);
+  float nrm = 0.f;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) nrm = fmaf(phi[k], phi[k], nrm);
+  nrm += 1.0f;
+  const float v_live = head1<HID>(th + g.o_W3, th[g.o_b3], phi);
+  const float e = valid ? (agg_in[((long)s * N + i) * ldb + b] - v_live) / nrm : 0.f;
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (HID + 1);
+  float proj[HID + 1];
+#pragma unroll
+  for (int k = 0; k < HID; ++k) proj[k] = e * phi[k];
+  proj[HID] = e;
+  block_reduce_store<HID + 1>(proj, red, out);
+}
+
 // W3 += (1/B) sum_chunks partial[0..HID) ; b3 += (1/B) sum partial[HID]     (cooperative agents)
 template <int HID>
 __global__ __launch_bounds__(64) void k_head_apply(const float* __restrict__ partials, float* __restrict__ theta,
@@ -546,6 +578,17 @@ RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, co
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_consensus_head_generic<HID_>), grid, block, smem, stream, a1t, theta, msg, nbr,
                                      coop, partials, agg_out, N, B, in_dim, ldp, ldb, nchunk, d, H));
   }
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_projection_residual(const float* a1t, const float* theta, const float* agg, const int* coop,
+                                             float* partials, int S, int N, int B, int in_dim, int hid, int ldp,
+                                             int ldb, void* stream) {
+  if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !agg || !coop || !partials) return RCMARL_ERR_ARG;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(nchunk, N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_projection<HID_>), grid, block, 0, stream, a1t, theta, agg, coop, partials, N, B,
+                                   in_dim, ldp, ldb, nchunk));
   return rcmarl_check_launch();
 }
 

@@ -110,6 +110,12 @@ class RPBCACEngine:
         self.ldb = pad64(self.cap)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.theta = {k: torch.zeros(S, N, self.ldp[k], **f32) for k in ("actor", "critic", "tr")}
+        if MALICIOUS in c.agent_label:
+            # Malicious agents keep a private critic for their own actor (adversarial_CAC_agents.py:101);
+            # only their rows of this matrix are meaningful
+            for d_ in (self.P, self.in_dim, self.out_dim, self.ldp):
+                d_["critic_local"] = d_["critic"]
+            self.theta["critic_local"] = torch.zeros(S, N, self.ldp["critic"], **f32)
         self.msg = {k: torch.zeros(S, N, self.ldp[k], **f32) for k in ("critic", "tr")}
         self.adam_m = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
@@ -152,7 +158,9 @@ class RPBCACEngine:
         self.coop_np = coop
         self.n_coop = int(coop.sum())
         self.coop = torch.tensor(coop, dtype=torch.int32, device=self.dev)
-        mode = np.array([(1 if c.common_reward else 0) if l == COOP else 0 for l in c.agent_label], dtype=np.int32)
+        # reward each agent fits on (train_agents.py:106-116): own / r_coop (common_reward) / -r_coop (Malicious)
+        mode = np.array([(1 if c.common_reward else 0) if l == COOP else (2 if l == MALICIOUS else 0)
+                         for l in c.agent_label], dtype=np.int32)
         self.fit_mode = torch.tensor(mode, **i32)
         self.episode = 0                      # global episode counter
         self.timers = {"rollout": 0.0, "phase1": 0.0, "phase2": 0.0, "phase3": 0.0, "blocks": 0}
@@ -177,6 +185,8 @@ class RPBCACEngine:
         vec = flatten_params(params)
         assert vec.size == self.P[net], (net, vec.size, self.P[net])
         self.theta[net][seed_idx, agent, :vec.size] = torch.from_numpy(vec).to(self.dev)
+        if net == "critic" and "critic_local" in self.theta:     # Malicious ctor: critic_local = copy(critic) (:101)
+            self.theta["critic_local"][seed_idx, agent, :vec.size] = self.theta["critic"][seed_idx, agent, :vec.size]
 
     def get_weights(self, seed_idx, agent, net):
         vec = self.theta[net][seed_idx, agent, :self.P[net]].detach().cpu().numpy()
@@ -187,6 +197,8 @@ class RPBCACEngine:
         arr = np.asarray(array, dtype=np.float32)
         assert arr.shape == (self.S, self.N, self.P[net])
         self.theta[net][:, :, :self.P[net]] = torch.from_numpy(arr).to(self.dev)
+        if net == "critic" and "critic_local" in self.theta:
+            self.theta["critic_local"].copy_(self.theta["critic"])
 
     def get_all_weights(self, net):
         return self.theta[net][:, :, :self.P[net]].detach().cpu().numpy()

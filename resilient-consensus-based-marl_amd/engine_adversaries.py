@@ -1,0 +1,129 @@
+"""Adversary message generators and actor updates of the batched engine.
+
+Replaces, for all seeds at once, what the reference does per adversarial agent in
+``training/train_agents.py:107-119,149-153`` through
+``agents/adversarial_CAC_agents.py``:
+
+  Faulty    transmits its frozen critic / TR                      (:45-55)
+  Greedy    fits critic / TR on its OWN reward, mini-batches of 32, 10 epochs,
+            in place (no rollback) and transmits them             (:228-253)
+  Malicious fits a private critic on its own reward (:137-152) and transmits a
+            "compromised" critic / TR fitted on -r_coop           (:121-135, :154-165;
+            train_agents.py:113-116)
+  all three actor_update = TD error of their own critic, then
+            fit(batch_size=200, epochs=1) with Adam               (:38-41, :111-117, :221-225)
+
+Every Keras ``fit`` is ONE kernel launch (csrc/minibatch_fit.hip): the whole
+sequence of mini-batch steps of one (seed, adversary) network runs inside one
+workgroup.  Keras shuffles with TensorFlow's RNG; here the permutations come from
+the stream the oracle defines (``default_rng([seed, n_th_fit_call])``), drawn in
+the reference's call order so that oracle and engine stay in lock step.
+"""
+import numpy as np
+import torch
+
+HID = 20
+COOP, FAULTY, GREEDY, MALICIOUS = "Cooperative", "Faulty", "Greedy", "Malicious"
+FIT_BATCH, FIT_EPOCHS, ACTOR_BATCH = 32, 10, 200
+
+
+class AdversaryPath:
+    def __init__(self, eng):
+        self.e = eng
+        labels = eng.cfg.agent_label
+        self.adv = [i for i, l in enumerate(labels) if l != COOP]
+        self.fit = [i for i in self.adv if labels[i] in (GREEDY, MALICIOUS)]
+        self.mal = [i for i in self.adv if labels[i] == MALICIOUS]
+        dev = eng.dev
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.adv_t = torch.tensor(self.adv, **i32)
+        self.fit_t = torch.tensor(self.fit, **i32) if self.fit else None
+        self.mal_t = torch.tensor(self.mal, **i32) if self.mal else None
+        self.fit_idx = torch.tensor(self.fit, dtype=torch.long, device=dev) if self.fit else None
+        self.mal_idx = torch.tensor(self.mal, dtype=torch.long, device=dev) if self.mal else None
+        self.calls = [0] * eng.S                       # ShuffleStream.calls per seed
+        self.adam_t = 0                                # Adam steps every adversary's actor has taken
+        f32 = dict(dtype=torch.float32, device=dev)
+        for k in ("r_own", "y_l", "delta_adv", "v_next_adv", "v_cur_adv"):
+            eng.ybuf[k] = torch.zeros(eng.S, eng.N, eng.ldb, **f32)
+        self.mode0 = torch.zeros(eng.N, **i32)
+
+    # -- the oracle's ShuffleStream, one per seed -------------------------------------------
+    def _perms(self, s, epochs, B):
+        g = np.random.default_rng([int(self.e.seeds[s]), self.calls[s]])
+        self.calls[s] += 1
+        return np.stack([g.permutation(B) for _ in range(epochs)]).astype(np.int32)
+
+    def _draw(self, plan, epochs, B):
+        """plan: list of (agent, key) in the reference's call order -> {key: int32 tensor [S][n][epochs][B]}"""
+        S = self.e.S
+        out = {}
+        for s in range(S):
+            for agent, key in plan:
+                out.setdefault(key, [[] for _ in range(S)])[s].append(self._perms(s, epochs, B))
+        return {k: torch.from_numpy(np.stack([np.stack(v[s]) for s in range(S)])).to(self.e.dev) for k, v in out.items()}
+
+    # -- phase I of every consensus epoch ----------------------------------------------------
+    def phase1(self, B):
+        e, L = self.e, self.e.lib
+        if not self.fit:
+            return                                     # only Faulty agents: msg rows already = frozen theta rows
+        labels = e.cfg.agent_label
+        plan = []
+        for i in self.fit:                             # train_agents.py:105-119, agent index order
+            if labels[i] == MALICIOUS:
+                plan.append((i, "local"))
+            plan.append((i, "tr"))
+            plan.append((i, "critic"))
+        perms = self._draw(plan, FIT_EPOCHS, B)
+        S, N = e.S, e.N
+        if self.mal:                                   # private critic: own reward, own bootstrap (:137-152)
+            rptr, rstride = e._x("r")
+            L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, B, e.ldb, e.stream)
+            e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"])
+            xptr, xstride = e._x("s")
+            L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic_local"].data_ptr(), self.mal_t.data_ptr(), len(self.mal),
+                                   e.ybuf["y_l"].data_ptr(), perms["local"].data_ptr(), S, N, B, e.in_c, HID,
+                                   e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, None, e.stream)
+        # transmitted TR: targets r_fit (own reward for Greedy, -r_coop for Malicious)
+        xptr, xstride = e._x("sa")
+        L.rcmarl_minibatch_fit(xptr, xstride, e.theta["tr"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
+                               e.ybuf["r_fit"].data_ptr(), perms["tr"].data_ptr(), S, N, B, e.in_r, HID, e.ldp["tr"],
+                               e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(), e.stream)
+        # transmitted critic: targets y_c = r_fit + gamma*V_theta(ns), computed from the pre-fit weights
+        xptr, xstride = e._x("s")
+        L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
+                               e.ybuf["y_c"].data_ptr(), perms["critic"].data_ptr(), S, N, B, e.in_c, HID,
+                               e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["critic"].data_ptr(),
+                               e.stream)
+        for net in ("tr", "critic"):                   # the fitted nets ARE the messages (no rollback)
+            e.msg[net].index_copy_(1, self.fit_idx, e.theta[net].index_select(1, self.fit_idx))
+
+    # -- phase III ---------------------------------------------------------------------------
+    def actor_updates(self, B):
+        e, L = self.e, self.e.lib
+        S, N, nl = e.S, e.N, e.n_last
+        row0 = B - nl
+        shuffle = nl > ACTOR_BATCH
+        perms = self._draw([(i, "actor") for i in self.adv], 1, nl)["actor"] if shuffle else None
+        own = e.theta["critic"]
+        if self.mal:
+            own = own.clone()
+            own.index_copy_(1, self.mal_idx, e.theta["critic_local"].index_select(1, self.mal_idx))
+        rptr, rstride = e._x("r", row0)
+        L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, nl, e.ldb, e.stream)
+        e._value("ns", own, "critic", e.ybuf["v_next_adv"], nl, row0)
+        e._value("s", own, "critic", e.ybuf["v_cur_adv"], nl, row0)
+        L.rcmarl_td_error(e.ybuf["r_own"].data_ptr(), e.ybuf["v_next_adv"].data_ptr(), e.ybuf["v_cur_adv"].data_ptr(),
+                          e.cfg.gamma, e.ybuf["delta_adv"].data_ptr(), S * N * e.ldb, e.stream)
+        sptr, sstride = e._x("s", row0)
+        L.rcmarl_minibatch_actor(sptr, sstride, e.theta["actor"].data_ptr(), e.adam_m.data_ptr(), e.adam_v.data_ptr(),
+                                 self.adv_t.data_ptr(), len(self.adv), e.ybuf["act_t"].data_ptr(),
+                                 e.ybuf["delta_adv"].data_ptr(), None if perms is None else perms.data_ptr(), S, N, nl,
+                                 e.in_c, HID, e.cfg.n_actions, e.ldp["actor"], e.ldb, ACTOR_BATCH, 1, e.cfg.slow_lr,
+                                 0.9, 0.999, 1e-7, self.adam_t, e.loss["actor"].data_ptr(), e.stream)
+        self.adam_t += (nl + ACTOR_BATCH - 1) // ACTOR_BATCH
+
+
+def attach(eng):
+    eng.adv = AdversaryPath(eng)

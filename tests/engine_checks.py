@@ -86,3 +86,8 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4):
                     tol = rtol_w * scale if net != "actor" else 0.05 * eng.cfg.slow_lr * max(1, eng.adam_t) + 1e-5
                     err = float(np.abs(a - b).max())
                     assert err <= tol, (s, i, net, err, tol)
+            if len(o_weights[s][i]) == 4:                       # Malicious: private critic (adversarial:180-182)
+                got = eng.get_weights(s, i, "critic_local")
+                for a, b in zip(got, o_weights[s][i][3]):
+                    scale = max(1.0, float(np.abs(b).max()))
+                    assert float(np.abs(a - b).max()) <= rtol_w * scale, (s, i, "critic_local")

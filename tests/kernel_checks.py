@@ -399,3 +399,115 @@ def check_rollout(bk, S, N, nrow, ncol, steps=6, mode="device"):
             np.testing.assert_array_equal(H["sa"][s, j], np.concatenate([st.astype(np.float32), act[s].astype(np.float32)[:, None]], axis=1).ravel())
     np.testing.assert_array_equal(bk.host(d_ret), want_ret)      # float64, same operation order
     assert n_flip == 0, "%d sampled actions differ from the oracle's Philox stream" % n_flip
+
+
+# ------------------------------------------------------------------------------------------
+def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shuffle=True):
+    """X1: whole mini-batch fit(batch_size, epochs) of the adversaries' critic/TR in one launch
+    vs oracle mlp_np.fit_mse with the same permutations."""
+    rng = np.random.default_rng(S * 31 + N * 7 + B + in_dim)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(params, ldp)
+    cap = B + 5
+    x = rng.normal(size=(S, cap, in_dim)).astype(np.float32)
+    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    advs = np.asarray(advs, np.int32)
+    nA = len(advs)
+    perm = np.stack([[[rng.permutation(B) for _ in range(epochs)] for _ in range(nA)] for _ in range(S)]).astype(np.int32)
+    d_x, d_th, d_y, d_adv, d_perm = bk.dev(x), bk.dev(theta), bk.dev(y), bk.dev(advs), bk.dev(perm)
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    bk.lib.rcmarl_minibatch_fit(bk.ptr(d_x), cap * in_dim, bk.ptr(d_th), bk.ptr(d_adv), nA, bk.ptr(d_y),
+                                bk.ptr(d_perm) if shuffle else None, S, N, B, in_dim, HID, ldp, ldb, bs, epochs, lr,
+                                bk.ptr(d_loss), bk.stream)
+    th_new, loss = bk.host(d_th), bk.host(d_loss)
+    for s in range(S):
+        for n in range(N):
+            if n not in advs:
+                np.testing.assert_array_equal(th_new[s, n], theta[s, n])
+                continue
+            k = list(advs).index(n)
+            pw = M.copy_params(params[s][n])
+            hist = M.fit_mse(pw, x[s, :B], y[s, n, :B], lr, epochs=epochs, batch_size=bs,
+                             perms=perm[s, k] if shuffle else np.tile(np.arange(B), (epochs, 1)))
+            got = unpack_row(th_new[s, n], in_dim, 1)
+            for q in range(6):
+                rel_close(got[q], pw[q], 2e-5, "minibatch fit param %d" % q)
+            assert abs(loss[s, n] - hist[0]) <= 2e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+
+
+def check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=200, lr=0.002, t0=0, shuffle=True):
+    """X1: the adversaries' actor fit(batch_size=200, epochs=1) with Adam vs oracle fit_actor_ce."""
+    rng = np.random.default_rng(S * 13 + N * 5 + B + in_dim)
+    A = 5
+    P, _ = geom(in_dim, A)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, A)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    act = rng.integers(0, A, size=(S, N, ldb)).astype(np.float32)
+    delta = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    advs = np.asarray(advs, np.int32)
+    nA = len(advs)
+    perm = np.stack([[[rng.permutation(B)] for _ in range(nA)] for _ in range(S)]).astype(np.int32)
+    m0 = (0.01 * rng.normal(size=theta.shape)).astype(np.float32) if t0 else np.zeros_like(theta)
+    v0 = (1e-4 * rng.random(size=theta.shape)).astype(np.float32) if t0 else np.zeros_like(theta)
+    d_x, d_th, d_act, d_delta, d_adv, d_perm = bk.dev(x), bk.dev(theta), bk.dev(act), bk.dev(delta), bk.dev(advs), bk.dev(perm)
+    d_m, d_v = bk.dev(m0), bk.dev(v0)
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    bk.lib.rcmarl_minibatch_actor(bk.ptr(d_x), B * in_dim, bk.ptr(d_th), bk.ptr(d_m), bk.ptr(d_v), bk.ptr(d_adv), nA,
+                                  bk.ptr(d_act), bk.ptr(d_delta), bk.ptr(d_perm) if shuffle else None, S, N, B, in_dim, HID,
+                                  A, ldp, ldb, bs, 1, lr, 0.9, 0.999, 1e-7, t0, bk.ptr(d_loss), bk.stream)
+    th_new, loss = bk.host(d_th), bk.host(d_loss)
+    nsteps = (B + bs - 1) // bs
+    for s in range(S):
+        for n in range(N):
+            if n not in advs:
+                np.testing.assert_array_equal(th_new[s, n], theta[s, n])
+                continue
+            k = list(advs).index(n)
+            pw = M.copy_params(params[s][n])
+            st = M.AdamState(pw, lr)
+            st.t = t0
+            st.m = unpack_row(m0[s, n], in_dim, A)
+            st.v = unpack_row(v0[s, n], in_dim, A)
+            l = M.fit_actor_ce(pw, st, x[s], act[s, n, :B], delta[s, n, :B], epochs=1, batch_size=bs,
+                               perms=perm[s, k] if shuffle else None)[0]
+            assert abs(loss[s, n] - l) <= 2e-5 * max(1.0, abs(l)), (loss[s, n], l)
+            got = unpack_row(th_new[s, n], in_dim, A)
+            for q in range(6):
+                assert np.abs(got[q] - pw[q]).max() <= 0.02 * lr * nsteps + 1e-6, ("mb actor param", q, np.abs(got[q] - pw[q]).max())
+
+
+def check_projection(bk, S, N, B, in_dim):
+    """K3 alone: projection step toward a caller-supplied aggregate."""
+    rng = np.random.default_rng(S + N + B + in_dim)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    live = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(live, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    agg = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    coop = np.ones(N, np.int32)
+    coop[N - 1] = 0
+    nchunk = (B + 255) // 256
+    d_x, d_th, d_agg, d_coop = bk.dev(x), bk.dev(theta), bk.dev(agg), bk.dev(coop)
+    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+    d_part = bk.dev(np.zeros((S, N, nchunk, HID + 1), np.float32))
+    L = bk.lib
+    _layer1(bk, d_x, B * in_dim, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    L.rcmarl_projection_residual(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_agg), bk.ptr(d_coop), bk.ptr(d_part), S, N, B, in_dim,
+                                 HID, ldp, ldb, bk.stream)
+    L.rcmarl_head_apply(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_coop), S, N, B, in_dim, HID, ldp, bk.stream)
+    th_new = bk.host(d_th)
+    for s in range(S):
+        for i in range(N):
+            if not coop[i]:
+                np.testing.assert_array_equal(th_new[s, i], theta[s, i])
+                continue
+            ag = O.CoopAgent(M.init_mlp(rng, in_dim, HID, 5), live[s][i], live[s][i], 0.002, 0.01, 0.9, 0)
+            ag.projection_step_critic(x[s], agg[s, i, :B, None])
+            got = unpack_row(th_new[s, i], in_dim, 1)
+            rel_close(got[4], ag.critic[4], 2e-5, "W3 after projection")
+            rel_close(got[5], ag.critic[5], 2e-5, "b3 after projection")

@@ -18,3 +18,11 @@ def test_engine_common_reward_H0():
                         common_reward=True)
     eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, "device", "cpu", emu_lib(), seeds=(5,))
     EC.compare(eng, logs, o_logs, o_w)
+
+
+@pytest.mark.parametrize("labels", [["Cooperative"] * 4 + ["Malicious"], ["Cooperative", "Greedy", "Cooperative", "Cooperative", "Faulty"]])
+def test_engine_with_adversaries(labels):
+    """BASELINE configs[1]: 4 cooperative + 1 adversary, H=1 (mini-batch message generators in one launch per fit)."""
+    args = EC.make_args(labels, H=1, n_episodes=4, max_ep_len=4, n_ep_fixed=2, n_epochs=2, buffer_size=12, seed=21)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(21, 22))
+    EC.compare(eng, logs, o_logs, o_w)

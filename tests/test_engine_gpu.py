@@ -28,3 +28,12 @@ def test_engine_12_agents_H2():
                         in_nodes=in_nodes)
     eng, logs, o_logs, o_w = EC.run_pair(args, 8, 8, "device", "cuda", None, seeds=(9, 10))
     EC.compare(eng, logs, o_logs, o_w)
+
+
+@pytest.mark.parametrize("labels", [["Cooperative"] * 4 + ["Malicious"], ["Cooperative", "Greedy", "Cooperative", "Cooperative", "Faulty"]])
+def test_engine_with_adversaries(labels):
+    """BASELINE configs[1] (4 cooperative + 1 Malicious, H=1) and a Greedy+Faulty mix: shuffled
+    mini-batch fits (32 x 10 epochs) and shuffled actor fits (200-row Adam mini-batches)."""
+    args = EC.make_args(labels, H=1, n_episodes=30, max_ep_len=20, n_ep_fixed=15, n_epochs=2, buffer_size=450, seed=300)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cuda", None, seeds=(300, 301))
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)

@@ -67,3 +67,18 @@ def test_reward_helpers(bk):
 @pytest.mark.parametrize("S,N,nrow,ncol,mode", [(2, 5, 5, 5, "device"), (1, 70, 16, 16, "device"), (2, 5, 5, 5, "host")])
 def test_rollout(bk, S, N, nrow, ncol, mode):
     KC.check_rollout(bk, S, N, nrow, ncol, steps=5, mode=mode)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(2, 5, 100, 10, [4], 32, True), (1, 5, 70, 15, [1, 3], 32, True),
+                                                          (1, 2, 40, 140, [0], 32, False)])
+def test_minibatch_fit(bk, S, N, B, in_dim, advs, bs, shuffle):
+    KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=shuffle)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,t0", [(2, 5, 100, 10, [4], 40, 0), (1, 3, 60, 6, [0, 2], 200, 7)])
+def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
+    KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=B > bs)
+
+
+def test_projection(bk):
+    KC.check_projection(bk, 2, 3, 300, 6)

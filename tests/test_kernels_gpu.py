@@ -78,3 +78,20 @@ def test_reward_helpers(bk):
 @pytest.mark.parametrize("S,N,nrow,ncol,mode", [(3, 5, 5, 5, "device"), (2, 70, 16, 16, "device"), (2, 5, 5, 5, "host")])
 def test_rollout(bk, S, N, nrow, ncol, mode):
     KC.check_rollout(bk, S, N, nrow, ncol, steps=20, mode=mode)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(2, 5, 1000, 10, [4], 32, True), (1, 5, 3000, 15, [1, 3], 32, True),
+                                                          (1, 64, 500, 192, [0, 63], 32, True), (1, 256, 200, 768, [7], 32, False)])
+def test_minibatch_fit(bk, S, N, B, in_dim, advs, bs, shuffle):
+    KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,t0", [(2, 5, 1000, 10, [4], 200, 0), (1, 5, 1000, 10, [0, 2], 200, 15),
+                                                     (1, 64, 400, 128, [5], 200, 3)])
+def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
+    KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=True)
+
+
+def test_projection(bk):
+    KC.check_projection(bk, 2, 5, 1000, 10)
+    KC.check_projection(bk, 1, 16, 700, 48)
