@@ -203,6 +203,25 @@ class RPBCACEngine:
     def get_all_weights(self, net):
         return self.theta[net][:, :, :self.P[net]].detach().cpu().numpy()
 
+    def load_adam(self, seed_idx, agent, m, v, t):
+        """Adam slots of one actor (flat fp32 vectors in parameter-row order) and its step count.
+        The batched engine keeps ONE step counter for all cooperative actors (they all take one step
+        per block), so `t` must agree across cooperative agents."""
+        n = self.P["actor"]
+        self.adam_m[seed_idx, agent, :n] = torch.from_numpy(np.asarray(m, np.float32)).to(self.dev)
+        self.adam_v[seed_idx, agent, :n] = torch.from_numpy(np.asarray(v, np.float32)).to(self.dev)
+        if self.cfg.agent_label[agent] == COOP:
+            self.adam_t = int(t)
+        else:
+            self._require_adversary_support()
+            self.adv.adam_t = int(t)
+
+    def dump_adam(self, seed_idx, agent):
+        n = self.P["actor"]
+        t = self.adam_t if self.cfg.agent_label[agent] == COOP else (self.adv.adam_t if hasattr(self, "adv") else 0)
+        return (self.adam_m[seed_idx, agent, :n].detach().cpu().numpy().copy(),
+                self.adam_v[seed_idx, agent, :n].detach().cpu().numpy().copy(), int(t))
+
     def init_glorot(self, base_seed=0):
         """Keras-default initialisation (Glorot-uniform kernels, zero biases; reference
         main.py:59-82) drawn from a NumPy generator per seed (TensorFlow's own init
@@ -226,7 +245,7 @@ class RPBCACEngine:
         d = np.asarray(desired, dtype=np.int32)
         if d.ndim == 2:
             d = np.broadcast_to(d, (self.S, self.N, 2))
-        self.goal.copy_(torch.from_numpy(np.ascontiguousarray(d)).to(self.dev))
+        self.goal.copy_(torch.from_numpy(np.array(d, dtype=np.int32)).to(self.dev))
 
     def load_replay(self, states, nstates, actions, rewards, seed_idx=0):
         """exp_buffer of the reference API (train_agents.py:36-40): lists of per-step arrays."""
