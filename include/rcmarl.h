@@ -162,6 +162,24 @@ int rcmarl_env_apply(const int* pos, const int* goal, const int* actions, int nr
 int rcmarl_env_reset(const int* pos_in, const unsigned long long* seeds, int nrow, int ncol, const double* scale,
                      int episode, int* pos, float* xs, double* ret, int S, int N, void* stream);
 
+/* Episode-parallel rollout (rng_mode 'device'): networks are frozen between update blocks
+ * (training/train_agents.py:86) and the Philox draws depend only on (seed, episode, step, agent), so the
+ * E episodes of a block are stepped together -- max_ep_len launches per block, actor weights read once per
+ * step for all episodes.  Episode-minor state (EP = E rounded up to 64, lanes = episodes):
+ * xsT[S][2N][EP], posT[S][N][2][EP], retT[S][N][EP] (double).  Replay row of (episode e, step j) =
+ * row0 + e*ep_len + j, i.e. the order the sequential loop (:46-80) would have produced.
+ * est[E][S][N] = start-state critic values (:60-62). */
+int rcmarl_rollout_step_episodes(const float* xsT, const int* posT, const int* goal, const float* theta,
+                                 const unsigned long long* seeds, int nrow, int ncol, const double* scale, float* rp_s,
+                                 float* rp_ns, float* rp_sa, float* rp_a, float* rp_r, long cap, long row0, int ep_len,
+                                 int* posT_next, float* xsT_next, double* retT, double gpow, int episode0, int step,
+                                 float mu, int S, int N, int E, int EP, int hid, int n_actions, int ldp, void* stream);
+int rcmarl_value_rows_episodes(const float* xsT, const float* theta, float* est, int S, int N, int E, int EP, int hid,
+                               int ldp, void* stream);
+int rcmarl_env_reset_episodes(const int* pos_in, const unsigned long long* seeds, int nrow, int ncol,
+                              const double* scale, int episode0, int* posT, float* xsT, double* retT, int S, int N,
+                              int E, int EP, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

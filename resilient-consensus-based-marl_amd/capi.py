@@ -89,6 +89,16 @@ SIGNATURES = {
     # pos_in, seeds, nrow, ncol, scale, episode, pos, xs, ret, S, N, stream
     "rcmarl_env_reset": [c_i32p, C.c_void_p, c_int, c_int, c_f64p, c_int, c_i32p, c_f32p, c_f64p, c_int, c_int,
                          c_stream],
+    # xsT, posT, goal, theta, seeds, nrow, ncol, scale, rp_s, rp_ns, rp_sa, rp_a, rp_r, cap, row0, ep_len, posT_next,
+    # xsT_next, retT, gpow, episode0, step, mu, S, N, E, EP, hid, n_actions, ldp, stream
+    "rcmarl_rollout_step_episodes": [c_f32p, c_i32p, c_i32p, c_f32p, C.c_void_p, c_int, c_int, c_f64p, c_f32p, c_f32p,
+                                     c_f32p, c_f32p, c_f32p, c_long, c_long, c_int, c_i32p, c_f32p, c_f64p, C.c_double,
+                                     c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # xsT, theta, est, S, N, E, EP, hid, ldp, stream
+    "rcmarl_value_rows_episodes": [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # pos_in, seeds, nrow, ncol, scale, episode0, posT, xsT, retT, S, N, E, EP, stream
+    "rcmarl_env_reset_episodes": [c_i32p, C.c_void_p, c_int, c_int, c_f64p, c_int, c_i32p, c_f32p, c_f64p, c_int, c_int,
+                                  c_int, c_int, c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk"}
 

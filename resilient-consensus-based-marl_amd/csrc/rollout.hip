@@ -204,6 +204,154 @@ __global__ __launch_bounds__(256) void k_env_reset(const int* __restrict__ pos_i
   ret[t] = 0.0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Episode-parallel rollout (rng_mode 'device').
+//
+// Between two update blocks every network is frozen (training/train_agents.py:86: updates happen
+// only after n_ep_fixed episodes) and, with the counter-based Philox stream, every draw is a pure
+// function of (seed, episode, step, agent).  The n_ep_fixed episodes of a block are therefore
+// independent and are stepped TOGETHER: one lane = one episode, one wavefront = one (seed, agent),
+// so the agent's actor weights are read ONCE per environment step for all E episodes (wave-uniform
+// scalar loads) instead of once per episode, and a block needs max_ep_len launches instead of
+// n_ep_fixed*max_ep_len.  State is kept episode-minor so lanes are coalesced:
+//   xsT[S][2N][EP]   scaled global state, feature-major      posT[S][N][2][EP]   integer cells
+//   retT[S][N][EP]   discounted returns (double)             EP = E rounded up to 64
+template <int HID>
+__device__ __forceinline__ void lane_hidden(const float* __restrict__ th, const NetGeom& g,
+                                            const float* __restrict__ xT /*[in_dim][EP]*/, int EP, int e,
+                                            float (&a2)[HID]) {
+  float acc[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) acc[j] = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < g.in_dim; ++k) {
+    const float xv = xT[(long)k * EP + e];
+    const float* w = th + (long)k * HID;
+#pragma unroll
+    for (int j = 0; j < HID; ++j) acc[j] = fmaf(xv, w[j], acc[j]);
+  }
+  float a1[HID];
+#pragma unroll
+  for (int j = 0; j < HID; ++j) a1[j] = rc_lrelu(acc[j] + th[g.o_b1 + j]);
+#pragma unroll
+  for (int k = 0; k < HID; ++k) a2[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < HID; ++j)
+#pragma unroll
+    for (int k = 0; k < HID; ++k) a2[k] = fmaf(a1[j], th[g.o_W2 + j * HID + k], a2[k]);
+#pragma unroll
+  for (int k = 0; k < HID; ++k) a2[k] = rc_lrelu(a2[k] + th[g.o_b2 + k]);
+}
+
+template <int HID, int A>
+__global__ __launch_bounds__(256) void k_rollout_step_ep(const float* __restrict__ xsT, const int* __restrict__ posT,
+                                                         const int* __restrict__ goal,
+                                                         const float* __restrict__ theta,
+                                                         const unsigned long long* __restrict__ seeds, EnvCfg cfg,
+                                                         Replay rp, long row0, int ep_len, int* __restrict__ posT_next,
+                                                         float* __restrict__ xsT_next, double* __restrict__ retT,
+                                                         double gpow, int episode0, int step, float mu, int N, int E,
+                                                         int EP, int ldp) {
+  const int s = blockIdx.y;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (i >= N) return;
+  const int e = blockIdx.z * 64 + (threadIdx.x & 63);
+  const int in_dim = 2 * N;
+  const NetGeom g = make_geom(in_dim, HID, A);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  float a2[HID];
+  lane_hidden<HID>(th, g, xsT + (long)s * in_dim * EP, EP, e, a2);
+  float p[A];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) acc = fmaf(a2[k], th[g.o_W3 + k * A + a], acc);
+    p[a] = acc + th[g.o_b3 + a];
+    mx = fmaxf(mx, p[a]);
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) { p[a] = expf(p[a] - mx); se += p[a]; }
+#pragma unroll
+  for (int a = 0; a < A; ++a) p[a] = p[a] / se;
+  if (e >= E) return;
+  const unsigned long long key = seeds[s];
+  const RcPhilox rn = rc_philox4x32_10((uint32_t)i, (uint32_t)step, (uint32_t)(episode0 + e), 0u, (uint32_t)key,
+                                       (uint32_t)(key >> 32));
+  const int a_rand = rc_mulhi_range(rn.r0, A);
+  const float u1 = rc_u01(rn.r1), u2 = rc_u01(rn.r2);
+  float c = 0.f;
+  int a_pol = 0;
+#pragma unroll
+  for (int a = 0; a < A - 1; ++a) { c += p[a]; a_pol += (u1 >= c) ? 1 : 0; }
+  const int act = (u2 < 1.0f - mu) ? a_pol : a_rand;
+  const long pi = (((long)s * N + i) * 2) * EP + e;
+  const int px = posT[pi], py = posT[pi + EP];
+  const long gi = ((long)s * N + i) * 2;
+  int nx, ny, rew;
+  env_transition(cfg, act, px, py, goal[gi], goal[gi + 1], nx, ny, rew);
+  const float sx = (float)(((double)px - cfg.mean_x) / cfg.std_x), sy = (float)(((double)py - cfg.mean_y) / cfg.std_y);
+  const float tx = (float)(((double)nx - cfg.mean_x) / cfg.std_x), ty = (float)(((double)ny - cfg.mean_y) / cfg.std_y);
+  const double rw = (double)rew / 5.0;
+  const long base = (long)s * rp.cap + row0 + (long)e * ep_len + step;     // replay row of (episode e, step)
+  rp.s[base * 2 * N + 2 * i] = sx;  rp.s[base * 2 * N + 2 * i + 1] = sy;
+  rp.ns[base * 2 * N + 2 * i] = tx; rp.ns[base * 2 * N + 2 * i + 1] = ty;
+  rp.sa[base * 3 * N + 3 * i] = sx; rp.sa[base * 3 * N + 3 * i + 1] = sy; rp.sa[base * 3 * N + 3 * i + 2] = (float)act;
+  rp.a[base * N + i] = (float)act;
+  rp.r[base * N + i] = (float)rw;
+  posT_next[pi] = nx; posT_next[pi + EP] = ny;
+  xsT_next[((long)s * in_dim + 2 * i) * EP + e] = tx;
+  xsT_next[((long)s * in_dim + 2 * i + 1) * EP + e] = ty;
+  retT[((long)s * N + i) * EP + e] += rw * gpow;
+}
+
+// est[(e*S + s)*N + i] = critic_i(start state of episode e)      (training/train_agents.py:60-62)
+template <int HID>
+__global__ __launch_bounds__(256) void k_value_rows_ep(const float* __restrict__ xsT, const float* __restrict__ theta,
+                                                       float* __restrict__ est, int S, int N, int E, int EP, int ldp) {
+  const int s = blockIdx.y;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (i >= N) return;
+  const int e = blockIdx.z * 64 + (threadIdx.x & 63);
+  const int in_dim = 2 * N;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  float a2[HID];
+  lane_hidden<HID>(th, g, xsT + (long)s * in_dim * EP, EP, e, a2);
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) v = fmaf(a2[k], th[g.o_W3 + k], v);
+  if (e < E) est[((long)e * S + s) * N + i] = v + th[g.o_b3];
+}
+
+__global__ __launch_bounds__(256) void k_env_reset_ep(const int* __restrict__ pos_in,
+                                                      const unsigned long long* __restrict__ seeds, EnvCfg cfg,
+                                                      int episode0, int* __restrict__ posT, float* __restrict__ xsT,
+                                                      double* __restrict__ retT, int S, int N, int E, int EP) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)S * N * EP) return;
+  const int e = (int)(t % EP);
+  const long si = t / EP;
+  const int s = (int)(si / N), i = (int)(si - (long)s * N);
+  int px = 0, py = 0;
+  if (e < E) {
+    if (pos_in) {
+      px = pos_in[si * 2]; py = pos_in[si * 2 + 1];
+    } else {
+      const unsigned long long key = seeds[s];
+      const RcPhilox rn = rc_philox4x32_10((uint32_t)i, 0u, (uint32_t)(episode0 + e), 1u, (uint32_t)key, (uint32_t)(key >> 32));
+      px = rc_mulhi_range(rn.r0, cfg.nrow); py = rc_mulhi_range(rn.r1, cfg.ncol);
+    }
+  }
+  posT[(si * 2) * EP + e] = px; posT[(si * 2 + 1) * EP + e] = py;
+  xsT[((long)s * 2 * N + 2 * i) * EP + e] = (float)(((double)px - cfg.mean_x) / cfg.std_x);
+  xsT[((long)s * 2 * N + 2 * i + 1) * EP + e] = (float)(((double)py - cfg.mean_y) / cfg.std_y);
+  retT[si * EP + e] = 0.0;
+}
+
 }  // namespace
 
 #define RC_HID_SWITCH(hid, STMT)               \
@@ -269,5 +417,45 @@ RCMARL_EXPORT int rcmarl_env_reset(const int* pos_in, const unsigned long long* 
   const EnvCfg cfg{nrow, ncol, scale[0], scale[1], scale[2], scale[3]};
   const dim3 grid(rc_ceil_div(S * N, 256)), block(256);
   RCMARL_LAUNCH(k_env_reset, grid, block, 0, stream, pos_in, seeds, cfg, episode, pos, xs, ret, S, N);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_rollout_step_episodes(const float* xsT, const int* posT, const int* goal, const float* theta,
+                                               const unsigned long long* seeds, int nrow, int ncol, const double* scale,
+                                               float* rp_s, float* rp_ns, float* rp_sa, float* rp_a, float* rp_r,
+                                               long cap, long row0, int ep_len, int* posT_next, float* xsT_next,
+                                               double* retT, double gpow, int episode0, int step, float mu, int S, int N,
+                                               int E, int EP, int hid, int n_actions, int ldp, void* stream) {
+  if (!xsT || !posT || !goal || !theta || !seeds || !scale || !rp_s || !rp_ns || !rp_sa || !rp_a || !rp_r ||
+      !posT_next || !xsT_next || !retT || row0 < 0 || E <= 0 || EP < E || (EP & 63) || ep_len <= 0 || step < 0 ||
+      step >= ep_len || row0 + (long)E * ep_len > cap || S <= 0 || N <= 0 || (ldp & 63))
+    return RCMARL_ERR_ARG;
+  if (n_actions != 5) return RCMARL_ERR_UNSUPPORTED;
+  const EnvCfg cfg{nrow, ncol, scale[0], scale[1], scale[2], scale[3]};
+  const Replay rp{rp_s, rp_ns, rp_sa, rp_a, rp_r, cap};
+  const dim3 grid(rc_ceil_div(N, 4), S, EP / 64), block(256);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_rollout_step_ep<HID_, 5>), grid, block, 0, stream, xsT, posT, goal, theta, seeds,
+                                   cfg, rp, row0, ep_len, posT_next, xsT_next, retT, gpow, episode0, step, mu, N, E, EP,
+                                   ldp));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_value_rows_episodes(const float* xsT, const float* theta, float* est, int S, int N, int E, int EP,
+                                             int hid, int ldp, void* stream) {
+  if (!xsT || !theta || !est || S <= 0 || N <= 0 || E <= 0 || EP < E || (EP & 63) || (ldp & 63)) return RCMARL_ERR_ARG;
+  const dim3 grid(rc_ceil_div(N, 4), S, EP / 64), block(256);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_value_rows_ep<HID_>), grid, block, 0, stream, xsT, theta, est, S, N, E, EP, ldp));
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_env_reset_episodes(const int* pos_in, const unsigned long long* seeds, int nrow, int ncol,
+                                            const double* scale, int episode0, int* posT, float* xsT, double* retT,
+                                            int S, int N, int E, int EP, void* stream) {
+  if ((!pos_in && !seeds) || !scale || !posT || !xsT || !retT || S <= 0 || N <= 0 || E <= 0 || EP < E || (EP & 63))
+    return RCMARL_ERR_ARG;
+  const EnvCfg cfg{nrow, ncol, scale[0], scale[1], scale[2], scale[3]};
+  const long total = (long)S * N * EP;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  RCMARL_LAUNCH(k_env_reset_ep, grid, block, 0, stream, pos_in, seeds, cfg, episode0, posT, xsT, retT, S, N, E, EP);
   return rcmarl_check_launch();
 }

@@ -135,6 +135,12 @@ class RPBCACEngine:
         self.pos = [torch.zeros(S, N, 2, **i32) for _ in range(2)]
         self.xs = [torch.zeros(S, 2 * N, **f32) for _ in range(2)]
         self.cur = 0
+        # episode-minor state of the episode-parallel rollout (rng_mode 'device'): lanes = episodes
+        self.EP = pad64(c.n_ep_fixed)
+        if c.rng_mode == "device":
+            self.posT = [torch.zeros(S, N, 2, self.EP, **i32) for _ in range(2)]
+            self.xsT = [torch.zeros(S, 2 * N, self.EP, **f32) for _ in range(2)]
+            self.retT = torch.zeros(S, N, self.EP, dtype=torch.float64, device=self.dev)
         self.goal = torch.zeros(S, N, 2, **i32)
         self.ret = torch.zeros(S, N, dtype=torch.float64, device=self.dev)
         self.ret_hist = torch.zeros(c.n_ep_fixed, S, N, dtype=torch.float64, device=self.dev)
@@ -330,6 +336,38 @@ class RPBCACEngine:
         self.ret_hist[ep_in_block].copy_(self.ret)
         self.episode += 1
 
+    def rollout_block(self, n_eps):
+        """n_eps (<= n_ep_fixed) episodes for all seeds, stepped TOGETHER (rng_mode 'device'): every network
+        is frozen between update blocks and the Philox draws depend only on (seed, episode, step, agent), so
+        the episodes are independent; max_ep_len launches instead of n_eps*max_ep_len, and the replay rows
+        land exactly where the sequential loop (train_agents.py:46-80) would have put them."""
+        c, L, S, N, EP = self.cfg, self.lib, self.S, self.N, self.EP
+        assert c.rng_mode == "device" and n_eps <= c.n_ep_fixed
+        pin = None
+        if not c.randomize_state:
+            pin = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(self.initial_state, dtype=np.int32),
+                                                                        (S, N, 2)))).to(self.dev)
+        L.rcmarl_env_reset_episodes(self._p(pin), self.seeds_dev.data_ptr(), c.nrow, c.ncol, self.scale.data_ptr(),
+                                    self.episode, self.posT[0].data_ptr(), self.xsT[0].data_ptr(), self.retT.data_ptr(),
+                                    S, N, n_eps, EP, self.stream)
+        L.rcmarl_value_rows_episodes(self.xsT[0].data_ptr(), self.theta["critic"].data_ptr(), self.est_hist.data_ptr(), S, N,
+                                     n_eps, EP, HID, self.ldp["critic"], self.stream)
+        rp = self._replay_ptrs()
+        cur = 0
+        for j in range(c.max_ep_len):
+            nxt = 1 - cur
+            L.rcmarl_rollout_step_episodes(self.xsT[cur].data_ptr(), self.posT[cur].data_ptr(), self.goal.data_ptr(),
+                                           self.theta["actor"].data_ptr(), self.seeds_dev.data_ptr(), c.nrow, c.ncol,
+                                           self.scale.data_ptr(), rp[0], rp[1], rp[2], rp[3], rp[4], self.cap, self.B,
+                                           c.max_ep_len, self.posT[nxt].data_ptr(), self.xsT[nxt].data_ptr(),
+                                           self.retT.data_ptr(), self.gpow[j], self.episode, j, c.mu, S, N, n_eps, EP, HID,
+                                           c.n_actions, self.ldp["actor"], self.stream)
+            cur = nxt
+        self.B += c.max_ep_len * n_eps
+        self.ret_hist[:n_eps].copy_(self.retT[:, :, :n_eps].permute(2, 0, 1))
+        self.pos[self.cur].copy_(self.posT[cur][:, :, :, n_eps - 1])      # where the last episode ended
+        self.episode += n_eps
+
     # ---- update block (train_agents.py:86-163) ---------------------------------------------
     def _x(self, key, row0=0):
         """(pointer, seed_stride) of replay tensor `key` starting at row `row0`."""
@@ -475,8 +513,11 @@ class RPBCACEngine:
         if self.profile_phases:
             self.sync()
             t0 = time.perf_counter()
-        for e in range(c.n_ep_fixed):
-            self.rollout_episode(e)
+        if c.rng_mode == "device":
+            self.rollout_block(c.n_ep_fixed)
+        else:
+            for e in range(c.n_ep_fixed):
+                self.rollout_episode(e)
         self._timed("rollout", t0)
         self.update_block()
         return self.episode_logs(c.n_ep_fixed)
@@ -512,8 +553,11 @@ class RPBCACEngine:
             if n == c.n_ep_fixed:
                 team, adv, est = self.run_block()
             else:                               # trailing episodes without an update (t % n_ep_fixed never hits)
-                for e in range(n):
-                    self.rollout_episode(e)
+                if c.rng_mode == "device":
+                    self.rollout_block(n)
+                else:
+                    for e in range(n):
+                        self.rollout_episode(e)
                 team, adv, est = self.episode_logs(n)
             logs["True_team_returns"].append(team)
             logs["True_adv_returns"].append(adv)
