@@ -21,6 +21,7 @@
 // order statistics come from a pruned min/max network (selnet_generated.inc).
 // HBM roofline: 4*(P read + P_hid written) bytes per (seed, agent).
 #include "rcmarl_common.h"
+#include <stdlib.h>
 #include "selnet_generated.inc"
 
 namespace {
@@ -126,6 +127,87 @@ __global__ __launch_bounds__(256) void k_consensus_params(const float* __restric
   }
 }
 
+// ---- v2: LDS-DMA double buffering, neighbour table in VGPRs -----------------------------------
+// One persistent workgroup per CU slot walks (seed, 64-column) tiles.  The [N][64] fp32 image of
+// tile t+1 streams global -> LDS with `global_load_lds_dwordx4` (no staging VGPRs, no commit pass)
+// into the second LDS buffer while tile t is aggregated, one barrier per tile.  A wave owns the
+// agents {w, w+nw, w+2nw, ...}; their neighbour lists never change, so they are loaded ONCE:
+// lane j of VGPR k holds the LDS byte offset of row nbr[agent_j][k], and the per-agent list is
+// pulled into SGPRs with v_readlane -- no scalar-memory latency inside the tile loop.
+#ifdef RCMARL_EMU
+__device__ __forceinline__ void rc_glds16(const float* g, float* lds_wave_base) {
+  const float4 v = *reinterpret_cast<const float4*>(g);
+  *reinterpret_cast<float4*>(lds_wave_base + 4 * hipemu::lane()) = v;
+}
+__device__ __forceinline__ int rc_readlane(int v, int l) { return __hipemu_xch(v, l); }
+#else
+__device__ __forceinline__ void rc_glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int rc_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+#endif
+
+template <int D, int H>
+__global__ __launch_bounds__(1024) void k_consensus_params_v2(const float* __restrict__ msg, float* __restrict__ theta,
+                                                              const int* __restrict__ nbr,
+                                                              const int* __restrict__ coop, int N, int ldp,
+                                                              int P_hid, int tiles_per_seed, int total_tiles,
+                                                              float* __restrict__ lo_dbg, float* __restrict__ hi_dbg) {
+  RCMARL_DYN_SMEM(float, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tile_floats = N * 64;
+  // neighbour table of this wave's agents (agent of slot j = wave + nw*j), as LDS byte offsets
+  const int my_agent = wave + nw * lane;
+  int tab[D];
+  int coop_l = 0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) tab[k] = 0;
+  if (my_agent < N) {
+    coop_l = coop[my_agent];
+#pragma unroll
+    for (int k = 0; k < D; ++k) tab[k] = nbr[my_agent * D + k] * 256;
+  }
+  const int n_slots = (N - wave + nw - 1) / nw;          // agents owned by this wave (<= 64)
+  const int rows_per_wave = (N + nw - 1) / nw;           // staging: wave w copies rows [w*rpw, (w+1)*rpw)
+  auto stage = [&](int t, float* buf) {
+    const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) * 64;
+    const float* m = msg + (size_t)s * N * ldp + c0;
+    const int r_begin = wave * rows_per_wave, r_end = min(N, r_begin + rows_per_wave);
+    for (int r = r_begin; r < r_end; r += 4) {           // one instruction = 4 rows x 256 B = 1 KiB of LDS
+      int row = r + (lane >> 4);
+      row = row < N ? row : N - 1;                       // (tail lanes re-read the last row into the slack rows)
+      rc_glds16(m + (size_t)row * ldp + 4 * (lane & 15), buf + (size_t)r * 64);
+    }
+  };
+  int t = blockIdx.x;
+  int cur = 0;
+  if (t < total_tiles) stage(t, lds);
+  for (; t < total_tiles; t += gridDim.x) {
+    __syncthreads();                                     // tile t landed (vmcnt drained); buffer cur^1 is free
+    const int tn = t + gridDim.x;
+    if (tn < total_tiles) stage(tn, lds + (cur ^ 1) * (tile_floats + 256));
+    const float* tile = lds + cur * (tile_floats + 256);
+    const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) * 64;
+    const bool col_ok = (c0 + lane) < P_hid;
+    const char* tb = reinterpret_cast<const char*>(tile + lane);
+    for (int j = 0; j < n_slots; ++j) {
+      if (!rc_readlane(coop_l, j)) continue;             // wave-uniform
+      float v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = *reinterpret_cast<const float*>(tb + rc_readlane(tab[k], j));
+      float lower, upper;
+      const float out = aggregate_regs<D, H>(v, lower, upper);
+      if (col_ok) {
+        const size_t o = ((size_t)s * N + (wave + nw * j)) * ldp + c0 + lane;
+        theta[o] = out;
+        if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+      }
+    }
+    cur ^= 1;
+  }
+}
+
 // Any (d, H) without a generated network: order statistics by rank counting
 // out of the LDS tile (O(d^2) LDS reads).  Correct for every d >= 2H+1; slow.
 __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* __restrict__ msg,
@@ -175,6 +257,29 @@ __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* _
   }
 }
 
+template <class K>
+bool k1_want_lds(K kernel, size_t smem) {
+#ifndef RCMARL_EMU
+  if (smem > 64 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+#endif
+  return true;
+}
+
+// v2 is instantiated only where the d values + the neighbour table fit 128 VGPRs (16 waves per CU)
+template <int DD, int HH>
+bool launch_v2(const float* msg, float* theta, const int* nbr, const int* coop, int N, int ldp, int P_hid, int tps,
+               int tot, float* lo_dbg, float* hi_dbg, int nwg, int threads, size_t smem, void* stream, int& rc) {
+  if constexpr (DD <= 32) {
+    if (!k1_want_lds(k_consensus_params_v2<DD, HH>, smem)) { rc = RCMARL_ERR_LAUNCH; return true; }
+    RCMARL_LAUNCH((k_consensus_params_v2<DD, HH>), dim3(nwg), dim3(threads), smem, stream, msg, theta, nbr, coop, N, ldp,
+                  P_hid, tps, tot, lo_dbg, hi_dbg);
+    return true;
+  } else {
+    return false;
+  }
+}
+
 }  // namespace
 
 // C-ABI: see include/rcmarl.h
@@ -203,6 +308,32 @@ RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const 
   if (nwg > total_tiles) nwg = total_tiles;
   const dim3 grid_p(nwg), grid(tiles_per_seed, S), block(256);
   bool done = false;
+  // v2 (LDS-DMA double buffer + VGPR neighbour table): whole tiles of 64 columns, two buffers in LDS
+  static int k1_variant = -1;
+  if (k1_variant < 0) { const char* e = getenv("RCMARL_K1"); k1_variant = e ? atoi(e) : 2; }
+  const size_t smem2 = 2 * ((size_t)N * 64 + 256) * sizeof(float);
+  if (k1_variant == 2 && smem2 <= 158 * 1024) {
+    const int tps = rc_ceil_div(P_hid, 64), tot = tps * S;
+    int wg_cu = (int)((160 * 1024) / (smem2 + 1024));
+    if (wg_cu > 4) wg_cu = 4;
+    const int threads = wg_cu >= 4 ? 256 : (wg_cu >= 2 ? 512 : 1024);
+    int nwg2 = 256 * wg_cu;
+#ifdef RCMARL_EMU
+    nwg2 = 3;
+#endif
+    if (nwg2 > tot) nwg2 = tot;
+    if (N <= 64 * (threads / 64)) {
+#define RC_CASE2(DD, HH)                                                                                             \
+      if (!done && d == DD && H == HH)                                                                               \
+        done = launch_v2<DD, HH>(msg, theta, nbr, coop, N, ldp, P_hid, tps, tot, lo_dbg, hi_dbg, nwg2, threads, smem2, \
+                                 stream, rc);
+      int rc = RCMARL_OK;
+      RCMARL_SELNET_COMBOS(RC_CASE2)
+#undef RC_CASE2
+      if (rc != RCMARL_OK) return rc;
+      if (done) return rcmarl_check_launch();
+    }
+  }
 #define RC_CASE(DD, HH)                                                                                              \
   if (!done && d == DD && H == HH) {                                                                                 \
     RCMARL_LAUNCH((k_consensus_params<DD, HH>), grid_p, block, smem, stream, msg, theta, nbr, coop, N, ldp, P_hid,   \

@@ -13,6 +13,7 @@
 // Layouts: X[S][rows][in] row-major (replay buffer), theta[S][N][ldp] parameter
 // rows, activations FEATURE-MAJOR a1t[S][N*hid][ldb] (contiguous over b).
 #include "rcmarl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -273,6 +274,32 @@ __global__ __launch_bounds__(256) void k_layer1_backward_adam(const float* __res
   gemm_tile(la, lb, epi, blockIdx.y * BM, blockIdx.x * BN, B);
 }
 
+#include "layer1_fast.inc"
+
+// 0 = generic kernels only, 1 = fast path single-buffered LDS (default: 3 workgroups per CU),
+// 2 = fast path double-buffered LDS (one barrier per tile, but 2 workgroups per CU; measured slower).
+// RCMARL_GEMM is a tuning/bisecting knob, read once.
+int gemm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RCMARL_GEMM");
+    v = e ? atoi(e) : 1;
+    if (v < 0 || v > 2) v = 1;
+  }
+  return v;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <class K>
+bool want_lds(K kernel, size_t smem) {
+#ifndef RCMARL_EMU
+  if (smem > 64 * 1024)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+#endif
+  return true;
+}
+
 bool bad_common(const void* a, const void* b, const void* c, int S, int N, int B, int in_dim, int hid, int ldp,
                 int ldb) {
   return !a || !b || !c || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) ||
@@ -284,6 +311,18 @@ bool bad_common(const void* a, const void* b, const void* c, int S, int N, int B
 RCMARL_EXPORT int rcmarl_layer1_forward(const float* x, long x_seed_stride, const float* theta, float* a1t, int S,
                                         int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream) {
   if (bad_common(x, theta, a1t, S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
+  const int var = gemm_variant();
+  if (var > 0 && hid == 20 && (in_dim % fast::FBK) == 0 && aligned16(x) && (x_seed_stride & 3) == 0) {
+    const dim3 grid(rc_ceil_div(B, fast::FBN), rc_ceil_div(N * 20, 160), S), block(256);
+    const size_t smem = fast::smem_fwd(var);
+    if (var == 1) {
+      RCMARL_LAUNCH((fast::k_fwd<1>), grid, block, smem, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
+    } else {
+      if (!want_lds(fast::k_fwd<2>, smem)) return RCMARL_ERR_LAUNCH;
+      RCMARL_LAUNCH((fast::k_fwd<2>), grid, block, smem, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
+    }
+    return rcmarl_check_launch();
+  }
   const dim3 grid(rc_ceil_div(B, BN), rc_ceil_div(N * hid, BM), S), block(256);
   RCMARL_LAUNCH(k_layer1_forward, grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, hid, ldp, ldb);
   return rcmarl_check_launch();
@@ -293,6 +332,21 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride,
                                              const int* mask, int S, int N, int B, int in_dim, int hid,
                                              int ldp, int ldb, float lr, void* stream) {
   if (bad_common(x, dz1t, theta, S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
+  const int var = gemm_variant();
+  if (var > 0 && hid == 20 && (in_dim & 3) == 0 && aligned16(x) && (x_seed_stride & 3) == 0) {
+    const dim3 grid(rc_ceil_div(N * 20, fast::FBN), rc_ceil_div(in_dim, 128), S), block(256);
+    const size_t smem = fast::smem_bwd(var);
+    const fast::ApplySgd ap{lr};
+    if (var == 1) {
+      RCMARL_LAUNCH((fast::k_bwd<1, fast::ApplySgd>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
+                    in_dim, ldp, ldb, ap);
+    } else {
+      if (!want_lds(fast::k_bwd<2, fast::ApplySgd>, smem)) return RCMARL_ERR_LAUNCH;
+      RCMARL_LAUNCH((fast::k_bwd<2, fast::ApplySgd>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
+                    in_dim, ldp, ldb, ap);
+    }
+    return rcmarl_check_launch();
+  }
   const dim3 grid(rc_ceil_div(N * hid, BN), rc_ceil_div(in_dim, BM), S), block(256);
   RCMARL_LAUNCH(k_layer1_backward_sgd, grid, block, 0, stream, x, x_seed_stride, dz1t, theta, mask, N, B, in_dim, hid,
                 ldp, ldb, lr);
@@ -304,6 +358,21 @@ RCMARL_EXPORT int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride
                                               int B, int in_dim, int hid, int ldp, int ldb, float alpha,
                                               float one_m_b1, float one_m_b2, float eps, void* stream) {
   if (bad_common(x, dz1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !adam_m || !adam_v) return RCMARL_ERR_ARG;
+  const int var = gemm_variant();
+  if (var > 0 && hid == 20 && (in_dim & 3) == 0 && aligned16(x) && (x_seed_stride & 3) == 0) {
+    const dim3 grid(rc_ceil_div(N * 20, fast::FBN), rc_ceil_div(in_dim, 128), S), block(256);
+    const size_t smem = fast::smem_bwd(var);
+    const fast::ApplyAdam ap{adam_m, adam_v, alpha, one_m_b1, one_m_b2, eps};
+    if (var == 1) {
+      RCMARL_LAUNCH((fast::k_bwd<1, fast::ApplyAdam>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
+                    in_dim, ldp, ldb, ap);
+    } else {
+      if (!want_lds(fast::k_bwd<2, fast::ApplyAdam>, smem)) return RCMARL_ERR_LAUNCH;
+      RCMARL_LAUNCH((fast::k_bwd<2, fast::ApplyAdam>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
+                    in_dim, ldp, ldb, ap);
+    }
+    return rcmarl_check_launch();
+  }
   const dim3 grid(rc_ceil_div(N * hid, BN), rc_ceil_div(in_dim, BM), S), block(256);
   RCMARL_LAUNCH(k_layer1_backward_adam, grid, block, 0, stream, x, x_seed_stride, dz1t, theta, adam_m, adam_v, mask, N,
                 B, in_dim, hid, ldp, ldb, alpha, one_m_b1, one_m_b2, eps);

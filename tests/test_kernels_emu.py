@@ -39,12 +39,12 @@ def test_consensus_params(bk, N, d, H, P, P_hid, graph):
     KC.check_consensus_params(bk, N, d, H, P, P_hid, graph)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 150, 6), (1, 7, 130, 21), (1, 2, 260, 136)])
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 150, 6), (1, 7, 130, 21), (1, 2, 260, 136), (2, 9, 150, 64), (1, 16, 70, 32)])
 def test_layer1_forward(bk, S, N, B, in_dim):
     KC.check_layer1_forward(bk, S, N, B, in_dim)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 3, 300, 6, None), (1, 7, 130, 21, 2), (1, 2, 70, 140, None)])
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 3, 300, 6, None), (1, 7, 130, 21, 2), (1, 2, 70, 140, None), (2, 9, 100, 32, 4), (1, 7, 45, 192, None)])
 def test_sgd_fit(bk, S, N, B, in_dim, masked):
     KC.check_sgd_fit(bk, S, N, B, in_dim, steps=2, masked_agent=masked)
 
@@ -55,7 +55,7 @@ def test_consensus_head(bk, S, N, B, in_dim, d, H, graph):
     KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 300, 6), (1, 5, 100, 10)])
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 300, 6), (1, 5, 100, 10), (1, 8, 70, 32)])
 def test_actor_step(bk, S, N, B, in_dim):
     KC.check_actor_step(bk, S, N, B, in_dim)
 

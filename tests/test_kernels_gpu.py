@@ -47,13 +47,13 @@ def test_consensus_params(bk, N, d, H, P, P_hid, graph):
     KC.check_consensus_params(bk, N, d, H, P, P_hid, graph)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 64, 700, 128), (2, 7, 130, 21), (1, 13, 3000, 39)])
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 64, 700, 128), (2, 7, 130, 21), (1, 13, 3000, 39), (2, 64, 3000, 192), (1, 256, 1000, 512), (1, 9, 150, 64)])
 def test_layer1_forward(bk, S, N, B, in_dim):
     KC.check_layer1_forward(bk, S, N, B, in_dim)
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (2, 5, 3000, 15, 4), (1, 32, 700, 64, 2),
-                                                 (1, 7, 130, 21, None)])
+                                                 (1, 7, 130, 21, None), (1, 64, 1000, 192, 5), (1, 128, 333, 256, None)])
 def test_sgd_fit(bk, S, N, B, in_dim, masked):
     KC.check_sgd_fit(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
 
@@ -65,7 +65,7 @@ def test_consensus_head(bk, S, N, B, in_dim, d, H, graph):
     KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 16, 300, 32)])
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 16, 300, 32), (1, 64, 1000, 128)])
 def test_actor_step(bk, S, N, B, in_dim):
     KC.check_actor_step(bk, S, N, B, in_dim, steps=3)
 
