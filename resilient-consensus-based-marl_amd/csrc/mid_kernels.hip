@@ -13,6 +13,7 @@
 //   k_mid_actor       softmax / TD-weighted sparse CE forward+backward            (:86-101)
 //   k_small_sgd / k_small_adam / k_head_apply   reduce partials, apply updates
 #include "rcmarl_common.h"
+#include <stdlib.h>
 #include "selnet_generated.inc"
 
 namespace {
@@ -129,6 +130,96 @@ __global__ __launch_bounds__(256) void k_mid_fit(float* __restrict__ a1t, const 
     for (int q = 0; q < ROWS; ++q) acc = fmaf(sA[j * LDR + q], sD[k * LDR + q], acc);
     out[PT::gW2 + e] = acc;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mid_fit, matrix-core reductions.  Everything a workgroup must SUM OVER ITS 256 ROWS is a
+// product of two [rows x <=22] panels, so it runs on the f32 MFMA instead of LDS loops / DPP trees:
+//   G1 = [a1 | 1]^T [dz2]                  -> gW2 (20x20), gb2 (row 20)
+//   G2 = [a2 | 1]^T [dz1 | dv | diff^2]    -> gW3 (col 20), gb1 (row 20), gb3 (20,20), loss (20,21)
+// v_mfma_f32_32x32x2_f32 consumes two rows per instruction (A[i][k=l>>5], B[k=l>>5][j]); the panels
+// are staged unit-major in LDS (sP[unit][row], stride 257 -> conflict-free fragment reads), each
+// wave reduces its 64 rows (32 MFMAs per product) and the four per-wave 32x32 partials are summed
+// through LDS.  Same fp32 products as before, different (k-ordered) summation order.
+template <int HID>
+__global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, const float* __restrict__ theta,
+                                                      const float* __restrict__ y, float* __restrict__ partials,
+                                                      int N, int B, int in_dim, int ldp, int ldb, int nchunk) {
+  typedef FitPart<HID> PT;
+  constexpr int NB2 = HID + 2;                       // columns of the second B panel
+  __shared__ float sA[HID * LDR];
+  __shared__ float sB[NB2 * LDR];
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  const int r = threadIdx.x, b = chunk * ROWS + r;
+  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  float a1[HID], a2[HID], dz2[HID], dz1[HID];
+  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+  layer2<HID>(th, g, a1, a2);
+  const float v = head1<HID>(th + g.o_W3, th[g.o_b3], a2);
+  const float diff = valid ? v - y[((long)s * N + i) * ldb + b] : 0.f;
+  const float dv = (2.0f * diff) / (float)B;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) dz2[k] = dv * th[g.o_W3 + k] * rc_lrelu_grad_from_act(a2[k]);
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    float da1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) da1 = fmaf(dz2[k], th[g.o_W2 + j * HID + k], da1);
+    dz1[j] = da1 * rc_lrelu_grad_from_act(a1[j]);
+    if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];   // in place, feature-major, coalesced
+  }
+  // rows beyond B contribute zero: their dz2/dz1/dv/diff are zero because diff is
+  rc_f32x16 acc1, acc2;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc1[q] = 0.f; acc2[q] = 0.f; }
+  const int ia = l31 < HID ? l31 : 0;                // clamped panel row for the fragment loads
+  const float a_const = l31 == HID ? 1.f : 0.f;     // A row 20 = ones, rows 21.. = zero
+  // ---- product 1
+#pragma unroll
+  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a1[k]; sB[k * LDR + r] = dz2[k]; }
+  __syncthreads();
+#pragma unroll 4
+  for (int m = 0; m < 32; ++m) {
+    const int rr = wave * 64 + 2 * m + half;
+    const float av = l31 < HID ? sA[ia * LDR + rr] : a_const;
+    const float bv = l31 < HID ? sB[ia * LDR + rr] : 0.f;
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);
+  }
+  __syncthreads();
+  // ---- product 2
+#pragma unroll
+  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a2[k]; sB[k * LDR + r] = dz1[k]; }
+  sB[HID * LDR + r] = dv;
+  sB[(HID + 1) * LDR + r] = diff * diff;
+  __syncthreads();
+  const int ib = l31 < NB2 ? l31 : 0;
+#pragma unroll 4
+  for (int m = 0; m < 32; ++m) {
+    const int rr = wave * 64 + 2 * m + half;
+    const float av = l31 < HID ? sA[ia * LDR + rr] : a_const;
+    const float bv = l31 < NB2 ? sB[ib * LDR + rr] : 0.f;
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2, 0, 0, 0);
+  }
+  __syncthreads();
+  // ---- per-wave partial records -> LDS (reusing sA: 4 x SIZE floats), then summed over the 4 waves
+  float* rec = sA + wave * PT::SIZE;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = (q & 3) + 8 * (q >> 2) + 4 * half, col = l31;     // D[row][col] of the 32x32 result
+    if (row < HID && col < HID) rec[PT::gW2 + row * HID + col] = acc1[q];
+    if (row == HID && col < HID) { rec[PT::gb2 + col] = acc1[q]; rec[PT::gb1 + col] = acc2[q]; }
+    if (row < HID && col == HID) rec[PT::gW3 + row] = acc2[q];
+    if (row == HID && col == HID) rec[PT::gb3] = acc2[q];
+    if (row == HID && col == HID + 1) rec[PT::loss] = acc2[q];
+  }
+  __syncthreads();
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
+  for (int e = r; e < PT::SIZE; e += ROWS)
+    out[e] = (sA[e] + sA[PT::SIZE + e]) + (sA[2 * PT::SIZE + e] + sA[3 * PT::SIZE + e]);
 }
 
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B
@@ -530,8 +621,15 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(nchunk, N, S), block(ROWS);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
-                                   ldp, ldb, nchunk));
+  static int variant = -1;         // RCMARL_MIDFIT=0 selects the LDS-loop / DPP-tree kernel (bisecting knob)
+  if (variant < 0) { const char* e = getenv("RCMARL_MIDFIT"); variant = e ? atoi(e) : 1; }
+  if (variant == 0) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
+                                     ldp, ldb, nchunk));
+  } else {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk));
+  }
   return rcmarl_check_launch();
 }
 

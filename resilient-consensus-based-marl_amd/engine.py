@@ -120,7 +120,12 @@ class RPBCACEngine:
         self.adam_m = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_t = 0
-        self.a1t = torch.zeros(S, N * HID, self.ldb, **f32)
+        self.a1t = torch.zeros(S, N * HID, self.ldb, **f32)          # scratch layer-1 activations
+        # per-net activation buffers: the consensus step leaves layer-1 activations of the live nets on the
+        # fit inputs there, which are exactly what step 0 of the next epoch's local fit needs (the fit starts
+        # from a copy of the live net and only W3,b3 moved since) -> one forward GEMM per net per epoch saved
+        self.a1net = {k: torch.zeros(S, N * HID, self.ldb, **f32) for k in ("critic", "tr")}
+        self.a1_cached = {"critic": False, "tr": False}
         self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
         self.rcoop = torch.zeros(S, self.ldb, **f32)
         nchunk_max = (self.cap + 255) // 256
@@ -374,25 +379,29 @@ class RPBCACEngine:
         w = self.rp[key].shape[2]
         return self.rp[key].data_ptr() + 4 * row0 * w, self.cap * w
 
-    def _layer1(self, xkey, theta, net, B, row0=0):
+    def _layer1(self, xkey, theta, net, B, row0=0, buf=None):
         ptr, stride = self._x(xkey, row0)
-        self.lib.rcmarl_layer1_forward(ptr, stride, theta.data_ptr(), self.a1t.data_ptr(), self.S, self.N, B,
+        buf = self.a1t if buf is None else buf
+        self.lib.rcmarl_layer1_forward(ptr, stride, theta.data_ptr(), buf.data_ptr(), self.S, self.N, B,
                                        self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 
     def _local_fit(self, net, xkey, y, B, mask):
         """5 full-batch SGD steps on the message copy (agents/resilient_CAC_agents.py:118,136)."""
         L, S, N = self.lib, self.S, self.N
         msg = self.msg[net]
+        a1 = self.a1net[net]
         ptr, stride = self._x(xkey)
         for step in range(self.cfg.local_fit_steps):
-            self._layer1(xkey, msg, net, B)
-            L.rcmarl_mid_fit(self.a1t.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(), S, N, B,
+            if not (step == 0 and self.a1_cached[net]):       # msg == live net: activations left by _consensus
+                self._layer1(xkey, msg, net, B, buf=a1)
+            L.rcmarl_mid_fit(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(), S, N, B,
                              self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
             L.rcmarl_small_sgd(self.partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
                                self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
                                self.ldp[net], self.cfg.fast_lr, self.stream)
-            L.rcmarl_layer1_backward_sgd(ptr, stride, self.a1t.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
+            L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
                                          self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
+        self.a1_cached[net] = False
 
     def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None):
         self._layer1(xkey, theta, net, B, row0)
@@ -406,10 +415,12 @@ class RPBCACEngine:
         g_hid = self.P[net] - (HID * 1 + 1)
         L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),
                                   self.coop.data_ptr(), S, N, self.ldp[net], g_hid, c.d, c.H, None, None, self.stream)
-        self._layer1(xkey, self.theta[net], net, B)
-        L.rcmarl_consensus_head(self.a1t.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
+        a1 = self.a1net[net]
+        self._layer1(xkey, self.theta[net], net, B, buf=a1)
+        L.rcmarl_consensus_head(a1.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
                                 self.nbr.data_ptr(), self.coop.data_ptr(), self.partials.data_ptr(), None, S, N, B,
                                 self.in_dim[net], HID, self.ldp[net], self.ldb, c.d, c.H, self.stream)
+        self.a1_cached[net] = self.reuse_activations       # hidden layers of the live net do not move until the next K1
         L.rcmarl_head_apply(self.partials.data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(), S, N, B,
                             self.in_dim[net], HID, self.ldp[net], self.stream)
 
@@ -422,6 +433,7 @@ class RPBCACEngine:
         return t0
 
     profile_phases = False
+    reuse_activations = True
 
     def update_block(self):
         c, L, S, N, B = self.cfg, self.lib, self.S, self.N, self.B
@@ -433,6 +445,7 @@ class RPBCACEngine:
         if self.profile_phases:
             self.sync()
             t0 = time.perf_counter()
+        self.a1_cached["critic"] = self.a1_cached["tr"] = False       # new replay rows
         rptr, rstride = self._x("r")
         L.rcmarl_team_reward(rptr, rstride, self.coop.data_ptr(), max(self.n_coop, 1), self.rcoop.data_ptr(), S, N, B,
                              self.ldb, self.stream)

@@ -265,6 +265,7 @@ def check_actor_step(bk, S, N, B, in_dim, steps=2, lr=0.002):
                                       bk.stream)
         losses.append(bk.host(d_loss).copy())
     th_new = bk.host(d_th)
+    errs = [[] for _ in range(6)]
     for s in range(S):
         for n in range(N):
             if not mask[n]:
@@ -277,14 +278,19 @@ def check_actor_step(bk, S, N, B, in_dim, steps=2, lr=0.002):
                 assert abs(losses[t][s, n] - l) <= 2e-5 * max(1.0, abs(l)), (t, losses[t][s, n], l)
             got = unpack_row(th_new[s, n], in_dim, A)
             for k in range(6):
-                # Adam normalises every gradient to a +-lr step: compare in units of lr.  An element whose
-                # gradient is ~eps (1e-7) can legitimately land anywhere in [-lr, lr] per step depending on the
-                # fp32 summation order, so a vanishing fraction of outliers up to 2*lr*steps is tolerated.
-                err = np.abs(got[k] - pw[k])
-                assert err.max() <= 2.0 * lr * steps + 1e-6, ("actor param", k, err.max())
-                assert np.mean(err > 0.02 * lr * steps + 1e-6) <= 2e-3, ("actor param outliers", k, np.mean(err > 0.02 * lr * steps))
+                errs[k].append(np.abs(got[k] - pw[k]).ravel())
+    for k in range(6):
+        # Adam turns every gradient into a ~+-lr step, so errors are judged in units of lr.  Two legitimate
+        # knife edges exist between any two fp32 summation orders: a pre-activation within rounding of 0
+        # flips its LeakyReLU slope (moves one unit's gradient column by a few %), and a gradient of
+        # magnitude ~eps can land anywhere in [-lr, lr].  Hence: bulk within 2% of a step, a vanishing
+        # fraction of outliers, none beyond 2 full steps per update.
+        e = np.concatenate(errs[k])
+        assert e.max() <= 2.0 * lr * steps + 1e-6, ("actor param", k, e.max())
+        assert np.mean(e > 0.02 * lr * steps + 1e-6) <= 2e-3, ("actor param outliers", k, np.mean(e > 0.02 * lr * steps))
 
 
+# ------------------------------------------------------------------------------------------
 def check_reward_helpers(bk, S, N, B):
     rng = np.random.default_rng(S + N + B)
     ldb = pad64(B)
