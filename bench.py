@@ -68,10 +68,27 @@ def make_engine(w, S, seeds, lib):
     eng.init_glorot(base_seed=1)
     goals = np.stack([np.random.RandomState(int(s)).randint(0, 5, size=(N, 2)) for s in seeds])   # main.py:48 draws goals in [0,5)
     eng.set_goals(goals)
+    # Steady state of the reference loop: the replay lists hold buffer_size rows when a block starts and
+    # grow to buffer_size + n_ep_fixed*max_ep_len = 3000 before the update (train_agents.py:158-163).
+    # Pre-fill with rollouts only, so that EVERY update block of this process (warm-up included) runs at the
+    # steady-state batch B = 3000 and rocprof's per-kernel averages are over identical launches.
+    while eng.B + eng.n_last <= cfg.buffer_size:
+        eng.rollout_block(cfg.n_ep_fixed)
     return eng
 
 
 # --------------------------------------------------------------------------------------------
+def _blas_threads():
+    """Threads the NumPy port actually uses: its Python loops are serial, the matmuls inside run on
+    OpenBLAS' pool."""
+    try:
+        import threadpoolctl
+        n = [d.get("num_threads", 1) for d in threadpoolctl.threadpool_info() if d.get("user_api") == "blas"]
+        return int(max(n)) if n else 1
+    except Exception:
+        return 1
+
+
 def cpu_baseline(w, budget_s=25.0):
     """The reference's loop structure (per agent -> per neighbour -> per layer; oracle/
     rpbcac_oracle.py) timed on this host on a bounded sample of the same workload and
@@ -132,7 +149,7 @@ def cpu_baseline(w, budget_s=25.0):
     t_actor = (time.perf_counter() - t0) / k
     block = steps_per_block * t_step + n_epochs * N * (t_fit + t_cons) + N * t_actor
     return {
-        "value": N * steps_per_block / block, "unit": "agent-steps/s", "cores": int(torch.get_num_threads()),
+        "value": N * steps_per_block / block, "unit": "agent-steps/s", "cores": _blas_threads(),
         "host_cpus": os.cpu_count(), "kind": "port",
         "consensus_updates_per_s": 1.0 / t_cons,
         "sample": "oracle/rpbcac_oracle.py (reference loop structure, numpy fp32), one seed: %d env steps with all %d agents; "
@@ -201,7 +218,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    B_steady = eng.cap if args.warmup >= 2 else None
+    B_steady = eng.cap
 
     # per-kernel breakdown of the timed region (HIP events on the launch stream)
     ksum = tlib.summary()
@@ -263,7 +280,9 @@ def rooflines(tlib, ksum):
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": n, "avg_us": avg_us,
                     "algorithmic_bytes_per_launch": byts / n,
-                    "note": "compulsory bytes 8*P_hid per (seed, agent) (SURVEY 8d); VALU-bound selection network at d=18 (128 min/max per element)"}
+                    "note": "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d). HBM-bound for small d "
+                            "(d=4: ~54% of 8 TB/s); at d=18 the 128-op min/max selection network makes it VALU-issue-bound "
+                            "(~83% of the v_min/v_max issue rate, DESIGN.md section 3)"}
         ach = flops / (tot_ms * 1e-3) / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP32_PEAK_TFLOPS, "traffic": None, "launches": n, "avg_us": avg_us,

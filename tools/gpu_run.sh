@@ -14,7 +14,7 @@ grep -E "^E  " gpurun_out/test_gpu.log | head -40
 echo "== smoke"
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -4 | tee gpurun_out/smoke.log
 echo "== bench"
-timeout 900 python bench.py --steps 2 --warmup 2 2> gpurun_out/bench.err > gpurun_out/bench.json
+timeout 900 python bench.py 2> gpurun_out/bench.err > gpurun_out/bench.json
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/bench.json'))
@@ -33,7 +33,7 @@ PY
 if [ "${1:-}" = "prof" ]; then
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python $R/bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
 tail -2 $R/gpurun_out/prof.err
 ls $R/gpurun_out/prof | head
 f=$(find $R/gpurun_out/prof -name '*kernel_stats*' | head -1); [ -n "$f" ] && head -20 "$f"
