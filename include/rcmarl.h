@@ -71,6 +71,37 @@ int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride, const float*
  * partials[S][N][nchunk][rcmarl_fit_partial_size(hid)] = [gW2|gb2|gW3|gb3|gb1|sum (v-y)^2]. */
 int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B, int in_dim,
                    int hid, int ldp, int ldb, void* stream);
+/* ---- lattice (exact bf16x3) form of the layer-1 GEMMs: csrc/lattice_gemm.hip, csrc/rcmarl_lattice.h ----
+ * The grid-world state/action columns are alpha_c * (small integer) (environments/grid_world.py:66-72,
+ * training/train_agents.py:89-93), so X*W1 and X^T*dZ1 can run on the bf16 matrix core with every
+ * product exact: integers K (bf16) times the three bf16 pieces of a fp32 value, fp32 accumulation.
+ * Same results as the f32 entry points above up to fp32 summation order (tests: 1e-6 relative).
+ * Packed bf16 operands ("PK", rcmarl_lattice.h): 8-KiB blocks [rows/128][kt][pieces][128][32];
+ * every *_rt / *_kt argument is the ALLOCATED number of 128-row tiles / 32-deep k-tiles of that buffer
+ * (bytes per seed = rt*kt*pieces*8192).
+ *
+ * rcmarl_lattice_encode: K = x/alpha (verified integer, |K| <= 256, else *flag = 1) packed as
+ *   kp  (rows = replay row, reduction = feature; forward operand)  and/or
+ *   ktp (rows = feature,    reduction = replay row; backward operand); either may be NULL.
+ *   Rows/features up to the next multiple of 256 replay rows / of the buffer extents are zero-filled. */
+int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, void* kp,
+                          int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag, void* stream);
+/* wp (3 pieces, rows = (agent,unit) column, reduction = feature) <- bf16x3 split of alpha[k]*W1[s][n][k][j] */
+int rcmarl_w1_split(const float* theta, const float* alpha, void* wp, int S, int N, int in_dim, int hid, int ldp,
+                    int wp_rt, int wp_kt, void* stream);
+/* = rcmarl_layer1_forward on (kp, wp); theta supplies b1 */
+int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt,
+                                  const float* theta, float* a1t, int S, int N, int B, int in_dim, int hid, int ldp,
+                                  int ldb, void* stream);
+/* = rcmarl_layer1_backward_sgd on (ktp, dzp): W1[k][col] -= lr * alpha[k] * sum_b K[b][k]*dz1[col][b] */
+int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt, int dzp_kt,
+                                       const float* alpha, float* theta, const int* mask, int S, int N, int B,
+                                       int in_dim, int hid, int ldp, float lr, void* stream);
+/* = rcmarl_mid_fit, but a1t is left intact and dz1 is written as dzp (3 exact bf16 pieces, rows = (agent,unit)
+ * column, reduction = replay row, zero beyond B) for rcmarl_layer1_backward_sgd_lattice. */
+int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
+                           int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+
 /* reduce the partials over chunks and apply SGD to b1,W2,b2,W3,b3; loss_out[S][N] (or NULL) = MSE. */
 int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
                      int B, int in_dim, int hid, int ldp, float lr, void* stream);

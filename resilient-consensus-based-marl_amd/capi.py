@@ -39,6 +39,21 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_stream],
     # a1t, theta, y, partials, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_fit": [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # lattice (exact bf16x3) layer-1 path, csrc/lattice_gemm.hip ------------------------------------------
+    # x, x_seed_stride, alpha, S, B, in_dim, kp, kp_rt, kp_kt, ktp, ktp_rt, ktp_kt, flag, stream
+    "rcmarl_lattice_encode": [c_f32p, c_long, c_f32p, c_int, c_int, c_int, c_u8p, c_int, c_int, c_u8p, c_int, c_int,
+                              c_i32p, c_stream],
+    # theta, alpha, wp, S, N, in_dim, hid, ldp, wp_rt, wp_kt, stream
+    "rcmarl_w1_split": [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1t, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_layer1_forward_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_stream],
+    # ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, stream
+    "rcmarl_layer1_backward_sgd_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_u8p, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
+    # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_stream],
     # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
     "rcmarl_small_sgd": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     # a1t, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream

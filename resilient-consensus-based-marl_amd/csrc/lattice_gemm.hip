@@ -1,0 +1,412 @@
+// Layer-1 GEMMs on the bf16 matrix core, exact ("lattice bf16x3" path; see rcmarl_lattice.h for
+// the arithmetic argument and the packed operand format).
+//
+//   rcmarl_lattice_encode              replay tensor X (fp32) -> integer lattice K, packed twice:
+//                                      Kp  (rows = replay row b, reduction = feature)   forward  B operand
+//                                      KTp (rows = feature,      reduction = b)         backward A operand
+//   rcmarl_w1_split                    W1 of every agent -> three bf16 pieces of alpha_k*W1, packed
+//                                      (rows = (agent,unit) column, reduction = feature) forward A operand
+//   rcmarl_layer1_forward_lattice      a1t = lrelu(K W' + b1)         = rcmarl_layer1_forward
+//   rcmarl_layer1_backward_sgd_lattice W1 -= lr * alpha_k * K^T dz1   = rcmarl_layer1_backward_sgd
+//                                      (dz1 pieces are emitted packed by rcmarl_mid_fit_lattice)
+//
+// One GEMM kernel serves both: D[m][n] = sum_{pa,pb} sum_k A_pa[m][k] B_pb[n][k], operands in PK
+// format, 256-thread workgroups (2x2 wavefronts), block tile (64 MT) x (64 NT), k-tile 32, two LDS
+// stages filled by global_load_lds_dwordx4 (linear 1-KiB bursts: the swizzle lives in the packed
+// format), one barrier per k-tile, v_mfma_f32_32x32x16_bf16.
+//   forward : PA=3 (W' pieces), PB=1 (K),  tile 128 x 256  -> per k16 step 10 ds_read_b128 : 24 MFMA
+//   backward: PA=1 (K^T),       PB=3 (dz), tile 256 x 128
+// Workgroups are numbered so that all tiles of one seed run on ONE XCD (block b -> XCD b%8): the
+// seed's small operand (K, 3 MB) stays in that XCD's L2 and the big one streams through once.
+#include "rcmarl_lattice.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __forceinline__ uint4 ld_u4(const unsigned char* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st_u4(unsigned char* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) { return (lo & 0xffffu) | (hi << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// encode: one workgroup = 32 replay rows x 128 features, transposed through LDS so that both packed
+// images are written in 16-byte chunks.
+__global__ __launch_bounds__(256) void k_lattice_encode(const float* __restrict__ x, long x_seed_stride,
+                                                        const float* __restrict__ alpha, int B, int in_dim,
+                                                        unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
+                                                        unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
+                                                        int* __restrict__ flag) {
+  __shared__ unsigned short tile[32][128 + 2];
+  const int s = blockIdx.z, b0 = blockIdx.y * 32, c0 = blockIdx.x * 128;
+  const int t = threadIdx.x;
+  {
+    const int cl = t & 127, c = c0 + cl;
+    const float al = c < in_dim ? alpha[c] : 1.f;
+    bool bad = false;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int bl = (t >> 7) + 2 * i, b = b0 + bl;
+      float kq = 0.f;
+      if (b < B && c < in_dim) {
+        const float xv = x[(long)s * x_seed_stride + (long)b * in_dim + c];
+        kq = rintf(xv / al);
+        // lattice property: x == alpha*K up to fp32 roundoff, |K| <= 256 (exact in bf16)
+        if (!(fabsf(kq) <= 256.f) || !(fabsf(fmaf(kq, al, -xv)) <= 4.76837158e-7f * fabsf(xv))) bad = true;
+      }
+      tile[bl][cl] = (unsigned short)rc_bf16_rne(kq);
+    }
+    if (bad) *flag = 1;
+  }
+  __syncthreads();
+  // KTp block (row tile c0/128, k-tile b0/32): 128 rows x 4 chunks
+  if (ktp != nullptr && (c0 >> 7) < ktp_rt && (b0 >> 5) < ktp_kt) {
+    unsigned char* blk = ktp + (long)s * ktp_rt * ktp_kt * RC_PK_BLOCK + ((long)(c0 >> 7) * ktp_kt + (b0 >> 5)) * RC_PK_BLOCK;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = t + 256 * q, r = idx >> 2, c4 = idx & 3;
+      uint4 v;
+      v.x = pack2(tile[8 * c4 + 0][r], tile[8 * c4 + 1][r]);
+      v.y = pack2(tile[8 * c4 + 2][r], tile[8 * c4 + 3][r]);
+      v.z = pack2(tile[8 * c4 + 4][r], tile[8 * c4 + 5][r]);
+      v.w = pack2(tile[8 * c4 + 6][r], tile[8 * c4 + 7][r]);
+      st_u4(blk + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), v);
+    }
+  }
+  // Kp: rows b0..b0+31 of row tile b0/128, k-tiles c0/32 .. +3
+  if (kp != nullptr && (b0 >> 7) < kp_rt) {
+    unsigned char* base = kp + (long)s * kp_rt * kp_kt * RC_PK_BLOCK + (long)(b0 >> 7) * kp_kt * RC_PK_BLOCK;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = t + 256 * q, bl = idx >> 4, ch = idx & 15;
+      const int kt = (c0 >> 5) + (ch >> 2), c4 = ch & 3, r = (b0 & 127) + bl;
+      if (kt < kp_kt) {
+        const unsigned short* src = &tile[bl][8 * ch];
+        uint4 v;
+        v.x = pack2(src[0], src[1]); v.y = pack2(src[2], src[3]);
+        v.z = pack2(src[4], src[5]); v.w = pack2(src[6], src[7]);
+        st_u4(base + (long)kt * RC_PK_BLOCK + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// W1 split: one workgroup = 128 (agent,unit) columns x 32 features -> three 8-KiB blocks.
+__global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ theta, const float* __restrict__ alpha,
+                                                  unsigned char* __restrict__ wp, int N, int in_dim, int ldp,
+                                                  int wp_rt, int wp_kt) {
+  const int s = blockIdx.z, rt = blockIdx.y, kt = blockIdx.x;
+  const int t = threadIdx.x, r = t & 127;
+  const int col = rt * 128 + r, ncols = N * 20;
+  const bool col_ok = col < ncols;
+  const int ag = col_ok ? col / 20 : 0, j = col - ag * 20;
+  const float* th = theta + ((long)s * N + ag) * ldp + j;
+  unsigned char* blk = wp + (long)s * wp_rt * wp_kt * 3 * RC_PK_BLOCK + ((long)rt * wp_kt + kt) * 3 * RC_PK_BLOCK;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c4 = (t >> 7) + 2 * q;
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kt * 32 + 8 * c4 + e;
+      const bool ok = col_ok && k < in_dim;
+      const float w = ok ? th[(long)k * 20] * alpha[k] : 0.f;
+      rc_split3(w, h[e], m[e], l[e]);
+    }
+    const int o = r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4);
+    uint4 v;
+    v.x = pack2(h[0], h[1]); v.y = pack2(h[2], h[3]); v.z = pack2(h[4], h[5]); v.w = pack2(h[6], h[7]);
+    st_u4(blk + o, v);
+    v.x = pack2(m[0], m[1]); v.y = pack2(m[2], m[3]); v.z = pack2(m[4], m[5]); v.w = pack2(m[6], m[7]);
+    st_u4(blk + RC_PK_BLOCK + o, v);
+    v.x = pack2(l[0], l[1]); v.y = pack2(l[2], l[3]); v.z = pack2(l[4], l[5]); v.w = pack2(l[6], l[7]);
+    st_u4(blk + 2 * RC_PK_BLOCK + o, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int PA, int PB, int MT, int NT> struct LatCfg {
+  static_assert(MT % 2 == 0 && NT % 2 == 0, "block tile sides are multiples of 128");
+  static constexpr int BM = 64 * MT, BN = 64 * NT;
+  static constexpr int ART = MT / 2, BRT = NT / 2;                  // 128-row tiles per block side
+  static constexpr int A_KB = ART * PA * 8, B_KB = BRT * PB * 8;    // KiB per k-tile stage
+  static constexpr int STAGE_KB = A_KB + B_KB, STAGE_BYTES = STAGE_KB * 1024;
+  static constexpr int GLDS = STAGE_KB / 4;                         // 1-KiB bursts per wavefront per stage
+  static_assert(STAGE_KB % 4 == 0, "stage splits evenly over 4 wavefronts");
+};
+
+struct LatOperands {
+  const unsigned char* a; const unsigned char* b;   // seed base of each packed operand
+  int a_kt, b_kt;                                   // allocated k-tiles (block stride along the row-tile axis)
+  int art0, brt0;                                   // first 128-row tile of this workgroup on each side
+};
+
+template <int PA, int PB, int MT, int NT>
+__device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
+                                             rc_f32x16 (&acc)[MT][NT]) {
+  typedef LatCfg<PA, PB, MT, NT> C;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+  // wave-uniform source of each of this wavefront's bursts at k-tile 0, and its per-k-tile advance
+  const unsigned char* gsrc[C::GLDS];
+  int gstep[C::GLDS];
+#pragma unroll
+  for (int i = 0; i < C::GLDS; ++i) {
+    const int q = wave + 4 * i;
+    if (q < C::A_KB) {
+      const int seg = q / (PA * 8), off = q - seg * (PA * 8);
+      gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * (PA * RC_PK_BLOCK) + off * 1024 + lane * 16;
+      gstep[i] = PA * RC_PK_BLOCK;
+    } else {
+      const int q2 = q - C::A_KB;
+      const int seg = q2 / (PB * 8), off = q2 - seg * (PB * 8);
+      gsrc[i] = op.b + ((long)(op.brt0 + seg) * op.b_kt) * (PB * RC_PK_BLOCK) + off * 1024 + lane * 16;
+      gstep[i] = PB * RC_PK_BLOCK;
+    }
+  }
+  auto stage = [&](int buf, int t) {
+    unsigned char* dst = lds + buf * C::STAGE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < C::GLDS; ++i) RC_GLDS16(gsrc[i] + (long)t * gstep[i], dst + i * 4096);
+  };
+
+  // fragment addresses: row = lane&31 (+ tile offsets), chunk = 2*kstep + lane>>5, XOR (row>>2)&3
+  const int sw = (l31 >> 2) & 3;
+  const int co0 = ((0 + half) ^ sw) << 4, co1 = ((2 + half) ^ sw) << 4;
+  int offA[MT], offB[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = wm * 32 * MT + 32 * mt + l31;
+    offA[mt] = (row >> 7) * PA * RC_PK_BLOCK + (row & 127) * 64;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wn * 32 * NT + 32 * nt + l31;
+    offB[nt] = C::A_KB * 1024 + (row >> 7) * PB * RC_PK_BLOCK + (row & 127) * 64;
+  }
+
+  stage(0, 0);
+  for (int t = 0; t < n_ktiles; ++t) {
+    RC_WAIT_VMEM();                 // this wavefront's bursts of tile t have landed ...
+    __syncthreads();                // ... and everybody's; all reads of buffer (t+1)&1 are done
+    if (t + 1 < n_ktiles) stage((t + 1) & 1, t + 1);
+    const unsigned char* st = lds + (t & 1) * C::STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int co = ks == 0 ? co0 : co1;
+      uint4 af[MT][PA], bf[NT][PB];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int p = 0; p < PA; ++p) af[mt][p] = ld_u4(st + offA[mt] + p * RC_PK_BLOCK + co);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < PB; ++p) bf[nt][p] = ld_u4(st + offB[nt] + p * RC_PK_BLOCK + co);
+      // smallest pieces first; consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int pa = PA - 1; pa >= 0; --pa)
+#pragma unroll
+        for (int pb = PB - 1; pb >= 0; --pb)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
+    }
+  }
+}
+
+// workgroup id -> (seed, tile w within the seed); all tiles of a seed on one XCD when S % 8 == 0
+__device__ __forceinline__ void lat_decode(int per_seed, int S, int& seed, int& w) {
+  const int g = blockIdx.x;
+  if ((S & 7) == 0) {
+    const int xcd = g & 7, q = g >> 3;
+    seed = xcd + 8 * (q / per_seed);
+    w = q % per_seed;
+  } else {
+    seed = g / per_seed;
+    w = g - seed * per_seed;
+  }
+}
+
+// ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
+__global__ __launch_bounds__(256, 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
+                                                        const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
+                                                        const float* __restrict__ theta, float* __restrict__ a1t, int S,
+                                                        int N, int B, int in_dim, int ldp, int ldb, int mtiles,
+                                                        int ntiles) {
+  constexpr int PA = 3, PB = 1, MT = 2, NT = 4;
+  typedef LatCfg<PA, PB, MT, NT> C;
+  RCMARL_DYN_SMEM(unsigned char, lds);
+  int s, w;
+  lat_decode(mtiles * ntiles, S, s, w);
+  const int bn = w % ntiles, bm = w / ntiles;                      // n fastest: neighbours share the W' panel
+  LatOperands op;
+  op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
+  op.b = kp + (long)s * kp_rt * kp_kt * (PB * RC_PK_BLOCK); op.b_kt = kp_kt; op.brt0 = bn * C::BRT;
+  rc_f32x16 acc[MT][NT];
+  lat_mainloop<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
+  // epilogue: a1t[col][b] = lrelu(z + b1[col])
+  const int ncols = N * 20;
+  const float* theta_s = theta + (long)s * N * ldp;
+  float* a1t_s = a1t + (long)s * ncols * ldb;
+  __syncthreads();
+  float* bias = reinterpret_cast<float*>(lds);
+  if (threadIdx.x < C::BM) {
+    const int col = bm * C::BM + threadIdx.x;
+    const int ag = col / 20;
+    bias[threadIdx.x] = col < ncols ? theta_s[(long)ag * ldp + in_dim * 20 + (col - ag * 20)] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = bn * C::BN + wn * 32 * NT + 32 * nt + (lane & 31);
+    if (n < B) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * 32 * MT + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int m = bm * C::BM + ml;
+          if (m < ncols) a1t_s[(long)m * ldb + n] = rc_lrelu(acc[mt][nt][r] + bias[ml]);
+        }
+    }
+  }
+}
+
+// ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
+__global__ __launch_bounds__(256, 2) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
+                                                             const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
+                                                             const float* __restrict__ alpha, float* __restrict__ theta,
+                                                             const int* __restrict__ mask, int S, int N, int B,
+                                                             int in_dim, int ldp, float lr, int mtiles, int ntiles) {
+  constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
+  typedef LatCfg<PA, PB, MT, NT> C;
+  RCMARL_DYN_SMEM(unsigned char, lds);
+  int s, w;
+  lat_decode(mtiles * ntiles, S, s, w);
+  const int bm = w % mtiles, bn = w / mtiles;                      // m fastest: neighbours share the dz panel
+  LatOperands op;
+  op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
+  op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
+  rc_f32x16 acc[MT][NT];
+  lat_mainloop<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
+  // epilogue: W1[k][col] -= lr * alpha_k * acc
+  const int ncols = N * 20;
+  __syncthreads();
+  float* al = reinterpret_cast<float*>(lds);
+  {
+    const int k = bm * C::BM + threadIdx.x;
+    al[threadIdx.x] = k < in_dim ? alpha[k] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = bn * C::BN + wn * 32 * NT + 32 * nt + (lane & 31);
+    if (col < ncols) {
+      const int ag = col / 20, j = col - ag * 20;
+      if (mask == nullptr || mask[ag]) {
+        float* th = theta + ((long)s * N + ag) * ldp + j;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kl = wm * 32 * MT + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int k = bm * C::BM + kl;
+            if (k < in_dim) {
+              float* wptr = th + (long)k * 20;
+              *wptr = *wptr - lr * (al[kl] * acc[mt][nt][r]);
+            }
+          }
+      }
+    }
+  }
+}
+
+template <class K>
+bool lat_want_lds(K kernel, size_t smem) {
+#ifndef RCMARL_EMU
+  static bool done = false;            // one attribute call per kernel instantiation
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return false;
+    done = true;
+  }
+#endif
+  return true;
+}
+
+}  // namespace
+
+RCMARL_EXPORT int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim,
+                                        void* kp, int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag,
+                                        void* stream) {
+  if (!x || !alpha || !flag || S <= 0 || B <= 0 || in_dim <= 0 || (!kp && !ktp)) return RCMARL_ERR_ARG;
+  const int b_pad = rc_ceil_div(B, 256) * 256;
+  if (kp && (kp_rt * 128 < b_pad || kp_kt * 32 < in_dim)) return RCMARL_ERR_ARG;
+  if (ktp && (ktp_rt * 128 < in_dim || ktp_kt * 32 < b_pad)) return RCMARL_ERR_ARG;
+  // features are swept up to the larger of the two images' extents so every block the GEMMs read is written
+  int c_ext = in_dim;
+  if (kp) c_ext = kp_kt * 32 > c_ext ? kp_kt * 32 : c_ext;
+  if (ktp) c_ext = ktp_rt * 128 > c_ext ? ktp_rt * 128 : c_ext;
+  const dim3 grid(rc_ceil_div(c_ext, 128), b_pad / 32, S), block(256);
+  RCMARL_LAUNCH(k_lattice_encode, grid, block, 0, stream, x, x_seed_stride, alpha, B, in_dim, (unsigned char*)kp, kp_rt,
+                kp_kt, (unsigned char*)ktp, ktp_rt, ktp_kt, flag);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_w1_split(const float* theta, const float* alpha, void* wp, int S, int N, int in_dim, int hid,
+                                  int ldp, int wp_rt, int wp_kt, void* stream) {
+  if (!theta || !alpha || !wp || S <= 0 || N <= 0 || in_dim <= 0 || (ldp & 63) || ldp < in_dim * hid + hid)
+    return RCMARL_ERR_ARG;
+  if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
+  if (wp_rt * 128 < N * 20 || wp_kt * 32 < in_dim) return RCMARL_ERR_ARG;
+  const dim3 grid(rc_ceil_div(in_dim, 32), rc_ceil_div(N * 20, 128), S), block(256);
+  RCMARL_LAUNCH(k_w1_split, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt,
+                                                int wp_kt, const float* theta, float* a1t, int S, int N, int B,
+                                                int in_dim, int hid, int ldp, int ldb, void* stream) {
+  if (!kp || !wp || !theta || !a1t || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) || (ldb & 63) || ldb < B ||
+      ldp < in_dim * hid + hid)
+    return RCMARL_ERR_ARG;
+  if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
+  const int mtiles = rc_ceil_div(N * 20, 128), ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
+  if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
+  const size_t smem = 2 * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
+  if (!lat_want_lds(k_lat_forward, smem)) return RCMARL_ERR_LAUNCH;
+  const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
+  RCMARL_LAUNCH(k_lat_forward, grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp,
+                kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
+                                                     int dzp_kt, const float* alpha, float* theta, const int* mask,
+                                                     int S, int N, int B, int in_dim, int hid, int ldp, float lr,
+                                                     void* stream) {
+  if (!ktp || !dzp || !alpha || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) ||
+      ldp < in_dim * hid + hid)
+    return RCMARL_ERR_ARG;
+  if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
+  const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * 20, 128), ktiles = rc_ceil_div(B, 32);
+  if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
+  const size_t smem = 2 * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
+  if (!lat_want_lds(k_lat_backward_sgd, smem)) return RCMARL_ERR_LAUNCH;
+  const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
+  RCMARL_LAUNCH(k_lat_backward_sgd, grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles);
+  return rcmarl_check_launch();
+}

@@ -12,7 +12,7 @@
 //   k_consensus_head  estimate consensus + projection residual                    (:168-206, :60-84)
 //   k_mid_actor       softmax / TD-weighted sparse CE forward+backward            (:86-101)
 //   k_small_sgd / k_small_adam / k_head_apply   reduce partials, apply updates
-#include "rcmarl_common.h"
+#include "rcmarl_lattice.h"
 #include <stdlib.h>
 #include "selnet_generated.inc"
 
@@ -141,10 +141,14 @@ __global__ __launch_bounds__(256) void k_mid_fit(float* __restrict__ a1t, const 
 // are staged unit-major in LDS (sP[unit][row], stride 257 -> conflict-free fragment reads), each
 // wave reduces its 64 rows (32 MFMAs per product) and the four per-wave 32x32 partials are summed
 // through LDS.  Same fp32 products as before, different (k-ordered) summation order.
-template <int HID>
+// EMIT: instead of overwriting a1t with dz1 (fp32, feature-major), write dz1 as three exact bf16
+// pieces in the packed layout the lattice backward GEMM reads (rcmarl_lattice.h: rows = (agent,unit)
+// column, reduction = replay row); rows b >= B of the last chunk are written as zeros.
+template <int HID, bool EMIT>
 __global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, const float* __restrict__ theta,
                                                       const float* __restrict__ y, float* __restrict__ partials,
-                                                      int N, int B, int in_dim, int ldp, int ldb, int nchunk) {
+                                                      int N, int B, int in_dim, int ldp, int ldb, int nchunk,
+                                                      unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
   typedef FitPart<HID> PT;
   constexpr int NB2 = HID + 2;                       // columns of the second B panel
   __shared__ float sA[HID * LDR];
@@ -170,7 +174,18 @@ __global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, c
 #pragma unroll
     for (int k = 0; k < HID; ++k) da1 = fmaf(dz2[k], th[g.o_W2 + j * HID + k], da1);
     dz1[j] = da1 * rc_lrelu_grad_from_act(a1[j]);
-    if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];   // in place, feature-major, coalesced
+    if (EMIT) {
+      if ((b >> 5) < dzp_kt) {
+        unsigned h, m, l;
+        rc_split3(dz1[j], h, m, l);
+        unsigned char* q = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + rc_pk_offset(i * HID + j, b, 0, dzp_kt, 3);
+        *reinterpret_cast<unsigned short*>(q) = (unsigned short)h;
+        *reinterpret_cast<unsigned short*>(q + RC_PK_BLOCK) = (unsigned short)m;
+        *reinterpret_cast<unsigned short*>(q + 2 * RC_PK_BLOCK) = (unsigned short)l;
+      }
+    } else {
+      if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];   // in place, feature-major, coalesced
+    }
   }
   // rows beyond B contribute zero: their dz2/dz1/dv/diff are zero because diff is
   rc_f32x16 acc1, acc2;
@@ -627,9 +642,21 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
                                      ldp, ldb, nchunk));
   } else {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk));
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk, (unsigned char*)nullptr, 0, 0));
   }
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials,
+                                         void* dzp, int dzp_rt, int dzp_kt, int S, int N, int B, int in_dim, int hid,
+                                         int ldp, int ldb, void* stream) {
+  if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials || !dzp) return RCMARL_ERR_ARG;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  if (dzp_rt * 128 < N * hid || dzp_kt < rc_ceil_div(B, 32)) return RCMARL_ERR_ARG;
+  const dim3 grid(nchunk, N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                   partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
   return rcmarl_check_launch();
 }
 

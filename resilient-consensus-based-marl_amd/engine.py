@@ -18,7 +18,10 @@ import time
 import numpy as np
 import torch
 
+import os
+
 from . import capi
+from . import lattice as LT
 
 HID = 20
 COOP, FAULTY, GREEDY, MALICIOUS = "Cooperative", "Faulty", "Greedy", "Malicious"
@@ -56,7 +59,7 @@ class EngineConfig:
     def __init__(self, n_agents, agent_label, in_nodes, H=0, gamma=0.9, slow_lr=0.002, fast_lr=0.01, n_actions=5,
                  n_states=2, max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000, common_reward=False,
                  nrow=5, ncol=5, n_seeds=1, rng_mode="device", mu=0.1, scaling=True, randomize_state=True,
-                 local_fit_steps=5):
+                 local_fit_steps=5, lattice="auto"):
         self.n_agents, self.agent_label = int(n_agents), list(agent_label)
         self.in_nodes = [list(map(int, row)) for row in in_nodes]
         self.H, self.gamma, self.slow_lr, self.fast_lr = int(H), float(gamma), float(slow_lr), float(fast_lr)
@@ -66,6 +69,7 @@ class EngineConfig:
         self.nrow, self.ncol, self.n_seeds = int(nrow), int(ncol), int(n_seeds)
         self.rng_mode, self.mu, self.scaling, self.randomize_state = rng_mode, float(mu), bool(scaling), bool(randomize_state)
         self.local_fit_steps = int(local_fit_steps)
+        self.lattice = lattice                # layer-1 GEMMs on the exact bf16x3 path: "auto" | True | False
         assert len(self.agent_label) == self.n_agents and len(self.in_nodes) == self.n_agents
         d = len(self.in_nodes[0])
         for i, row in enumerate(self.in_nodes):
@@ -104,6 +108,7 @@ class RPBCACEngine:
         self.P = {"actor": net_numel(self.in_c, c.n_actions), "critic": net_numel(self.in_c, 1), "tr": net_numel(self.in_r, 1)}
         self.in_dim = {"actor": self.in_c, "critic": self.in_c, "tr": self.in_r}
         self.out_dim = {"actor": c.n_actions, "critic": 1, "tr": 1}
+        self.in_dim_x = {"s": self.in_c, "ns": self.in_c, "sa": self.in_r}      # width of each replay tensor
         self.ldp = {k: pad64(v) for k, v in self.P.items()}
         self.n_last = c.max_ep_len * c.n_ep_fixed
         self.cap = c.buffer_size + self.n_last
@@ -176,8 +181,63 @@ class RPBCACEngine:
         self.episode = 0                      # global episode counter
         self.timers = {"rollout": 0.0, "phase1": 0.0, "phase2": 0.0, "phase3": 0.0, "blocks": 0}
         self.gpow = [float(c.gamma ** j) for j in range(c.max_ep_len)]
+        self._init_lattice()
         self.initial_state = None             # used when randomize_state is False
         self.np_rngs = None                   # rng_mode='numpy': one RandomState-like object per seed
+
+    # ---- lattice (exact bf16x3) layer-1 path: csrc/lattice_gemm.hip, lattice.py ------------
+    def _init_lattice(self):
+        """Packed bf16 operands of the lattice GEMMs.  Policy "auto": on from 16 agents up (below that the
+        128x256 tiles are mostly padding and the f32-MFMA kernels are launch-bound anyway);
+        RCMARL_LATTICE=0/1 overrides.  The path is only USED for an update block whose replay rows pass the
+        lattice check of rcmarl_lattice_encode (always true for rows produced by the grid-world)."""
+        c = self.cfg
+        want = c.lattice
+        env = os.environ.get("RCMARL_LATTICE")
+        if env is not None:
+            want = env not in ("0", "false", "False", "")
+        if want == "auto":
+            want = self.N >= 16
+        self.lat_enabled = bool(want)
+        self.lat_active = False               # set per update block by _lattice_encode
+        if not self.lat_enabled:
+            return
+        u8 = lambda rk, pieces: torch.zeros(self.S * LT.Geometry.nbytes(rk, pieces), dtype=torch.uint8, device=self.dev)
+        self.lat_geom = {"s": LT.Geometry(self.N, self.in_c, self.cap), "sa": LT.Geometry(self.N, self.in_r, self.cap)}
+        self.lat_geom["ns"] = self.lat_geom["s"]
+        self.lat_kp = {k: u8(self.lat_geom[k].kp, 1) for k in ("s", "ns", "sa")}
+        self.lat_ktp = {k: u8(self.lat_geom[k].ktp, 1) for k in ("s", "sa")}
+        self.lat_wp = u8(self.lat_geom["sa"].wp, 3)          # scratch, sized for the wider (state-action) input
+        self.lat_dzp = u8(self.lat_geom["sa"].dzp, 3)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.lat_alpha = {"s": torch.tensor(LT.column_alpha(self.N, 2, c.nrow, c.ncol, c.scaling), **f32),
+                          "sa": torch.tensor(LT.column_alpha(self.N, 3, c.nrow, c.ncol, c.scaling), **f32)}
+        self.lat_alpha["ns"] = self.lat_alpha["s"]
+        self.lat_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+
+    def _lattice_encode(self, B):
+        """Once per update block: integer-lattice images of the replay tensors (rows 0..B)."""
+        self.lat_active = False
+        if not self.lat_enabled:
+            return
+        L = self.lib
+        self.lat_flag.zero_()
+        for k in ("s", "ns", "sa"):
+            g = self.lat_geom[k]
+            ptr, stride = self._x(k)
+            ktp = self.lat_ktp.get(k)
+            L.rcmarl_lattice_encode(ptr, stride, self.lat_alpha[k].data_ptr(), self.S, B, self.in_dim_x[k],
+                                    self.lat_kp[k].data_ptr(), g.kp[0], g.kp[1], self._p8(ktp), g.ktp[0], g.ktp[1],
+                                    self.lat_flag.data_ptr(), self.stream)
+        self.lat_active = int(self.lat_flag.item()) == 0       # one host read per update block
+        self.lat_B = B
+
+    @staticmethod
+    def _p8(t):
+        return None if t is None else t.data_ptr()
+
+    def _lattice_ok(self, xkey, B, row0):
+        return self.lat_active and row0 == 0 and B == self.lat_B and xkey in self.lat_kp
 
     # ---- plumbing -------------------------------------------------------------------------
     @property
@@ -382,6 +442,14 @@ class RPBCACEngine:
     def _layer1(self, xkey, theta, net, B, row0=0, buf=None):
         ptr, stride = self._x(xkey, row0)
         buf = self.a1t if buf is None else buf
+        if self._lattice_ok(xkey, B, row0):
+            g, L = self.lat_geom[xkey], self.lib
+            L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), self.lat_wp.data_ptr(), self.S, self.N,
+                              self.in_dim[net], HID, self.ldp[net], g.wp[0], g.wp[1], self.stream)
+            L.rcmarl_layer1_forward_lattice(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], self.lat_wp.data_ptr(), g.wp[0],
+                                            g.wp[1], theta.data_ptr(), buf.data_ptr(), self.S, self.N, B, self.in_dim[net],
+                                            HID, self.ldp[net], self.ldb, self.stream)
+            return
         self.lib.rcmarl_layer1_forward(ptr, stride, theta.data_ptr(), buf.data_ptr(), self.S, self.N, B,
                                        self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 
@@ -391,16 +459,29 @@ class RPBCACEngine:
         msg = self.msg[net]
         a1 = self.a1net[net]
         ptr, stride = self._x(xkey)
+        lat = self._lattice_ok(xkey, B, 0) and xkey in self.lat_ktp
+        g = self.lat_geom[xkey] if lat else None
         for step in range(self.cfg.local_fit_steps):
             if not (step == 0 and self.a1_cached[net]):       # msg == live net: activations left by _consensus
                 self._layer1(xkey, msg, net, B, buf=a1)
-            L.rcmarl_mid_fit(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(), S, N, B,
-                             self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+            if lat:
+                L.rcmarl_mid_fit_lattice(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(),
+                                         self.lat_dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B, self.in_dim[net], HID,
+                                         self.ldp[net], self.ldb, self.stream)
+            else:
+                L.rcmarl_mid_fit(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(), S, N, B,
+                                 self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
             L.rcmarl_small_sgd(self.partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
                                self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
                                self.ldp[net], self.cfg.fast_lr, self.stream)
-            L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
-                                         self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
+            if lat:
+                L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1],
+                                                     self.lat_dzp.data_ptr(), g.dzp[0], g.dzp[1],
+                                                     self.lat_alpha[xkey].data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N,
+                                                     B, self.in_dim[net], HID, self.ldp[net], self.cfg.fast_lr, self.stream)
+            else:
+                L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
+                                             self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
         self.a1_cached[net] = False
 
     def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None):
@@ -446,6 +527,7 @@ class RPBCACEngine:
             self.sync()
             t0 = time.perf_counter()
         self.a1_cached["critic"] = self.a1_cached["tr"] = False       # new replay rows
+        self._lattice_encode(B)
         rptr, rstride = self._x("r")
         L.rcmarl_team_reward(rptr, rstride, self.coop.data_ptr(), max(self.n_coop, 1), self.rcoop.data_ptr(), S, N, B,
                              self.ldb, self.stream)

@@ -25,7 +25,7 @@ def init_weights(rng, n_agents):
     return out
 
 
-def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3):
+def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3, lattice="auto"):
     """Run the oracle (one run per seed) and the engine (all seeds batched); return both results."""
     n = args["n_agents"]
     S = len(seeds)
@@ -35,7 +35,7 @@ def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3
     cfg = EngineConfig(n, args["agent_label"], args["in_nodes"], H=args["H"], gamma=args["gamma"], slow_lr=args["slow_lr"],
                        fast_lr=args["fast_lr"], max_ep_len=args["max_ep_len"], n_ep_fixed=args["n_ep_fixed"],
                        n_epochs=args["n_epochs"], buffer_size=args["buffer_size"], common_reward=args["common_reward"],
-                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode)
+                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode, lattice=lattice)
     eng = RPBCACEngine(cfg, seeds=list(seeds), device=device, lib=lib)
     for s in range(S):
         for i in range(n):

@@ -35,6 +35,8 @@ struct dim3 {
 };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
@@ -57,6 +59,7 @@ struct State {
   std::vector<int> wave_arrived; std::vector<unsigned long long> wave_gen;
   // wave exchange scratch: [wave][lane][slot]
   std::vector<float> xch_f; std::vector<unsigned long long> xch_u;
+  std::vector<unsigned> xch_m;        // [wave][lane][8 dwords]: operands of the bf16 MFMA emulation
   std::vector<char> dyn_smem;
 };
 State& st();
@@ -162,6 +165,43 @@ inline floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, floatx4 c,
   return d;
 }
 
+// ---- bf16 MFMA 32x32x16 (8 bf16 per lane per operand, packed in a uint4) ---------
+// lane l supplies A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31] (e = 0..7, element e in
+// bits 16*(e&1) of dword e>>1); D layout as the f32 forms.  Products of two bf16 are exact in
+// fp32; the 16 of them are added to the accumulator in k order.
+inline float __hipemu_bf16(unsigned dword, int hi) {
+  unsigned bits = (hi ? (dword >> 16) : (dword & 0xffffu)) << 16;
+  float f; memcpy(&f, &bits, 4); return f;
+}
+inline floatx16 __hipemu_mfma_f32_32x32x16_bf16(uint4 a, uint4 b, floatx16 c) {
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  unsigned* m = &s.xch_m[((size_t)w * 64 + l) * 8];
+  m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+  hipemu::wave_barrier();
+  floatx16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 16; ++k) {
+      const unsigned* ma = &s.xch_m[((size_t)w * 64 + row + 32 * (k >> 3)) * 8];
+      const unsigned* mb = &s.xch_m[((size_t)w * 64 + col + 32 * (k >> 3)) * 8 + 4];
+      int e = k & 7;
+      acc += __hipemu_bf16(ma[e >> 1], e & 1) * __hipemu_bf16(mb[e >> 1], e & 1);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
+// global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16 (the hardware takes the
+// base from M0, i.e. from the first lane), global source per lane.
+inline void __hipemu_glds16(const void* gsrc, void* lds_base) {
+  unsigned long long base0 = __hipemu_xch((unsigned long long)(uintptr_t)lds_base, 0);
+  memcpy(reinterpret_cast<char*>((uintptr_t)base0) + 16 * hipemu::lane(), gsrc, 16);
+}
+
 // dynamic LDS
 #define HIPEMU_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::st().dyn_smem.data())
 
@@ -169,5 +209,7 @@ inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; 
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }

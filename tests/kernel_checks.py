@@ -521,3 +521,169 @@ def check_projection(bk, S, N, B, in_dim):
             got = unpack_row(th_new[s, i], in_dim, 1)
             rel_close(got[4], ag.critic[4], 2e-5, "W3 after projection")
             rel_close(got[5], ag.critic[5], 2e-5, "b3 after projection")
+
+
+# ------------------------------------------------------------------------------------------
+# lattice (exact bf16x3) layer-1 path: csrc/lattice_gemm.hip
+from rcmarl_amd import lattice as LT  # noqa: E402
+
+
+def lattice_rows(rng, S, B, n_agents, width, nrow, ncol, scaling=True):
+    """Replay rows exactly as the environment produces them (environments/grid_world.py:66-72:
+    float64 (pos-mean)/std, cast to fp32 at training/train_agents.py:89-92) + raw action columns."""
+    pos = np.stack([rng.integers(0, nrow, size=(S, B, n_agents)), rng.integers(0, ncol, size=(S, B, n_agents))], axis=-1)
+    if scaling:
+        mean = np.array([np.mean(np.arange(nrow)), np.mean(np.arange(ncol))])
+        std = np.array([np.std(np.arange(nrow)), np.std(np.arange(ncol))])
+    else:
+        mean, std = np.zeros(2), np.ones(2)
+    xs = ((pos - mean) / std)
+    if width == 3:
+        act = rng.integers(0, 5, size=(S, B, n_agents, 1)).astype(np.float64)
+        xs = np.concatenate([xs, act], axis=-1)
+    x = xs.reshape(S, B, n_agents * width).astype(np.float32)
+    return x, LT.column_alpha(n_agents, width, nrow, ncol, scaling)
+
+
+class LatticeBuffers:
+    def __init__(self, bk, S, N, in_dim, cap):
+        g = LT.Geometry(N, in_dim, cap)
+        self.g, self.S = g, S
+        z = lambda rk, pieces: bk.dev(np.full(S * LT.Geometry.nbytes(rk, pieces) // 2, 0x7fc0, np.uint16))   # NaN fill
+        self.kp, self.ktp, self.wp, self.dzp = z(g.kp, 1), z(g.ktp, 1), z(g.wp, 3), z(g.dzp, 3)
+        self.flag = bk.dev(np.zeros(1, np.int32))
+
+
+def _encode(bk, lb, d_x, x_stride, d_alpha, S, B, in_dim, with_t=True):
+    g = lb.g
+    bk.lib.rcmarl_lattice_encode(bk.ptr(d_x), x_stride, bk.ptr(d_alpha), S, B, in_dim, bk.ptr(lb.kp), g.kp[0], g.kp[1],
+                                 bk.ptr(lb.ktp) if with_t else None, g.ktp[0], g.ktp[1], bk.ptr(lb.flag), bk.stream)
+
+
+def _layer1_lattice(bk, lb, d_alpha, d_theta, d_a1t, S, N, B, in_dim, ldp, ldb):
+    g = lb.g
+    bk.lib.rcmarl_w1_split(bk.ptr(d_theta), bk.ptr(d_alpha), bk.ptr(lb.wp), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], bk.stream)
+    bk.lib.rcmarl_layer1_forward_lattice(bk.ptr(lb.kp), g.kp[0], g.kp[1], bk.ptr(lb.wp), g.wp[0], g.wp[1], bk.ptr(d_theta),
+                                         bk.ptr(d_a1t), S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+
+
+def check_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling=True):
+    rng = np.random.default_rng(B * 7 + n_agents + width)
+    x, alpha = lattice_rows(rng, S, B, n_agents, width, nrow, ncol, scaling)
+    in_dim = n_agents * width
+    lb = LatticeBuffers(bk, S, n_agents, in_dim, B)
+    d_x, d_al = bk.dev(x), bk.dev(alpha)
+    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)
+    kp, ktp, flag = bk.host(lb.kp).reshape(S, -1), bk.host(lb.ktp).reshape(S, -1), bk.host(lb.flag)
+    assert flag[0] == 0
+    K = np.rint(x.astype(np.float64) / alpha.astype(np.float64)).astype(np.float32)
+    assert np.abs(K).max() <= 256 and np.abs(K).max() > 0
+    g = lb.g
+    b_pad = (B + 255) // 256 * 256
+    for s in range(S):
+        got = LT.pk_unpack(kp[s], b_pad, g.kp[1] * 32, g.kp[1], 1)[0]
+        want = np.zeros_like(got)
+        want[:B, :in_dim] = K[s]
+        np.testing.assert_array_equal(got, want)
+        got = LT.pk_unpack(ktp[s], g.ktp[0] * 128, b_pad, g.ktp[1], 1)[0]
+        want = np.zeros_like(got)
+        want[:in_dim, :B] = K[s].T
+        np.testing.assert_array_equal(got, want)
+    # a tensor that is NOT on the lattice must raise the flag
+    x2 = x.copy()
+    x2[S - 1, B // 2, in_dim // 2] += np.float32(0.013)
+    _encode(bk, lb, bk.dev(x2), B * in_dim, d_al, S, B, in_dim)
+    assert bk.host(lb.flag)[0] == 1
+
+
+def check_lattice_forward(bk, S, N, B, width, nrow, ncol, scaling=True):
+    rng = np.random.default_rng(B + N * 3 + width)
+    in_dim = N * width
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(params, ldp)
+    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol, scaling)
+    lb = LatticeBuffers(bk, S, N, in_dim, B)
+    d_x, d_al, d_th = bk.dev(x), bk.dev(alpha), bk.dev(theta)
+    d_a = bk.dev(np.full((S, N * HID, ldb), np.nan, np.float32))
+    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim, with_t=False)
+    _layer1_lattice(bk, lb, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    a1t = bk.host(d_a)
+    assert bk.host(lb.flag)[0] == 0
+    # the three pieces reproduce alpha*W1 exactly
+    wp = bk.host(lb.wp).reshape(S, -1)
+    for s in range(S):
+        pieces = LT.pk_unpack(wp[s], N * HID, in_dim, lb.g.wp[1], 3).astype(np.float64)
+        w1 = np.stack([params[s][n][0] for n in range(N)], axis=0)                     # [N][in][HID]
+        want = (w1 * alpha[None, :, None]).astype(np.float32).transpose(0, 2, 1).reshape(N * HID, in_dim)
+        np.testing.assert_array_equal((pieces[0] + pieces[1] + pieces[2]).astype(np.float32), want)
+    for s in range(S):
+        x64 = x[s].astype(np.float64)
+        for n in range(N):
+            z = x64 @ params[s][n][0].astype(np.float64) + params[s][n][1].astype(np.float64)
+            want = np.where(z > 0, z, 0.1 * z)
+            rel_close(a1t[s, n * HID:(n + 1) * HID, :B].T, want, 2e-6, "a1 (lattice)")
+    assert np.isnan(a1t[:, :, B:]).all()                                              # nothing written beyond B
+
+
+def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamma=0.9, masked_agent=None):
+    """check_sgd_fit on the lattice path: encode -> [w1_split -> forward_lattice -> mid_fit_lattice ->
+    small_sgd -> backward_sgd_lattice] x steps, against the same oracle fit."""
+    rng = np.random.default_rng(S * 1000 + N * 100 + B + width)
+    in_dim = N * width
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(params, ldp)
+    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol)
+    nx, _ = lattice_rows(rng, S, B, N, width, nrow, ncol)
+    r_applied = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.int32)
+    if masked_agent is not None:
+        mask[masked_agent] = 0
+    nchunk = (B + 255) // 256
+    psz = bk.lib.rcmarl_fit_partial_size(HID)
+    lb, lbn = LatticeBuffers(bk, S, N, in_dim, B), LatticeBuffers(bk, S, N, in_dim, B)
+    g = lb.g
+    d_x, d_nx, d_al, d_th, d_r, d_mask = bk.dev(x), bk.dev(nx), bk.dev(alpha), bk.dev(theta), bk.dev(r_applied), bk.dev(mask)
+    d_msg = bk.dev(theta.copy())
+    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+    d_y = bk.dev(np.zeros((S, N, ldb), np.float32))
+    d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    L = bk.lib
+    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)
+    _encode(bk, lbn, d_nx, B * in_dim, d_al, S, B, in_dim, with_t=False)
+    _layer1_lattice(bk, lbn, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    L.rcmarl_mid_value(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_r), gamma, bk.ptr(d_y), S, N, B, in_dim, HID, ldp, ldb,
+                       bk.stream)
+    for st in range(steps):
+        _layer1_lattice(bk, lb, d_al, d_msg, d_a, S, N, B, in_dim, ldp, ldb)
+        a_before = bk.host(d_a).copy() if st == 0 else None
+        L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
+                                 S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+        if st == 0:
+            np.testing.assert_array_equal(bk.host(d_a), a_before)                    # activations left intact
+        L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
+                           in_dim, HID, ldp, lr, bk.stream)
+        L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
+                                             bk.ptr(d_al), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
+                                             bk.stream)
+    assert bk.host(lb.flag)[0] == 0 and bk.host(lbn.flag)[0] == 0
+    msg, y, loss = bk.host(d_msg), bk.host(d_y), bk.host(d_loss)
+    for s in range(S):
+        for n in range(N):
+            p0 = params[s][n]
+            target = r_applied[s, n, :B, None] + np.float32(gamma) * M.forward(p0, nx[s])
+            rel_close(y[s, n, :B], target[:, 0], 3e-6, "td target (lattice)")
+            if not mask[n]:
+                np.testing.assert_array_equal(msg[s, n], theta[s, n])
+                continue
+            pw = M.copy_params(p0)
+            hist = M.fit_mse(pw, x[s], target, lr, epochs=steps)
+            got = unpack_row(msg[s, n], in_dim, 1)
+            for k in range(6):
+                rel_close(got[k], pw[k], 1e-5, "fit param %d (lattice)" % k)
+            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+    np.testing.assert_array_equal(bk.host(d_th), theta)

@@ -26,3 +26,12 @@ def test_engine_with_adversaries(labels):
     args = EC.make_args(labels, H=1, n_episodes=4, max_ep_len=4, n_ep_fixed=2, n_epochs=2, buffer_size=12, seed=21)
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(21, 22))
     EC.compare(eng, logs, o_logs, o_w)
+
+
+@pytest.mark.parametrize("labels,nrow,ncol", [(["Cooperative"] * 5, 5, 5), (["Cooperative"] * 4 + ["Malicious"], 7, 4)])
+def test_engine_lattice_path_matches_oracle(labels, nrow, ncol):
+    """Same end-to-end check with the layer-1 GEMMs forced onto the exact bf16x3 (lattice) kernels."""
+    args = EC.make_args(labels, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=31)
+    eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, "device", "cpu", emu_lib(), seeds=(31, 32), lattice=True)
+    assert eng.lat_enabled and eng.lat_active          # the replay rows passed the lattice check -> path was used
+    EC.compare(eng, logs, o_logs, o_w)

@@ -37,3 +37,17 @@ def test_engine_with_adversaries(labels):
     args = EC.make_args(labels, H=1, n_episodes=30, max_ep_len=20, n_ep_fixed=15, n_epochs=2, buffer_size=450, seed=300)
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cuda", None, seeds=(300, 301))
     EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)
+
+
+@pytest.mark.parametrize("n,nrow,ncol,labels", [(5, 5, 5, None), (20, 16, 12, None), (5, 5, 5, ["Cooperative"] * 4 + ["Malicious"])])
+def test_engine_lattice_path(n, nrow, ncol, labels):
+    """Layer-1 GEMMs on the exact bf16x3 (lattice) kernels: same parity bar as the f32-MFMA path.
+    n=20 is above the engine's own "auto" threshold; n=5 forces the path on the reference's config."""
+    labels = labels or ["Cooperative"] * n
+    d = 4 if n == 5 else 6
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    args = EC.make_args(labels, H=1 if n == 5 else 2, n_episodes=20, max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=300,
+                        seed=41, in_nodes=in_nodes)
+    eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, "device", "cuda", None, seeds=(41, 42), lattice=True if n == 5 else "auto")
+    assert eng.lat_enabled and eng.lat_active
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4 if "Malicious" in labels else 2e-4)

@@ -82,3 +82,20 @@ def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
 
 def test_projection(bk):
     KC.check_projection(bk, 2, 3, 300, 6)
+
+
+# ---- lattice (exact bf16x3) layer-1 path -----------------------------------------------------
+@pytest.mark.parametrize("S,n_agents,B,width,nrow,ncol,scaling", [(2, 5, 70, 2, 5, 5, True), (1, 50, 300, 3, 32, 16, True),
+                                                                    (1, 7, 33, 3, 9, 9, False)])
+def test_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling):
+    KC.check_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol", [(2, 5, 70, 2, 5, 5), (1, 13, 260, 3, 32, 32), (1, 7, 40, 2, 128, 3)])
+def test_lattice_forward(bk, S, N, B, width, nrow, ncol):
+    KC.check_lattice_forward(bk, S, N, B, width, nrow, ncol)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 3, 300, 2, 5, 5, None), (1, 7, 130, 3, 16, 16, 2)])
+def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
+    KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)

@@ -95,3 +95,23 @@ def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
 def test_projection(bk):
     KC.check_projection(bk, 2, 5, 1000, 10)
     KC.check_projection(bk, 1, 16, 700, 48)
+
+
+# ---- lattice (exact bf16x3) layer-1 path -----------------------------------------------------
+@pytest.mark.parametrize("S,n_agents,B,width,nrow,ncol,scaling", [(2, 5, 1000, 2, 5, 5, True), (1, 64, 700, 3, 16, 16, True),
+                                                                    (2, 256, 3000, 3, 32, 32, True), (1, 7, 33, 3, 9, 9, False)])
+def test_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling):
+    KC.check_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol", [(2, 5, 1000, 2, 5, 5), (1, 64, 700, 3, 16, 16), (8, 64, 3000, 2, 16, 16),
+                                                   (1, 256, 1000, 2, 32, 32), (1, 13, 3000, 3, 128, 7)])
+def test_lattice_forward(bk, S, N, B, width, nrow, ncol):
+    KC.check_lattice_forward(bk, S, N, B, width, nrow, ncol)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (2, 5, 3000, 3, 5, 5, 4),
+                                                          (1, 64, 1000, 3, 16, 16, 5), (8, 32, 700, 2, 16, 16, 2),
+                                                          (1, 128, 333, 2, 32, 32, None)])
+def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
+    KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)

@@ -96,8 +96,51 @@ def mid(L, S=16, N=256, B=3000):
         print("cons_head d=%d H=%d %8.1f us" % (d, H, t))
 
 
+def lattice(L, S=16, N=256, B=3000):
+    """lattice (exact bf16x3) layer-1 GEMMs + their producers, on random lattice inputs."""
+    from rcmarl_amd import lattice as LT
+    st = torch.cuda.current_stream().cuda_stream
+    for width in (2, 3):
+        in_dim = width * N
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        g = LT.Geometry(N, in_dim, B)
+        pos = torch.randint(0, 32, (S, B, in_dim), device="cuda").float()
+        std = float(np.std(np.arange(32)))
+        x = ((pos - 15.5) / std).contiguous()
+        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
+        theta = torch.randn(S, N, ldp, device="cuda") * 0.05
+        a1t = torch.zeros(S, N * HID, ldb, device="cuda")
+        y = torch.randn(S, N, ldb, device="cuda")
+        mask = torch.ones(N, dtype=torch.int32, device="cuda")
+        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
+        kp, ktp, wp, dzp = u8(g.kp, 1), u8(g.ktp, 1), u8(g.wp, 3), u8(g.dzp, 3)
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        nchunk = (B + 255) // 256
+        part = torch.zeros(S * N * nchunk * L.rcmarl_fit_partial_size(HID), device="cuda")
+        flops = 2.0 * S * N * HID * B * in_dim
+        t = timeit(lambda: L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0],
+                                                   g.kp[1], ktp.data_ptr(), g.ktp[0], g.ktp[1], flag.data_ptr(), st))
+        print("encode    in=%4d  %8.1f us   flag=%d" % (in_dim, t, int(flag.item())))
+        t = timeit(lambda: L.rcmarl_w1_split(theta.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0],
+                                             g.wp[1], st))
+        print("w1_split  in=%4d  %8.1f us  (%.2f TB/s r+w)" % (in_dim, t, 10.0 * S * N * HID * in_dim / t / 1e6))
+        t = timeit(lambda: L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1],
+                                                           theta.data_ptr(), a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st))
+        print("fwd_lat   in=%4d  %8.1f us  %6.1f TF/s fp32-equivalent (%.0f TF/s bf16 executed)" % (in_dim, t, flops / t / 1e6,
+                                                                                                   3 * flops / t / 1e6))
+        t = timeit(lambda: L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
+                                                    g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st))
+        print("mid_fit_l in=%4d  %8.1f us" % (in_dim, t))
+        t = timeit(lambda: L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0],
+                                                                g.dzp[1], alpha.data_ptr(), theta.data_ptr(), mask.data_ptr(), S, N,
+                                                                B, in_dim, HID, ldp, 1e-6, st))
+        print("bwd_lat   in=%4d  %8.1f us  %6.1f TF/s fp32-equivalent (%.0f TF/s bf16 executed)" % (in_dim, t, flops / t / 1e6,
+                                                                                                   3 * flops / t / 1e6))
+
+
 if __name__ == "__main__":
     L = capi.load()
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "mid": mid}[what](L)
+    {"gemm": gemm, "k1": k1, "mid": mid, "lattice": lattice}[what](L)
