@@ -255,7 +255,7 @@ def main():
             out["kernels"] = {k.replace("rcmarl_", ""): {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[2], 2),
                                                         "frac": round(v[1] / tot_ms, 4)} for k, v in
                               sorted(ksum.items(), key=lambda kv: -kv[1][1])}
-            out["roofline"], out["roofline_consensus"] = rooflines(tlib, ksum)
+            out["roofline"], out["roofline_consensus"], out["roofline_gemm"] = rooflines(tlib, ksum, args.workload)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(w)
@@ -267,28 +267,72 @@ def main():
         dist.destroy_process_group()
 
 
-def rooflines(tlib, ksum):
-    """roofline objects for the time-dominant kernel and for the consensus kernel (K1)."""
+BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
+
+# kernel -> (bound, note).  "mfma_bf16x3": fp32-equivalent flops 2MNK against the bf16 dense peak; the kernel
+# EXECUTES 3x those flops (three exact bf16 passes per fp32 product), so its ceiling is peak/3.
+ROOFLINE_KIND = {
+    "rcmarl_consensus_params": ("hbm", "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d). HBM-bound for "
+                                "small d (d=4: ~54% of 8 TB/s); at d=18 the 128-op min/max selection network makes it "
+                                "VALU-issue-bound (~83% of the v_min/v_max issue rate, DESIGN.md section 3)"),
+    "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
+                               "dz1 pieces written = 200 B; the kernel is VALU-issue-bound today (PMC: 1929 VALU + 769 SALU "
+                               "instructions and 64 f32 MFMAs per wavefront), DESIGN.md section 3"),
+    "rcmarl_mid_fit": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 read + 20 fp32 written"),
+    "rcmarl_w1_split": ("hbm", "reads W1 (4 B/weight), writes three bf16 pieces (6 B/weight)"),
+    "rcmarl_layer1_forward_lattice": ("mfma_bf16x3", ""),
+    "rcmarl_layer1_backward_sgd_lattice": ("mfma_bf16x3", ""),
+}
+
+
+def _pmc_traffic(workload):
+    """Per-launch HBM bytes from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_<workload>.json; FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%s.json" % workload)))
+    if not files:
+        return {}
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get("traffic_bytes_per_launch", {})
+    except Exception:
+        return {}
+
+
+def rooflines(tlib, ksum, workload=None):
+    """roofline objects for the time-dominant kernel, the consensus kernel (K1) and the layer-1 GEMM."""
     work = tlib.work
     dom = max(ksum.items(), key=lambda kv: kv[1][1])[0]
+    pmc = _pmc_traffic(workload) if workload else {}
 
     def obj(name):
         n, tot_ms, avg_us = ksum[name]
         flops, byts = work.get(name, (0.0, 0.0))
-        if name == "rcmarl_consensus_params":
+        kind, note = ROOFLINE_KIND.get(name, ("mfma_f32", ""))
+        traffic = pmc.get(name.replace("rcmarl_", ""))
+        if kind == "hbm":
             ach = byts / (tot_ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": n, "avg_us": avg_us,
-                    "algorithmic_bytes_per_launch": byts / n,
-                    "note": "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d). HBM-bound for small d "
-                            "(d=4: ~54% of 8 TB/s); at d=18 the 128-op min/max selection network makes it VALU-issue-bound "
-                            "(~83% of the v_min/v_max issue rate, DESIGN.md section 3)"}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches": n, "avg_us": avg_us,
+                    "algorithmic_bytes_per_launch": byts / n, "note": note}
         ach = flops / (tot_ms * 1e-3) / 1e12
+        if kind == "mfma_bf16x3":
+            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / BF16_PEAK_TFLOPS, "traffic": traffic, "launches": n, "avg_us": avg_us,
+                    "algorithmic_flops_per_launch": flops / n,
+                    "executed": {"achieved": 3 * ach, "frac": 3 * ach / BF16_PEAK_TFLOPS,
+                                 "what": "bf16 MFMA flops actually issued = 3 x algorithmic"},
+                    "note": "exact fp32 GEMM as three bf16 passes (integer-lattice operand x bf16 pieces of the fp32 "
+                            "operand, v_mfma_f32_32x32x16_bf16, fp32 accumulate): achieved = fp32-equivalent 2MNK flops; "
+                            "ceiling of the method = bf16 dense peak / 3 = 833 TFLOP/s; the f32-input MFMA it replaces "
+                            "peaks at 157.3"}
         return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP32_PEAK_TFLOPS, "traffic": None, "launches": n, "avg_us": avg_us,
+                "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "launches": n, "avg_us": avg_us,
                 "algorithmic_flops_per_launch": flops / n,
                 "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
-    return obj(dom), (obj("rcmarl_consensus_params") if "rcmarl_consensus_params" in ksum else None)
+    gemm = next((k for k in ("rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward") if k in ksum), None)
+    return (obj(dom), obj("rcmarl_consensus_params") if "rcmarl_consensus_params" in ksum else None,
+            obj(gemm) if gemm else None)
 
 
 if __name__ == "__main__":

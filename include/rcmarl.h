@@ -93,10 +93,13 @@ int rcmarl_w1_split(const float* theta, const float* alpha, void* wp, int S, int
 int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt,
                                   const float* theta, float* a1t, int S, int N, int B, int in_dim, int hid, int ldp,
                                   int ldb, void* stream);
-/* = rcmarl_layer1_backward_sgd on (ktp, dzp): W1[k][col] -= lr * alpha[k] * sum_b K[b][k]*dz1[col][b] */
+/* = rcmarl_layer1_backward_sgd on (ktp, dzp): W1[k][col] -= lr * alpha[k] * sum_b K[b][k]*dz1[col][b].
+ * wp_out (or NULL): additionally receives what rcmarl_w1_split would produce from the UPDATED theta (masked
+ * agents: from their unchanged rows), so the next forward of the same local fit needs no split pass. */
 int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt, int dzp_kt,
                                        const float* alpha, float* theta, const int* mask, int S, int N, int B,
-                                       int in_dim, int hid, int ldp, float lr, void* stream);
+                                       int in_dim, int hid, int ldp, float lr, void* wp_out, int wp_rt, int wp_kt,
+                                       void* stream);
 /* = rcmarl_mid_fit, but a1t is left intact and dz1 is written as dzp (3 exact bf16 pieces, rows = (agent,unit)
  * column, reduction = replay row, zero beyond B) for rcmarl_layer1_backward_sgd_lattice. */
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,

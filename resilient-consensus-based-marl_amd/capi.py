@@ -48,9 +48,10 @@ SIGNATURES = {
     # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1t, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_layer1_forward_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_stream],
-    # ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, stream
+    # ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, wp_out, wp_rt, wp_kt,
+    # stream
     "rcmarl_layer1_backward_sgd_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_u8p, c_int,
-                                           c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
+                                           c_int, c_int, c_int, c_int, c_int, c_float, c_u8p, c_int, c_int, c_stream],
     # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_stream],

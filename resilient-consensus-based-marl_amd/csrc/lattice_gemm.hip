@@ -104,22 +104,22 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int c4 = (t >> 7) + 2 * q;
-    unsigned h[8], m[8], l[8];
+    float w[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = kt * 32 + 8 * c4 + e;
       const bool ok = col_ok && k < in_dim;
-      const float w = ok ? th[(long)k * 20] * alpha[k] : 0.f;
-      rc_split3(w, h[e], m[e], l[e]);
+      w[e] = ok ? th[(long)k * 20] * alpha[k] : 0.f;
     }
+    uint4 vh, vm, vl;
+    rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
+    rc_split3_pair(w[2], w[3], vh.y, vm.y, vl.y);
+    rc_split3_pair(w[4], w[5], vh.z, vm.z, vl.z);
+    rc_split3_pair(w[6], w[7], vh.w, vm.w, vl.w);
     const int o = r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4);
-    uint4 v;
-    v.x = pack2(h[0], h[1]); v.y = pack2(h[2], h[3]); v.z = pack2(h[4], h[5]); v.w = pack2(h[6], h[7]);
-    st_u4(blk + o, v);
-    v.x = pack2(m[0], m[1]); v.y = pack2(m[2], m[3]); v.z = pack2(m[4], m[5]); v.w = pack2(m[6], m[7]);
-    st_u4(blk + RC_PK_BLOCK + o, v);
-    v.x = pack2(l[0], l[1]); v.y = pack2(l[2], l[3]); v.z = pack2(l[4], l[5]); v.w = pack2(l[6], l[7]);
-    st_u4(blk + 2 * RC_PK_BLOCK + o, v);
+    st_u4(blk + o, vh);
+    st_u4(blk + RC_PK_BLOCK + o, vm);
+    st_u4(blk + 2 * RC_PK_BLOCK + o, vl);
   }
 }
 
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256, 2) void k_lat_backward_sgd(const unsigned char
                                                              const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
                                                              const float* __restrict__ alpha, float* __restrict__ theta,
                                                              const int* __restrict__ mask, int S, int N, int B,
-                                                             int in_dim, int ldp, float lr, int mtiles, int ntiles) {
+                                                             int in_dim, int ldp, float lr, int mtiles, int ntiles,
+                                                             unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt) {
   constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void k_lat_backward_sgd(const unsigned char
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
   lat_mainloop<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
-  // epilogue: W1[k][col] -= lr * alpha_k * acc
+  // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
+  // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
+  // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
   const int ncols = N * 20;
   __syncthreads();
   float* al = reinterpret_cast<float*>(lds);
@@ -310,24 +313,46 @@ __global__ __launch_bounds__(256, 2) void k_lat_backward_sgd(const unsigned char
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col = bn * C::BN + wn * 32 * NT + 32 * nt + (lane & 31);
+    const int cl = wn * 32 * NT + 32 * nt + (lane & 31);                 // column within the 128-wide tile
+    const int col = bn * C::BN + cl;
     if (col < ncols) {
       const int ag = col / 20, j = col - ag * 20;
-      if (mask == nullptr || mask[ag]) {
-        float* th = theta + ((long)s * N + ag) * ldp + j;
+      const bool upd = mask == nullptr || mask[ag];
+      float* th = theta + ((long)s * N + ag) * ldp + j;
+      unsigned char* wrow = wp_out == nullptr ? nullptr
+          : wp_out + (long)s * wp_rt * wp_kt * (3 * RC_PK_BLOCK) + (long)bn * wp_kt * (3 * RC_PK_BLOCK) + cl * 64 + half * 8;
+      const int sw = (cl >> 2) & 3;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int kt = bm * (C::BM / 32) + wm * MT + mt;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kl = wm * 32 * MT + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int gq = 0; gq < 4; ++gq) {
+          float wn4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kl = wm * 32 * MT + 32 * mt + 8 * gq + 4 * half + e;
             const int k = bm * C::BM + kl;
+            float w = 0.f;
             if (k < in_dim) {
               float* wptr = th + (long)k * 20;
-              *wptr = *wptr - lr * (al[kl] * acc[mt][nt][r]);
+              w = *wptr;
+              if (upd) { w = w - lr * (al[kl] * acc[mt][nt][4 * gq + e]); *wptr = w; }
             }
+            wn4[e] = w * al[kl];
           }
+          if (wrow != nullptr && kt < wp_kt) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            rc_split3_pair(wn4[0], wn4[1], h0, m0, l0);
+            rc_split3_pair(wn4[2], wn4[3], h1, m1, l1);
+            unsigned char* q = wrow + (long)kt * (3 * RC_PK_BLOCK) + ((gq ^ sw) << 4);
+            *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(q + RC_PK_BLOCK) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(q + 2 * RC_PK_BLOCK) = make_uint2(l0, l1);
+          }
+        }
       }
     }
   }
@@ -396,17 +421,19 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
 RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
                                                      int dzp_kt, const float* alpha, float* theta, const int* mask,
                                                      int S, int N, int B, int in_dim, int hid, int ldp, float lr,
-                                                     void* stream) {
+                                                     void* wp_out, int wp_rt, int wp_kt, void* stream) {
   if (!ktp || !dzp || !alpha || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) ||
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
   if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
   const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * 20, 128), ktiles = rc_ceil_div(B, 32);
   if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
+  if (wp_out && (wp_rt < ntiles || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
   const size_t smem = 2 * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
   if (!lat_want_lds(k_lat_backward_sgd, smem)) return RCMARL_ERR_LAUNCH;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
   RCMARL_LAUNCH(k_lat_backward_sgd, grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
-                (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles);
+                (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                (unsigned char*)wp_out, wp_rt, wp_kt);
   return rcmarl_check_launch();
 }

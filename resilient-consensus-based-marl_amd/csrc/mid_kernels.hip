@@ -237,6 +237,172 @@ __global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, c
     out[e] = (sA[e] + sA[PT::SIZE + e]) + (sA[2 * PT::SIZE + e] + sA[3 * PT::SIZE + e]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_mid_fit, third form: same arithmetic (every fmaf chain keeps its order -> bit-identical dz1, a2, v),
+// restructured for the VALU issue rate, which is what bounds this kernel (PMC: 1929 VALU + 769 SALU
+// instructions per wavefront before, against 400 packed FMAs of real work):
+//   * the agent's W2 (row-major and transposed), b2, W3 live in LDS; a row of 20 weights arrives with five
+//     broadcast ds_read_b128 instead of a latency-bound s_load + s_waitcnt per row;
+//   * both 20x20 products are axpy-shaped, so they run as v_pk_fma_f32 (two units per instruction);
+//   * the matrix-core reductions read their 32-row fragments from panels that CONTAIN the constant rows
+//     (ones / zeros), so no per-fragment select;
+//   * the bf16 pieces of dz1 come from v_cvt_pk_bf16_f32 pairs and leave through unconditional 2-byte stores.
+template <int HID, bool EMIT>
+__global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, const float* __restrict__ theta,
+                                                    const float* __restrict__ y, float* __restrict__ partials, int N,
+                                                    int B, int in_dim, int ldp, int ldb, int nchunk,
+                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
+  static_assert(HID % 4 == 0, "rows of W2 are read as float4");
+  typedef FitPart<HID> PT;
+  constexpr int RA = HID + 2;                        // sA rows: HID data | ones | zeros
+  constexpr int RB = HID + 3;                        // sB rows: HID data | dv | diff^2 | zeros
+  constexpr int H2 = HID / 2;
+  __shared__ __attribute__((aligned(16))) float sW2[HID * HID];
+  __shared__ __attribute__((aligned(16))) float sW2T[HID * HID];
+  __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];        // b2 | W3 | b3
+  __shared__ float sP[(RA + RB) * LDR];            // both panels; reused for the 32x32 results of the 4 wavefronts
+  static_assert((RA + RB) * LDR >= 4 * 2 * 1024, "result matrices fit in the panel buffer");
+  float* sA = sP;
+  float* sB = sP + RA * LDR;
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  const int r = threadIdx.x, b = chunk * ROWS + r;
+  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
+  const bool valid = b < B;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  for (int e = r; e < HID * HID; e += ROWS) {
+    const float w = th[g.o_W2 + e];
+    const int j = e / HID, k = e - j * HID;
+    sW2[e] = w;
+    sW2T[k * HID + j] = w;
+  }
+  if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];       // b2, W3, b3 are contiguous in the parameter row
+  sA[HID * LDR + r] = 1.f;
+  sA[(HID + 1) * LDR + r] = 0.f;
+  sB[(HID + 2) * LDR + r] = 0.f;
+  float a1[HID];
+  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+  __syncthreads();
+  // ---- layer 2 forward: a2[k] = lrelu(sum_j a1[j] W2[j][k] + b2[k]), j ascending
+  rc_f2 z2[H2];
+#pragma unroll
+  for (int q = 0; q < H2; ++q) z2[q] = rc_f2{0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < HID; ++j) {
+    const rc_f2 aj = rc_bcast2(a1[j]);
+#pragma unroll
+    for (int q4 = 0; q4 < HID / 4; ++q4) {
+      const float4 w = *reinterpret_cast<const float4*>(&sW2[j * HID + 4 * q4]);
+      z2[2 * q4] = rc_fma2(aj, rc_f2{w.x, w.y}, z2[2 * q4]);
+      z2[2 * q4 + 1] = rc_fma2(aj, rc_f2{w.z, w.w}, z2[2 * q4 + 1]);
+    }
+  }
+  float a2[HID], dz2[HID];
+  float v = 0.f;
+#pragma unroll
+  for (int q = 0; q < H2; ++q) {
+    a2[2 * q] = rc_lrelu(z2[q].x + sV[2 * q]);
+    a2[2 * q + 1] = rc_lrelu(z2[q].y + sV[2 * q + 1]);
+  }
+#pragma unroll
+  for (int k = 0; k < HID; ++k) v = fmaf(a2[k], sV[HID + k], v);
+  v += sV[2 * HID];
+  const float diff = valid ? v - y[((long)s * N + i) * ldb + b] : 0.f;
+  const float dv = (2.0f * diff) / (float)B;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) dz2[k] = dv * sV[HID + k] * rc_lrelu_grad_from_act(a2[k]);
+  // ---- layer 2 backward: dz1[j] = (sum_k dz2[k] W2[j][k]) * lrelu'(z1[j]), k ascending
+  rc_f2 da[H2];
+#pragma unroll
+  for (int q = 0; q < H2; ++q) da[q] = rc_f2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    const rc_f2 dk = rc_bcast2(dz2[k]);
+#pragma unroll
+    for (int q4 = 0; q4 < HID / 4; ++q4) {
+      const float4 w = *reinterpret_cast<const float4*>(&sW2T[k * HID + 4 * q4]);
+      da[2 * q4] = rc_fma2(dk, rc_f2{w.x, w.y}, da[2 * q4]);
+      da[2 * q4 + 1] = rc_fma2(dk, rc_f2{w.z, w.w}, da[2 * q4 + 1]);
+    }
+  }
+  float dz1[HID];
+#pragma unroll
+  for (int q = 0; q < H2; ++q) {
+    dz1[2 * q] = da[q].x * rc_lrelu_grad_from_act(a1[2 * q]);
+    dz1[2 * q + 1] = da[q].y * rc_lrelu_grad_from_act(a1[2 * q + 1]);
+  }
+  if (EMIT) {
+    // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + j (uniform), k = b (lane): the lane part of the byte
+    // offset is fixed, the row part XORs bits 4-5
+    // (workgroup-uniform pointer + 32-bit lane offset -> saddr/voffset stores, no 64-bit VALU address math)
+    unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + (long)(chunk * (ROWS / 32)) * (3 * RC_PK_BLOCK);
+    const unsigned lane_off = (unsigned)(r >> 5) * (3 * RC_PK_BLOCK) + (((r & 31) >> 3) << 4) + (r & 7) * 2;
+    const unsigned lane_off1 = lane_off + RC_PK_BLOCK, lane_off2 = lane_off + 2 * RC_PK_BLOCK;
+#pragma unroll
+    for (int q = 0; q < H2; ++q) {
+      unsigned h, m, l;
+      rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = i * HID + 2 * q + u;
+        unsigned char* p = base + (long)(row >> 7) * dzp_kt * (3 * RC_PK_BLOCK) + (row & 127) * 64;
+        const unsigned sw = (unsigned)(((row >> 2) & 3) << 4);     // the piece offsets ride in the lane offset
+        *reinterpret_cast<unsigned short*>(p + (lane_off ^ sw)) = (unsigned short)(u ? h >> 16 : h);
+        *reinterpret_cast<unsigned short*>(p + (lane_off1 ^ sw)) = (unsigned short)(u ? m >> 16 : m);
+        *reinterpret_cast<unsigned short*>(p + (lane_off2 ^ sw)) = (unsigned short)(u ? l >> 16 : l);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < HID; ++j)
+      if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];
+  }
+  // ---- reductions over the 256 rows on the f32 matrix core (as k_mid_fit_mfma):
+  //   G1 = [a1 | 1]^T [dz2]                 -> gW2, gb2
+  //   G2 = [a2 | 1]^T [dz1 | dv | diff^2]   -> gW3, gb1, gb3, loss
+  rc_f32x16 acc1, acc2;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc1[q] = 0.f; acc2[q] = 0.f; }
+  const int ia = (l31 < HID + 1 ? l31 : HID + 1) * LDR + wave * 64 + half;       // rows >= HID+1 -> zeros
+  const int ib1 = (l31 < HID ? l31 : HID + 2) * LDR + wave * 64 + half;
+  const int ib2 = (l31 < HID + 2 ? l31 : HID + 2) * LDR + wave * 64 + half;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a1[k]; sB[k * LDR + r] = dz2[k]; }
+  __syncthreads();
+#pragma unroll 8
+  for (int m = 0; m < 32; ++m) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib1 + 2 * m], acc1, 0, 0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a2[k]; sB[k * LDR + r] = dz1[k]; }
+  sB[HID * LDR + r] = dv;
+  sB[(HID + 1) * LDR + r] = diff * diff;
+  __syncthreads();
+#pragma unroll 8
+  for (int m = 0; m < 32; ++m) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib2 + 2 * m], acc2, 0, 0, 0);
+  __syncthreads();
+  // all 2 x 1024 results of each wavefront go to LDS unconditionally; the record is gathered from them
+  float* mat = sP + wave * 2048;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = (q & 3) + 8 * (q >> 2) + 4 * half;                   // D[row][col = l31]
+    mat[row * 32 + l31] = acc1[q];
+    mat[1024 + row * 32 + l31] = acc2[q];
+  }
+  __syncthreads();
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
+  for (int e = r; e < PT::SIZE; e += ROWS) {
+    int src;
+    if (e < PT::gb2) { const int j = e / HID; src = j * 32 + (e - j * HID); }          // gW2[j][k] = G1[j][k]
+    else if (e < PT::gW3) src = HID * 32 + (e - PT::gb2);                                // gb2[k]    = G1[HID][k]
+    else if (e < PT::gb3) src = 1024 + (e - PT::gW3) * 32 + HID;                         // gW3[k]    = G2[k][HID]
+    else if (e < PT::gb1) src = 1024 + HID * 32 + HID;                                   // gb3       = G2[HID][HID]
+    else if (e < PT::loss) src = 1024 + HID * 32 + (e - PT::gb1);                        // gb1[j]    = G2[HID][j]
+    else src = 1024 + HID * 32 + HID + 1;                                                // loss      = G2[HID][HID+1]
+    out[e] = (sP[src] + sP[2048 + src]) + (sP[4096 + src] + sP[6144 + src]);
+  }
+}
+
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B
 template <int HID>
 __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ partials, float* __restrict__ theta,
@@ -613,6 +779,16 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
   if (t < n_total) delta[t] = r_team[t] + gamma * v_next[t] - v_cur[t];
 }
 
+int midfit_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RCMARL_MIDFIT");
+    v = e ? atoi(e) : 2;
+    if (v < 0 || v > 2) v = 2;
+  }
+  return v;
+}
+
 bool bad_mid(const void* a, const void* b, int S, int N, int B, int in_dim, int hid, int ldp, int ldb) {
   return !a || !b || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) || ldb < B;
 }
@@ -636,9 +812,11 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(nchunk, N, S), block(ROWS);
-  static int variant = -1;         // RCMARL_MIDFIT=0 selects the LDS-loop / DPP-tree kernel (bisecting knob)
-  if (variant < 0) { const char* e = getenv("RCMARL_MIDFIT"); variant = e ? atoi(e) : 1; }
-  if (variant == 0) {
+  const int variant = midfit_variant();   // RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 (default) v3
+  if (variant == 2) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk, (unsigned char*)nullptr, 0, 0));
+  } else if (variant == 0) {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
                                      ldp, ldb, nchunk));
   } else {
@@ -653,10 +831,15 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
                                          int ldp, int ldb, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials || !dzp) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS);
-  if (dzp_rt * 128 < N * hid || dzp_kt < rc_ceil_div(B, 32)) return RCMARL_ERR_ARG;
+  if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(nchunk, N, S), block(ROWS);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                   partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  if (midfit_variant() == 2) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  } else {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta,
+                                     y, partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  }
   return rcmarl_check_launch();
 }
 

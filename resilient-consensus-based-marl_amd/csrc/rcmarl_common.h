@@ -103,3 +103,14 @@ __device__ __forceinline__ float rc_wave_sum_lane63(float v) {
 }
 
 static inline int rc_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Two fp32 lanes per register pair: v_pk_fma_f32 / v_pk_mul_f32 run 128 FMAs per wavefront instruction in the
+// 4-cycle issue slot a plain v_fma_f32 spends on 64 (the 157 TFLOP/s fp32 vector peak is the PACKED rate).
+#ifdef RCMARL_EMU
+struct rc_f2 { float x, y; };
+__device__ __forceinline__ rc_f2 rc_fma2(rc_f2 a, rc_f2 b, rc_f2 c) { return rc_f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
+typedef float rc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rc_f2 rc_fma2(rc_f2 a, rc_f2 b, rc_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+__device__ __forceinline__ rc_f2 rc_bcast2(float v) { return rc_f2{v, v}; }

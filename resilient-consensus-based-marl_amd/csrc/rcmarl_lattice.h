@@ -49,6 +49,27 @@ __device__ __forceinline__ void rc_split3(float w, unsigned& h, unsigned& m, uns
   l = rc_bf16_rne(r2);
 }
 
+// the same split for two values at once; piece of w0 in bits 0-15, of w1 in bits 16-31 of each output
+// (device: v_cvt_pk_bf16_f32 rounds both to nearest even in one instruction, v_pk_add_f32 forms both residuals)
+#ifdef RCMARL_EMU
+__device__ __forceinline__ void rc_split3_pair(float w0, float w1, unsigned& h, unsigned& m, unsigned& l) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  rc_split3(w0, h0, m0, l0);
+  rc_split3(w1, h1, m1, l1);
+  h = h0 | (h1 << 16); m = m0 | (m1 << 16); l = l0 | (l1 << 16);
+}
+#else
+typedef __bf16 rc_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rc_split3_pair(float w0, float w1, unsigned& h, unsigned& m, unsigned& l) {
+  rc_f2 v = {w0, w1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rc_bf16x2));
+  const rc_f2 r1 = v - rc_f2{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, rc_bf16x2));
+  const rc_f2 r2 = r1 - rc_f2{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, rc_bf16x2));
+}
+#endif
+
 #ifdef RCMARL_EMU
 __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c) {
   return __hipemu_mfma_f32_32x32x16_bf16(a, b, c);

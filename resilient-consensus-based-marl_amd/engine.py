@@ -439,13 +439,14 @@ class RPBCACEngine:
         w = self.rp[key].shape[2]
         return self.rp[key].data_ptr() + 4 * row0 * w, self.cap * w
 
-    def _layer1(self, xkey, theta, net, B, row0=0, buf=None):
+    def _layer1(self, xkey, theta, net, B, row0=0, buf=None, wp_fresh=False):
         ptr, stride = self._x(xkey, row0)
         buf = self.a1t if buf is None else buf
         if self._lattice_ok(xkey, B, row0):
             g, L = self.lat_geom[xkey], self.lib
-            L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), self.lat_wp.data_ptr(), self.S, self.N,
-                              self.in_dim[net], HID, self.ldp[net], g.wp[0], g.wp[1], self.stream)
+            if not wp_fresh:
+                L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), self.lat_wp.data_ptr(), self.S, self.N,
+                                  self.in_dim[net], HID, self.ldp[net], g.wp[0], g.wp[1], self.stream)
             L.rcmarl_layer1_forward_lattice(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], self.lat_wp.data_ptr(), g.wp[0],
                                             g.wp[1], theta.data_ptr(), buf.data_ptr(), self.S, self.N, B, self.in_dim[net],
                                             HID, self.ldp[net], self.ldb, self.stream)
@@ -461,9 +462,10 @@ class RPBCACEngine:
         ptr, stride = self._x(xkey)
         lat = self._lattice_ok(xkey, B, 0) and xkey in self.lat_ktp
         g = self.lat_geom[xkey] if lat else None
+        wp_fresh = False
         for step in range(self.cfg.local_fit_steps):
             if not (step == 0 and self.a1_cached[net]):       # msg == live net: activations left by _consensus
-                self._layer1(xkey, msg, net, B, buf=a1)
+                self._layer1(xkey, msg, net, B, buf=a1, wp_fresh=wp_fresh)
             if lat:
                 L.rcmarl_mid_fit_lattice(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(),
                                          self.lat_dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B, self.in_dim[net], HID,
@@ -478,7 +480,9 @@ class RPBCACEngine:
                 L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1],
                                                      self.lat_dzp.data_ptr(), g.dzp[0], g.dzp[1],
                                                      self.lat_alpha[xkey].data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N,
-                                                     B, self.in_dim[net], HID, self.ldp[net], self.cfg.fast_lr, self.stream)
+                                                     B, self.in_dim[net], HID, self.ldp[net], self.cfg.fast_lr,
+                                                     self.lat_wp.data_ptr(), g.wp[0], g.wp[1], self.stream)
+                wp_fresh = True           # the epilogue left the split of the updated W1 in lat_wp
             else:
                 L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
                                              self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)

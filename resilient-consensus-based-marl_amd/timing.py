@@ -24,6 +24,14 @@ WORK = {
     "rcmarl_consensus_params": lambda a: (0.0, 8.0 * a[4] * a[5] * a[7]),
     # a1t, theta, y, partials, S, N, B, in_dim, hid: layers 2-3 fwd+bwd ~ (8 h^2 + 12 h) flops per (row, agent)
     "rcmarl_mid_fit": lambda a: (a[4] * a[5] * a[6] * (8.0 * a[8] ** 2 + 12.0 * a[8]), 8.0 * a[4] * a[5] * a[6] * a[8]),
+    # lattice path: fp32-EQUIVALENT flops 2*M*N*K (the kernel executes 3x that on the bf16 matrix core)
+    "rcmarl_layer1_forward_lattice": lambda a: _gemm_flops(a, 8),
+    "rcmarl_layer1_backward_sgd_lattice": lambda a: _gemm_flops(a, 9),
+    # a1t, theta, y, partials, dzp, rt, kt, S, N, B, in_dim, hid: reads a1 (4 B), writes 3 bf16 pieces of dz1 (6 B)
+    "rcmarl_mid_fit_lattice": lambda a: (a[7] * a[8] * a[9] * (8.0 * a[11] ** 2 + 12.0 * a[11]),
+                                         10.0 * a[7] * a[8] * a[9] * a[11]),
+    # theta, alpha, wp, S, N, in_dim, hid: reads W1 (4 B), writes 3 pieces (6 B)
+    "rcmarl_w1_split": lambda a: (0.0, 10.0 * a[3] * a[4] * a[5] * a[6]),
 }
 
 

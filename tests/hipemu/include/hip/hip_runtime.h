@@ -38,6 +38,7 @@ struct float2 { float x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 namespace hipemu {

@@ -560,9 +560,10 @@ def _encode(bk, lb, d_x, x_stride, d_alpha, S, B, in_dim, with_t=True):
                                  bk.ptr(lb.ktp) if with_t else None, g.ktp[0], g.ktp[1], bk.ptr(lb.flag), bk.stream)
 
 
-def _layer1_lattice(bk, lb, d_alpha, d_theta, d_a1t, S, N, B, in_dim, ldp, ldb):
+def _layer1_lattice(bk, lb, d_alpha, d_theta, d_a1t, S, N, B, in_dim, ldp, ldb, split=True):
     g = lb.g
-    bk.lib.rcmarl_w1_split(bk.ptr(d_theta), bk.ptr(d_alpha), bk.ptr(lb.wp), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], bk.stream)
+    if split:
+        bk.lib.rcmarl_w1_split(bk.ptr(d_theta), bk.ptr(d_alpha), bk.ptr(lb.wp), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], bk.stream)
     bk.lib.rcmarl_layer1_forward_lattice(bk.ptr(lb.kp), g.kp[0], g.kp[1], bk.ptr(lb.wp), g.wp[0], g.wp[1], bk.ptr(d_theta),
                                          bk.ptr(d_a1t), S, N, B, in_dim, HID, ldp, ldb, bk.stream)
 
@@ -659,7 +660,9 @@ def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamm
     L.rcmarl_mid_value(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_r), gamma, bk.ptr(d_y), S, N, B, in_dim, HID, ldp, ldb,
                        bk.stream)
     for st in range(steps):
-        _layer1_lattice(bk, lb, d_al, d_msg, d_a, S, N, B, in_dim, ldp, ldb)
+        # from step 1 on the forward operand comes from the previous backward's epilogue (odd steps also re-split,
+        # which must give the same bytes)
+        _layer1_lattice(bk, lb, d_al, d_msg, d_a, S, N, B, in_dim, ldp, ldb, split=(st == 0))
         a_before = bk.host(d_a).copy() if st == 0 else None
         L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
                                  S, N, B, in_dim, HID, ldp, ldb, bk.stream)
@@ -669,7 +672,16 @@ def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamm
                            in_dim, HID, ldp, lr, bk.stream)
         L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
                                              bk.ptr(d_al), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
-                                             bk.stream)
+                                             bk.ptr(lb.wp), g.wp[0], g.wp[1], bk.stream)
+        if st == steps - 1:                                   # fused pieces == what a fresh split of the result gives
+            fused = bk.host(lb.wp).copy()
+            L.rcmarl_w1_split(bk.ptr(d_msg), bk.ptr(d_al), bk.ptr(lb.wp), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], bk.stream)
+            fresh = bk.host(lb.wp).reshape(S, -1)
+            fused = fused.reshape(S, -1)
+            for s_ in range(S):
+                for pc in range(3):
+                    idx = LT.pk_element_index(N * HID, in_dim, g.wp[1], 3, pc)
+                    np.testing.assert_array_equal(fused[s_][idx], fresh[s_][idx])
     assert bk.host(lb.flag)[0] == 0 and bk.host(lbn.flag)[0] == 0
     msg, y, loss = bk.host(d_msg), bk.host(d_y), bk.host(d_loss)
     for s in range(S):

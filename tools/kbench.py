@@ -134,7 +134,7 @@ def lattice(L, S=16, N=256, B=3000):
         print("mid_fit_l in=%4d  %8.1f us" % (in_dim, t))
         t = timeit(lambda: L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0],
                                                                 g.dzp[1], alpha.data_ptr(), theta.data_ptr(), mask.data_ptr(), S, N,
-                                                                B, in_dim, HID, ldp, 1e-6, st))
+                                                                B, in_dim, HID, ldp, 1e-6, wp.data_ptr(), g.wp[0], g.wp[1], st))
         print("bwd_lat   in=%4d  %8.1f us  %6.1f TF/s fp32-equivalent (%.0f TF/s bf16 executed)" % (in_dim, t, flops / t / 1e6,
                                                                                                    3 * flops / t / 1e6))
 
