@@ -140,10 +140,11 @@ struct LatOperands {
   int art0, brt0;                                   // first 128-row tile of this workgroup on each side
 };
 
-template <int PA, int PB, int MT, int NT>
+template <int PA, int PB, int MT, int NT, int NSTAGE>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
                                              rc_f32x16 (&acc)[MT][NT]) {
   typedef LatCfg<PA, PB, MT, NT> C;
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "LDS ring depth");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wm = wave >> 1, wn = wave & 1;
@@ -163,19 +164,21 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
     const int q = wave + 4 * i;
     if (q < C::A_KB) {
       const int seg = q / (PA * 8), off = q - seg * (PA * 8);
-      gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * (PA * RC_PK_BLOCK) + off * 1024 + lane * 16;
+      gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * (PA * RC_PK_BLOCK) + off * 1024;
       gstep[i] = PA * RC_PK_BLOCK;
     } else {
       const int q2 = q - C::A_KB;
       const int seg = q2 / (PB * 8), off = q2 - seg * (PB * 8);
-      gsrc[i] = op.b + ((long)(op.brt0 + seg) * op.b_kt) * (PB * RC_PK_BLOCK) + off * 1024 + lane * 16;
+      gsrc[i] = op.b + ((long)(op.brt0 + seg) * op.b_kt) * (PB * RC_PK_BLOCK) + off * 1024;
       gstep[i] = PB * RC_PK_BLOCK;
     }
   }
+  const unsigned lane16 = lane * 16;
+  const rc_lds_t lds0 = rc_lds_addr(lds) + wave * 1024;
   auto stage = [&](int buf, int t) {
-    unsigned char* dst = lds + buf * C::STAGE_BYTES + wave * 1024;
+    const rc_lds_t dst = lds0 + buf * C::STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < C::GLDS; ++i) RC_GLDS16(gsrc[i] + (long)t * gstep[i], dst + i * 4096);
+    for (int i = 0; i < C::GLDS; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, dst + i * 4096);
   };
 
   // fragment addresses: row = lane&31 (+ tile offsets), chunk = 2*kstep + lane>>5, XOR (row>>2)&3
@@ -193,12 +196,20 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
     offB[nt] = C::A_KB * 1024 + (row >> 7) * PB * RC_PK_BLOCK + (row & 127) * 64;
   }
 
+  // ring of NSTAGE stages: tile t+NSTAGE-1 is requested right after the barrier that retires tile t-1
   stage(0, 0);
+  if (NSTAGE == 3 && n_ktiles > 1) stage(1, 1);
+  int cur = 0;                                        // t % NSTAGE
   for (int t = 0; t < n_ktiles; ++t) {
-    RC_WAIT_VMEM();                 // this wavefront's bursts of tile t have landed ...
-    __syncthreads();                // ... and everybody's; all reads of buffer (t+1)&1 are done
-    if (t + 1 < n_ktiles) stage((t + 1) & 1, t + 1);
-    const unsigned char* st = lds + (t & 1) * C::STAGE_BYTES;
+    // this wavefront's bursts of tile t have landed (NSTAGE 3: tile t+1's may still be in flight) ...
+    if (NSTAGE == 3 && t + 1 < n_ktiles) RC_WAIT_VMEM_N(C::GLDS); else RC_WAIT_VMEM();
+    __syncthreads();                // ... and everybody's; all reads of the buffer refilled next are done
+    if (t + NSTAGE - 1 < n_ktiles) {
+      const int nb = cur == 0 ? NSTAGE - 1 : cur - 1;           // (t + NSTAGE - 1) % NSTAGE
+      stage(nb, t + NSTAGE - 1);
+    }
+    const unsigned char* st = lds + cur * C::STAGE_BYTES;
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int co = ks == 0 ? co0 : co1;
@@ -237,23 +248,40 @@ __device__ __forceinline__ void lat_decode(int per_seed, int S, int& seed, int& 
   }
 }
 
+// De-phasing aid: the two workgroups that share a CU start together and would otherwise run their
+// (memory-bound) prologue/epilogue and their (matrix-core-bound) k-loop in lockstep.  First-wave workgroups
+// whose bit `bit` of (id/8) is set sleep `n` x ~4 us once, so the pair drifts half a tile apart and one's
+// epilogue overlaps the other's k-loop.  Pure scheduling: no effect on results.
+__device__ __forceinline__ void lat_stagger(int bit, int n) {
+#ifndef RCMARL_EMU
+  if (bit >= 0 && blockIdx.x < 512u && (((blockIdx.x >> 3) >> bit) & 1u))
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+}
+
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
-__global__ __launch_bounds__(256, 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
+template <int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
                                                         const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                         const float* __restrict__ theta, float* __restrict__ a1t, int S,
                                                         int N, int B, int in_dim, int ldp, int ldb, int mtiles,
-                                                        int ntiles) {
+                                                        int ntiles, int dbg_same_tile, int stg_bit, int stg_n) {
   constexpr int PA = 3, PB = 1, MT = 2, NT = 4;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
   lat_decode(mtiles * ntiles, S, s, w);
+  lat_stagger(stg_bit, stg_n);
   const int bn = w % ntiles, bm = w / ntiles;                      // n fastest: neighbours share the W' panel
   LatOperands op;
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
   op.b = kp + (long)s * kp_rt * kp_kt * (PB * RC_PK_BLOCK); op.b_kt = kp_kt; op.brt0 = bn * C::BRT;
+  if (dbg_same_tile) {              // measurement aid only (RCMARL_LAT_SAMETILE=1): every workgroup streams ONE
+    op.a = wp; op.art0 = 0;         // panel pair, i.e. the k-loop with a perfectly cached memory system
+    op.b = kp; op.brt0 = 0;
+  }
   rc_f32x16 acc[MT][NT];
-  lat_mainloop<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
+  lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * 20;
   const float* theta_s = theta + (long)s * N * ldp;
@@ -284,23 +312,26 @@ __global__ __launch_bounds__(256, 2) void k_lat_forward(const unsigned char* __r
 }
 
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
-__global__ __launch_bounds__(256, 2) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
+template <int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
                                                              const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
                                                              const float* __restrict__ alpha, float* __restrict__ theta,
                                                              const int* __restrict__ mask, int S, int N, int B,
                                                              int in_dim, int ldp, float lr, int mtiles, int ntiles,
-                                                             unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt) {
+                                                             unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt,
+                                                             int stg_bit, int stg_n) {
   constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
   lat_decode(mtiles * ntiles, S, s, w);
+  lat_stagger(stg_bit, stg_n);
   const int bm = w % mtiles, bn = w / mtiles;                      // m fastest: neighbours share the dz panel
   LatOperands op;
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
-  lat_mainloop<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
+  lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
@@ -361,14 +392,26 @@ __global__ __launch_bounds__(256, 2) void k_lat_backward_sgd(const unsigned char
 template <class K>
 bool lat_want_lds(K kernel, size_t smem) {
 #ifndef RCMARL_EMU
-  static bool done = false;            // one attribute call per kernel instantiation
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return false;
-    done = true;
-  }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return false;
 #endif
   return true;
+}
+
+int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int lat_stagger_bit() { static int v = lat_env_int("RCMARL_LAT_STAGGER_BIT", -1); return v; }
+int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
+
+// LDS ring depth of the lattice GEMMs: 2 (80 KiB, two workgroups per CU) or 3 (120 KiB, one workgroup per CU,
+// a tile more of load lead).  RCMARL_LAT_STAGES is a tuning knob, read once.
+int lat_stages() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RCMARL_LAT_STAGES");
+    v = e ? atoi(e) : 2;
+    if (v != 2 && v != 3) v = 2;
+  }
+  return v;
 }
 
 }  // namespace
@@ -410,11 +453,21 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
   const int mtiles = rc_ceil_div(N * 20, 128), ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
   if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
-  const size_t smem = 2 * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
-  if (!lat_want_lds(k_lat_forward, smem)) return RCMARL_ERR_LAUNCH;
+  const int ns = lat_stages();
+  static const int dbg = getenv("RCMARL_LAT_SAMETILE") ? atoi(getenv("RCMARL_LAT_SAMETILE")) : 0;
+  const size_t smem = (size_t)ns * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
-  RCMARL_LAUNCH(k_lat_forward, grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp,
-                kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles);
+  if (ns == 2) {
+    static const bool ok = lat_want_lds(k_lat_forward<2>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_forward<2>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
+  } else {
+    static const bool ok = lat_want_lds(k_lat_forward<3>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_forward<3>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
+  }
   return rcmarl_check_launch();
 }
 
@@ -429,11 +482,21 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * 20, 128), ktiles = rc_ceil_div(B, 32);
   if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
   if (wp_out && (wp_rt < ntiles || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
-  const size_t smem = 2 * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
-  if (!lat_want_lds(k_lat_backward_sgd, smem)) return RCMARL_ERR_LAUNCH;
+  const int ns = lat_stages();
+  const size_t smem = (size_t)ns * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
-  RCMARL_LAUNCH(k_lat_backward_sgd, grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
-                (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                (unsigned char*)wp_out, wp_rt, wp_kt);
+  if (ns == 2) {
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<2>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<2>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
+  } else {
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<3>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<3>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
+  }
   return rcmarl_check_launch();
 }

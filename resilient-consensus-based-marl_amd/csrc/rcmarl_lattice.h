@@ -75,7 +75,11 @@ __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c)
   return __hipemu_mfma_f32_32x32x16_bf16(a, b, c);
 }
 #define RC_GLDS16(gsrc, lds_base) __hipemu_glds16((gsrc), (lds_base))
+#define RC_GLDS16S(sbase, voff, lds_base) __hipemu_glds16((sbase) + (voff), (lds_base))
+typedef unsigned char* rc_lds_t;                               // an LDS location handed to RC_GLDS16S
+__device__ __forceinline__ rc_lds_t rc_lds_addr(unsigned char* p) { return p; }
 #define RC_WAIT_VMEM() ((void)0)
+#define RC_WAIT_VMEM_N(n) ((void)0)
 #else
 typedef __bf16 rc_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c) {
@@ -93,5 +97,18 @@ __device__ __forceinline__ void rc_glds16(const void* gsrc, const void* lds_base
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0v) : "memory", "m0");
 }
 #define RC_GLDS16(gsrc, lds_base) rc_glds16((gsrc), (lds_base))
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the per-k-tile address
+// update is two SALU adds instead of 64-bit VALU arithmetic in every lane
+typedef unsigned rc_lds_t;                                     // LDS byte address (M0 value), plain integer arithmetic
+__device__ __forceinline__ rc_lds_t rc_lds_addr(unsigned char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(p);
+}
+__device__ __forceinline__ void rc_glds16s(const unsigned char* sbase, unsigned voff, rc_lds_t lds_addr) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(m0v)
+               : "memory", "m0");
+}
+#define RC_GLDS16S(sbase, voff, lds_base) rc_glds16s((sbase), (voff), (lds_base))
 #define RC_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define RC_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif

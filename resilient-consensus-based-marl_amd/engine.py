@@ -341,6 +341,59 @@ class RPBCACEngine:
         return ([s[b].reshape(N, 2).astype(np.float64) for b in range(B)], [ns[b].reshape(N, 2).astype(np.float64) for b in range(B)],
                 [a[b].reshape(N, 1).astype(np.float64) for b in range(B)], [r[b].reshape(N, 1).astype(np.float64) for b in range(B)])
 
+    # ---- mid-run checkpoint (the reference only saves final weights, main.py:119-121) ------
+    _CKPT_TENSORS = ("goal", "adam_m", "adam_v", "ret_hist", "est_hist")
+
+    def state_dict(self):
+        """Everything a bit-identical resume needs: parameters, Adam slots and step counts, replay rows,
+        agent positions, goals and the RNG position (device mode: the episode counter of the counter-based
+        Philox stream; numpy mode: the per-seed RandomState states)."""
+        c = self.cfg
+        sd = {"format": 1, "S": self.S, "N": self.N, "seeds": list(self.seeds), "episode": self.episode, "B": self.B,
+              "adam_t": self.adam_t, "cur": self.cur, "labels": list(c.agent_label), "in_nodes": c.in_nodes,
+              "theta": {k: v.detach().cpu() for k, v in self.theta.items()},
+              "replay": {k: v[:, :self.B].detach().cpu() for k, v in self.rp.items()},
+              "pos": self.pos[self.cur].detach().cpu(), "xs": self.xs[self.cur].detach().cpu()}
+        for k in self._CKPT_TENSORS:
+            sd[k] = getattr(self, k).detach().cpu()
+        if hasattr(self, "adv"):
+            sd["adv"] = self.adv.state_dict()
+        if self.np_rngs is not None:
+            sd["np_rngs"] = [r.get_state() for r in self.np_rngs]
+        return sd
+
+    def load_state_dict(self, sd):
+        if sd.get("format") != 1 or sd["S"] != self.S or sd["N"] != self.N or list(sd["labels"]) != list(self.cfg.agent_label):
+            raise ValueError("checkpoint does not match this engine (format/S/N/agent labels)")
+        self.seeds = [int(x) for x in sd["seeds"]]
+        self.seeds_dev.copy_(torch.tensor(np.asarray(self.seeds, dtype=np.uint64).view(np.int64), dtype=torch.int64))
+        self.episode, self.B, self.adam_t, self.cur = int(sd["episode"]), int(sd["B"]), int(sd["adam_t"]), int(sd["cur"])
+        for k, v in sd["theta"].items():
+            self.theta[k].copy_(v)
+        for k, v in sd["replay"].items():
+            self.rp[k][:, :self.B].copy_(v)
+        self.pos[self.cur].copy_(sd["pos"])
+        self.xs[self.cur].copy_(sd["xs"])
+        for k in self._CKPT_TENSORS:
+            getattr(self, k).copy_(sd[k])
+        if "adv" in sd:
+            self._require_adversary_support()
+            self.adv.load_state_dict(sd["adv"])
+        if "np_rngs" in sd:
+            self.np_rngs = []
+            for st in sd["np_rngs"]:
+                r = np.random.RandomState()
+                r.set_state(st)
+                self.np_rngs.append(r)
+        self.a1_cached["critic"] = self.a1_cached["tr"] = False
+        self.lat_active = False
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+
     # ---- rollout (train_agents.py:46-80) ---------------------------------------------------
     def _reset(self, host_positions=None):
         c, L = self.cfg, self.lib

@@ -48,6 +48,12 @@ class AdversaryPath:
             eng.ybuf[k] = torch.zeros(eng.S, eng.N, eng.ldb, **f32)
         self.mode0 = torch.zeros(eng.N, **i32)
 
+    def state_dict(self):
+        return {"calls": list(self.calls), "adam_t": self.adam_t}
+
+    def load_state_dict(self, sd):
+        self.calls, self.adam_t = [int(x) for x in sd["calls"]], int(sd["adam_t"])
+
     # -- the oracle's ShuffleStream, one per seed -------------------------------------------
     def _perms(self, s, epochs, B):
         g = np.random.default_rng([int(self.e.seeds[s]), self.calls[s]])

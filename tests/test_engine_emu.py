@@ -35,3 +35,36 @@ def test_engine_lattice_path_matches_oracle(labels, nrow, ncol):
     eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, "device", "cpu", emu_lib(), seeds=(31, 32), lattice=True)
     assert eng.lat_enabled and eng.lat_active          # the replay rows passed the lattice check -> path was used
     EC.compare(eng, logs, o_logs, o_w)
+
+
+@pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 5, "device"), (["Cooperative"] * 4 + ["Greedy"], "device"),
+                                             (["Cooperative"] * 5, "numpy")])
+def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
+    """Train 3 blocks straight vs 1 block -> save -> fresh engine -> load -> 2 blocks: same logs, same bits
+    (weights, Adam slots, replay rows, RNG position all travel in the checkpoint)."""
+    import numpy as np
+    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+
+    def make():
+        cfg = EngineConfig(5, labels, EC.CIRC5, H=1, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, nrow=5, ncol=5,
+                           n_seeds=2, rng_mode=rng_mode, lattice=True)
+        eng = RPBCACEngine(cfg, seeds=[7, 8], device="cpu", lib=emu_lib())
+        eng.init_glorot(base_seed=3)
+        eng.set_goals(np.array([[1, 2], [0, 0], [4, 4], [2, 3], [3, 1]]))
+        if rng_mode == "numpy":
+            eng.np_rngs = [np.random.RandomState(70 + s) for s in range(2)]
+        return eng
+    a = make()
+    la = a.train(6)
+    b = make()
+    lb1 = b.train(2)
+    b.save_checkpoint(str(tmp_path / "ck.pt"))
+    c = make()
+    c.init_glorot(base_seed=99)                       # different weights: everything must come from the file
+    c.load_checkpoint(str(tmp_path / "ck.pt"))
+    lc = c.train(4)
+    for k in la:
+        np.testing.assert_array_equal(la[k], np.concatenate([lb1[k], lc[k]], axis=0))
+    for net in ("actor", "critic", "tr"):
+        np.testing.assert_array_equal(a.get_all_weights(net), c.get_all_weights(net))
+    np.testing.assert_array_equal(a.adam_m.numpy(), c.adam_m.numpy())

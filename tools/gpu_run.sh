@@ -20,7 +20,7 @@ import json
 d=json.load(open('gpurun_out/bench.json'))
 print({k:d[k] for k in ('value','ms_per_step','consensus_updates_per_s','consensus_updates_per_s_phase2_only','phase_seconds_per_block')})
 for k,v in list(d['kernels'].items())[:8]: print(k, v)
-print('roofline', d['roofline']); print('roofline_consensus', d['roofline_consensus']); print('cpu', d.get('cpu_baseline',{}).get('value'), d.get('speedup_vs_cpu_port'))
+print('roofline', d['roofline']); print('roofline_consensus', d['roofline_consensus']); print('roofline_gemm', d.get('roofline_gemm')); print('cpu', d.get('cpu_baseline',{}).get('value'), d.get('speedup_vs_cpu_port'))
 PY
 tail -3 gpurun_out/bench.err
 echo "== bench target workload"
@@ -31,10 +31,13 @@ d=json.load(open('gpurun_out/bench_target.json'))
 print({k:d[k] for k in ('value','ms_per_step','consensus_updates_per_s_phase2_only')}); print('roofline_consensus', d['roofline_consensus'])
 PY
 if [ "${1:-}" = "prof" ]; then
+echo "== bench without per-launch events (host/event overhead check)"
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('no-events ms_per_step', d['ms_per_step'], 'value', d['value'])"
 echo "== rocprof"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err
 tail -2 $R/gpurun_out/prof.err
 ls $R/gpurun_out/prof | head
-f=$(find $R/gpurun_out/prof -name '*kernel_stats*' | head -1); [ -n "$f" ] && head -20 "$f"
+f=$(find $R/gpurun_out/prof -name '*kernel_stats*' | head -1); [ -n "$f" ] && head -12 "$f" | cut -c1-220
+cd $R; bash tools/gpu_pmc_bench.sh cfg4_shard ${2:-r01}
 fi
