@@ -42,6 +42,11 @@ WORKLOADS = {
                            desc="north_star target: 256 agents, 5x5 grid, H=1, circulant d=4, 16 seeds per GPU"),
     "cfg3": dict(N=64, nrow=16, ncol=16, H=4, d=10, S=32, graph="regular",
                  desc="BASELINE configs[2]: 64 agents, 16x16 grid, random 9-regular in-graph + self (d=10), H=4, 32 seeds per GPU"),
+    # BASELINE configs[1] (the reference's own adversarial scenario, .../malicious/H=1), many seeds per GPU
+    "cfg2_batched": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=512, graph="circulant",
+                         labels=["Cooperative"] * 4 + ["Malicious"],
+                         desc="BASELINE configs[1]: 4 cooperative + 1 Malicious agent, 5x5 grid, H=1, circulant d=4, "
+                              "512 independent seeds per GPU"),
     "cfg1_batched": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=512, graph="circulant",
                          desc="5 cooperative agents, 5x5 grid, H=1, 512 seeds per GPU"),
 }
@@ -61,7 +66,7 @@ def build_graph(kind, N, d, seed=0):
 def make_engine(w, S, seeds, lib):
     from rcmarl_amd.engine import EngineConfig, RPBCACEngine
     N = w["N"]
-    cfg = EngineConfig(N, ["Cooperative"] * N, build_graph(w["graph"], N, w["d"]), H=w["H"], gamma=0.9, slow_lr=0.002,
+    cfg = EngineConfig(N, w.get("labels", ["Cooperative"] * N), build_graph(w["graph"], N, w["d"]), H=w["H"], gamma=0.9, slow_lr=0.002,
                        fast_lr=0.01, max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000, nrow=w["nrow"],
                        ncol=w["ncol"], n_seeds=S, rng_mode="device")
     eng = RPBCACEngine(cfg, seeds=seeds, device="cuda", lib=lib)

@@ -105,6 +105,13 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
                            int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
 
+/* Shuffle permutations of the adversaries' mini-batch fits (Keras fit(shuffle=True) inside
+ * agents/adversarial_CAC_agents.py:38-41,131-135,163-165,237-253).  TensorFlow's shuffle RNG is not reproducible
+ * outside TensorFlow; the shuffle is DEFINED here (csrc/shuffle.hip; same statement in the oracle):
+ * perm[s][q][e][.] = row order that sorts Philox4x32-10(counter = (row, e, calls[q], 2), key = seeds[s]).word0.
+ * seeds: uint64[S]; calls: int[n] (index of each fit call in the run); perm: int[S][n][epochs][B], B <= 8192. */
+int rcmarl_shuffle_perms(const void* seeds, const int* calls, int n, int epochs, int B, int* perm, int S, void* stream);
+
 /* reduce the partials over chunks and apply SGD to b1,W2,b2,W3,b3; loss_out[S][N] (or NULL) = MSE. */
 int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
                      int B, int in_dim, int hid, int ldp, float lr, void* stream);

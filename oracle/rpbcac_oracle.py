@@ -100,18 +100,25 @@ class GridWorldOracle:
 # deterministic shuffles for the mini-batch adversaries
 # ----------------------------------------------------------------------------
 class ShuffleStream:
-    """Keras' fit() shuffles with TensorFlow's RNG, which cannot be reproduced
-    here; the oracle defines the shuffle: the n-th mini-batch fit of a run uses
-    ``default_rng([seed, n]).permutation(B)`` once per epoch.  The HIP engine
-    draws from an identical stream, call for call."""
+    """Keras' fit() shuffles with TensorFlow's RNG, which cannot be reproduced here; the shuffle is
+    DEFINED (identically in csrc/shuffle.hip): epoch e of the n-th mini-batch fit of a run visits the
+    rows in the order that sorts  key(p) = Philox4x32-10(counter=(p, e, n, stream 2), key=seed).word0,
+    ties broken by the lower row index.  Counter-based, so the HIP engine produces all permutations of
+    all seeds in one launch; it draws from the identical stream, call for call."""
 
     def __init__(self, seed):
         self.seed, self.calls = int(seed), 0
 
     def perms(self, epochs, B):
-        g = np.random.default_rng([self.seed, self.calls])
+        from . import philox_np as PH
+        k0, k1 = PH.seed_key(self.seed)
+        rows = np.arange(B, dtype=np.uint64)
+        out = []
+        for e in range(epochs):
+            r0 = PH.philox4x32(rows, e, self.calls, 2, k0, k1)[0].astype(np.uint64)
+            out.append(np.argsort((r0 << np.uint64(32)) | rows, kind="stable"))
         self.calls += 1
-        return np.stack([g.permutation(B) for _ in range(epochs)]).astype(np.int32)
+        return np.stack(out).astype(np.int32)
 
 
 # ----------------------------------------------------------------------------

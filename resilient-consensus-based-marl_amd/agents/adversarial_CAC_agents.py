@@ -4,9 +4,10 @@ message generators the resilient consensus must withstand.
 Same constructors and methods as the reference (Faulty :19-73, Malicious :90-182,
 Greedy :200-275).  Keras' shuffled mini-batch ``fit`` calls are single kernel
 launches (csrc/minibatch_fit.hip).  The shuffle permutations come from a
-process-wide stream (``set_shuffle_seed``): the n-th mini-batch fit of a run uses
-``default_rng([seed, n])`` -- the definition the oracle uses, since TensorFlow's
-own shuffle RNG cannot be reproduced outside TensorFlow.
+process-wide stream (``set_shuffle_seed``): epoch e of the n-th mini-batch fit of a run visits
+the rows in the order that sorts Philox(counter=(row, e, n, 2), key=seed) (csrc/shuffle.hip) -- a
+definition, shared with the oracle, since TensorFlow's own shuffle RNG cannot be reproduced
+outside TensorFlow.
 """
 import numpy as np
 
@@ -20,9 +21,9 @@ def set_shuffle_seed(seed):
 
 
 def _perms(epochs, B):
-    g = np.random.default_rng([_shuffle["seed"], _shuffle["calls"]])
+    p = single.get_ops().shuffle_perms(_shuffle["seed"], _shuffle["calls"], epochs, B)
     _shuffle["calls"] += 1
-    return np.stack([g.permutation(B) for _ in range(epochs)]).astype(np.int32)
+    return p
 
 
 def _nrows(x):

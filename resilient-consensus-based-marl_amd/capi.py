@@ -55,6 +55,8 @@ SIGNATURES = {
     # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_stream],
+    # seeds(u64[S]), calls(int[n]), n, epochs, B, perm(int[S][n][epochs][B]), S, stream
+    "rcmarl_shuffle_perms": [C.c_void_p, c_i32p, c_int, c_int, c_int, c_i32p, c_int, c_stream],
     # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
     "rcmarl_small_sgd": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     # a1t, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream

@@ -16,8 +16,9 @@ Replaces, for all seeds at once, what the reference does per adversarial agent i
 Every Keras ``fit`` is ONE kernel launch (csrc/minibatch_fit.hip): the whole
 sequence of mini-batch steps of one (seed, adversary) network runs inside one
 workgroup.  Keras shuffles with TensorFlow's RNG; here the permutations come from
-the stream the oracle defines (``default_rng([seed, n_th_fit_call])``), drawn in
-the reference's call order so that oracle and engine stay in lock step.
+a counter-based stream (csrc/shuffle.hip, generated on the device for all seeds at once; the oracle
+states the same definition), consumed in the reference's call order so that oracle and engine stay in
+lock step.
 """
 import numpy as np
 import torch
@@ -54,20 +55,25 @@ class AdversaryPath:
     def load_state_dict(self, sd):
         self.calls, self.adam_t = [int(x) for x in sd["calls"]], int(sd["adam_t"])
 
-    # -- the oracle's ShuffleStream, one per seed -------------------------------------------
-    def _perms(self, s, epochs, B):
-        g = np.random.default_rng([int(self.e.seeds[s]), self.calls[s]])
-        self.calls[s] += 1
-        return np.stack([g.permutation(B) for _ in range(epochs)]).astype(np.int32)
-
+    # -- the shuffle stream (csrc/shuffle.hip; oracle: ShuffleStream), all seeds in one launch ------------
     def _draw(self, plan, epochs, B):
-        """plan: list of (agent, key) in the reference's call order -> {key: int32 tensor [S][n][epochs][B]}"""
-        S = self.e.S
+        """plan: list of (agent, key) in the reference's call order -> {key: int32 tensor [S][n_key][epochs][B]}.
+        Every seed makes the same sequence of fit calls, so the call numbers are shared."""
+        e = self.e
+        base = self.calls[0]
+        by_key = {}
+        for pos, (agent, key) in enumerate(plan):
+            by_key.setdefault(key, []).append(base + pos)
         out = {}
-        for s in range(S):
-            for agent, key in plan:
-                out.setdefault(key, [[] for _ in range(S)])[s].append(self._perms(s, epochs, B))
-        return {k: torch.from_numpy(np.stack([np.stack(v[s]) for s in range(S)])).to(self.e.dev) for k, v in out.items()}
+        for key, call_ids in by_key.items():
+            calls = torch.tensor(call_ids, dtype=torch.int32, device=e.dev)
+            perm = torch.empty(e.S, len(call_ids), epochs, B, dtype=torch.int32, device=e.dev)
+            e.lib.rcmarl_shuffle_perms(e.seeds_dev.data_ptr(), calls.data_ptr(), len(call_ids), epochs, B, perm.data_ptr(),
+                                       e.S, e.stream)
+            out[key] = perm
+            self._keep = (calls, perm)                 # keep the small call table alive until the launch has run
+        self.calls = [c + len(plan) for c in self.calls]
+        return out
 
     # -- phase I of every consensus epoch ----------------------------------------------------
     def phase1(self, B):

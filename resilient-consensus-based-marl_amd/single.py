@@ -272,6 +272,14 @@ class RowOps:
         return unflat(self._host(theta)[0, 0], in_dim, A), float(self._host(loss)[0, 0])
 
     # ---- X1: the adversaries' mini-batch fits (agents/adversarial_CAC_agents.py) ---------------
+    def shuffle_perms(self, seed, call, epochs, B):
+        """[epochs][B] int32 permutations of the call-th mini-batch fit (csrc/shuffle.hip)."""
+        seeds = self._t(np.asarray([int(seed) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64).view(np.int64))
+        calls = self._t(np.asarray([int(call)], np.int32))
+        out = self._zeros(1, 1, int(epochs), int(B), dtype=torch.int32)
+        self.lib.rcmarl_shuffle_perms(seeds.data_ptr(), calls.data_ptr(), 1, int(epochs), int(B), out.data_ptr(), 1, self.stream)
+        return self._host(out)[0, 0]
+
     def minibatch_fit(self, params, x, y, lr, batch_size=32, epochs=10, perms=None):
         in_dim, out_dim = dims_of(params)
         assert out_dim == 1

@@ -699,3 +699,61 @@ def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamm
                 rel_close(got[k], pw[k], 1e-5, "fit param %d (lattice)" % k)
             assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
     np.testing.assert_array_equal(bk.host(d_th), theta)
+
+
+def check_lattice_vs_f32(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01):
+    rng = np.random.default_rng(N + B + width)
+    in_dim = N * width
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    theta = np.zeros((S, N, ldp), np.float32)
+    lim = np.sqrt(6.0 / (in_dim + HID))
+    theta[:, :, :in_dim * HID] = rng.uniform(-lim, lim, size=(S, N, in_dim * HID)).astype(np.float32)
+    theta[:, :, in_dim * HID:P] = rng.uniform(-0.4, 0.4, size=(S, N, P - in_dim * HID)).astype(np.float32)
+    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol)
+    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.int32)
+    nchunk = (B + 255) // 256
+    psz = bk.lib.rcmarl_fit_partial_size(HID)
+    L = bk.lib
+    res = {}
+    for path in ("f32", "lattice"):
+        d_x, d_al, d_th, d_y, d_mask = bk.dev(x), bk.dev(alpha), bk.dev(theta.copy()), bk.dev(y), bk.dev(mask)
+        d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+        d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+        if path == "lattice":
+            lb = LatticeBuffers(bk, S, N, in_dim, B)
+            g = lb.g
+            _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)
+        a_first = None
+        for st in range(steps):
+            if path == "f32":
+                _layer1(bk, d_x, B * in_dim, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+            else:
+                _layer1_lattice(bk, lb, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb, split=(st == 0))
+            if st == 0:
+                a_first = bk.host(d_a).copy()
+            if path == "f32":
+                L.rcmarl_mid_fit(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+            else:
+                L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0],
+                                         g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+            L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_mask), None, S, N, B, in_dim, HID, ldp, lr, bk.stream)
+            if path == "f32":
+                L.rcmarl_layer1_backward_sgd(bk.ptr(d_x), B * in_dim, bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_mask), S, N, B,
+                                             in_dim, HID, ldp, ldb, lr, bk.stream)
+            else:
+                L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
+                                                     bk.ptr(d_al), bk.ptr(d_th), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
+                                                     bk.ptr(lb.wp), g.wp[0], g.wp[1], bk.stream)
+        res[path] = (a_first, bk.host(d_th).copy())
+        if path == "lattice":
+            assert bk.host(lb.flag)[0] == 0
+    a_f, th_f = res["f32"]
+    a_l, th_l = res["lattice"]
+    rel_close(a_l[:, :, :B], a_f[:, :, :B], 2e-6, "a1 lattice vs f32")
+    # the update itself is small (lr * gradient): compare the CHANGE of the weights, relative to its own size
+    d_f, d_l = th_f - theta, th_l - theta
+    assert np.abs(d_f).max() > 0
+    err = float(np.abs(d_l - d_f).max())
+    assert err <= 2e-4 * float(np.abs(d_f).max()), (err, float(np.abs(d_f).max()))

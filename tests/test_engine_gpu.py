@@ -51,3 +51,36 @@ def test_engine_lattice_path(n, nrow, ncol, labels):
     eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, "device", "cuda", None, seeds=(41, 42), lattice=True if n == 5 else "auto")
     assert eng.lat_enabled and eng.lat_active
     EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4 if "Malicious" in labels else 2e-4)
+
+
+def test_engine_full_size_lattice_equals_f32_path():
+    """BASELINE configs[3] shape (256 agents, 32x32 grid, H=8, d=18; 2 of the 16 seeds of a GPU shard): one whole
+    training block with the layer-1 GEMMs on the lattice kernels vs on the f32-MFMA kernels.  The rollout is
+    identical (it precedes the first update), the updated weights agree to fp32 roundoff accumulated over the block."""
+    import numpy as np
+    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+    n, d = 256, 18
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    out = {}
+    for lat in (False, True):
+        cfg = EngineConfig(n, ["Cooperative"] * n, in_nodes, H=8, max_ep_len=20, n_ep_fixed=50, n_epochs=2, buffer_size=2000,
+                           nrow=32, ncol=32, n_seeds=2, rng_mode="device", lattice=lat)
+        eng = RPBCACEngine(cfg, seeds=[1000, 1001])
+        eng.init_glorot(base_seed=1)
+        eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(n, 2)) for s in (1000, 1001)]))
+        logs = eng.train(50)
+        assert eng.lat_active == lat
+        out[lat] = (logs, {k: eng.get_all_weights(k) for k in ("actor", "critic", "tr")})
+    for k in out[False][0]:
+        if k == "Estimated_team_returns":
+            np.testing.assert_allclose(out[True][0][k], out[False][0][k], rtol=1e-5, atol=1e-6)
+        else:
+            np.testing.assert_array_equal(out[True][0][k], out[False][0][k])
+    for net in ("critic", "tr"):
+        a, b = out[True][1][net], out[False][1][net]
+        assert float(np.abs(a - b).max()) <= 2e-4 * max(1.0, float(np.abs(b).max())), net
+    # the actor's first Adam step is lr*g/(|g|+eps) ~ lr*sign(g): entries whose gradient is ~0 may flip, so the
+    # statement for the actor is statistical
+    a, b = out[True][1]["actor"], out[False][1]["actor"]
+    diff = np.abs(a - b)
+    assert float(diff.mean()) <= 1e-5 and float((diff > 1e-4).mean()) <= 1e-3, (float(diff.mean()), float((diff > 1e-4).mean()))

@@ -115,3 +115,11 @@ def test_lattice_forward(bk, S, N, B, width, nrow, ncol):
                                                           (1, 128, 333, 2, 32, 32, None)])
 def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("width", [2, 3])
+def test_lattice_equals_f32_path_at_full_size(bk, width):
+    """BASELINE configs[3] sizes (N=256 agents, B=3000 rows, 32x32 grid): the bf16x3 lattice GEMMs and the
+    f32-MFMA GEMMs are independent implementations of the same fp32 math -> they must agree to fp32 roundoff
+    (forward activations, and W1 after two full SGD steps through mid_fit)."""
+    KC.check_lattice_vs_f32(bk, S=2, N=256, B=3000, width=width, nrow=32, ncol=32, steps=2)

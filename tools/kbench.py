@@ -71,6 +71,26 @@ def k1(L, S=16, N=256):
             print("K1 d=%2d H=%d P_hid=%5d  %7.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (d, H, P_hid, t, byts / t / 1e3, byts / t / 1e3 / 80))
 
 
+def k1_cfg5(L):
+    """BASELINE configs[4] phase II-b on ONE of 8 GPUs: 1024 agents, d=66, H=32, the 512-wide critic's hidden
+    parameters column-sharded 8 ways (each output column needs only its own column of the d
+    neighbour rows, so the shard needs no exchange inside the step)."""
+    st = torch.cuda.current_stream().cuda_stream
+    N, d, H = 1024, 66, 32
+    P_hid_full = 2048 * 512 + 512 + 512 * 512 + 512
+    P_hid = (P_hid_full + 7) // 8
+    ldp = pad64(P_hid + 1)
+    msg = torch.randn(1, N, ldp, device="cuda")
+    theta = torch.zeros(1, N, ldp, device="cuda")
+    nbr = torch.tensor([[(i + k) % N for k in range(d)] for i in range(N)], dtype=torch.int32, device="cuda")
+    coop = torch.ones(N, dtype=torch.int32, device="cuda")
+    t = timeit(lambda: L.rcmarl_consensus_params(msg.data_ptr(), theta.data_ptr(), nbr.data_ptr(), coop.data_ptr(), 1, N, ldp,
+                                                 P_hid, d, H, None, None, st), iters=5, warm=2)
+    byts = 8.0 * N * P_hid
+    print("K1 cfg5 shard: N=%d d=%d H=%d P_hid/8=%d  %9.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  -> %.1f consensus-updates/s/GPU-shard"
+          % (N, d, H, P_hid, t, byts / t / 1e3, byts / t / 1e3 / 80, N / (t * 1e-6)))
+
+
 def mid(L, S=16, N=256, B=3000):
     st = torch.cuda.current_stream().cuda_stream
     in_dim = 2 * N
@@ -143,4 +163,4 @@ if __name__ == "__main__":
     L = capi.load()
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "mid": mid, "lattice": lattice}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice}[what](L)
