@@ -248,9 +248,9 @@ __global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, c
 //     (ones / zeros), so no per-fragment select;
 //   * the bf16 pieces of dz1 come from v_cvt_pk_bf16_f32 pairs and leave through unconditional 2-byte stores.
 template <int HID, bool EMIT>
-__global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, const float* __restrict__ theta,
                                                     const float* __restrict__ y, float* __restrict__ partials, int N,
-                                                    int B, int in_dim, int ldp, int ldb, int nchunk,
+                                                    int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
                                                     unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
   static_assert(HID % 4 == 0, "rows of W2 are read as float4");
   typedef FitPart<HID> PT;
@@ -261,13 +261,15 @@ __global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, con
   __shared__ __attribute__((aligned(16))) float sW2T[HID * HID];
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];        // b2 | W3 | b3
   __shared__ float sP[(RA + RB) * LDR];            // both panels; reused for the 32x32 results of the 4 wavefronts
-  static_assert((RA + RB) * LDR >= 4 * 2 * 1024, "result matrices fit in the panel buffer");
+  static_assert((RA + RB) * LDR >= 4 * 1088 && 2 * HID + 2 <= 64, "result area fits in the panel buffer");
   float* sA = sP;
   float* sB = sP + RA * LDR;
-  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
-  const int r = threadIdx.x, b = chunk * ROWS + r;
+  // one workgroup walks `cpw` consecutive 256-row chunks of one agent: the weights are staged once, and the
+  // activations of chunk c+1 are requested before chunk c is processed (HBM latency hides behind the VALU phase)
+  const int s = blockIdx.z, i = blockIdx.y;
+  const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
+  const int r = threadIdx.x;
   const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
-  const bool valid = b < B;
   const NetGeom g = make_geom(in_dim, HID, 1);
   const float* th = theta + ((long)s * N + i) * ldp;
   const long row0 = ((long)s * N + i) * HID;
@@ -278,12 +280,20 @@ __global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, con
     sW2T[k * HID + j] = w;
   }
   if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];       // b2, W3, b3 are contiguous in the parameter row
-  sA[HID * LDR + r] = 1.f;
+  sA[HID * LDR + r] = 1.f;                           // constant rows of the panels: ones (gb2), zeros (padding)
   sA[(HID + 1) * LDR + r] = 0.f;
   sB[(HID + 2) * LDR + r] = 0.f;
-  float a1[HID];
-  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+  const float* yrow = y + ((long)s * N + i) * ldb;
+  float a1[HID], ycur;
+  {
+    const int b0 = c_begin * ROWS + r;
+    load_a1<HID>(a1t, row0, ldb, b0, b0 < B, a1);
+    ycur = b0 < B ? yrow[b0] : 0.f;
+  }
   __syncthreads();
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+  const int b = chunk * ROWS + r;
+  const bool valid = b < B;
   // ---- layer 2 forward: a2[k] = lrelu(sum_j a1[j] W2[j][k] + b2[k]), j ascending
   rc_f2 z2[H2];
 #pragma unroll
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, con
 #pragma unroll
   for (int k = 0; k < HID; ++k) v = fmaf(a2[k], sV[HID + k], v);
   v += sV[2 * HID];
-  const float diff = valid ? v - y[((long)s * N + i) * ldb + b] : 0.f;
+  const float diff = valid ? v - ycur : 0.f;
   const float dv = (2.0f * diff) / (float)B;
 #pragma unroll
   for (int k = 0; k < HID; ++k) dz2[k] = dv * sV[HID + k] * rc_lrelu_grad_from_act(a2[k]);
@@ -358,36 +368,46 @@ __global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, con
     for (int j = 0; j < HID; ++j)
       if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];
   }
-  // ---- reductions over the 256 rows on the f32 matrix core (as k_mid_fit_mfma):
-  //   G1 = [a1 | 1]^T [dz2]                 -> gW2, gb2
-  //   G2 = [a2 | 1]^T [dz1 | dv | diff^2]   -> gW3, gb1, gb3, loss
-  rc_f32x16 acc1, acc2;
+  // ---- reductions over the 256 rows.  Only gW2 = a1^T dz2 (and gb2, its ones row) is an outer product: it runs
+  // on the f32 matrix core, G1 = [a1 | 1]^T [dz2], 32 MFMAs per wavefront.  Everything else is a plain sum over
+  // rows of a per-lane value -- gW3[k] = sum a2[k]*dv, gb1[j] = sum dz1[j], gb3 = sum dv, loss = sum diff^2 (2*HID+2
+  // values): DPP wave reductions, issued BETWEEN the MFMAs so they run in the matrix pipe's shadow.
+  constexpr int NS = 2 * HID + 2;
+  float sm[NS];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) { acc1[q] = 0.f; acc2[q] = 0.f; }
+  for (int k = 0; k < HID; ++k) { sm[k] = a2[k] * dv; sm[HID + k] = dz1[k]; }
+  sm[2 * HID] = dv;
+  sm[2 * HID + 1] = diff * diff;
+  rc_f32x16 acc1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
   const int ia = (l31 < HID + 1 ? l31 : HID + 1) * LDR + wave * 64 + half;       // rows >= HID+1 -> zeros
   const int ib1 = (l31 < HID ? l31 : HID + 2) * LDR + wave * 64 + half;
-  const int ib2 = (l31 < HID + 2 ? l31 : HID + 2) * LDR + wave * 64 + half;
 #pragma unroll
   for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a1[k]; sB[k * LDR + r] = dz2[k]; }
+  if (chunk + 1 < c_end) {                           // a1 is dead from here on: request the next chunk's rows now,
+    const int bn = b + ROWS;                         // they arrive behind the matrix-core phase
+    load_a1<HID>(a1t, row0, ldb, bn, bn < B, a1);
+    ycur = bn < B ? yrow[bn] : 0.f;
+  }
   __syncthreads();
-#pragma unroll 8
-  for (int m = 0; m < 32; ++m) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib1 + 2 * m], acc1, 0, 0, 0);
-  __syncthreads();
+  static_assert(NS % 3 == 0 && NS / 3 <= 16, "three sums ride behind every second MFMA");
 #pragma unroll
-  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a2[k]; sB[k * LDR + r] = dz1[k]; }
-  sB[HID * LDR + r] = dv;
-  sB[(HID + 1) * LDR + r] = diff * diff;
-  __syncthreads();
-#pragma unroll 8
-  for (int m = 0; m < 32; ++m) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib2 + 2 * m], acc2, 0, 0, 0);
-  __syncthreads();
-  // all 2 x 1024 results of each wavefront go to LDS unconditionally; the record is gathered from them
-  float* mat = sP + wave * 2048;
+  for (int m = 0; m < 32; ++m) {
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib1 + 2 * m], acc1, 0, 0, 0);
+    if ((m & 1) == 0 && 3 * (m >> 1) < NS) rc_wave_sum3_lane63(sm[3 * (m >> 1)], sm[3 * (m >> 1) + 1], sm[3 * (m >> 1) + 2]);
+  }
+  __syncthreads();                                   // panels fully consumed: the buffer becomes the result area
+  // per wavefront: the 32x32 G1 tile, then the NS wave sums (lane 63 holds them)
+  float* mat = sP + wave * (1024 + 64);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int row = (q & 3) + 8 * (q >> 2) + 4 * half;                   // D[row][col = l31]
     mat[row * 32 + l31] = acc1[q];
-    mat[1024 + row * 32 + l31] = acc2[q];
+  }
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) mat[1024 + k] = sm[k];
   }
   __syncthreads();
   float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
@@ -395,12 +415,14 @@ __global__ __launch_bounds__(256) void k_mid_fit_v3(float* __restrict__ a1t, con
     int src;
     if (e < PT::gb2) { const int j = e / HID; src = j * 32 + (e - j * HID); }          // gW2[j][k] = G1[j][k]
     else if (e < PT::gW3) src = HID * 32 + (e - PT::gb2);                                // gb2[k]    = G1[HID][k]
-    else if (e < PT::gb3) src = 1024 + (e - PT::gW3) * 32 + HID;                         // gW3[k]    = G2[k][HID]
-    else if (e < PT::gb1) src = 1024 + HID * 32 + HID;                                   // gb3       = G2[HID][HID]
-    else if (e < PT::loss) src = 1024 + HID * 32 + (e - PT::gb1);                        // gb1[j]    = G2[HID][j]
-    else src = 1024 + HID * 32 + HID + 1;                                                // loss      = G2[HID][HID+1]
-    out[e] = (sP[src] + sP[2048 + src]) + (sP[4096 + src] + sP[6144 + src]);
+    else if (e < PT::gb3) src = 1024 + (e - PT::gW3);                                    // gW3[k]    = sm[k]
+    else if (e < PT::gb1) src = 1024 + 2 * HID;                                          // gb3       = sm[2 HID]
+    else if (e < PT::loss) src = 1024 + HID + (e - PT::gb1);                             // gb1[j]    = sm[HID + j]
+    else src = 1024 + 2 * HID + 1;                                                       // loss
+    out[e] = (sP[src] + sP[1088 + src]) + (sP[2 * 1088 + src] + sP[3 * 1088 + src]);
   }
+  __syncthreads();                                   // result area read out before the next chunk's panels land
+  }  // chunk loop
 }
 
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B
@@ -789,6 +811,16 @@ int midfit_variant() {
   return v;
 }
 
+// chunks of 256 rows one k_mid_fit_v3 workgroup walks (RCMARL_MIDFIT_CPW overrides; default: half the chunks of an
+// agent, at most 6 -- two workgroups per agent keep the grid wide enough at small S*N)
+int midfit_cpw(int nchunk) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("RCMARL_MIDFIT_CPW"); env = e ? atoi(e) : 0; }
+  int c = env > 0 ? env : (nchunk + 1) / 2;
+  if (env <= 0 && c > 6) c = 6;
+  return c < 1 ? 1 : c;
+}
+
 bool bad_mid(const void* a, const void* b, int S, int N, int B, int in_dim, int hid, int ldp, int ldb) {
   return !a || !b || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) || ldb < B;
 }
@@ -814,8 +846,10 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   const dim3 grid(nchunk, N, S), block(ROWS);
   const int variant = midfit_variant();   // RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 (default) v3
   if (variant == 2) {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk, (unsigned char*)nullptr, 0, 0));
+    const int cpw = midfit_cpw(nchunk);
+    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
   } else if (variant == 0) {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
                                      ldp, ldb, nchunk));
@@ -834,8 +868,10 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(nchunk, N, S), block(ROWS);
   if (midfit_variant() == 2) {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
+    const int cpw = midfit_cpw(nchunk);
+    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
   } else {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta,
                                      y, partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));

@@ -102,6 +102,32 @@ __device__ __forceinline__ float rc_wave_sum_lane63(float v) {
 #endif
 }
 
+// Three independent wave sums at once (results in lane 63 of each): 18 v_add_f32 with the DPP modifier FUSED
+// (hipcc lowers the update_dpp form above to v_mov + v_mov_dpp + v_add, three issue slots per step).  The three
+// chains are interleaved so that every DPP read is two instructions behind the write it depends on (the
+// VALU-write -> DPP-read hazard needs 2 wait states, and nothing pads inside an asm statement); the leading
+// s_nop covers the producers of a, b, c.
+__device__ __forceinline__ void rc_wave_sum3_lane63(float& a, float& b, float& c) {
+#ifdef RCMARL_EMU
+  a = rc_wave_sum(a); b = rc_wave_sum(b); c = rc_wave_sum(c);
+#else
+#define RC_DPP3(mod)                          \
+  "v_add_f32_dpp %0, %0, %0 " mod "\n\t"      \
+  "v_add_f32_dpp %1, %1, %1 " mod "\n\t"      \
+  "v_add_f32_dpp %2, %2, %2 " mod "\n\t"
+  asm volatile("s_nop 1\n\t"
+               RC_DPP3("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               RC_DPP3("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               RC_DPP3("row_half_mirror row_mask:0xf bank_mask:0xf")
+               RC_DPP3("row_mirror row_mask:0xf bank_mask:0xf")
+               RC_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               RC_DPP3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c));
+#undef RC_DPP3
+#endif
+}
+
 static inline int rc_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Two fp32 lanes per register pair: v_pk_fma_f32 / v_pk_mul_f32 run 128 FMAs per wavefront instruction in the
