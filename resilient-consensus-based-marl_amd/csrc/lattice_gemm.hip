@@ -235,6 +235,111 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
   }
 }
 
+// The same k-loop on a ring of FOUR half-stages (k16 each, 20 KiB; same 80 KiB of LDS): the loads of half-stage
+// h+3 are requested while half-stage h is computed, i.e. 1.5 k-tiles of lead instead of 1, and the wait before a
+// barrier is a COUNTED vmcnt that leaves the two youngest half-stages in flight.  A half-stage takes the 32-byte
+// half of every 64-byte packed row that holds logical chunks {2h, 2h+1} (physical half h ^ bit3(row), the
+// format's XOR swizzle); the LDS image is [128 rows][32 B] per block with the two chunks placed so that the
+// fragment read  row*32 + ((lane>>5) ^ bit3(row))*16  is bank-conflict free (the placement is made on the SOURCE
+// address of the LDS-DMA, whose destination is lane-linear).
+template <int PA, int PB, int MT, int NT>
+__device__ __forceinline__ void lat_mainloop_half(const LatOperands& op, int n_ktiles, unsigned char* lds,
+                                                  rc_f32x16 (&acc)[MT][NT]) {
+  typedef LatCfg<PA, PB, MT, NT> C;
+  constexpr int HALF_BYTES = C::STAGE_BYTES / 2, HBLK = RC_PK_BLOCK / 2;   // 4 KiB per (row tile, piece) per half
+  constexpr int GL = C::STAGE_KB / 2 / 4;                                  // bursts per wavefront per half-stage
+  static_assert((C::STAGE_KB / 2) % 4 == 0, "half-stage splits evenly over 4 wavefronts");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+  // burst q (1 KiB = 32 rows x 32 B of one block): block index q/4, rows 32*(q%4)..; lane -> (row, slot u)
+  const unsigned char* gsrc[GL];
+  int gstep[GL];
+  unsigned voff0[GL], voff1[GL];            // per-lane source offsets for h = 0 / h = 1
+#pragma unroll
+  for (int i = 0; i < GL; ++i) {
+    const int q = wave + 4 * i;
+    const int blk = q >> 2, r = 32 * (q & 3) + (lane >> 1), u = lane & 1;
+    const int b3 = (r >> 3) & 1, b2 = (r >> 2) & 1;
+    const unsigned sub = (unsigned)((u ^ b2 ^ b3) << 4);
+    voff0[i] = r * 64 + ((0 ^ b3) << 5) + sub;
+    voff1[i] = r * 64 + ((1 ^ b3) << 5) + sub;
+    if (blk < C::ART * PA) {
+      const int seg = blk / PA, pc = blk - seg * PA;
+      gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * (PA * RC_PK_BLOCK) + pc * RC_PK_BLOCK;
+      gstep[i] = PA * RC_PK_BLOCK;
+    } else {
+      const int b2i = blk - C::ART * PA;
+      const int seg = b2i / PB, pc = b2i - seg * PB;
+      gsrc[i] = op.b + ((long)(op.brt0 + seg) * op.b_kt) * (PB * RC_PK_BLOCK) + pc * RC_PK_BLOCK;
+      gstep[i] = PB * RC_PK_BLOCK;
+    }
+  }
+  const rc_lds_t lds0 = rc_lds_addr(lds) + wave * 1024;
+  auto stage = [&](int slot, int hs) {                         // half-stage hs = 2*t + h
+    const rc_lds_t dst = lds0 + slot * HALF_BYTES;
+    const int t = hs >> 1;
+    if (hs & 1) {
+#pragma unroll
+      for (int i = 0; i < GL; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], voff1[i], dst + i * 4096);
+    } else {
+#pragma unroll
+      for (int i = 0; i < GL; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], voff0[i], dst + i * 4096);
+    }
+  };
+  const int b3l = (l31 >> 3) & 1;
+  const int co = (half ^ b3l) << 4;
+  int offA[MT], offB[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = wm * 32 * MT + 32 * mt + l31;
+    offA[mt] = (row >> 7) * PA * HBLK + (row & 127) * 32 + co;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wn * 32 * NT + 32 * nt + l31;
+    offB[nt] = C::ART * PA * HBLK + (row >> 7) * PB * HBLK + (row & 127) * 32 + co;
+  }
+  const int total = 2 * n_ktiles;
+  stage(0, 0);
+  if (total > 1) stage(1, 1);
+  if (total > 2) stage(2, 2);
+  int cur = 0;
+  for (int hs = 0; hs < total; ++hs) {
+    if (hs + 2 < total) RC_WAIT_VMEM_N(2 * GL);
+    else if (hs + 1 < total) RC_WAIT_VMEM_N(GL);
+    else RC_WAIT_VMEM();
+    __syncthreads();
+    if (hs + 3 < total) stage((cur + 3) & 3, hs + 3);
+    const unsigned char* st = lds + cur * HALF_BYTES;
+    cur = (cur + 1) & 3;
+    uint4 af[MT][PA], bf[NT][PB];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int p = 0; p < PA; ++p) af[mt][p] = ld_u4(st + offA[mt] + p * HBLK);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int p = 0; p < PB; ++p) bf[nt][p] = ld_u4(st + offB[nt] + p * HBLK);
+#pragma unroll
+    for (int pa = PA - 1; pa >= 0; --pa)
+#pragma unroll
+      for (int pb = PB - 1; pb >= 0; --pb)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
+  }
+}
+
 // workgroup id -> (seed, tile w within the seed); all tiles of a seed on one XCD when S % 8 == 0
 __device__ __forceinline__ void lat_decode(int per_seed, int S, int& seed, int& w) {
   const int g = blockIdx.x;
@@ -261,7 +366,7 @@ __device__ __forceinline__ void lat_stagger(int bit, int n) {
 
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
 template <int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
+__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
                                                         const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                         const float* __restrict__ theta, float* __restrict__ a1t, int S,
                                                         int N, int B, int in_dim, int ldp, int ldb, int mtiles,
@@ -281,7 +386,8 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_forward(const 
     op.b = kp; op.brt0 = 0;
   }
   rc_f32x16 acc[MT][NT];
-  lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (in_dim + 31) >> 5, lds, acc);
+  if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
+  else lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * 20;
   const float* theta_s = theta + (long)s * N * ldp;
@@ -313,7 +419,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_forward(const 
 
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
 template <int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
+__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
                                                              const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
                                                              const float* __restrict__ alpha, float* __restrict__ theta,
                                                              const int* __restrict__ mask, int S, int N, int B,
@@ -331,7 +437,8 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void k_lat_backward_sgd(c
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
-  lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (B + 31) >> 5, lds, acc);
+  if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
+  else lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
@@ -402,14 +509,15 @@ int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); retu
 int lat_stagger_bit() { static int v = lat_env_int("RCMARL_LAT_STAGGER_BIT", -1); return v; }
 int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
 
-// LDS ring depth of the lattice GEMMs: 2 (80 KiB, two workgroups per CU) or 3 (120 KiB, one workgroup per CU,
-// a tile more of load lead).  RCMARL_LAT_STAGES is a tuning knob, read once.
+// LDS ring of the lattice GEMMs: 2 full k32 stages (80 KiB, two workgroups per CU), 3 (120 KiB, one workgroup per
+// CU, a tile more of load lead; measured slower) or 4 HALF stages (80 KiB, 1.5 tiles of lead, counted vmcnt).
+// RCMARL_LAT_STAGES is a tuning knob, read once.
 int lat_stages() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("RCMARL_LAT_STAGES");
     v = e ? atoi(e) : 2;
-    if (v != 2 && v != 3) v = 2;
+    if (v != 2 && v != 3 && v != 4) v = 2;
   }
   return v;
 }
@@ -455,12 +563,17 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
   const int ns = lat_stages();
   static const int dbg = getenv("RCMARL_LAT_SAMETILE") ? atoi(getenv("RCMARL_LAT_SAMETILE")) : 0;
-  const size_t smem = (size_t)ns * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
+  const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
   if (ns == 2) {
     static const bool ok = lat_want_lds(k_lat_forward<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_forward<2>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
+  } else if (ns == 4) {
+    static const bool ok = lat_want_lds(k_lat_forward<4>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_forward<4>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
                   (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
   } else {
     static const bool ok = lat_want_lds(k_lat_forward<3>, smem);
@@ -483,12 +596,18 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
   if (wp_out && (wp_rt < ntiles || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
   const int ns = lat_stages();
-  const size_t smem = (size_t)ns * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
+  const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
   if (ns == 2) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<2>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
+  } else if (ns == 4) {
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<4>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<4>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
                   (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
   } else {

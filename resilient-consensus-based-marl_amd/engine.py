@@ -136,6 +136,7 @@ class RPBCACEngine:
         nchunk_max = (self.cap + 255) // 256
         psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
         self.partials = torch.zeros(S * N * nchunk_max * psz, **f32)
+        self.partials_side = None             # second record buffer, allocated when the two local fits overlap
         self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
         # replay buffers [S][cap][w*N]
         self.rp = {k: torch.zeros(S, self.cap, w * N, **f32) for k, w in (("s", 2), ("ns", 2), ("sa", 3), ("a", 1), ("r", 1))}
@@ -207,8 +208,10 @@ class RPBCACEngine:
         self.lat_geom["ns"] = self.lat_geom["s"]
         self.lat_kp = {k: u8(self.lat_geom[k].kp, 1) for k in ("s", "ns", "sa")}
         self.lat_ktp = {k: u8(self.lat_geom[k].ktp, 1) for k in ("s", "sa")}
-        self.lat_wp = u8(self.lat_geom["sa"].wp, 3)          # scratch, sized for the wider (state-action) input
-        self.lat_dzp = u8(self.lat_geom["sa"].dzp, 3)
+        # scratch per input family (the TR and critic local fits may run concurrently on two streams)
+        self.lat_wp_f = {"sa": u8(self.lat_geom["sa"].wp, 3), "s": u8(self.lat_geom["s"].wp, 3)}
+        self.lat_dzp_f = {"sa": u8(self.lat_geom["sa"].dzp, 3), "s": u8(self.lat_geom["s"].dzp, 3)}
+        self.lat_wp_f["ns"] = self.lat_wp_f["s"]
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.lat_alpha = {"s": torch.tensor(LT.column_alpha(self.N, 2, c.nrow, c.ncol, c.scaling), **f32),
                           "sa": torch.tensor(LT.column_alpha(self.N, 3, c.nrow, c.ncol, c.scaling), **f32)}
@@ -497,17 +500,18 @@ class RPBCACEngine:
         buf = self.a1t if buf is None else buf
         if self._lattice_ok(xkey, B, row0):
             g, L = self.lat_geom[xkey], self.lib
+            wp = self.lat_wp_f[xkey]
             if not wp_fresh:
-                L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), self.lat_wp.data_ptr(), self.S, self.N,
+                L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), wp.data_ptr(), self.S, self.N,
                                   self.in_dim[net], HID, self.ldp[net], g.wp[0], g.wp[1], self.stream)
-            L.rcmarl_layer1_forward_lattice(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], self.lat_wp.data_ptr(), g.wp[0],
+            L.rcmarl_layer1_forward_lattice(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0],
                                             g.wp[1], theta.data_ptr(), buf.data_ptr(), self.S, self.N, B, self.in_dim[net],
                                             HID, self.ldp[net], self.ldb, self.stream)
             return
         self.lib.rcmarl_layer1_forward(ptr, stride, theta.data_ptr(), buf.data_ptr(), self.S, self.N, B,
                                        self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 
-    def _local_fit(self, net, xkey, y, B, mask):
+    def _local_fit(self, net, xkey, y, B, mask, partials=None):
         """5 full-batch SGD steps on the message copy (agents/resilient_CAC_agents.py:118,136)."""
         L, S, N = self.lib, self.S, self.N
         msg = self.msg[net]
@@ -515,26 +519,28 @@ class RPBCACEngine:
         ptr, stride = self._x(xkey)
         lat = self._lattice_ok(xkey, B, 0) and xkey in self.lat_ktp
         g = self.lat_geom[xkey] if lat else None
+        dzp, wp = (self.lat_dzp_f[xkey], self.lat_wp_f[xkey]) if lat else (None, None)
+        partials = self.partials if partials is None else partials
         wp_fresh = False
         for step in range(self.cfg.local_fit_steps):
             if not (step == 0 and self.a1_cached[net]):       # msg == live net: activations left by _consensus
                 self._layer1(xkey, msg, net, B, buf=a1, wp_fresh=wp_fresh)
             if lat:
-                L.rcmarl_mid_fit_lattice(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(),
-                                         self.lat_dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B, self.in_dim[net], HID,
+                L.rcmarl_mid_fit_lattice(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), partials.data_ptr(),
+                                         dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B, self.in_dim[net], HID,
                                          self.ldp[net], self.ldb, self.stream)
             else:
-                L.rcmarl_mid_fit(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), self.partials.data_ptr(), S, N, B,
+                L.rcmarl_mid_fit(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), partials.data_ptr(), S, N, B,
                                  self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
-            L.rcmarl_small_sgd(self.partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+            L.rcmarl_small_sgd(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
                                self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
                                self.ldp[net], self.cfg.fast_lr, self.stream)
             if lat:
                 L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1],
-                                                     self.lat_dzp.data_ptr(), g.dzp[0], g.dzp[1],
+                                                     dzp.data_ptr(), g.dzp[0], g.dzp[1],
                                                      self.lat_alpha[xkey].data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N,
                                                      B, self.in_dim[net], HID, self.ldp[net], self.cfg.fast_lr,
-                                                     self.lat_wp.data_ptr(), g.wp[0], g.wp[1], self.stream)
+                                                     wp.data_ptr(), g.wp[0], g.wp[1], self.stream)
                 wp_fresh = True           # the epilogue left the split of the updated W1 in lat_wp
             else:
                 L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
@@ -572,6 +578,18 @@ class RPBCACEngine:
 
     profile_phases = False
     reuse_activations = True
+    overlap_fits = None                   # None: RCMARL_OVERLAP env (default off); True/False forces
+
+    def _overlap_ok(self):
+        want = self.overlap_fits
+        if want is None:
+            want = os.environ.get("RCMARL_OVERLAP", "0") not in ("0", "", "false")
+        if not (want and self.dev.type == "cuda" and not hasattr(self, "adv")):
+            return False
+        if self.partials_side is None:
+            self.partials_side = torch.zeros_like(self.partials)
+            self.side_stream = torch.cuda.Stream(device=self.dev)
+        return True
 
     def update_block(self):
         c, L, S, N, B = self.cfg, self.lib, self.S, self.N, self.B
@@ -592,11 +610,28 @@ class RPBCACEngine:
                                     self.ybuf["r_fit"].data_ptr(), S, N, B, self.ldb, self.stream)
         for _ in range(c.n_epochs):
             # I) local fits of TR and critic on a copy (= the transmitted message); live nets untouched
-            self.msg["tr"].copy_(self.theta["tr"])
-            self.msg["critic"].copy_(self.theta["critic"])
-            self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
-            self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
-            self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+            if self._overlap_ok():
+                # the two local fits are independent until the consensus step: TR on a side stream, critic on the
+                # main one (the VALU/LDS-bound mid kernels of one net fill the gaps of the other's matrix-core GEMMs)
+                main = torch.cuda.current_stream()
+                fork = torch.cuda.Event()
+                fork.record(main)
+                with torch.cuda.stream(self.side_stream):
+                    self.side_stream.wait_event(fork)
+                    self.msg["tr"].copy_(self.theta["tr"])
+                    self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop, partials=self.partials_side)
+                    join = torch.cuda.Event()
+                    join.record(self.side_stream)
+                self.msg["critic"].copy_(self.theta["critic"])
+                self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
+                self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+                main.wait_event(join)
+            else:
+                self.msg["tr"].copy_(self.theta["tr"])
+                self.msg["critic"].copy_(self.theta["critic"])
+                self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+                self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
+                self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
             self._adversary_messages(B)
             t0 = self._timed("phase1", t0)
             # II) resilient consensus (cooperative agents)
@@ -695,6 +730,19 @@ class RPBCACEngine:
                 estm[e, s] = np.mean(est[e, s][coop]) if n_coop else np.nan
         return team, adv, estm
 
+    _diverged_warned = False
+
+    def _warn_if_diverged(self):
+        """The reference's plain-SGD local fits diverge to NaN when fast_lr is too large for the input width
+        (e.g. 0.01 at N = 256); it would carry on silently.  One warning per engine, one reduction per block."""
+        if self._diverged_warned:
+            return
+        if not all(bool(torch.isfinite(self.theta[k]).all().item()) for k in ("critic", "tr", "actor")):
+            import warnings
+            warnings.warn("rcmarl_amd: non-finite network weights after an update block (training diverged; "
+                          "lower fast_lr -- the reference's 0.01 is unstable beyond ~64 agents)", RuntimeWarning)
+            self._diverged_warned = True
+
     def train(self, n_episodes):
         """Full loop; returns dict of per-episode arrays [n_episodes][S]."""
         c = self.cfg
@@ -704,6 +752,7 @@ class RPBCACEngine:
             n = min(c.n_ep_fixed, n_episodes - done)
             if n == c.n_ep_fixed:
                 team, adv, est = self.run_block()
+                self._warn_if_diverged()
             else:                               # trailing episodes without an update (t % n_ep_fixed never hits)
                 if c.rng_mode == "device":
                     self.rollout_block(n)
