@@ -105,6 +105,17 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
                            int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
 
+/* Fused local-fit step for SMALL networks (in_dim <= 32: the reference's own 5-agent configurations).  One launch
+ * = rcmarl_layer1_forward + rcmarl_mid_fit + the gradient of rcmarl_layer1_backward_sgd: layer 1 is computed
+ * from the replay rows inside the kernel (no a1t round trip) and gW1 = X^T dz1 joins the per-chunk record,
+ * partials[S][N][nchunk][rcmarl_fit_small_partial_size(hid, in_dim)] = [rcmarl_mid_fit record | gW1(in_dim x hid)].
+ * rcmarl_small_sgd_full then applies the whole record (W1 included) to theta. */
+int rcmarl_fit_small_partial_size(int hid, int in_dim);
+int rcmarl_fit_step_small(const float* x, long x_seed_stride, const float* theta, const float* y, float* partials,
+                          int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+int rcmarl_small_sgd_full(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N, int B,
+                          int in_dim, int hid, int ldp, float lr, void* stream);
+
 /* Shuffle permutations of the adversaries' mini-batch fits (Keras fit(shuffle=True) inside
  * agents/adversarial_CAC_agents.py:38-41,131-135,163-165,237-253).  TensorFlow's shuffle RNG is not reproducible
  * outside TensorFlow; the shuffle is DEFINED here (csrc/shuffle.hip; same statement in the oracle):

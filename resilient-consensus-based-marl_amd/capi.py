@@ -55,6 +55,12 @@ SIGNATURES = {
     # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_stream],
+    "rcmarl_fit_small_partial_size": [c_int, c_int],
+    # x, x_seed_stride, theta, y, partials, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_fit_step_small": [c_f32p, c_long, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_stream],
+    # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
+    "rcmarl_small_sgd_full": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     # seeds(u64[S]), calls(int[n]), n, epochs, B, perm(int[S][n][epochs][B]), S, stream
     "rcmarl_shuffle_perms": [C.c_void_p, c_i32p, c_int, c_int, c_int, c_i32p, c_int, c_stream],
     # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
@@ -118,7 +124,8 @@ SIGNATURES = {
     "rcmarl_env_reset_episodes": [c_i32p, C.c_void_p, c_int, c_int, c_f64p, c_int, c_i32p, c_f32p, c_f64p, c_int, c_int,
                                   c_int, c_int, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk"}
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
+             "rcmarl_fit_small_partial_size"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",
           3: "RCMARL_ERR_UNSUPPORTED (shape outside the compiled kernels)"}

@@ -275,6 +275,14 @@ __global__ __launch_bounds__(256) void k_layer1_backward_adam(const float* __res
 }
 
 #include "layer1_fast.inc"
+#include "layer1_small.inc"
+
+// RCMARL_L1_SMALL=0 keeps networks with <= 32 inputs on the generic GEMM kernels (bisecting knob)
+bool small_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RCMARL_L1_SMALL"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 
 // 0 = generic kernels only, 1 = fast path single-buffered LDS (default: 3 workgroups per CU),
 // 2 = fast path double-buffered LDS (one barrier per tile, but 2 workgroups per CU; measured slower).
@@ -312,6 +320,15 @@ RCMARL_EXPORT int rcmarl_layer1_forward(const float* x, long x_seed_stride, cons
                                         int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream) {
   if (bad_common(x, theta, a1t, S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
   const int var = gemm_variant();
+  if (hid == 20 && in_dim <= 32 && small_enabled()) {
+    const dim3 grid(rc_ceil_div(B, small::SROWS), N, S), block(256);
+    if (in_dim <= 16) {
+      RCMARL_LAUNCH((small::k_fwd<16>), grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
+    } else {
+      RCMARL_LAUNCH((small::k_fwd<32>), grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
+    }
+    return rcmarl_check_launch();
+  }
   if (var > 0 && hid == 20 && (in_dim % fast::FBK) == 0 && aligned16(x) && (x_seed_stride & 3) == 0) {
     const dim3 grid(rc_ceil_div(B, fast::FBN), rc_ceil_div(N * 20, 160), S), block(256);
     const size_t smem = fast::smem_fwd(var);
@@ -333,6 +350,17 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride,
                                              int ldp, int ldb, float lr, void* stream) {
   if (bad_common(x, dz1t, theta, S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
   const int var = gemm_variant();
+  if (hid == 20 && in_dim <= 32 && small_enabled()) {
+    const dim3 grid(N, S), block(256);
+    if (in_dim <= 16) {
+      RCMARL_LAUNCH((small::k_bwd_sgd<16>), grid, block, 0, stream, x, x_seed_stride, dz1t, theta, mask, N, B, in_dim, ldp,
+                    ldb, lr);
+    } else {
+      RCMARL_LAUNCH((small::k_bwd_sgd<32>), grid, block, 0, stream, x, x_seed_stride, dz1t, theta, mask, N, B, in_dim, ldp,
+                    ldb, lr);
+    }
+    return rcmarl_check_launch();
+  }
   if (var > 0 && hid == 20 && (in_dim & 3) == 0 && aligned16(x) && (x_seed_stride & 3) == 0) {
     const dim3 grid(rc_ceil_div(N * 20, fast::FBN), rc_ceil_div(in_dim, 128), S), block(256);
     const size_t smem = fast::smem_bwd(var);

@@ -247,11 +247,19 @@ __global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, c
 //   * the matrix-core reductions read their 32-row fragments from panels that CONTAIN the constant rows
 //     (ones / zeros), so no per-fragment select;
 //   * the bf16 pieces of dz1 come from v_cvt_pk_bf16_f32 pairs and leave through unconditional 2-byte stores.
-template <int HID, bool EMIT>
+// KP > 0 ("fused layer 1", small networks: in_dim <= KP <= 32, the reference's own 5-agent configurations): the
+// workgroup also computes layer 1 from the replay row (in_dim x HID weights in LDS) instead of reading a1t, and
+// reduces gW1 = X^T dz1 as a second matrix-core product, so one launch replaces layer1_forward + mid_fit +
+// layer1_backward of a local-fit step and the a1t round trip through HBM disappears.  The record then is
+// [FitPart | gW1(in_dim x HID)] (rec_size floats); rcmarl_small_sgd_full applies all of it.
+template <int HID, bool EMIT, int KP>
 __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, const float* __restrict__ theta,
                                                     const float* __restrict__ y, float* __restrict__ partials, int N,
                                                     int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
-                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
+                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
+                                                    const float* __restrict__ x, long x_seed_stride, int rec_size) {
+  static_assert(!(EMIT && KP > 0) && (KP == 0 || KP == 16 || KP == 32), "fused layer 1 is an f32-path variant");
+  constexpr bool FUSE1 = KP > 0;
   static_assert(HID % 4 == 0, "rows of W2 are read as float4");
   typedef FitPart<HID> PT;
   constexpr int RA = HID + 2;                        // sA rows: HID data | ones | zeros
@@ -261,7 +269,10 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
   __shared__ __attribute__((aligned(16))) float sW2T[HID * HID];
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];        // b2 | W3 | b3
   __shared__ float sP[(RA + RB) * LDR];            // both panels; reused for the 32x32 results of the 4 wavefronts
-  static_assert((RA + RB) * LDR >= 4 * 1088 && 2 * HID + 2 <= 64, "result area fits in the panel buffer");
+  __shared__ __attribute__((aligned(16))) float sW1[FUSE1 ? KP * HID + HID : 4];      // fused: W1 rows (zero padded) | b1
+  __shared__ float sX[FUSE1 ? ROWS * KP : 4];        // fused: the chunk's replay rows exactly as they lie in memory
+  constexpr int WSZ = FUSE1 ? 1088 + 32 * KP : 1088; // floats of results per wavefront: G1 | sums | (G0: KP x 32)
+  static_assert((RA + RB) * LDR >= 4 * WSZ && 2 * HID + 2 <= 64, "result area fits in the panel buffer");
   float* sA = sP;
   float* sB = sP + RA * LDR;
   // one workgroup walks `cpw` consecutive 256-row chunks of one agent: the weights are staged once, and the
@@ -280,12 +291,16 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
     sW2T[k * HID + j] = w;
   }
   if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];       // b2, W3, b3 are contiguous in the parameter row
+  if (FUSE1) {
+    for (int e = r; e < KP * HID; e += ROWS) sW1[e] = e < in_dim * HID ? th[e] : 0.f;
+    if (r < HID) sW1[KP * HID + r] = th[g.o_b1 + r];
+  }
   sA[HID * LDR + r] = 1.f;                           // constant rows of the panels: ones (gb2), zeros (padding)
   sA[(HID + 1) * LDR + r] = 0.f;
   sB[(HID + 2) * LDR + r] = 0.f;
   const float* yrow = y + ((long)s * N + i) * ldb;
   float a1[HID], ycur;
-  {
+  if (!FUSE1) {
     const int b0 = c_begin * ROWS + r;
     load_a1<HID>(a1t, row0, ldb, b0, b0 < B, a1);
     ycur = b0 < B ? yrow[b0] : 0.f;
@@ -294,6 +309,33 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
   const int b = chunk * ROWS + r;
   const bool valid = b < B;
+  if (FUSE1) {
+    // ---- layer 1 from the replay rows: a1[j] = lrelu(sum_k x[k] W1[k][j] + b1[j]), k ascending (= the GEMM's order).
+    // The chunk's 256 rows are one contiguous run of the replay tensor: coalesced copy into LDS, row-major.
+    const float* xg = x + (long)s * x_seed_stride + (long)chunk * ROWS * in_dim;
+    const int n_valid = min(ROWS, B - chunk * ROWS) * in_dim;
+    for (int e = r; e < ROWS * in_dim; e += ROWS) sX[e] = e < n_valid ? xg[e] : 0.f;
+    ycur = valid ? yrow[b] : 0.f;
+    __syncthreads();
+    rc_f2 z1[H2];
+#pragma unroll
+    for (int q = 0; q < H2; ++q) z1[q] = rc_f2{0.f, 0.f};
+#pragma unroll 2
+    for (int k = 0; k < in_dim; ++k) {
+      const rc_f2 xk = rc_bcast2(sX[r * in_dim + k]);
+#pragma unroll
+      for (int q4 = 0; q4 < HID / 4; ++q4) {
+        const float4 w = *reinterpret_cast<const float4*>(&sW1[k * HID + 4 * q4]);
+        z1[2 * q4] = rc_fma2(xk, rc_f2{w.x, w.y}, z1[2 * q4]);
+        z1[2 * q4 + 1] = rc_fma2(xk, rc_f2{w.z, w.w}, z1[2 * q4 + 1]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < H2; ++q) {
+      a1[2 * q] = rc_lrelu(z1[q].x + sW1[KP * HID + 2 * q]);
+      a1[2 * q + 1] = rc_lrelu(z1[q].y + sW1[KP * HID + 2 * q + 1]);
+    }
+  }
   // ---- layer 2 forward: a2[k] = lrelu(sum_j a1[j] W2[j][k] + b2[k]), j ascending
   rc_f2 z2[H2];
 #pragma unroll
@@ -363,7 +405,7 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
         *reinterpret_cast<unsigned short*>(p + (lane_off2 ^ sw)) = (unsigned short)(u ? l >> 16 : l);
       }
     }
-  } else {
+  } else if (!FUSE1) {
 #pragma unroll
     for (int j = 0; j < HID; ++j)
       if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];
@@ -385,7 +427,8 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
   const int ib1 = (l31 < HID ? l31 : HID + 2) * LDR + wave * 64 + half;
 #pragma unroll
   for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a1[k]; sB[k * LDR + r] = dz2[k]; }
-  if (chunk + 1 < c_end) {                           // a1 is dead from here on: request the next chunk's rows now,
+  if (FUSE1) { sA[HID * LDR + r] = 1.f; sA[(HID + 1) * LDR + r] = 0.f; }      // (the larger fused result area reaches them)
+  if (!FUSE1 && chunk + 1 < c_end) {                 // a1 is dead from here on: request the next chunk's rows now,
     const int bn = b + ROWS;                         // they arrive behind the matrix-core phase
     load_a1<HID>(a1t, row0, ldb, bn, bn < B, a1);
     ycur = bn < B ? yrow[bn] : 0.f;
@@ -397,49 +440,92 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib1 + 2 * m], acc1, 0, 0, 0);
     if ((m & 1) == 0 && 3 * (m >> 1) < NS) rc_wave_sum3_lane63(sm[3 * (m >> 1)], sm[3 * (m >> 1) + 1], sm[3 * (m >> 1) + 2]);
   }
+  // second product (fused): gW1 = X^T dz1 on v_mfma_f32_16x16x4_f32 -- KP/16 feature tiles x 2 unit tiles, 4 rows a
+  // step.  A[i = feature][k = row] comes straight from the packed replay rows in LDS, B[k = row][j = unit] from the
+  // dz1 panel (units >= HID read the zero row).
+  constexpr int FT = FUSE1 ? KP / 16 : 1;
+  rc_f32x4 acc0[FT][2];
+  if (FUSE1) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HID; ++k) sB[k * LDR + r] = dz1[k];
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc0[f][u][q] = 0.f;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int ib0 = (l15 < HID ? l15 : HID + 2) * LDR + wave * 64 + kq;
+    const int ib16 = (16 + l15 < HID ? 16 + l15 : HID + 2) * LDR + wave * 64 + kq;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+      const float b0 = sB[ib0 + 4 * m], b1 = sB[ib16 + 4 * m];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const int feat = 16 * f + l15;
+        const float av = feat < in_dim ? sX[(wave * 64 + kq + 4 * m) * in_dim + feat] : 0.f;
+        acc0[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc0[f][0], 0, 0, 0);
+        acc0[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc0[f][1], 0, 0, 0);
+      }
+    }
+  }
   __syncthreads();                                   // panels fully consumed: the buffer becomes the result area
-  // per wavefront: the 32x32 G1 tile, then the NS wave sums (lane 63 holds them)
-  float* mat = sP + wave * (1024 + 64);
+  // per wavefront: the 32x32 G1 tile, then the NS wave sums (lane 63 holds them), then (fused) the G0 tile
+  float* mat = sP + wave * WSZ;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int row = (q & 3) + 8 * (q >> 2) + 4 * half;                   // D[row][col = l31]
     mat[row * 32 + l31] = acc1[q];
+  }
+  if (FUSE1) {                                       // 16x16 tiles: D[row = (lane>>4)*4 + q][col = lane&15]
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mat[1088 + (16 * f + (lane >> 4) * 4 + q) * 32 + 16 * u + (lane & 15)] = acc0[f][u][q];
   }
   if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) mat[1024 + k] = sm[k];
   }
   __syncthreads();
-  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
-  for (int e = r; e < PT::SIZE; e += ROWS) {
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (FUSE1 ? rec_size : PT::SIZE);
+  for (int e = r; e < (FUSE1 ? PT::SIZE + in_dim * HID : PT::SIZE); e += ROWS) {
     int src;
     if (e < PT::gb2) { const int j = e / HID; src = j * 32 + (e - j * HID); }          // gW2[j][k] = G1[j][k]
     else if (e < PT::gW3) src = HID * 32 + (e - PT::gb2);                                // gb2[k]    = G1[HID][k]
     else if (e < PT::gb3) src = 1024 + (e - PT::gW3);                                    // gW3[k]    = sm[k]
     else if (e < PT::gb1) src = 1024 + 2 * HID;                                          // gb3       = sm[2 HID]
     else if (e < PT::loss) src = 1024 + HID + (e - PT::gb1);                             // gb1[j]    = sm[HID + j]
-    else src = 1024 + 2 * HID + 1;                                                       // loss
-    out[e] = (sP[src] + sP[1088 + src]) + (sP[2 * 1088 + src] + sP[3 * 1088 + src]);
+    else if (e == PT::loss) src = 1024 + 2 * HID + 1;                                    // loss
+    else { const int q = e - PT::SIZE, k = q / HID; src = 1088 + k * 32 + (q - k * HID); }   // gW1[k][j] = G0[k][j]
+    out[e] = (sP[src] + sP[WSZ + src]) + (sP[2 * WSZ + src] + sP[3 * WSZ + src]);
   }
   __syncthreads();                                   // result area read out before the next chunk's panels land
   }  // chunk loop
 }
 
-// theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B
+// theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B.
+// rec_size > FitPart::SIZE: the record also carries gW1 (fused layer 1) and W1 is updated too.
 template <int HID>
 __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ partials, float* __restrict__ theta,
                                                    const int* __restrict__ mask,
                                                    float* __restrict__ loss_out, int N, int B, int in_dim, int ldp,
-                                                   int nchunk, float lr) {
+                                                   int nchunk, float lr, int rec_size) {
   typedef FitPart<HID> PT;
   const int s = blockIdx.y, i = blockIdx.x;
   if (mask && !mask[i]) return;
   const NetGeom g = make_geom(in_dim, HID, 1);
   float* th = theta + ((long)s * N + i) * ldp;
-  const float* pp = partials + ((long)s * N + i) * nchunk * PT::SIZE;
-  for (int e = threadIdx.x; e < PT::SIZE; e += blockDim.x) {
+  const float* pp = partials + ((long)s * N + i) * nchunk * rec_size;
+  const int n_apply = rec_size > PT::SIZE ? PT::SIZE + in_dim * HID : PT::SIZE;
+  for (int e = threadIdx.x; e < n_apply; e += blockDim.x) {
     float sum = 0.f;
-    for (int c = 0; c < nchunk; ++c) sum += pp[(long)c * PT::SIZE + e];
+    for (int c = 0; c < nchunk; ++c) sum += pp[(long)c * rec_size + e];
     if (e == PT::loss) {
       if (loss_out) loss_out[(long)s * N + i] = sum / (float)B;
       continue;
@@ -449,7 +535,8 @@ __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ par
     else if (e < PT::gW3) o = g.o_b2 + (e - PT::gb2);
     else if (e < PT::gb3) o = g.o_W3 + (e - PT::gW3);
     else if (e < PT::gb1) o = g.o_b3;
-    else o = g.o_b1 + (e - PT::gb1);
+    else if (e < PT::loss) o = g.o_b1 + (e - PT::gb1);
+    else o = e - PT::SIZE;                               // W1[k][j], row-major at the start of the parameter row
     th[o] = th[o] - lr * sum;
   }
 }
@@ -848,8 +935,8 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   if (variant == 2) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 0>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, (const float*)nullptr, 0L, 0));
   } else if (variant == 0) {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
                                      ldp, ldb, nchunk));
@@ -870,8 +957,9 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   if (midfit_variant() == 2) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true, 0>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
+                                     (const float*)nullptr, 0L, 0));
   } else {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta,
                                      y, partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
@@ -885,7 +973,43 @@ RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const in
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(N, S), block(256);
   RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
-                                   in_dim, ldp, nchunk, lr));
+                                   in_dim, ldp, nchunk, lr, (int)FitPart<HID_>::SIZE));
+  return rcmarl_check_launch();
+}
+
+// ---- fused local-fit step for small networks (in_dim <= 32): layer 1 + layers 2-3 + all gradients in one launch
+RCMARL_EXPORT int rcmarl_fit_small_partial_size(int hid, int in_dim) { return hid * hid + 3 * hid + 2 + in_dim * hid; }
+
+RCMARL_EXPORT int rcmarl_fit_step_small(const float* x, long x_seed_stride, const float* theta, const float* y,
+                                        float* partials, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                                        void* stream) {
+  if (!x || !theta || !y || !partials || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) || (ldb & 63) || ldb < B)
+    return RCMARL_ERR_ARG;
+  if (in_dim > 32) return RCMARL_ERR_UNSUPPORTED;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const int cpw = midfit_cpw(nchunk);
+  const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
+  const int rec = rcmarl_fit_small_partial_size(hid, in_dim);
+  if (in_dim <= 16) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 16>), grid3, block, 0, stream, (float*)nullptr, theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, x,
+                                     x_seed_stride, rec));
+  } else {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 32>), grid3, block, 0, stream, (float*)nullptr, theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, x,
+                                     x_seed_stride, rec));
+  }
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_small_sgd_full(const float* partials, float* theta, const int* mask, float* loss_out, int S,
+                                        int N, int B, int in_dim, int hid, int ldp, float lr, void* stream) {
+  if (!partials || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0) return RCMARL_ERR_ARG;
+  if (in_dim > 32) return RCMARL_ERR_UNSUPPORTED;
+  const int nchunk = rc_ceil_div(B, ROWS);
+  const dim3 grid(N, S), block(256);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
+                                   in_dim, ldp, nchunk, lr, rcmarl_fit_small_partial_size(hid, in_dim)));
   return rcmarl_check_launch();
 }
 

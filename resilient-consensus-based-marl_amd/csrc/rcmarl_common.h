@@ -24,6 +24,7 @@
 #define RCMARL_DYN_SMEM(type, name) HIPEMU_DYN_SMEM(type, name)
 #define RCMARL_EXPORT extern "C"
 typedef floatx16 rc_f32x16;
+typedef floatx4 rc_f32x4;
 #else
 // hipGetLastError() is sticky across the whole runtime (PyTorch's own calls included):
 // drop any stale error first so rcmarl_check_launch() reports THIS launch only.
@@ -34,6 +35,7 @@ typedef floatx16 rc_f32x16;
   type* name = reinterpret_cast<type*>(name##_raw)
 #define RCMARL_EXPORT extern "C" __attribute__((visibility("default")))
 typedef float rc_f32x16 __attribute__((ext_vector_type(16)));
+typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 static inline int rcmarl_check_launch() {

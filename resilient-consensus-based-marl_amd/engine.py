@@ -135,6 +135,12 @@ class RPBCACEngine:
         self.rcoop = torch.zeros(S, self.ldb, **f32)
         nchunk_max = (self.cap + 255) // 256
         psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
+        # networks with at most 32 inputs (the reference's 5-agent scenarios): one fused launch per local-fit step
+        # (measured slower than the three small kernels it replaces -- 1.72 vs 1.42 ms per step at 512 seeds x 5
+        # agents: two workgroups per CU and a long dependent chain -- so it is opt-in: RCMARL_SMALL_FUSED=1)
+        self.small_fused = self.in_r <= 32 and os.environ.get("RCMARL_SMALL_FUSED", "0") not in ("0", "false")
+        if self.small_fused:
+            psz = max(psz, lib.rcmarl_fit_small_partial_size(HID, self.in_r))
         self.partials = torch.zeros(S * N * nchunk_max * psz, **f32)
         self.partials_side = None             # second record buffer, allocated when the two local fits overlap
         self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
@@ -521,6 +527,16 @@ class RPBCACEngine:
         g = self.lat_geom[xkey] if lat else None
         dzp, wp = (self.lat_dzp_f[xkey], self.lat_wp_f[xkey]) if lat else (None, None)
         partials = self.partials if partials is None else partials
+        if not lat and self.small_fused:
+            # layer 1, layers 2-3 and every gradient of a step in ONE launch (no a1t round trip), then one apply
+            for step in range(self.cfg.local_fit_steps):
+                L.rcmarl_fit_step_small(ptr, stride, msg.data_ptr(), y.data_ptr(), partials.data_ptr(), S, N, B,
+                                        self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+                L.rcmarl_small_sgd_full(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+                                        self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
+                                        self.ldp[net], self.cfg.fast_lr, self.stream)
+            self.a1_cached[net] = False
+            return
         wp_fresh = False
         for step in range(self.cfg.local_fit_steps):
             if not (step == 0 and self.a1_cached[net]):       # msg == live net: activations left by _consensus

@@ -186,6 +186,44 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
     np.testing.assert_array_equal(bk.host(d_th), theta)           # live weights untouched (rollback)
 
 
+def check_fit_step_small(bk, S, N, B, in_dim, steps=2, lr=0.01, masked_agent=None):
+    """check_sgd_fit through the fused small-network step: rcmarl_fit_step_small -> rcmarl_small_sgd_full."""
+    rng = np.random.default_rng(S * 1000 + N * 100 + B + in_dim + 7)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    yv = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.int32)
+    if masked_agent is not None:
+        mask[masked_agent] = 0
+    nchunk = (B + 255) // 256
+    psz = bk.lib.rcmarl_fit_small_partial_size(HID, in_dim)
+    assert psz == bk.lib.rcmarl_fit_partial_size(HID) + in_dim * HID
+    d_x, d_y, d_mask, d_msg = bk.dev(x), bk.dev(yv), bk.dev(mask), bk.dev(theta.copy())
+    d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    L = bk.lib
+    for st in range(steps):
+        L.rcmarl_fit_step_small(bk.ptr(d_x), B * in_dim, bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part), S, N, B, in_dim, HID, ldp,
+                                ldb, bk.stream)
+        L.rcmarl_small_sgd_full(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
+                                in_dim, HID, ldp, lr, bk.stream)
+    msg, loss = bk.host(d_msg), bk.host(d_loss)
+    for s in range(S):
+        for n in range(N):
+            if not mask[n]:
+                np.testing.assert_array_equal(msg[s, n], theta[s, n])
+                continue
+            pw = M.copy_params(params[s][n])
+            hist = M.fit_mse(pw, x[s], yv[s, n, :B, None], lr, epochs=steps)
+            got = unpack_row(msg[s, n], in_dim, 1)
+            for k in range(6):
+                rel_close(got[k], pw[k], 1e-5, "fused fit param %d" % k)
+            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+
+
 def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
     """K2+K3: estimate consensus + projection step of the output layer."""
     rng = np.random.default_rng(S + N * 10 + B + d * 7 + H)

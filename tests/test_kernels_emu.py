@@ -99,3 +99,9 @@ def test_lattice_forward(bk, S, N, B, width, nrow, ncol):
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 3, 300, 2, 5, 5, None), (1, 7, 130, 3, 16, 16, 2)])
 def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 3, 300, 10, None), (1, 4, 130, 15, 2), (1, 2, 70, 32, None), (1, 3, 45, 21, None),
+                                                 (1, 2, 700, 10, None)])     # 3 chunks: the multi-chunk walk of one workgroup
+def test_fit_step_small(bk, S, N, B, in_dim, masked):
+    KC.check_fit_step_small(bk, S, N, B, in_dim, steps=2, masked_agent=masked)

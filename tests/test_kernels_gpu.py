@@ -123,3 +123,9 @@ def test_lattice_equals_f32_path_at_full_size(bk, width):
     f32-MFMA GEMMs are independent implementations of the same fp32 math -> they must agree to fp32 roundoff
     (forward activations, and W1 after two full SGD steps through mid_fit)."""
     KC.check_lattice_vs_f32(bk, S=2, N=256, B=3000, width=width, nrow=32, ncol=32, steps=2)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (2, 5, 3000, 15, 4), (4, 5, 700, 15, None), (1, 10, 333, 30, 2),
+                                                 (3, 16, 1000, 32, None), (1, 8, 130, 24, None)])
+def test_fit_step_small(bk, S, N, B, in_dim, masked):
+    KC.check_fit_step_small(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
