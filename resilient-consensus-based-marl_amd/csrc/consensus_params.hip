@@ -184,7 +184,14 @@ __global__ __launch_bounds__(1024) void k_consensus_params_v2(const float* __res
   int cur = 0;
   if (t < total_tiles) stage(t, lds);
   for (; t < total_tiles; t += gridDim.x) {
-    __syncthreads();                                     // tile t landed (vmcnt drained); buffer cur^1 is free
+    // Tile t must have LANDED before anybody reads it.  hipcc does NOT put the vmcnt(0) in front of this barrier
+    // by itself when the LDS-DMA was issued in the previous trip of the loop (it did only for the first tile):
+    // without the explicit wait short tiles (small N, small d) were aggregated from stale LDS -- wrong and
+    // run-to-run different results at e.g. N=5, d=4, S>=256.
+#ifndef RCMARL_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();                                     // everybody's part of tile t landed; buffer cur^1 is free
     const int tn = t + gridDim.x;
     if (tn < total_tiles) stage(tn, lds + (cur ^ 1) * (tile_floats + 256));
     const float* tile = lds + cur * (tile_floats + 256);

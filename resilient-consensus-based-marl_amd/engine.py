@@ -563,9 +563,10 @@ class RPBCACEngine:
                                              self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
         self.a1_cached[net] = False
 
-    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None):
-        self._layer1(xkey, theta, net, B, row0)
-        self.lib.rcmarl_mid_value(self.a1t.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
+    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None):
+        buf = self.a1t if scratch is None else scratch
+        self._layer1(xkey, theta, net, B, row0, buf=buf)
+        self.lib.rcmarl_mid_value(buf.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
                                   self.S, self.N, B, self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 
     def _consensus(self, net, xkey, B):
@@ -645,10 +646,15 @@ class RPBCACEngine:
             else:
                 self.msg["tr"].copy_(self.theta["tr"])
                 self.msg["critic"].copy_(self.theta["critic"])
-                self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+                # TD target first (it depends on the live critic only), so the adversaries' message generators --
+                # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
+                # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
                 self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
+                join = self._adversary_messages_async(B)
+                self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
-            self._adversary_messages(B)
+                if join is not None:
+                    torch.cuda.current_stream().wait_event(join)
             t0 = self._timed("phase1", t0)
             # II) resilient consensus (cooperative agents)
             self._consensus("critic", "s", B)
@@ -702,6 +708,25 @@ class RPBCACEngine:
     def _adversary_messages(self, B):
         if hasattr(self, "adv"):
             self.adv.phase1(B)
+
+    def _adversary_messages_async(self, B):
+        """adv.phase1 on the side stream (GPU) -> the event to wait for before the consensus step; inline otherwise."""
+        if not hasattr(self, "adv"):
+            return None
+        if self.dev.type != "cuda" or os.environ.get("RCMARL_ADV_ASYNC", "1") in ("0", "false"):
+            self.adv.phase1(B)
+            return None
+        if getattr(self, "adv_stream", None) is None:
+            self.adv_stream = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(self.adv_stream):
+            self.adv_stream.wait_event(fork)
+            self.adv.phase1(B)
+            join = torch.cuda.Event()
+            join.record(self.adv_stream)
+        return join
 
     def _adversary_actor_updates(self, B):
         if hasattr(self, "adv"):

@@ -48,6 +48,7 @@ class AdversaryPath:
         for k in ("r_own", "y_l", "delta_adv", "v_next_adv", "v_cur_adv"):
             eng.ybuf[k] = torch.zeros(eng.S, eng.N, eng.ldb, **f32)
         self.mode0 = torch.zeros(eng.N, **i32)
+        self.a1t = torch.zeros_like(eng.a1t)            # own layer-1 scratch: phase1 may run beside the cooperative fits
 
     def state_dict(self):
         return {"calls": list(self.calls), "adam_t": self.adam_t}
@@ -92,7 +93,7 @@ class AdversaryPath:
         if self.mal:                                   # private critic: own reward, own bootstrap (:137-152)
             rptr, rstride = e._x("r")
             L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, B, e.ldb, e.stream)
-            e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"])
+            e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"], scratch=self.a1t)
             xptr, xstride = e._x("s")
             L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic_local"].data_ptr(), self.mal_t.data_ptr(), len(self.mal),
                                    e.ybuf["y_l"].data_ptr(), perms["local"].data_ptr(), S, N, B, e.in_c, HID,

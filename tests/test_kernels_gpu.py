@@ -129,3 +129,12 @@ def test_lattice_equals_f32_path_at_full_size(bk, width):
                                                  (3, 16, 1000, 32, None), (1, 8, 130, 24, None)])
 def test_fit_step_small(bk, S, N, B, in_dim, masked):
     KC.check_fit_step_small(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("N,d,H,P,P_hid,S", [(5, 4, 1, 761, 740, 512), (5, 4, 0, 661, 640, 300), (12, 6, 2, 1200, 1100, 128)])
+def test_consensus_params_short_tiles_many_seeds(bk, N, d, H, P, P_hid, S):
+    """Regression: with few agents and a small d a tile is aggregated in less time than the LDS-DMA of the next one
+    needs; the persistent walk must wait for it (K1 v2 once read stale LDS here: wrong, run-to-run different results).
+    Checked against the oracle and for bit-identical repetition."""
+    KC.check_consensus_params(bk, N, d, H, P, P_hid, "circ", S=S)
+    KC.check_consensus_params(bk, N, d, H, P, P_hid, "circ", S=S)
