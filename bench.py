@@ -36,7 +36,8 @@ HBM_PEAK_GBS = 8000.0         # spec; ~6290 GB/s measured copy ceiling
 # except fast_lr at N = 256: the reference's plain full-batch SGD local fit DIVERGES to NaN there (768 unscaled
 # inputs; the oracle reproduces it: oracle fit at N=256, lr=0.01 -> NaN within 10 epochs, lr <= 0.005 converges).
 # A benchmark on NaN weights would be meaningless (and data-dependent clocks would flatter it), so the N=256
-# workloads use fast_lr = 0.01 * 64/N = 0.0025 and main() asserts that every weight is finite at the end.
+# workloads use fast_lr = 0.01 * 64/N = 0.0025 (and cfg3, N = 64 with a bootstrapped critic, 0.005), and main()
+# asserts that every weight is finite at the end.
 WORKLOADS = {
     # BASELINE.json configs[3] sharded over the node: 128 seeds / 8 GPUs = 16 seeds per GPU (weak scaling)
     "cfg4_shard": dict(N=256, nrow=32, ncol=32, H=8, d=18, S=16, graph="circulant", fast_lr=0.0025,
@@ -45,7 +46,7 @@ WORKLOADS = {
     # the configuration the north-star targets are quoted on
     "target_N256_H1": dict(N=256, nrow=5, ncol=5, H=1, d=4, S=16, graph="circulant", fast_lr=0.0025,
                            desc="north_star target: 256 agents, 5x5 grid, H=1, circulant d=4, 16 seeds per GPU"),
-    "cfg3": dict(N=64, nrow=16, ncol=16, H=4, d=10, S=32, graph="regular",
+    "cfg3": dict(N=64, nrow=16, ncol=16, H=4, d=10, S=32, graph="regular", fast_lr=0.005,
                  desc="BASELINE configs[2]: 64 agents, 16x16 grid, random 9-regular in-graph + self (d=10), H=4, 32 seeds per GPU"),
     # BASELINE configs[1] (the reference's own adversarial scenario, .../malicious/H=1), many seeds per GPU
     "cfg2_batched": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=512, graph="circulant",
