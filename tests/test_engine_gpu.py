@@ -91,20 +91,22 @@ def test_engine_full_size_lattice_equals_f32_path():
     assert float(diff.mean()) <= 1e-5 and float((diff > 1e-4).mean()) <= 1e-3, (float(diff.mean()), float((diff > 1e-4).mean()))
 
 
-@pytest.mark.parametrize("labels", [["Cooperative"] * 5, ["Cooperative"] * 4 + ["Malicious"]])
+@pytest.mark.parametrize("labels", [["Cooperative"] * 5, ["Cooperative"] * 4 + ["Malicious"], ["Cooperative"] * 20])
 def test_engine_run_to_run_bit_identical(labels):
     """No atomics, no unordered reductions, every LDS-DMA waited for: the same scenario twice gives the same bits
     (256 seeds x 5 agents is the shape that exposed a missing wait in the consensus kernel)."""
     import numpy as np
     from rcmarl_amd.engine import EngineConfig, RPBCACEngine
-    S = 256
+    n = len(labels)
+    S = 256 if n == 5 else 32                      # 20 agents: the lattice (bf16x3) layer-1 path
+    in_nodes = EC.CIRC5 if n == 5 else [[(i + k) % n for k in range(4)] for i in range(n)]
     res = []
     for rep in range(2):
-        cfg = EngineConfig(5, labels, EC.CIRC5, H=1, n_seeds=S, rng_mode="device", max_ep_len=20, n_ep_fixed=20, n_epochs=4,
-                           buffer_size=800)
+        cfg = EngineConfig(n, labels, in_nodes, H=1, n_seeds=S, rng_mode="device", max_ep_len=20, n_ep_fixed=20, n_epochs=4,
+                           buffer_size=800, nrow=8 if n > 5 else 5, ncol=8 if n > 5 else 5)
         eng = RPBCACEngine(cfg, seeds=list(range(100, 100 + S)))
         eng.init_glorot(base_seed=1)
-        eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(5, 2)) for s in range(S)]))
+        eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(n, 2)) for s in range(S)]))
         logs = eng.train(40)
         res.append((logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}))
     for k in res[0][0]:
