@@ -364,6 +364,16 @@ __device__ __forceinline__ void lat_stagger(int bit, int n) {
 #endif
 }
 
+// Static priority for every other workgroup (bit `bit` of id/8): the two workgroups that share a SIMD otherwise
+// interleave their MFMAs round-robin, finish their k-tile bursts together and then both sit in the barrier/load
+// phase with the matrix pipe idle.  With one of them at s_setprio 1 its burst runs first and the other's fills the
+// gap: the pair ping-pongs instead of marching in step.  Pure scheduling hint: no effect on results.
+__device__ __forceinline__ void lat_prio(int bit) {
+#ifndef RCMARL_EMU
+  if (bit >= 0 && (((blockIdx.x >> 3) >> bit) & 1u)) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
 template <int NSTAGE>
 __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
@@ -376,7 +386,8 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
   lat_decode(mtiles * ntiles, S, s, w);
-  lat_stagger(stg_bit, stg_n);
+  lat_stagger((stg_bit & 0xff) - 1, stg_n);
+  lat_prio((stg_bit >> 8) - 1);
   const int bn = w % ntiles, bm = w / ntiles;                      // n fastest: neighbours share the W' panel
   LatOperands op;
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
@@ -431,7 +442,8 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
   lat_decode(mtiles * ntiles, S, s, w);
-  lat_stagger(stg_bit, stg_n);
+  lat_stagger((stg_bit & 0xff) - 1, stg_n);
+  lat_prio((stg_bit >> 8) - 1);
   const int bm = w % mtiles, bn = w / mtiles;                      // m fastest: neighbours share the dz panel
   LatOperands op;
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
@@ -506,7 +518,11 @@ bool lat_want_lds(K kernel, size_t smem) {
 }
 
 int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-int lat_stagger_bit() { static int v = lat_env_int("RCMARL_LAT_STAGGER_BIT", -1); return v; }
+// packed scheduling knobs handed to the kernels: bits 0-7 = stagger bit + 1 (0 = off), bits 8.. = priority bit + 1
+int lat_stagger_bit() {
+  static int v = ((lat_env_int("RCMARL_LAT_PRIO_BIT", -1) + 1) << 8) | ((lat_env_int("RCMARL_LAT_STAGGER_BIT", -1) + 1) & 0xff);
+  return v;
+}
 int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
 
 // LDS ring of the lattice GEMMs: 2 full k32 stages (80 KiB, two workgroups per CU), 3 (120 KiB, one workgroup per

@@ -501,10 +501,10 @@ class RPBCACEngine:
         w = self.rp[key].shape[2]
         return self.rp[key].data_ptr() + 4 * row0 * w, self.cap * w
 
-    def _layer1(self, xkey, theta, net, B, row0=0, buf=None, wp_fresh=False):
+    def _layer1(self, xkey, theta, net, B, row0=0, buf=None, wp_fresh=False, lattice=True):
         ptr, stride = self._x(xkey, row0)
         buf = self.a1t if buf is None else buf
-        if self._lattice_ok(xkey, B, row0):
+        if lattice and self._lattice_ok(xkey, B, row0):
             g, L = self.lat_geom[xkey], self.lib
             wp = self.lat_wp_f[xkey]
             if not wp_fresh:
@@ -564,8 +564,10 @@ class RPBCACEngine:
         self.a1_cached[net] = False
 
     def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None):
+        """scratch: private activation buffer of a caller that may run beside the main stream (the adversaries); such a
+        caller also stays off the lattice path, whose packed-operand scratch belongs to the main stream."""
         buf = self.a1t if scratch is None else scratch
-        self._layer1(xkey, theta, net, B, row0, buf=buf)
+        self._layer1(xkey, theta, net, B, row0, buf=buf, lattice=scratch is None)
         self.lib.rcmarl_mid_value(buf.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
                                   self.S, self.N, B, self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 

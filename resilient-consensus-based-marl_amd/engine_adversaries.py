@@ -89,28 +89,61 @@ class AdversaryPath:
             plan.append((i, "tr"))
             plan.append((i, "critic"))
         perms = self._draw(plan, FIT_EPOCHS, B)
+        self._keep_perms = perms                       # other streams read them: keep the memory until the next call
         S, N = e.S, e.N
+        # The (up to) three fits are independent networks and each is ONE latency-bound workgroup per (seed, adversary):
+        # on a GPU they run side by side on three streams (forked from / joined to the current one).
+        par = e.dev.type == "cuda" and __import__("os").environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false")
+        cur = torch.cuda.current_stream() if par else None
+        if par and not hasattr(self, "fit_streams"):
+            self.fit_streams = [torch.cuda.Stream(device=e.dev) for _ in range(2)]
+        fork = None
+        if par:
+            fork = torch.cuda.Event()
+            fork.record(cur)
+        joins = []
+
+        def on(idx):
+            """context for fit #idx: stream idx-1 of the pool for idx >= 1, the current stream for idx == 0"""
+            import contextlib
+            if not par or idx == 0:
+                return contextlib.nullcontext()
+            st = self.fit_streams[idx - 1]
+            st.wait_event(fork)
+            return torch.cuda.stream(st)
+
+        def done(idx):
+            if par and idx > 0:
+                ev = torch.cuda.Event()
+                ev.record(self.fit_streams[idx - 1])
+                joins.append(ev)
         if self.mal:                                   # private critic: own reward, own bootstrap (:137-152)
-            rptr, rstride = e._x("r")
-            L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, B, e.ldb, e.stream)
-            e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"], scratch=self.a1t)
-            xptr, xstride = e._x("s")
-            L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic_local"].data_ptr(), self.mal_t.data_ptr(), len(self.mal),
-                                   e.ybuf["y_l"].data_ptr(), perms["local"].data_ptr(), S, N, B, e.in_c, HID,
-                                   e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, None, e.stream)
+            with on(2):
+                rptr, rstride = e._x("r")
+                L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, B, e.ldb, e.stream)
+                e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"], scratch=self.a1t)
+                xptr, xstride = e._x("s")
+                L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic_local"].data_ptr(), self.mal_t.data_ptr(), len(self.mal),
+                                       e.ybuf["y_l"].data_ptr(), perms["local"].data_ptr(), S, N, B, e.in_c, HID,
+                                       e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, None, e.stream)
+                done(2)
         # transmitted TR: targets r_fit (own reward for Greedy, -r_coop for Malicious)
-        xptr, xstride = e._x("sa")
-        L.rcmarl_minibatch_fit(xptr, xstride, e.theta["tr"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
-                               e.ybuf["r_fit"].data_ptr(), perms["tr"].data_ptr(), S, N, B, e.in_r, HID, e.ldp["tr"],
-                               e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(), e.stream)
+        with on(1):
+            xptr, xstride = e._x("sa")
+            L.rcmarl_minibatch_fit(xptr, xstride, e.theta["tr"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
+                                   e.ybuf["r_fit"].data_ptr(), perms["tr"].data_ptr(), S, N, B, e.in_r, HID, e.ldp["tr"],
+                                   e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(), e.stream)
+            e.msg["tr"].index_copy_(1, self.fit_idx, e.theta["tr"].index_select(1, self.fit_idx))   # the fitted net IS the message
+            done(1)
         # transmitted critic: targets y_c = r_fit + gamma*V_theta(ns), computed from the pre-fit weights
         xptr, xstride = e._x("s")
         L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
                                e.ybuf["y_c"].data_ptr(), perms["critic"].data_ptr(), S, N, B, e.in_c, HID,
                                e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["critic"].data_ptr(),
                                e.stream)
-        for net in ("tr", "critic"):                   # the fitted nets ARE the messages (no rollback)
-            e.msg[net].index_copy_(1, self.fit_idx, e.theta[net].index_select(1, self.fit_idx))
+        e.msg["critic"].index_copy_(1, self.fit_idx, e.theta["critic"].index_select(1, self.fit_idx))
+        for ev in joins:
+            cur.wait_event(ev)
 
     # -- phase III ---------------------------------------------------------------------------
     def actor_updates(self, B):
