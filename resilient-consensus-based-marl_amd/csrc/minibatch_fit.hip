@@ -18,6 +18,7 @@
 // an INPUT here (perm[S][n_adv][epochs][B], drawn by the host from the stream the oracle defines,
 // oracle/rpbcac_oracle.py::ShuffleStream).  perm == NULL keeps the natural row order.
 #include "rcmarl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -253,6 +254,248 @@ __global__ __launch_bounds__(256) void k_minibatch_train(MbArgs a) {
   for (int e = t; e < g.P; e += 256) th[e] = Ws[e];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The MSE fits again, ONE WAVEFRONT per (seed, adversary) network (in_dim <= 20, i.e. up to 10 agents for the
+// critic / 6 for the team-reward net: the reference's scenarios).  k_minibatch_train spends most of a 32-row step
+// in ~12 workgroup barriers and in single-thread reduction loops; a wavefront needs neither:
+//   lane = (row r = lane&31 of the 32-row tile, half h = lane>>5); half h computes units 10h..10h+9 of both hidden
+//   layers (v_pk_fma_f32, weights broadcast from LDS) and the halves swap their ten values with one cross-half
+//   shuffle per value; every gradient is a matrix-core product over the 32 rows,
+//     P1 = [a1 | 1 | 0 | a2[0:10]]^T [dz2 | dv | 0]   -> gW2, gb2, gW3[0:10], gb3
+//     P2 = [x  | 1 | a2[10:20] | 0]^T [dz1 | dv | 0]  -> gW1, gb1, gW3[10:20]
+//   (16 v_mfma_f32_32x32x2_f32 each; operands transposed through two LDS panels, ordered by the wavefront's own
+//   program order -- no barrier).  Tiles of a mini-batch keep accumulating in the MFMA registers; the SGD step is
+//   applied from the D layout straight into the LDS copy of the parameters (W2 also kept transposed).
+// Same arithmetic as k_minibatch_train up to the order in which the 32 rows of a tile are summed.
+constexpr int WP_W = 864, WP_W2T = 404, WP_LD = 33, WP_A = 32 * WP_LD, WP_B = 22 * WP_LD;
+constexpr int WP_FLOATS = WP_W + WP_W2T + 2 * WP_A + WP_B;  // LDS floats per wavefront (16.4 KiB)
+
+#ifdef RCMARL_EMU
+#define RC_WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define RC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+template <int INMAX>                                        // inputs padded to INMAX (16 or 20): branch-free loops
+__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
+  constexpr int HID = 20, U = 10, XR = 11;                    // XR: first x row of the P2 panel
+  RCMARL_DYN_SMEM(float, smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int net = blockIdx.x * 4 + wave;
+  if (net >= n_nets) return;                               // (wave-uniform; the kernel has no workgroup barrier)
+  const int s = net / a.n_adv, adv = net - s * a.n_adv;
+  float* W = smem + wave * WP_FLOATS;
+  float* W2T = W + WP_W;
+  float* pA = W2T + WP_W2T;                                  // P1 A panel
+  float* pA2 = pA + WP_A;                                    // P2 A panel
+  float* pB = pA2 + WP_A;
+  const int in = a.in_dim;
+  const NetGeom g = make_geom(in, HID, 1);
+  const int agent = a.agents[adv];
+  const long row = (long)s * a.N + agent;
+  float* th = a.theta + row * a.ldp;
+  const float* xg = a.x + (long)s * a.x_seed_stride;
+  const float* yv = a.y + row * a.ldb;
+  const int* perm = a.perm ? a.perm + ((long)s * a.n_adv + adv) * a.epochs * a.B : nullptr;
+  const int r = lane & 31, h = lane >> 5, u0 = U * h, l31 = r;
+  for (int e = lane; e < g.P; e += 64) W[e] = th[e];
+  RC_WAVE_SYNC();
+  for (int e = lane; e < HID * HID; e += 64) { const int j = e / HID, k = e - j * HID; W2T[k * HID + j] = W[g.o_W2 + e]; }
+  for (int e = lane; e < WP_B; e += 64) pB[e] = 0.f;       // incl. the zero row 21
+  for (int e = lane; e < WP_A; e += 64) {                  // constant rows: P1 ones (20) / zeros (21), P2 ones (0) / zero tail
+    pA[e] = (e / WP_LD) == 20 ? 1.f : 0.f;
+    pA2[e] = (e / WP_LD) == 0 ? 1.f : 0.f;
+  }
+  RC_WAVE_SYNC();
+  rc_f32x16 acc1, acc2;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc1[q] = 0.f; acc2[q] = 0.f; }
+  // parameter owned by accumulator slot q of this lane in P1 / P2 (D[row = (q&3) + 8(q>>2) + 4h][col = lane&31]);
+  // WP_W - 1 / WP_W2T - 1 are dummy words nobody reads
+  int ix1[16], ixT[16], ix2[16];
+  float wr1[16], wr2[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int rw = (q & 3) + 8 * (q >> 2) + 4 * h, col = l31;
+    int i1 = WP_W - 1, iT = WP_W2T - 1, i2 = WP_W - 1;
+    if (col < HID) {
+      if (rw < HID) { i1 = g.o_W2 + rw * HID + col; iT = col * HID + rw; }
+      else if (rw == HID) i1 = g.o_b2 + col;
+      if (rw == 0) i2 = g.o_b1 + col;
+      else if (rw >= XR && rw < XR + in) i2 = (rw - XR) * HID + col;
+    } else if (col == HID) {
+      if (rw >= 22) i1 = g.o_W3 + (rw - 22);
+      else if (rw == HID) i1 = g.o_b3;
+      if (rw >= 1 && rw <= U) i2 = g.o_W3 + U + (rw - 1);
+    }
+    ix1[q] = i1; ixT[q] = iT; ix2[q] = i2;
+    wr1[q] = W[i1]; wr2[q] = W[i2];
+  }
+  const int ibp = (l31 < 21 ? l31 : 21) * WP_LD + h;       // B-panel row of this lane (cols >= 21 read zeros)
+  const int iap = l31 * WP_LD + h;
+  float loss_part = 0.f;
+  // The walk over (epoch, mini-batch, 32-row tile) is flattened so that the rows of tile t+1 (shuffle index, then the
+  // input row and the target: two dependent trips to L2) are requested while tile t is processed -- a single
+  // wavefront has nothing else to hide that latency with.
+  const int tpb = (a.bs + 31) / 32, nbatch = (a.B + a.bs - 1) / a.bs, tpe = tpb * nbatch, T = tpe * a.epochs;
+  auto fetch = [&](int t, float (&xo)[INMAX], float& yo, bool& vo) {
+    const int ep = t / tpe, w = t - ep * tpe, bi = w / tpb, lo = bi * a.bs;
+    const int nb = min(a.bs, a.B - lo), nrt = nb - (w - bi * tpb) * 32;
+    vo = r < nrt;
+    const int p = lo + (w - bi * tpb) * 32 + (vo ? r : 0);
+    const int b = vo ? (perm ? perm[(long)ep * a.B + p] : p) : 0;
+#pragma unroll
+    for (int k = 0; k < INMAX; ++k) xo[k] = (vo && k < in) ? xg[(long)b * in + k] : 0.f;
+    yo = vo ? yv[b] : 0.f;
+  };
+  float xn[INMAX], ybn;
+  bool validn;
+  fetch(0, xn, ybn, validn);
+  for (int t = 0; t < T; ++t) {
+    {
+      {
+        const int ep = t / tpe, w = t - ep * tpe, bi = w / tpb;
+        const int nb = min(a.bs, a.B - bi * a.bs);
+        const bool last_tile = (w - bi * tpb) == tpb - 1, last_of_epoch = w == tpe - 1;
+        float x[INMAX];
+#pragma unroll
+        for (int k = 0; k < INMAX; ++k) x[k] = xn[k];
+        const float yb = ybn;
+        const bool valid = validn;
+        if (t + 1 < T) fetch(t + 1, xn, ybn, validn);
+        // ---- layer 1, own ten units
+        rc_f2 z1[U / 2];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) z1[q] = rc_f2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < INMAX; ++k) {                    // rows >= in_dim multiply x = 0 (whatever finite weight follows W1)
+          const rc_f2 xk = rc_bcast2(x[k]);
+#pragma unroll
+          for (int q = 0; q < U / 2; ++q) {
+            const float2 w = *reinterpret_cast<const float2*>(&W[k * HID + u0 + 2 * q]);
+            z1[q] = rc_fma2(xk, rc_f2{w.x, w.y}, z1[q]);
+          }
+        }
+        float a1[U], a1o[U];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) {
+          a1[2 * q] = rc_lrelu(z1[q].x + W[g.o_b1 + u0 + 2 * q]);
+          a1[2 * q + 1] = rc_lrelu(z1[q].y + W[g.o_b1 + u0 + 2 * q + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a1o[u] = __shfl_xor(a1[u], 32, 64);
+        // ---- layer 2, own ten units: z2[u] = sum_j a1[j] W2[j][u], j ascending
+        rc_f2 z2[U / 2];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) z2[q] = rc_f2{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < HID; ++j) {
+          const float aj = j < U ? (h ? a1o[j] : a1[j]) : (h ? a1[j - U] : a1o[j - U]);
+          const rc_f2 ajj = rc_bcast2(aj);
+#pragma unroll
+          for (int q = 0; q < U / 2; ++q) {
+            const float2 w = *reinterpret_cast<const float2*>(&W[g.o_W2 + j * HID + u0 + 2 * q]);
+            z2[q] = rc_fma2(ajj, rc_f2{w.x, w.y}, z2[q]);
+          }
+        }
+        float a2[U], a2o[U];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) {
+          a2[2 * q] = rc_lrelu(z2[q].x + W[g.o_b2 + u0 + 2 * q]);
+          a2[2 * q + 1] = rc_lrelu(z2[q].y + W[g.o_b2 + u0 + 2 * q + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) a2o[u] = __shfl_xor(a2[u], 32, 64);
+        // ---- head and loss gradient (both halves compute the same v)
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < HID; ++k) {
+          const float ak = k < U ? (h ? a2o[k] : a2[k]) : (h ? a2[k - U] : a2o[k - U]);
+          v = fmaf(ak, W[g.o_W3 + k], v);
+        }
+        v += W[g.o_b3];
+        const float diff = valid ? v - yb : 0.f;
+        const float dv = (2.0f * diff) / (float)nb;
+        if (ep == 0 && h == 0) loss_part += diff * diff;
+        float dz2[U], dz2o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dz2[u] = dv * W[g.o_W3 + u0 + u] * rc_lrelu_grad_from_act(a2[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) dz2o[u] = __shfl_xor(dz2[u], 32, 64);
+        // ---- dz1, own ten units: da1[u] = sum_k dz2[k] W2[u][k], k ascending (W2 transposed in LDS)
+        rc_f2 da[U / 2];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) da[q] = rc_f2{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < HID; ++k) {
+          const float dk = k < U ? (h ? dz2o[k] : dz2[k]) : (h ? dz2[k - U] : dz2o[k - U]);
+          const rc_f2 dkk = rc_bcast2(dk);
+#pragma unroll
+          for (int q = 0; q < U / 2; ++q) {
+            const float2 w = *reinterpret_cast<const float2*>(&W2T[k * HID + u0 + 2 * q]);
+            da[q] = rc_fma2(dkk, rc_f2{w.x, w.y}, da[q]);
+          }
+        }
+        float dz1[U];
+#pragma unroll
+        for (int q = 0; q < U / 2; ++q) {
+          dz1[2 * q] = da[q].x * rc_lrelu_grad_from_act(a1[2 * q]);
+          dz1[2 * q + 1] = da[q].y * rc_lrelu_grad_from_act(a1[2 * q + 1]);
+        }
+        // ---- P1 = [a1 | 1 | 0 | a2[0:10]]^T [dz2 | dv | 0]
+        RC_WAVE_SYNC();                                      // previous product's fragments consumed
+#pragma unroll
+        for (int u = 0; u < U; ++u) { pA[(u0 + u) * WP_LD + r] = a1[u]; pB[(u0 + u) * WP_LD + r] = dz2[u]; }
+        if (h == 0) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) pA[(22 + u) * WP_LD + r] = a2[u];
+          pB[20 * WP_LD + r] = dv;
+        }
+        RC_WAVE_SYNC();
+#pragma unroll 4
+        for (int m = 0; m < 16; ++m) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA[iap + 2 * m], pB[ibp + 2 * m], acc1, 0, 0, 0);
+        // ---- P2 = [1 | a2[10:20] | x | 0]^T [dz1 | dv | 0]   (own A panel: its constant rows are written once)
+        RC_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < INMAX / 2; ++k) pA2[(XR + 2 * k + h) * WP_LD + r] = h ? x[2 * k + 1] : x[2 * k];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pB[(u0 + u) * WP_LD + r] = dz1[u];
+        if (h == 1) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) pA2[(1 + u) * WP_LD + r] = a2[u];
+        }
+        RC_WAVE_SYNC();
+#pragma unroll 4
+        for (int m = 0; m < 16; ++m) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA2[iap + 2 * m], pB[ibp + 2 * m], acc2, 0, 0, 0);
+        if (last_tile) {
+          // ---- SGD step in the D layout.  Each lane keeps the parameters its 2 x 16 accumulator slots own in
+          // registers (master copy) and only WRITES the broadcast copies in LDS: no read-modify-write latency
+          // chain, no branches (slots that own nothing write a dummy word).
+          RC_WAVE_SYNC();
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            wr1[q] = wr1[q] - a.lr * acc1[q];
+            wr2[q] = wr2[q] - a.lr * acc2[q];
+            W[ix1[q]] = wr1[q];
+            W2T[ixT[q]] = wr1[q];
+            W[ix2[q]] = wr2[q];
+            acc1[q] = 0.f; acc2[q] = 0.f;
+          }
+          RC_WAVE_SYNC();
+        }
+        if (ep == 0 && last_of_epoch && a.loss_out) {          // Keras History: first-epoch loss
+          float tl = loss_part;
+#pragma unroll
+          for (int mk = 16; mk >= 1; mk >>= 1) tl += __shfl_xor(tl, mk, 64);
+          if (lane == 0) a.loss_out[row] = tl / (float)a.B;
+        }
+      }
+    }
+  }
+  RC_WAVE_SYNC();
+  for (int e = lane; e < g.P; e += 64) th[e] = W[e];
+}
+
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
   const NetGeom g = make_geom(in_dim, hid, out);
   const int Ppad = (g.P + 3) & ~3;
@@ -286,6 +529,26 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
   a.x = x; a.x_seed_stride = x_seed_stride; a.theta = theta; a.agents = agents; a.y = y; a.perm = perm;
   a.loss_out = loss_out; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb;
   a.bs = batch_size < B ? batch_size : B; a.epochs = epochs; a.n_adv = n_adv; a.lr = lr;
+  static int wave_ok = -1;               // RCMARL_MB_WAVE=0 keeps the workgroup-per-network kernel (bisecting knob)
+  if (wave_ok < 0) { const char* e = getenv("RCMARL_MB_WAVE"); wave_ok = e ? atoi(e) : 1; }
+  if (wave_ok && in_dim <= 20) {
+    const int n_nets = n_adv * S;
+    const size_t smem = (size_t)4 * WP_FLOATS * sizeof(float);
+#ifndef RCMARL_EMU
+    static const bool attr_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_minibatch_wave<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_minibatch_wave<20>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) == hipSuccess;
+    if (!attr_ok) return RCMARL_ERR_LAUNCH;
+#endif
+    if (in_dim <= 16) {
+      RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
+    } else {
+      RCMARL_LAUNCH((k_minibatch_wave<20>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
+    }
+    return rcmarl_check_launch();
+  }
   return mb_launch(k_minibatch_train<20, 1, false>, a, S, mb_smem_bytes(in_dim, 20, 1), stream);
 }
 

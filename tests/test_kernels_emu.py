@@ -70,7 +70,8 @@ def test_rollout(bk, S, N, nrow, ncol, mode):
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(2, 5, 100, 10, [4], 32, True), (1, 5, 70, 15, [1, 3], 32, True),
-                                                          (1, 2, 40, 140, [0], 32, False)])
+                                                          (1, 2, 40, 140, [0], 32, False), (1, 6, 90, 18, [2, 5], 40, True),
+                                                          (3, 5, 50, 20, [0], 7, True)])      # multi-tile batches, ragged tails
 def test_minibatch_fit(bk, S, N, B, in_dim, advs, bs, shuffle):
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=shuffle)
 

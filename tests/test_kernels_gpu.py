@@ -81,7 +81,9 @@ def test_rollout(bk, S, N, nrow, ncol, mode):
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(2, 5, 1000, 10, [4], 32, True), (1, 5, 3000, 15, [1, 3], 32, True),
-                                                          (1, 64, 500, 192, [0, 63], 32, True), (1, 256, 200, 768, [7], 32, False)])
+                                                          (1, 64, 500, 192, [0, 63], 32, True), (1, 256, 200, 768, [7], 32, False),
+                                                          (7, 6, 900, 18, [2, 5], 40, True), (9, 5, 333, 20, [0], 7, True),
+                                                          (300, 5, 400, 15, [4], 32, True)])
 def test_minibatch_fit(bk, S, N, B, in_dim, advs, bs, shuffle):
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle)
 

@@ -91,6 +91,22 @@ def k1_cfg5(L):
           % (N, d, H, P_hid, t, byts / t / 1e3, byts / t / 1e3 / 80, N / (t * 1e-6)))
 
 
+def minibatch(L, S=512, N=5, B=3000):
+    """adversary mini-batch fit (fit(batch_size=32, epochs=10)) alone: one launch = 940 sequential SGD steps per net"""
+    st = torch.cuda.current_stream().cuda_stream
+    for in_dim in (2 * N, 3 * N):
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        x = torch.randn(S, B, in_dim, device="cuda")
+        theta = torch.randn(S, N, ldp, device="cuda") * 0.05
+        y = torch.randn(S, N, ldb, device="cuda")
+        agents = torch.tensor([N - 1], dtype=torch.int32, device="cuda")
+        perm = torch.stack([torch.stack([torch.randperm(B, device="cuda") for _ in range(10)]) for _ in range(S)]).to(torch.int32).reshape(S, 1, 10, B).contiguous()
+        t = timeit(lambda: L.rcmarl_minibatch_fit(x.data_ptr(), B * in_dim, theta.data_ptr(), agents.data_ptr(), 1, y.data_ptr(), perm.data_ptr(),
+                                                  S, N, B, in_dim, HID, ldp, ldb, 32, 10, 1e-4, None, st), iters=3, warm=1)
+        print("minibatch_fit in=%3d S=%d: %9.1f us per launch, %.2f us per SGD step" % (in_dim, S, t, t / (10 * ((B + 31) // 32))))
+
+
 def mid(L, S=16, N=256, B=3000):
     st = torch.cuda.current_stream().cuda_stream
     in_dim = 2 * N
@@ -163,4 +179,4 @@ if __name__ == "__main__":
     L = capi.load()
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "minibatch": minibatch}[what](L)
