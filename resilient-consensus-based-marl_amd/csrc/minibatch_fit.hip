@@ -272,8 +272,17 @@ constexpr int WP_FLOATS = WP_W + WP_W2T + 2 * WP_A + WP_B;  // LDS floats per wa
 
 #ifdef RCMARL_EMU
 #define RC_WAVE_SYNC() hipemu::wave_barrier()
+__device__ __forceinline__ float rc_other_half(float v) { return __shfl_xor(v, 32, 64); }
 #else
 #define RC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// value of the same row's lane in the other half (lane ^ 32): v_permlane32_swap_b32 exchanges lanes 32-63 of its
+// first operand with lanes 0-31 of its second -- one VALU instruction + a select instead of a trip through the
+// LDS crossbar (ds_bpermute)
+__device__ __forceinline__ float rc_other_half(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float((threadIdx.x & 32) ? sw[0] : sw[1]);
+}
 #endif
 
 template <int INMAX>                                        // inputs padded to INMAX (16 or 20): branch-free loops
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
           a1[2 * q + 1] = rc_lrelu(z1[q].y + W[g.o_b1 + u0 + 2 * q + 1]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) a1o[u] = __shfl_xor(a1[u], 32, 64);
+        for (int u = 0; u < U; ++u) a1o[u] = rc_other_half(a1[u]);
         // ---- layer 2, own ten units: z2[u] = sum_j a1[j] W2[j][u], j ascending
         rc_f2 z2[U / 2];
 #pragma unroll
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
           a2[2 * q + 1] = rc_lrelu(z2[q].y + W[g.o_b2 + u0 + 2 * q + 1]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) a2o[u] = __shfl_xor(a2[u], 32, 64);
+        for (int u = 0; u < U; ++u) a2o[u] = rc_other_half(a2[u]);
         // ---- head and loss gradient (both halves compute the same v)
         float v = 0.f;
 #pragma unroll
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
 #pragma unroll
         for (int u = 0; u < U; ++u) dz2[u] = dv * W[g.o_W3 + u0 + u] * rc_lrelu_grad_from_act(a2[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) dz2o[u] = __shfl_xor(dz2[u], 32, 64);
+        for (int u = 0; u < U; ++u) dz2o[u] = rc_other_half(dz2[u]);
         // ---- dz1, own ten units: da1[u] = sum_k dz2[k] W2[u][k], k ascending (W2 transposed in LDS)
         rc_f2 da[U / 2];
 #pragma unroll
