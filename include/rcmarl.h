@@ -232,6 +232,51 @@ int rcmarl_env_reset_episodes(const int* pos_in, const unsigned long long* seeds
                               const double* scale, int episode0, int* posT, float* xsT, double* retT, int S, int N,
                               int E, int EP, void* stream);
 
+/* ---- wide networks (any hidden width: BASELINE configs[4], the 512-unit critic) -- csrc/wide_kernels.hip ----
+ * The reference builds its networks in main.py:59-82 with 20 hidden units; a wider model object handed to the same
+ * agent API makes every layer a true dense GEMM per agent (f32 MFMA), the 1-unit head a column/row pass over the
+ * feature-major activations act[S][N*hid][ldb].  Same reference functions as the hid = 20 entry points above.
+ *
+ * out[s][n][j][b] = lrelu(sum_k W[k][j] in(k,b) + bias[j]); W = theta[s][n] + w_off (K x J, Keras kernel order),
+ * bias = theta[s][n] + b_off.  in_row_major != 0: in[s][b][k] (replay rows; ld_in floats per row; agent stride 0 for
+ * the shared global state), else feature-major in[s][n][k][b] with ld_in = its row length.   (model(x), agents/
+ * resilient_CAC_agents.py:95-97,114) */
+int rcmarl_dense_forward(const float* in, long in_seed_stride, long in_agent_stride, int in_row_major, int ld_in,
+                         const float* theta, int w_off, int b_off, float* out, int S, int N, int B, int K, int J,
+                         int ldp, int ldb, void* stream);
+/* dz_in[s][n][k][b] = (sum_j W[k][j] dz_out[j][b]) * lrelu'(act_in[k][b])      (backward of fit(), :118,:136) */
+int rcmarl_dense_backward_data(const float* dz_out, const float* theta, int w_off, const float* act_in, float* dz_in,
+                               int S, int N, int B, int K, int J, int ldp, int ldb, void* stream);
+/* W[k][j] -= lr * sum_b in(k,b) dz[j][b] for agents with mask[n] != 0 (mask NULL: all)   (plain SGD step of fit()) */
+int rcmarl_dense_backward_sgd(const float* in, long in_seed_stride, long in_agent_stride, int in_row_major, int ld_in,
+                              const float* dz, float* theta, int w_off, const int* mask, int S, int N, int B, int K,
+                              int J, int ldp, int ldb, float lr, void* stream);
+int rcmarl_wide_grad_size(int hid);      /* floats per (seed, agent) of `grads`: [gW3 (hid) | gb3 | gb2 (hid) | gb1 (hid)] */
+int rcmarl_wide_rows_per_chunk(void);    /* `losspart` holds ceil(B / this) floats per (seed, agent) */
+/* out[s][n][b] = a2[:,b] . W3 + b3, or r_applied + gamma * that (TD target, :114-115) */
+int rcmarl_wide_head_value(const float* a2, const float* theta, const float* r_applied, float gamma, float* out, int S,
+                           int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+/* MSE head of fit() (:118): dz3 = 2 (V - y) / B; a2 is OVERWRITTEN by dz2 = W3 dz3 lrelu'(a2); grads gets gW3, gb3, gb2;
+ * losspart the chunk sums of (V - y)^2 */
+int rcmarl_wide_head_fit(float* a2, const float* theta, const float* y, float* dz3, float* grads, float* losspart, int S,
+                         int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+/* grads.gb1[j] = sum_b dz1[j][b] */
+int rcmarl_wide_bias_grad(const float* dz1, float* grads, int S, int N, int B, int hid, int ldb, void* stream);
+/* b1, b2, W3, b3 -= lr * grads (masked agents); loss_out[s][n] = sum(losspart)/B if not NULL */
+int rcmarl_wide_small_sgd(const float* grads, const float* losspart, float* theta, const int* mask, float* loss_out,
+                          int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream);
+/* K2+K3 (resilient_consensus_critic + critic_update_team, :168-206 + :60-71) for a wide head.  phi = layer-2
+ * activations of the live net.  Scratch: hmat [S][N][d+1][hid], hb [S][N][d+1], est [S][N][d+1][ldb],
+ * ebuf [S][N][ldb].  grads[s][n][0..hid] = [sum_b e phi | sum_b e] for cooperative agents, e = (agg - V_live) /
+ * (|phi|^2 + 1); agg_out optional.  agg_in != NULL: projection toward that aggregate only (msg/nbr/hmat/hb/est unused) */
+int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float* msg, const int* nbr, const int* coop,
+                               const float* agg_in, float* hmat, float* hb, float* est, float* ebuf, float* grads,
+                               float* agg_out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, int d, int H,
+                               void* stream);
+/* W3 += grads[0..hid)/B, b3 += grads[hid]/B (cooperative agents) */
+int rcmarl_wide_head_apply(const float* grads, float* theta, const int* coop, int S, int N, int B, int in_dim, int hid,
+                           int ldp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,9 +123,37 @@ SIGNATURES = {
     # pos_in, seeds, nrow, ncol, scale, episode0, posT, xsT, retT, S, N, E, EP, stream
     "rcmarl_env_reset_episodes": [c_i32p, C.c_void_p, c_int, c_int, c_f64p, c_int, c_i32p, c_f32p, c_f64p, c_int, c_int,
                                   c_int, c_int, c_stream],
+    # ---- wide networks (csrc/wide_kernels.hip) -----------------------------------------------------------
+    # in, in_seed_stride, in_agent_stride, in_row_major, ld_in, theta, w_off, b_off, out, S, N, B, K, J, ldp, ldb, stream
+    "rcmarl_dense_forward": [c_f32p, c_long, c_long, c_int, c_int, c_f32p, c_int, c_int, c_f32p, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_stream],
+    # dz_out, theta, w_off, act_in, dz_in, S, N, B, K, J, ldp, ldb, stream
+    "rcmarl_dense_backward_data": [c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_stream],
+    # in, in_seed_stride, in_agent_stride, in_row_major, ld_in, dz, theta, w_off, mask, S, N, B, K, J, ldp, ldb, lr, stream
+    "rcmarl_dense_backward_sgd": [c_f32p, c_long, c_long, c_int, c_int, c_f32p, c_f32p, c_int, c_i32p, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
+    "rcmarl_wide_grad_size": [c_int],
+    "rcmarl_wide_rows_per_chunk": [],
+    # a2, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_wide_head_value": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_stream],
+    # a2, theta, y, dz3, grads, losspart, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_wide_head_fit": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_int, c_stream],
+    # dz1, grads, S, N, B, hid, ldb, stream
+    "rcmarl_wide_bias_grad": [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # grads, losspart, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
+    "rcmarl_wide_small_sgd": [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                              c_stream],
+    # phi, theta, msg, nbr, coop, agg_in, hmat, hb, est, ebuf, grads, agg_out, S, N, B, in_dim, hid, ldp, ldb, d, H, stream
+    "rcmarl_wide_consensus_head": [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                   c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # grads, theta, coop, S, N, B, in_dim, hid, ldp, stream
+    "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
-             "rcmarl_fit_small_partial_size"}
+             "rcmarl_fit_small_partial_size", "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",
           3: "RCMARL_ERR_UNSUPPORTED (shape outside the compiled kernels)"}

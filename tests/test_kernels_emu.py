@@ -106,3 +106,24 @@ def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
                                                  (1, 2, 700, 10, None)])     # 3 chunks: the multi-chunk walk of one workgroup
 def test_fit_step_small(bk, S, N, B, in_dim, masked):
     KC.check_fit_step_small(bk, S, N, B, in_dim, steps=2, masked_agent=masked)
+
+
+# ---- wide networks (hid != 20): dense-GEMM path, csrc/wide_kernels.hip -------------------------------
+import wide_checks as WC
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,hid", [(2, 3, 72, 12, 32),      # float4 staging
+                                              (1, 2, 150, 10, 40),     # scalar staging (unaligned K / rows), 2 n-tiles
+                                              (1, 2, 40, 136, 132)])   # > 1 m-tile, k tail
+def test_wide_forward(bk, S, N, B, in_dim, hid):
+    WC.check_wide_forward(bk, S, N, B, in_dim, hid)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,hid,masked", [(2, 3, 72, 12, 32, None), (1, 3, 70, 10, 24, 1), (1, 2, 260, 16, 64, None)])
+def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
+    WC.check_wide_fit(bk, S, N, B, in_dim, hid, steps=2, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 72, 10, 32, 4, 1, "circ"), (1, 8, 140, 16, 24, 7, 2, "rand")])
+def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
+    WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)

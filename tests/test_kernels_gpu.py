@@ -140,3 +140,24 @@ def test_consensus_params_short_tiles_many_seeds(bk, N, d, H, P, P_hid, S):
     Checked against the oracle and for bit-identical repetition."""
     KC.check_consensus_params(bk, N, d, H, P, P_hid, "circ", S=S)
     KC.check_consensus_params(bk, N, d, H, P, P_hid, "circ", S=S)
+
+
+# ---- wide networks (hid != 20): dense-GEMM path, csrc/wide_kernels.hip -------------------------------
+import wide_checks as WC
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,hid", [(2, 5, 1000, 12, 64), (1, 3, 3000, 10, 40), (1, 4, 700, 256, 512), (1, 2, 333, 136, 132)])
+def test_wide_forward(bk, S, N, B, in_dim, hid):
+    WC.check_wide_forward(bk, S, N, B, in_dim, hid)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,hid,masked", [(2, 5, 1000, 12, 64, None), (1, 3, 701, 10, 24, 1), (1, 4, 3000, 128, 512, 2),
+                                                     (1, 16, 1000, 32, 128, None)])
+def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
+    WC.check_wide_fit(bk, S, N, B, in_dim, hid, steps=3, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 1000, 10, 64, 4, 1, "circ"), (1, 24, 700, 48, 128, 10, 4, "rand"),
+                                                        (1, 70, 300, 140, 512, 66, 32, "circ")])
+def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
+    WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)

@@ -1,0 +1,181 @@
+"""Wide-network (hid != 20) kernel checks shared by the hipemu and GPU tests: the dense-GEMM path of
+csrc/wide_kernels.hip against the same oracle functions as the 20-unit kernels (kernel_checks.py)."""
+import numpy as np
+
+from oracle import mlp_np as M
+from oracle import rpbcac_oracle as O
+from kernel_checks import pad64, pack_rows, unpack_row, circulant, random_regular, rel_close
+
+
+def wgeom(in_dim, hid):
+    o_b1 = in_dim * hid
+    o_W2 = o_b1 + hid
+    o_b2 = o_W2 + hid * hid
+    o_W3 = o_b2 + hid
+    o_b3 = o_W3 + hid
+    return dict(o_b1=o_b1, o_W2=o_W2, o_b2=o_b2, o_W3=o_W3, o_b3=o_b3, P=o_b3 + 1, P_hid=o_W3)
+
+
+def wide_params(rng, S, N, in_dim, hid, bias_scale=0.1):
+    out = []
+    for s in range(S):
+        row = []
+        for n in range(N):
+            p = M.init_mlp(rng, in_dim, hid, 1)
+            for k in (1, 3, 5):
+                p[k] += (bias_scale * rng.normal(size=p[k].shape)).astype(np.float32)
+            row.append(p)
+        out.append(row)
+    return out
+
+
+class WideBuffers:
+    """Device scratch of the wide path for S seeds x N agents, B rows."""
+
+    def __init__(self, bk, S, N, B, hid, d=1):
+        ldb = pad64(B)
+        z = lambda *sh: bk.dev(np.zeros(sh, np.float32))
+        self.a1, self.a2, self.dz1 = z(S, N * hid, ldb), z(S, N * hid, ldb), z(S, N * hid, ldb)
+        self.dz3 = z(S, N, ldb)
+        self.grads = z(S, N, bk.lib.rcmarl_wide_grad_size(hid))
+        self.losspart = z(S, N, (B + bk.lib.rcmarl_wide_rows_per_chunk() - 1) // bk.lib.rcmarl_wide_rows_per_chunk())
+        self.hmat, self.hb, self.est, self.ebuf = z(S, N, d + 1, hid), z(S, N, d + 1), z(S, N, d + 1, ldb), z(S, N, ldb)
+
+
+def forward2(bk, wb, d_x, x_stride, d_theta, S, N, B, in_dim, hid, ldp, ldb):
+    """layers 1 and 2 of every agent: replay rows -> wb.a1 -> wb.a2"""
+    g, L = wgeom(in_dim, hid), bk.lib
+    L.rcmarl_dense_forward(bk.ptr(d_x), x_stride, 0, 1, in_dim, bk.ptr(d_theta), 0, g["o_b1"], bk.ptr(wb.a1), S, N, B, in_dim,
+                           hid, ldp, ldb, bk.stream)
+    L.rcmarl_dense_forward(bk.ptr(wb.a1), N * hid * ldb, hid * ldb, 0, ldb, bk.ptr(d_theta), g["o_W2"], g["o_b2"],
+                           bk.ptr(wb.a2), S, N, B, hid, hid, ldp, ldb, bk.stream)
+
+
+def fit_step(bk, wb, d_x, x_stride, d_msg, d_y, d_mask, d_loss, S, N, B, in_dim, hid, ldp, ldb, lr):
+    """one full-batch SGD step of fit() on all three layers (the sequence engine._local_fit_wide runs)"""
+    g, L = wgeom(in_dim, hid), bk.lib
+    forward2(bk, wb, d_x, x_stride, d_msg, S, N, B, in_dim, hid, ldp, ldb)
+    L.rcmarl_wide_head_fit(bk.ptr(wb.a2), bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(wb.dz3), bk.ptr(wb.grads), bk.ptr(wb.losspart),
+                           S, N, B, in_dim, hid, ldp, ldb, bk.stream)
+    L.rcmarl_dense_backward_data(bk.ptr(wb.a2), bk.ptr(d_msg), g["o_W2"], bk.ptr(wb.a1), bk.ptr(wb.dz1), S, N, B, hid, hid,
+                                 ldp, ldb, bk.stream)
+    L.rcmarl_wide_bias_grad(bk.ptr(wb.dz1), bk.ptr(wb.grads), S, N, B, hid, ldb, bk.stream)
+    L.rcmarl_dense_backward_sgd(bk.ptr(wb.a1), N * hid * ldb, hid * ldb, 0, ldb, bk.ptr(wb.a2), bk.ptr(d_msg), g["o_W2"],
+                                bk.ptr(d_mask), S, N, B, hid, hid, ldp, ldb, lr, bk.stream)
+    L.rcmarl_dense_backward_sgd(bk.ptr(d_x), x_stride, 0, 1, in_dim, bk.ptr(wb.dz1), bk.ptr(d_msg), 0, bk.ptr(d_mask), S, N,
+                                B, in_dim, hid, ldp, ldb, lr, bk.stream)
+    L.rcmarl_wide_small_sgd(bk.ptr(wb.grads), bk.ptr(wb.losspart), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss), S, N, B,
+                            in_dim, hid, ldp, lr, bk.stream)
+
+
+def check_wide_forward(bk, S, N, B, in_dim, hid):
+    rng = np.random.default_rng(S * 1000 + N * 100 + B + in_dim + hid)
+    g = wgeom(in_dim, hid)
+    ldp, ldb = pad64(g["P"]), pad64(B)
+    params = wide_params(rng, S, N, in_dim, hid)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    r = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    d_x, d_th, d_r = bk.dev(x), bk.dev(theta), bk.dev(r)
+    wb = WideBuffers(bk, S, N, B, hid)
+    d_v = bk.dev(np.zeros((S, N, ldb), np.float32))
+    d_y = bk.dev(np.zeros((S, N, ldb), np.float32))
+    forward2(bk, wb, d_x, B * in_dim, d_th, S, N, B, in_dim, hid, ldp, ldb)
+    bk.lib.rcmarl_wide_head_value(bk.ptr(wb.a2), bk.ptr(d_th), None, 0.0, bk.ptr(d_v), S, N, B, in_dim, hid, ldp, ldb, bk.stream)
+    bk.lib.rcmarl_wide_head_value(bk.ptr(wb.a2), bk.ptr(d_th), bk.ptr(d_r), 0.9, bk.ptr(d_y), S, N, B, in_dim, hid, ldp, ldb,
+                                  bk.stream)
+    a1, a2, v, y = bk.host(wb.a1), bk.host(wb.a2), bk.host(d_v), bk.host(d_y)
+    for s in range(S):
+        for n in range(N):
+            p = params[s][n]
+            z1 = x[s] @ p[0] + p[1]
+            w1 = np.where(z1 > 0, z1, np.float32(0.1) * z1)
+            z2 = w1 @ p[2] + p[3]
+            w2 = np.where(z2 > 0, z2, np.float32(0.1) * z2)
+            rel_close(a1[s, n * hid:(n + 1) * hid, :B].T, w1, 2e-6, "layer-1 activations")
+            rel_close(a2[s, n * hid:(n + 1) * hid, :B].T, w2, 4e-6, "layer-2 activations")
+            want = M.forward(p, x[s])[:, 0]
+            rel_close(v[s, n, :B], want, 5e-6, "value")
+            rel_close(y[s, n, :B], r[s, n, :B] + np.float32(0.9) * want, 5e-6, "td target")
+
+
+def check_wide_fit(bk, S, N, B, in_dim, hid, steps=2, lr=0.01, masked_agent=None):
+    """`steps` full-batch SGD steps through the dense-GEMM path vs the oracle's fit (M.fit_mse)."""
+    rng = np.random.default_rng(S * 1000 + N * 100 + B + in_dim + hid + 1)
+    g = wgeom(in_dim, hid)
+    ldp, ldb = pad64(g["P"]), pad64(B)
+    params = wide_params(rng, S, N, in_dim, hid)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    yv = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.int32)
+    if masked_agent is not None:
+        mask[masked_agent] = 0
+    d_x, d_y, d_mask, d_msg = bk.dev(x), bk.dev(yv), bk.dev(mask), bk.dev(theta.copy())
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    wb = WideBuffers(bk, S, N, B, hid)
+    for st in range(steps):
+        fit_step(bk, wb, d_x, B * in_dim, d_msg, d_y, d_mask, d_loss if st == 0 else None, S, N, B, in_dim, hid, ldp, ldb, lr)
+    msg, loss = bk.host(d_msg), bk.host(d_loss)
+    for s in range(S):
+        for n in range(N):
+            if not mask[n]:
+                np.testing.assert_array_equal(msg[s, n], theta[s, n])
+                continue
+            pw = M.copy_params(params[s][n])
+            hist = M.fit_mse(pw, x[s], yv[s, n, :B, None], lr, epochs=steps)
+            got = unpack_row(msg[s, n], in_dim, 1, hid)
+            for k in range(6):
+                rel_close(got[k], pw[k], 1e-5, "wide fit param %d" % k)
+            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+
+
+def check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph="circ"):
+    """K2+K3 for a wide head vs the oracle agent (consensus_estimates_critic + projection_step_critic)."""
+    rng = np.random.default_rng(S + N * 10 + B + d * 7 + H + hid)
+    g = wgeom(in_dim, hid)
+    P, P_hid = g["P"], g["P_hid"]
+    ldp, ldb = pad64(P), pad64(B)
+    live = wide_params(rng, S, N, in_dim, hid)
+    msgp = wide_params(rng, S, N, in_dim, hid)
+    theta, msg = pack_rows(live, ldp), pack_rows(msgp, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
+    coop = np.ones(N, np.int32)
+    coop[0] = 0
+    for s in range(S):                              # an outlier head among the messages
+        msg[s, 1, P_hid:P] *= 50.0
+        msgp[s][1][4] = msgp[s][1][4] * np.float32(50.0)
+        msgp[s][1][5] = msgp[s][1][5] * np.float32(50.0)
+    d_x, d_th, d_msg, d_nbr, d_coop = bk.dev(x), bk.dev(theta), bk.dev(msg), bk.dev(nbr), bk.dev(coop)
+    d_agg = bk.dev(np.zeros((S, N, ldb), np.float32))
+    wb = WideBuffers(bk, S, N, B, hid, d)
+    L = bk.lib
+    forward2(bk, wb, d_x, B * in_dim, d_th, S, N, B, in_dim, hid, ldp, ldb)
+    L.rcmarl_wide_consensus_head(bk.ptr(wb.a2), bk.ptr(d_th), bk.ptr(d_msg), bk.ptr(d_nbr), bk.ptr(d_coop), None,
+                                 bk.ptr(wb.hmat), bk.ptr(wb.hb), bk.ptr(wb.est), bk.ptr(wb.ebuf), bk.ptr(wb.grads),
+                                 bk.ptr(d_agg), S, N, B, in_dim, hid, ldp, ldb, d, H, bk.stream)
+    L.rcmarl_wide_head_apply(bk.ptr(wb.grads), bk.ptr(d_th), bk.ptr(d_coop), S, N, B, in_dim, hid, ldp, bk.stream)
+    th_new, agg = bk.host(d_th), bk.host(d_agg)
+    # K3 alone toward the aggregate just computed, from the original heads: must land on the same W3, b3
+    d_th2 = bk.dev(theta)
+    L.rcmarl_wide_consensus_head(bk.ptr(wb.a2), bk.ptr(d_th2), None, None, bk.ptr(d_coop), bk.ptr(d_agg), None, None, None,
+                                 bk.ptr(wb.ebuf), bk.ptr(wb.grads), None, S, N, B, in_dim, hid, ldp, ldb, d, H, bk.stream)
+    L.rcmarl_wide_head_apply(bk.ptr(wb.grads), bk.ptr(d_th2), bk.ptr(d_coop), S, N, B, in_dim, hid, ldp, bk.stream)
+    th_proj = bk.host(d_th2)
+    for s in range(S):
+        for i in range(N):
+            if not coop[i]:
+                np.testing.assert_array_equal(th_new[s, i], theta[s, i])
+                continue
+            ag = O.CoopAgent(M.init_mlp(rng, in_dim, 20, 5), live[s][i], live[s][i], 0.002, 0.01, 0.9, H)
+            want_agg = ag.consensus_estimates_critic(x[s], [msgp[s][j] for j in nbr[i]])
+            # fp32 summation order only: a 512-term head on top of two GEMM layers carries ~4x the roundoff of a 128-term one
+            rel_close(agg[s, i, :B], want_agg[:, 0], 1e-5 if hid <= 128 else 4e-5, "estimate aggregate")
+            ag.projection_step_critic(x[s], want_agg)
+            got = unpack_row(th_new[s, i], in_dim, 1, hid)
+            for k in range(4):
+                np.testing.assert_array_equal(got[k], live[s][i][k])          # hidden layers frozen
+            rel_close(got[4], ag.critic[4], 3e-5 if hid <= 128 else 1e-4, "W3 after projection")
+            rel_close(got[5], ag.critic[5], 3e-5 if hid <= 128 else 1e-4, "b3 after projection")
+            rel_close(th_proj[s, i, :P], th_new[s, i, :P], 2e-6, "projection toward a given aggregate")

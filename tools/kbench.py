@@ -175,8 +175,51 @@ def lattice(L, S=16, N=256, B=3000):
                                                                                                    3 * flops / t / 1e6))
 
 
+def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
+    """the dense-GEMM path at the cfg-5 shape (1024 agents x 512-wide critic, here a 64-agent slice)"""
+    st = torch.cuda.current_stream().cuda_stream
+    o_b1 = in_dim * hid
+    o_W2 = o_b1 + hid
+    o_b2 = o_W2 + hid * hid
+    P = o_b2 + hid + hid + 1
+    ldp, ldb = pad64(P), pad64(B)
+    x = torch.randn(S, B, in_dim, device="cuda")
+    theta = torch.randn(S, N, ldp, device="cuda") * 0.02
+    a1, a2, dz1 = (torch.zeros(S, N * hid, ldb, device="cuda") for _ in range(3))
+    y = torch.randn(S, N, ldb, device="cuda")
+    dz3 = torch.zeros(S, N, ldb, device="cuda")
+    grads = torch.zeros(S, N, L.rcmarl_wide_grad_size(hid), device="cuda")
+    lp = torch.zeros(S, N, (B + 255) // 256, device="cuda")
+    mask = torch.ones(N, dtype=torch.int32, device="cuda")
+    f1, f2 = 2.0 * S * N * hid * B * in_dim, 2.0 * S * N * hid * B * hid
+    rows = [
+        ("fwd L1 (W1^T x)", f1, lambda: L.rcmarl_dense_forward(x.data_ptr(), B * in_dim, 0, 1, in_dim, theta.data_ptr(), 0, o_b1,
+                                                               a1.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)),
+        ("fwd L2 (W2^T a1)", f2, lambda: L.rcmarl_dense_forward(a1.data_ptr(), N * hid * ldb, hid * ldb, 0, ldb, theta.data_ptr(),
+                                                                o_W2, o_b2, a2.data_ptr(), S, N, B, hid, hid, ldp, ldb, st)),
+        ("head fit", 0, lambda: L.rcmarl_wide_head_fit(a2.data_ptr(), theta.data_ptr(), y.data_ptr(), dz3.data_ptr(),
+                                                       grads.data_ptr(), lp.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)),
+        ("bwd data L2 (W2 dz2)", f2, lambda: L.rcmarl_dense_backward_data(a2.data_ptr(), theta.data_ptr(), o_W2, a1.data_ptr(),
+                                                                          dz1.data_ptr(), S, N, B, hid, hid, ldp, ldb, st)),
+        ("bias grad", 0, lambda: L.rcmarl_wide_bias_grad(dz1.data_ptr(), grads.data_ptr(), S, N, B, hid, ldb, st)),
+        ("bwd W2 (a1 dz2^T)", f2, lambda: L.rcmarl_dense_backward_sgd(a1.data_ptr(), N * hid * ldb, hid * ldb, 0, ldb, a2.data_ptr(),
+                                                                       theta.data_ptr(), o_W2, mask.data_ptr(), S, N, B, hid, hid,
+                                                                       ldp, ldb, 1e-9, st)),
+        ("bwd W1 (x^T dz1^T)", f1, lambda: L.rcmarl_dense_backward_sgd(x.data_ptr(), B * in_dim, 0, 1, in_dim, dz1.data_ptr(),
+                                                                        theta.data_ptr(), 0, mask.data_ptr(), S, N, B, in_dim, hid,
+                                                                        ldp, ldb, 1e-9, st)),
+    ]
+    tot = 0.0
+    for name, fl, fn in rows:
+        t = timeit(fn, iters=5, warm=2)
+        tot += t
+        print("%-22s %9.1f us  %s" % (name, t, ("%6.1f TF/s (%.0f%% of the 157 TF/s f32 MFMA peak)" % (fl / t / 1e6, fl / t / 1e6 / 1.573))
+                                         if fl else ""))
+    print("one SGD step, %d agents: %.2f ms  -> 1024 agents: %.1f ms" % (N, tot / 1e3, tot / 1e3 * 1024 / N))
+
+
 if __name__ == "__main__":
     L = capi.load()
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "minibatch": minibatch}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "minibatch": minibatch, "wide": wide}[what](L)
