@@ -55,6 +55,11 @@ WORKLOADS = {
                               "512 independent seeds per GPU"),
     "cfg1_batched": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=512, graph="circulant",
                          desc="5 cooperative agents, 5x5 grid, H=1, 512 seeds per GPU"),
+    # BASELINE configs[4] as ONE instance on ONE GPU (the 8-GPU agent/column sharding of SURVEY.md 8e is not built):
+    # only the critic is widened to 512 units (BASELINE: "wide (512-unit) critic"), team-reward net and actor keep 20
+    "cfg5_1gpu": dict(N=1024, nrow=32, ncol=32, H=32, d=66, S=1, graph="circulant", fast_lr=0.0005, critic_hid=512,
+                      desc="BASELINE configs[4] on one GPU: 1024 agents, 512-unit critic (dense f32-MFMA GEMM path), 20-unit "
+                           "team-reward net and actor, 32x32 grid, H=32, circulant in-degree d=66 (=2H+2), one instance"),
 }
 
 
@@ -74,7 +79,7 @@ def make_engine(w, S, seeds, lib):
     N = w["N"]
     cfg = EngineConfig(N, w.get("labels", ["Cooperative"] * N), build_graph(w["graph"], N, w["d"]), H=w["H"], gamma=0.9, slow_lr=0.002,
                        fast_lr=w.get("fast_lr", 0.01), max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000, nrow=w["nrow"],
-                       ncol=w["ncol"], n_seeds=S, rng_mode="device")
+                       ncol=w["ncol"], n_seeds=S, rng_mode="device", critic_hid=w.get("critic_hid", 20))
     eng = RPBCACEngine(cfg, seeds=seeds, device="cuda", lib=lib)
     eng.init_glorot(base_seed=1)
     goals = np.stack([np.random.RandomState(int(s)).randint(0, 5, size=(N, 2)) for s in seeds])   # main.py:48 draws goals in [0,5)
@@ -110,8 +115,12 @@ def cpu_baseline(w, budget_s=25.0):
     B, n_last, n_epochs, steps_per_block = 3000, 1000, 10, 1000
     rng = np.random.default_rng(0)
     in_nodes = build_graph(w["graph"], N, d)
-    agents = [O.CoopAgent(M.init_mlp(rng, 2 * N, 20, 5), M.init_mlp(rng, 2 * N, 20, 1), M.init_mlp(rng, 3 * N, 20, 1),
-                          0.002, 0.01, 0.9, H) for _ in range(N)]
+    chid = w.get("critic_hid", 20)
+    k = (4 if chid == 20 else 2) if N >= 64 else min(N, 5)           # agents whose update phases are timed
+    # only the k sampled agents need a critic of their own (a 512-unit critic at N = 1024 is 4 MB per agent)
+    critics = [M.init_mlp(rng, 2 * N, chid, 1) for _ in range(k)]
+    agents = [O.CoopAgent(M.init_mlp(rng, 2 * N, 20, 5), critics[i] if i < k else critics[0], M.init_mlp(rng, 3 * N, 20, 1),
+                          0.002, 0.01, 0.9, H) for i in range(N)]
     goals = rng.integers(0, 5, size=(N, 2))
     env = O.GridWorldOracle(w["nrow"], w["ncol"], N, goals, None, True, True, rng_mode="device", seed=1)
     # (a) rollout: per-agent batch-of-one policy forward + numpy RNG draws + python env step
@@ -132,7 +141,6 @@ def cpu_baseline(w, budget_s=25.0):
     a = rng.integers(0, 5, size=(B, N, 1)).astype(np.float32)
     r = -rng.integers(0, 9, size=(B, N, 1)).astype(np.float32) / 5
     sa = np.concatenate([s, a], axis=-1)
-    k = 4 if N >= 64 else min(N, 5)
     sample = list(range(k))
     t0 = time.perf_counter()
     msgs_c, msgs_t = [], []
@@ -256,7 +264,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
                        "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady, "fast_lr": c.fast_lr, "slow_lr": c.slow_lr, "weights_finite": finite,
-                       "env_steps_per_block": env_steps, "n_epochs": c.n_epochs, "hidden": 20,
+                       "env_steps_per_block": env_steps, "n_epochs": c.n_epochs, "hidden": 20, "critic_hidden": c.critic_hid,
                        "parallelism": "seed-sharded, %d seeds/GPU x %d GPU, one all-reduce of return curves" % (S, world)},
             "consensus_updates_per_s": cons_updates / dt,
             "consensus_updates_per_s_phase2_only": (S * eng.n_coop * c.n_epochs) / ph["phase2"] if ph["phase2"] > 0 else None,

@@ -59,7 +59,7 @@ class EngineConfig:
     def __init__(self, n_agents, agent_label, in_nodes, H=0, gamma=0.9, slow_lr=0.002, fast_lr=0.01, n_actions=5,
                  n_states=2, max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000, common_reward=False,
                  nrow=5, ncol=5, n_seeds=1, rng_mode="device", mu=0.1, scaling=True, randomize_state=True,
-                 local_fit_steps=5, lattice="auto"):
+                 local_fit_steps=5, lattice="auto", critic_hid=HID):
         self.n_agents, self.agent_label = int(n_agents), list(agent_label)
         self.in_nodes = [list(map(int, row)) for row in in_nodes]
         self.H, self.gamma, self.slow_lr, self.fast_lr = int(H), float(gamma), float(slow_lr), float(fast_lr)
@@ -70,6 +70,9 @@ class EngineConfig:
         self.rng_mode, self.mu, self.scaling, self.randomize_state = rng_mode, float(mu), bool(scaling), bool(randomize_state)
         self.local_fit_steps = int(local_fit_steps)
         self.lattice = lattice                # layer-1 GEMMs on the exact bf16x3 path: "auto" | True | False
+        # hidden width of the critic (the reference builds 20-unit networks, main.py:59-82; BASELINE configs[4] widens
+        # the critic to 512 units): any other width runs the dense-GEMM path of csrc/wide_kernels.hip
+        self.critic_hid = int(critic_hid)
         assert len(self.agent_label) == self.n_agents and len(self.in_nodes) == self.n_agents
         d = len(self.in_nodes[0])
         for i, row in enumerate(self.in_nodes):
@@ -86,6 +89,10 @@ class EngineConfig:
         for lab in self.agent_label:
             if lab not in (COOP, FAULTY, GREEDY, MALICIOUS):
                 raise ValueError("unknown agent label %r" % lab)
+        if self.critic_hid < 1:
+            raise ValueError("critic_hid must be positive")
+        if self.critic_hid != HID and any(lab != COOP for lab in self.agent_label):
+            raise ValueError("a wide critic (critic_hid != 20) is supported for cooperative agents only")
 
     @property
     def d(self):
@@ -105,7 +112,9 @@ class RPBCACEngine:
         S, N = c.n_seeds, c.n_agents
         self.S, self.N = S, N
         self.in_c, self.in_r = N * c.n_states, N * (c.n_states + 1)
-        self.P = {"actor": net_numel(self.in_c, c.n_actions), "critic": net_numel(self.in_c, 1), "tr": net_numel(self.in_r, 1)}
+        self.hid = {"actor": HID, "critic": c.critic_hid, "tr": HID}
+        self.P = {"actor": net_numel(self.in_c, c.n_actions), "critic": net_numel(self.in_c, 1, c.critic_hid),
+                  "tr": net_numel(self.in_r, 1)}
         self.in_dim = {"actor": self.in_c, "critic": self.in_c, "tr": self.in_r}
         self.out_dim = {"actor": c.n_actions, "critic": 1, "tr": 1}
         self.in_dim_x = {"s": self.in_c, "ns": self.in_c, "sa": self.in_r}      # width of each replay tensor
@@ -118,7 +127,7 @@ class RPBCACEngine:
         if MALICIOUS in c.agent_label:
             # Malicious agents keep a private critic for their own actor (adversarial_CAC_agents.py:101);
             # only their rows of this matrix are meaningful
-            for d_ in (self.P, self.in_dim, self.out_dim, self.ldp):
+            for d_ in (self.P, self.in_dim, self.out_dim, self.ldp, self.hid):
                 d_["critic_local"] = d_["critic"]
             self.theta["critic_local"] = torch.zeros(S, N, self.ldp["critic"], **f32)
         self.msg = {k: torch.zeros(S, N, self.ldp[k], **f32) for k in ("critic", "tr")}
@@ -129,8 +138,9 @@ class RPBCACEngine:
         # per-net activation buffers: the consensus step leaves layer-1 activations of the live nets on the
         # fit inputs there, which are exactly what step 0 of the next epoch's local fit needs (the fit starts
         # from a copy of the live net and only W3,b3 moved since) -> one forward GEMM per net per epoch saved
-        self.a1net = {k: torch.zeros(S, N * HID, self.ldb, **f32) for k in ("critic", "tr")}
+        self.a1net = {k: torch.zeros(S, N * self.hid[k], self.ldb, **f32) for k in ("critic", "tr")}
         self.a1_cached = {"critic": False, "tr": False}
+        self._init_wide()
         self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
         self.rcoop = torch.zeros(S, self.ldb, **f32)
         nchunk_max = (self.cap + 255) // 256
@@ -191,6 +201,91 @@ class RPBCACEngine:
         self._init_lattice()
         self.initial_state = None             # used when randomize_state is False
         self.np_rngs = None                   # rng_mode='numpy': one RandomState-like object per seed
+
+    # ---- wide critic (hid != 20): dense-GEMM path, csrc/wide_kernels.hip ---------------------
+    def _init_wide(self):
+        """Scratch of the dense-GEMM path: layer-1/2 activations and dz1 of one network family, the head's
+        gradient records and the neighbour-estimate matrix of the consensus step."""
+        self.wide = self.hid["critic"] != HID
+        if not self.wide:
+            return
+        S, N, L, hid, d = self.S, self.N, self.lib, self.hid["critic"], self.cfg.d
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        assert self.ldb >= self.EP_pad()
+        self.w_a1, self.w_a2, self.w_dz1 = (torch.zeros(S, N * hid, self.ldb, **f32) for _ in range(3))
+        self.w_dz3, self.w_ebuf, self.w_v = (torch.zeros(S, N, self.ldb, **f32) for _ in range(3))
+        self.w_grads = torch.zeros(S, N, L.rcmarl_wide_grad_size(hid), **f32)
+        self.w_losspart = torch.zeros(S, N, (self.cap + L.rcmarl_wide_rows_per_chunk() - 1) // L.rcmarl_wide_rows_per_chunk(), **f32)
+        self.w_hmat, self.w_hb = torch.zeros(S, N, d + 1, hid, **f32), torch.zeros(S, N, d + 1, **f32)
+        self.w_est = torch.zeros(S, N, d + 1, self.ldb, **f32)
+
+    def EP_pad(self):
+        return pad64(self.cfg.n_ep_fixed)
+
+    def _wide_offsets(self, net):
+        in_dim, hid = self.in_dim[net], self.hid[net]
+        o_b1 = in_dim * hid
+        o_W2 = o_b1 + hid
+        return o_b1, o_W2, o_W2 + hid * hid
+
+    def _wide_forward(self, xkey, theta, net, B, row0=0, a1=None, skip_layer1=False, x=None):
+        """layers 1 and 2 of a wide net for every (seed, agent): a1 (default: scratch), then self.w_a2.
+        x: (ptr, seed_stride, row_major, ld) of an input other than a replay tensor (rollout start states)."""
+        L, S, N, hid = self.lib, self.S, self.N, self.hid[net]
+        o_b1, o_W2, o_b2 = self._wide_offsets(net)
+        a1 = self.w_a1 if a1 is None else a1
+        if not skip_layer1:
+            if x is None:
+                ptr, stride = self._x(xkey, row0)
+                x = (ptr, stride, 1, self.in_dim_x[xkey])
+            L.rcmarl_dense_forward(x[0], x[1], 0, x[2], x[3], theta.data_ptr(), 0, o_b1, a1.data_ptr(), S, N, B,
+                                   self.in_dim[net], hid, self.ldp[net], self.ldb, self.stream)
+        L.rcmarl_dense_forward(a1.data_ptr(), N * hid * self.ldb, hid * self.ldb, 0, self.ldb, theta.data_ptr(), o_W2, o_b2,
+                               self.w_a2.data_ptr(), S, N, B, hid, hid, self.ldp[net], self.ldb, self.stream)
+
+    def _local_fit_wide(self, net, xkey, y, B, mask):
+        """_local_fit for a wide net: every layer of every step is a dense GEMM per agent (f32 MFMA)."""
+        L, S, N, hid, in_dim = self.lib, self.S, self.N, self.hid[net], self.in_dim[net]
+        msg, a1, a2, dz1 = self.msg[net], self.a1net[net], self.w_a2, self.w_dz1
+        ldp, ldb, st, lr = self.ldp[net], self.ldb, self.stream, self.cfg.fast_lr
+        _, o_W2, _ = self._wide_offsets(net)
+        ptr, stride = self._x(xkey)
+        for step in range(self.cfg.local_fit_steps):
+            self._wide_forward(xkey, msg, net, B, a1=a1, skip_layer1=(step == 0 and self.a1_cached[net]))
+            L.rcmarl_wide_head_fit(a2.data_ptr(), msg.data_ptr(), y.data_ptr(), self.w_dz3.data_ptr(), self.w_grads.data_ptr(),
+                                   self.w_losspart.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)      # a2 now holds dz2
+            L.rcmarl_dense_backward_data(a2.data_ptr(), msg.data_ptr(), o_W2, a1.data_ptr(), dz1.data_ptr(), S, N, B, hid, hid,
+                                         ldp, ldb, st)
+            L.rcmarl_wide_bias_grad(dz1.data_ptr(), self.w_grads.data_ptr(), S, N, B, hid, ldb, st)
+            # every gradient above came from the pre-step weights; now the updates
+            L.rcmarl_dense_backward_sgd(a1.data_ptr(), N * hid * ldb, hid * ldb, 0, ldb, a2.data_ptr(), msg.data_ptr(), o_W2,
+                                        mask.data_ptr(), S, N, B, hid, hid, ldp, ldb, lr, st)
+            L.rcmarl_dense_backward_sgd(ptr, stride, 0, 1, self.in_dim_x[xkey], dz1.data_ptr(), msg.data_ptr(), 0,
+                                        mask.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, lr, st)
+            L.rcmarl_wide_small_sgd(self.w_grads.data_ptr(), self.w_losspart.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+                                    self.loss[net].data_ptr() if step == 0 else None, S, N, B, in_dim, hid, ldp, lr, st)
+        self.a1_cached[net] = False
+
+    def _consensus_wide(self, net, xkey, B):
+        L, S, N, c, hid = self.lib, self.S, self.N, self.cfg, self.hid[net]
+        L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),
+                                  self.coop.data_ptr(), S, N, self.ldp[net], self.P[net] - (hid + 1), c.d, c.H, None, None,
+                                  self.stream)
+        self._wide_forward(xkey, self.theta[net], net, B, a1=self.a1net[net])
+        L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
+                                     self.nbr.data_ptr(), self.coop.data_ptr(), None, self.w_hmat.data_ptr(),
+                                     self.w_hb.data_ptr(), self.w_est.data_ptr(), self.w_ebuf.data_ptr(),
+                                     self.w_grads.data_ptr(), None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb,
+                                     c.d, c.H, self.stream)
+        self.a1_cached[net] = self.reuse_activations
+        L.rcmarl_wide_head_apply(self.w_grads.data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(), S, N, B,
+                                 self.in_dim[net], hid, self.ldp[net], self.stream)
+
+    def _value_wide(self, xkey, theta, net, out, B, row0=0, r_applied=None, x=None):
+        self._wide_forward(xkey, theta, net, B, row0, x=x)
+        self.lib.rcmarl_wide_head_value(self.w_a2.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma,
+                                        out.data_ptr(), self.S, self.N, B, self.in_dim[net], self.hid[net], self.ldp[net],
+                                        self.ldb, self.stream)
 
     # ---- lattice (exact bf16x3) layer-1 path: csrc/lattice_gemm.hip, lattice.py ------------
     def _init_lattice(self):
@@ -270,7 +365,7 @@ class RPBCACEngine:
 
     def get_weights(self, seed_idx, agent, net):
         vec = self.theta[net][seed_idx, agent, :self.P[net]].detach().cpu().numpy()
-        return unflatten_params(vec, self.in_dim[net], self.out_dim[net])
+        return unflatten_params(vec, self.in_dim[net], self.out_dim[net], self.hid[net])
 
     def set_all_weights(self, net, array):
         """array: [S][N][P] fp32."""
@@ -312,7 +407,7 @@ class RPBCACEngine:
                 rng = np.random.default_rng([int(base_seed), int(self.seeds[s]) & 0x7FFFFFFF, {"actor": 0, "critic": 1, "tr": 2}[net]])
                 for n in range(self.N):
                     o = 0
-                    for sh in net_shapes(self.in_dim[net], self.out_dim[net]):
+                    for sh in net_shapes(self.in_dim[net], self.out_dim[net], self.hid[net]):
                         cnt = int(np.prod(sh))
                         if len(sh) == 2:
                             lim = math.sqrt(6.0 / (sh[0] + sh[1]))
@@ -428,8 +523,12 @@ class RPBCACEngine:
         else:
             self._reset(None if c.randomize_state else np.broadcast_to(np.asarray(self.initial_state), (S, N, 2)))
         # expected returns at the start state (train_agents.py:60-62)
-        L.rcmarl_value_rows(self.xs[self.cur].data_ptr(), self.theta["critic"].data_ptr(), self.est.data_ptr(), S, N,
-                            self.in_c, HID, self.ldp["critic"], self.stream)
+        if self.wide:
+            self._value_wide(None, self.theta["critic"], "critic", self.w_v, 1, x=(self.xs[self.cur].data_ptr(), 2 * N, 1, 2 * N))
+            self.est.copy_(self.w_v[:, :, 0])
+        else:
+            L.rcmarl_value_rows(self.xs[self.cur].data_ptr(), self.theta["critic"].data_ptr(), self.est.data_ptr(), S, N,
+                                self.in_c, HID, self.ldp["critic"], self.stream)
         self.est_hist[ep_in_block].copy_(self.est)
         rp = self._replay_ptrs()
         for j in range(c.max_ep_len):
@@ -477,8 +576,12 @@ class RPBCACEngine:
         L.rcmarl_env_reset_episodes(self._p(pin), self.seeds_dev.data_ptr(), c.nrow, c.ncol, self.scale.data_ptr(),
                                     self.episode, self.posT[0].data_ptr(), self.xsT[0].data_ptr(), self.retT.data_ptr(),
                                     S, N, n_eps, EP, self.stream)
-        L.rcmarl_value_rows_episodes(self.xsT[0].data_ptr(), self.theta["critic"].data_ptr(), self.est_hist.data_ptr(), S, N,
-                                     n_eps, EP, HID, self.ldp["critic"], self.stream)
+        if self.wide:      # start states are episode-minor xsT[S][2N][EP]: a feature-major layer-1 input
+            self._value_wide(None, self.theta["critic"], "critic", self.w_v, n_eps, x=(self.xsT[0].data_ptr(), 2 * N * EP, 0, EP))
+            self.est_hist[:n_eps].copy_(self.w_v[:, :, :n_eps].permute(2, 0, 1))
+        else:
+            L.rcmarl_value_rows_episodes(self.xsT[0].data_ptr(), self.theta["critic"].data_ptr(), self.est_hist.data_ptr(), S, N,
+                                         n_eps, EP, HID, self.ldp["critic"], self.stream)
         rp = self._replay_ptrs()
         cur = 0
         for j in range(c.max_ep_len):
@@ -519,6 +622,8 @@ class RPBCACEngine:
 
     def _local_fit(self, net, xkey, y, B, mask, partials=None):
         """5 full-batch SGD steps on the message copy (agents/resilient_CAC_agents.py:118,136)."""
+        if self.hid[net] != HID:
+            return self._local_fit_wide(net, xkey, y, B, mask)
         L, S, N = self.lib, self.S, self.N
         msg = self.msg[net]
         a1 = self.a1net[net]
@@ -566,6 +671,8 @@ class RPBCACEngine:
     def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None):
         """scratch: private activation buffer of a caller that may run beside the main stream (the adversaries); such a
         caller also stays off the lattice path, whose packed-operand scratch belongs to the main stream."""
+        if self.hid[net] != HID:
+            return self._value_wide(xkey, theta, net, out, B, row0, r_applied)
         buf = self.a1t if scratch is None else scratch
         self._layer1(xkey, theta, net, B, row0, buf=buf, lattice=scratch is None)
         self.lib.rcmarl_mid_value(buf.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
@@ -574,6 +681,8 @@ class RPBCACEngine:
     def _consensus(self, net, xkey, B):
         """Phase II for one network family: hidden-layer consensus (K1), then estimate
         consensus + projection step of the output layer (K2+K3)."""
+        if self.hid[net] != HID:
+            return self._consensus_wide(net, xkey, B)
         L, S, N, c = self.lib, self.S, self.N, self.cfg
         g_hid = self.P[net] - (HID * 1 + 1)
         L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),

@@ -32,6 +32,13 @@ WORK = {
                                          10.0 * a[7] * a[8] * a[9] * a[11]),
     # theta, alpha, wp, S, N, in_dim, hid: reads W1 (4 B), writes 3 pieces (6 B)
     "rcmarl_w1_split": lambda a: (0.0, 10.0 * a[3] * a[4] * a[5] * a[6]),
+    # wide path (csrc/wide_kernels.hip): dense per-agent GEMMs, 2*S*N*B*K*J flops
+    # in, zs, za, rm, ld, theta, w_off, b_off, out, S, N, B, K, J
+    "rcmarl_dense_forward": lambda a: (2.0 * a[9] * a[10] * a[11] * a[12] * a[13], 0.0),
+    # dz_out, theta, w_off, act_in, dz_in, S, N, B, K, J
+    "rcmarl_dense_backward_data": lambda a: (2.0 * a[5] * a[6] * a[7] * a[8] * a[9], 0.0),
+    # in, zs, za, rm, ld, dz, theta, w_off, mask, S, N, B, K, J
+    "rcmarl_dense_backward_sgd": lambda a: (2.0 * a[9] * a[10] * a[11] * a[12] * a[13], 0.0),
 }
 
 

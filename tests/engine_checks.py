@@ -17,25 +17,25 @@ def make_args(labels, H, n_episodes, max_ep_len, n_ep_fixed, n_epochs, buffer_si
             "common_reward": common_reward, "summary_dir": "./", "pretrained_agents": False, "random_seed": seed}
 
 
-def init_weights(rng, n_agents):
+def init_weights(rng, n_agents, critic_hid=20):
     out = []
     for _ in range(n_agents):
-        out.append({"actor": M.init_mlp(rng, 2 * n_agents, 20, 5), "critic": M.init_mlp(rng, 2 * n_agents, 20, 1),
+        out.append({"actor": M.init_mlp(rng, 2 * n_agents, 20, 5), "critic": M.init_mlp(rng, 2 * n_agents, critic_hid, 1),
                     "tr": M.init_mlp(rng, 3 * n_agents, 20, 1)})
     return out
 
 
-def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3, lattice="auto"):
+def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3, lattice="auto", critic_hid=20):
     """Run the oracle (one run per seed) and the engine (all seeds batched); return both results."""
     n = args["n_agents"]
     S = len(seeds)
     wrng = np.random.default_rng(weight_seed)
-    W = [init_weights(wrng, n) for _ in range(S)]
+    W = [init_weights(wrng, n, critic_hid) for _ in range(S)]
     goals = [np.random.default_rng(100 + s).integers(0, min(5, nrow), size=(n, 2)) for s in range(S)]
     cfg = EngineConfig(n, args["agent_label"], args["in_nodes"], H=args["H"], gamma=args["gamma"], slow_lr=args["slow_lr"],
                        fast_lr=args["fast_lr"], max_ep_len=args["max_ep_len"], n_ep_fixed=args["n_ep_fixed"],
                        n_epochs=args["n_epochs"], buffer_size=args["buffer_size"], common_reward=args["common_reward"],
-                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode, lattice=lattice)
+                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode, lattice=lattice, critic_hid=critic_hid)
     eng = RPBCACEngine(cfg, seeds=list(seeds), device=device, lib=lib)
     for s in range(S):
         for i in range(n):

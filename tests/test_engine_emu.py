@@ -37,6 +37,16 @@ def test_engine_lattice_path_matches_oracle(labels, nrow, ncol):
     EC.compare(eng, logs, o_logs, o_w)
 
 
+@pytest.mark.parametrize("rng_mode,critic_hid,H", [("device", 32, 1), ("numpy", 24, 0)])
+def test_engine_wide_critic_matches_oracle(rng_mode, critic_hid, H):
+    """BASELINE configs[4] in miniature: a critic wider than the reference's 20 units runs the dense-GEMM path
+    (csrc/wide_kernels.hip) for its local fits, TD targets, estimate consensus and start-state values."""
+    args = EC.make_args(["Cooperative"] * 5, H=H, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=41)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, rng_mode, "cpu", emu_lib(), seeds=(41, 42), critic_hid=critic_hid)
+    assert eng.wide
+    EC.compare(eng, logs, o_logs, o_w)
+
+
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])
 def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
     """Train 3 blocks straight vs 1 block -> save -> fresh engine -> load -> 2 blocks: same logs, same bits
