@@ -89,6 +89,10 @@ int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha
 /* wp (3 pieces, rows = (agent,unit) column, reduction = feature) <- bf16x3 split of alpha[k]*W1[s][n][k][j] */
 int rcmarl_w1_split(const float* theta, const float* alpha, void* wp, int S, int N, int in_dim, int hid, int ldp,
                     int wp_rt, int wp_kt, void* stream);
+/* dzp (3 pieces, rows = (agent,unit) column, reduction = replay row, zero beyond B) <- bf16x3 split of the fp32
+ * feature-major dz[S][N*hid][ldb]: the backward operand when dz1 was produced by rcmarl_dense_backward_data */
+int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int N, int B, int hid, int ldb, int dzp_rt, int dzp_kt,
+                           void* stream);
 /* = rcmarl_layer1_forward on (kp, wp); theta supplies b1 */
 int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt,
                                   const float* theta, float* a1t, int S, int N, int B, int in_dim, int hid, int ldp,

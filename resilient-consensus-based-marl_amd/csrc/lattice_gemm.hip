@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256) void k_lattice_encode(const float* __restrict_
 // W1 split: one workgroup = 128 (agent,unit) columns x 32 features -> three 8-KiB blocks.
 __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ theta, const float* __restrict__ alpha,
                                                   unsigned char* __restrict__ wp, int N, int in_dim, int ldp,
-                                                  int wp_rt, int wp_kt) {
+                                                  int wp_rt, int wp_kt, int hid) {
   const int s = blockIdx.z, rt = blockIdx.y, kt = blockIdx.x;
   const int t = threadIdx.x, r = t & 127;
-  const int col = rt * 128 + r, ncols = N * 20;
+  const int col = rt * 128 + r, ncols = N * hid;
   const bool col_ok = col < ncols;
-  const int ag = col_ok ? col / 20 : 0, j = col - ag * 20;
+  const int ag = col_ok ? col / hid : 0, j = col - ag * hid;
   const float* th = theta + ((long)s * N + ag) * ldp + j;
   unsigned char* blk = wp + (long)s * wp_rt * wp_kt * 3 * RC_PK_BLOCK + ((long)rt * wp_kt + kt) * 3 * RC_PK_BLOCK;
 #pragma unroll
@@ -109,7 +109,40 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
     for (int e = 0; e < 8; ++e) {
       const int k = kt * 32 + 8 * c4 + e;
       const bool ok = col_ok && k < in_dim;
-      w[e] = ok ? th[(long)k * 20] * alpha[k] : 0.f;
+      w[e] = ok ? th[(long)k * hid] * alpha[k] : 0.f;
+    }
+    uint4 vh, vm, vl;
+    rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
+    rc_split3_pair(w[2], w[3], vh.y, vm.y, vl.y);
+    rc_split3_pair(w[4], w[5], vh.z, vm.z, vl.z);
+    rc_split3_pair(w[6], w[7], vh.w, vm.w, vl.w);
+    const int o = r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4);
+    st_u4(blk + o, vh);
+    st_u4(blk + RC_PK_BLOCK + o, vm);
+    st_u4(blk + 2 * RC_PK_BLOCK + o, vl);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dz pack: fp32 feature-major dz[S][rows][ldb] (rows = (agent,unit)) -> three exact bf16 pieces in PK form
+// (reduction = replay row), zero beyond B / beyond the last row: the backward operand of a wide net, whose dz1 comes
+// out of a dense GEMM (wide_kernels.hip) instead of mid_fit's fused epilogue.  One workgroup = 128 rows x 32 rows b.
+__global__ __launch_bounds__(256) void k_dz_pack(const float* __restrict__ dz, unsigned char* __restrict__ dzp, int nrows,
+                                                 int B, int ldb, int dzp_rt, int dzp_kt) {
+  const int s = blockIdx.z, rt = blockIdx.y, kt = blockIdx.x;
+  const int t = threadIdx.x, r = t & 127;
+  const int row = rt * 128 + r;
+  const bool row_ok = row < nrows;
+  const float* src = dz + ((long)s * nrows + (row_ok ? row : 0)) * ldb;
+  unsigned char* blk = dzp + (long)s * dzp_rt * dzp_kt * 3 * RC_PK_BLOCK + ((long)rt * dzp_kt + kt) * 3 * RC_PK_BLOCK;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c4 = (t >> 7) + 2 * q;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kt * 32 + 8 * c4 + e;
+      w[e] = (row_ok && k < B) ? src[k] : 0.f;
     }
     uint4 vh, vm, vl;
     rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
@@ -380,7 +413,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
                                                         const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                         const float* __restrict__ theta, float* __restrict__ a1t, int S,
                                                         int N, int B, int in_dim, int ldp, int ldb, int mtiles,
-                                                        int ntiles, int dbg_same_tile, int stg_bit, int stg_n) {
+                                                        int ntiles, int dbg_same_tile, int stg_bit, int stg_n, int hid) {
   constexpr int PA = 3, PB = 1, MT = 2, NT = 4;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
@@ -400,15 +433,15 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
   else lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
-  const int ncols = N * 20;
+  const int ncols = N * hid;
   const float* theta_s = theta + (long)s * N * ldp;
   float* a1t_s = a1t + (long)s * ncols * ldb;
   __syncthreads();
   float* bias = reinterpret_cast<float*>(lds);
   if (threadIdx.x < C::BM) {
     const int col = bm * C::BM + threadIdx.x;
-    const int ag = col / 20;
-    bias[threadIdx.x] = col < ncols ? theta_s[(long)ag * ldp + in_dim * 20 + (col - ag * 20)] : 0.f;
+    const int ag = col / hid;
+    bias[threadIdx.x] = col < ncols ? theta_s[(long)ag * ldp + in_dim * hid + (col - ag * hid)] : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
@@ -436,7 +469,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
                                                              const int* __restrict__ mask, int S, int N, int B,
                                                              int in_dim, int ldp, float lr, int mtiles, int ntiles,
                                                              unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt,
-                                                             int stg_bit, int stg_n) {
+                                                             int stg_bit, int stg_n, int hid) {
   constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
@@ -454,7 +487,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
-  const int ncols = N * 20;
+  const int ncols = N * hid;
   __syncthreads();
   float* al = reinterpret_cast<float*>(lds);
   {
@@ -469,7 +502,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
     const int cl = wn * 32 * NT + 32 * nt + (lane & 31);                 // column within the 128-wide tile
     const int col = bn * C::BN + cl;
     if (col < ncols) {
-      const int ag = col / 20, j = col - ag * 20;
+      const int ag = col / hid, j = col - ag * hid;
       const bool upd = mask == nullptr || mask[ag];
       float* th = theta + ((long)s * N + ag) * ldp + j;
       unsigned char* wrow = wp_out == nullptr ? nullptr
@@ -487,7 +520,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
             const int k = bm * C::BM + kl;
             float w = 0.f;
             if (k < in_dim) {
-              float* wptr = th + (long)k * 20;
+              float* wptr = th + (long)k * hid;
               w = *wptr;
               if (upd) { w = w - lr * (al[kl] * acc[mt][nt][4 * gq + e]); *wptr = w; }
             }
@@ -561,10 +594,19 @@ RCMARL_EXPORT int rcmarl_w1_split(const float* theta, const float* alpha, void* 
                                   int ldp, int wp_rt, int wp_kt, void* stream) {
   if (!theta || !alpha || !wp || S <= 0 || N <= 0 || in_dim <= 0 || (ldp & 63) || ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
-  if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
-  if (wp_rt * 128 < N * 20 || wp_kt * 32 < in_dim) return RCMARL_ERR_ARG;
-  const dim3 grid(rc_ceil_div(in_dim, 32), rc_ceil_div(N * 20, 128), S), block(256);
-  RCMARL_LAUNCH(k_w1_split, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt);
+  if (hid <= 0) return RCMARL_ERR_ARG;
+  if ((long)wp_rt * 128 < (long)N * hid || wp_kt * 32 < in_dim) return RCMARL_ERR_ARG;
+  const dim3 grid(rc_ceil_div(in_dim, 32), rc_ceil_div(N * hid, 128), S), block(256);
+  RCMARL_LAUNCH(k_w1_split, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt, hid);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int N, int B, int hid, int ldb, int dzp_rt,
+                                         int dzp_kt, void* stream) {
+  if (!dz || !dzp || S <= 0 || N <= 0 || B <= 0 || hid <= 0 || ldb < B) return RCMARL_ERR_ARG;
+  const int rts = rc_ceil_div(N * hid, 128), kts = rc_ceil_div(B, 32);
+  if (dzp_rt < rts || dzp_kt < kts) return RCMARL_ERR_ARG;
+  RCMARL_LAUNCH(k_dz_pack, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
   return rcmarl_check_launch();
 }
 
@@ -574,8 +616,8 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   if (!kp || !wp || !theta || !a1t || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) || (ldb & 63) || ldb < B ||
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
-  if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
-  const int mtiles = rc_ceil_div(N * 20, 128), ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
+  if (hid <= 0) return RCMARL_ERR_ARG;
+  const int mtiles = rc_ceil_div(N * hid, 128), ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
   if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
   const int ns = lat_stages();
   static const int dbg = getenv("RCMARL_LAT_SAMETILE") ? atoi(getenv("RCMARL_LAT_SAMETILE")) : 0;
@@ -585,17 +627,17 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
     static const bool ok = lat_want_lds(k_lat_forward<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_forward<2>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
-                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n(), hid);
   } else if (ns == 4) {
     static const bool ok = lat_want_lds(k_lat_forward<4>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_forward<4>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
-                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n(), hid);
   } else {
     static const bool ok = lat_want_lds(k_lat_forward<3>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_forward<3>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
-                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n());
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n(), hid);
   }
   return rcmarl_check_launch();
 }
@@ -607,8 +649,8 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   if (!ktp || !dzp || !alpha || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) ||
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
-  if (hid != 20) return RCMARL_ERR_UNSUPPORTED;
-  const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * 20, 128), ktiles = rc_ceil_div(B, 32);
+  if (hid <= 0) return RCMARL_ERR_ARG;
+  const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * hid, 128), ktiles = rc_ceil_div(B, 32);
   if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
   if (wp_out && (wp_rt < ntiles || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
   const int ns = lat_stages();
@@ -619,19 +661,19 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<2>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);
   } else if (ns == 4) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<4>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<4>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);
   } else {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<3>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<3>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n());
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);
   }
   return rcmarl_check_launch();
 }

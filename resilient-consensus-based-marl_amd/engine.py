@@ -228,18 +228,28 @@ class RPBCACEngine:
         o_W2 = o_b1 + hid
         return o_b1, o_W2, o_W2 + hid * hid
 
-    def _wide_forward(self, xkey, theta, net, B, row0=0, a1=None, skip_layer1=False, x=None):
+    def _wide_forward(self, xkey, theta, net, B, row0=0, a1=None, skip_layer1=False, x=None, wp_fresh=False):
         """layers 1 and 2 of a wide net for every (seed, agent): a1 (default: scratch), then self.w_a2.
         x: (ptr, seed_stride, row_major, ld) of an input other than a replay tensor (rollout start states)."""
         L, S, N, hid = self.lib, self.S, self.N, self.hid[net]
         o_b1, o_W2, o_b2 = self._wide_offsets(net)
         a1 = self.w_a1 if a1 is None else a1
         if not skip_layer1:
-            if x is None:
-                ptr, stride = self._x(xkey, row0)
-                x = (ptr, stride, 1, self.in_dim_x[xkey])
-            L.rcmarl_dense_forward(x[0], x[1], 0, x[2], x[3], theta.data_ptr(), 0, o_b1, a1.data_ptr(), S, N, B,
-                                   self.in_dim[net], hid, self.ldp[net], self.ldb, self.stream)
+            if x is None and self._lattice_ok(xkey, B, row0):
+                # layer 1 on the exact bf16x3 kernels (80 % of a 2048 -> 512 -> 512 -> 1 critic's flops)
+                g, wp = self.lat_geom[xkey], self.lat_wp_f[xkey]
+                if not wp_fresh:
+                    L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), wp.data_ptr(), S, N,
+                                      self.in_dim[net], hid, self.ldp[net], g.wp[0], g.wp[1], self.stream)
+                L.rcmarl_layer1_forward_lattice(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0],
+                                                g.wp[1], theta.data_ptr(), a1.data_ptr(), S, N, B, self.in_dim[net], hid,
+                                                self.ldp[net], self.ldb, self.stream)
+            else:
+                if x is None:
+                    ptr, stride = self._x(xkey, row0)
+                    x = (ptr, stride, 1, self.in_dim_x[xkey])
+                L.rcmarl_dense_forward(x[0], x[1], 0, x[2], x[3], theta.data_ptr(), 0, o_b1, a1.data_ptr(), S, N, B,
+                                       self.in_dim[net], hid, self.ldp[net], self.ldb, self.stream)
         L.rcmarl_dense_forward(a1.data_ptr(), N * hid * self.ldb, hid * self.ldb, 0, self.ldb, theta.data_ptr(), o_W2, o_b2,
                                self.w_a2.data_ptr(), S, N, B, hid, hid, self.ldp[net], self.ldb, self.stream)
 
@@ -250,8 +260,11 @@ class RPBCACEngine:
         ldp, ldb, st, lr = self.ldp[net], self.ldb, self.stream, self.cfg.fast_lr
         _, o_W2, _ = self._wide_offsets(net)
         ptr, stride = self._x(xkey)
+        lat = self._lattice_ok(xkey, B, 0) and xkey in self.lat_ktp
+        g = self.lat_geom[xkey] if lat else None
+        wp_fresh = False
         for step in range(self.cfg.local_fit_steps):
-            self._wide_forward(xkey, msg, net, B, a1=a1, skip_layer1=(step == 0 and self.a1_cached[net]))
+            self._wide_forward(xkey, msg, net, B, a1=a1, skip_layer1=(step == 0 and self.a1_cached[net]), wp_fresh=wp_fresh)
             L.rcmarl_wide_head_fit(a2.data_ptr(), msg.data_ptr(), y.data_ptr(), self.w_dz3.data_ptr(), self.w_grads.data_ptr(),
                                    self.w_losspart.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)      # a2 now holds dz2
             L.rcmarl_dense_backward_data(a2.data_ptr(), msg.data_ptr(), o_W2, a1.data_ptr(), dz1.data_ptr(), S, N, B, hid, hid,
@@ -260,8 +273,17 @@ class RPBCACEngine:
             # every gradient above came from the pre-step weights; now the updates
             L.rcmarl_dense_backward_sgd(a1.data_ptr(), N * hid * ldb, hid * ldb, 0, ldb, a2.data_ptr(), msg.data_ptr(), o_W2,
                                         mask.data_ptr(), S, N, B, hid, hid, ldp, ldb, lr, st)
-            L.rcmarl_dense_backward_sgd(ptr, stride, 0, 1, self.in_dim_x[xkey], dz1.data_ptr(), msg.data_ptr(), 0,
-                                        mask.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, lr, st)
+            if lat:
+                dzp, wp = self.lat_dzp_f[xkey], self.lat_wp_f[xkey]
+                L.rcmarl_lattice_pack_dz(dz1.data_ptr(), dzp.data_ptr(), S, N, B, hid, ldb, g.dzp[0], g.dzp[1], st)
+                L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
+                                                     g.dzp[0], g.dzp[1], self.lat_alpha[xkey].data_ptr(), msg.data_ptr(),
+                                                     mask.data_ptr(), S, N, B, in_dim, hid, ldp, lr, wp.data_ptr(), g.wp[0],
+                                                     g.wp[1], st)
+                wp_fresh = True           # the epilogue left the split of the updated W1 in lat_wp
+            else:
+                L.rcmarl_dense_backward_sgd(ptr, stride, 0, 1, self.in_dim_x[xkey], dz1.data_ptr(), msg.data_ptr(), 0,
+                                            mask.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, lr, st)
             L.rcmarl_wide_small_sgd(self.w_grads.data_ptr(), self.w_losspart.data_ptr(), msg.data_ptr(), mask.data_ptr(),
                                     self.loss[net].data_ptr() if step == 0 else None, S, N, B, in_dim, hid, ldp, lr, st)
         self.a1_cached[net] = False
@@ -305,7 +327,10 @@ class RPBCACEngine:
         if not self.lat_enabled:
             return
         u8 = lambda rk, pieces: torch.zeros(self.S * LT.Geometry.nbytes(rk, pieces), dtype=torch.uint8, device=self.dev)
-        self.lat_geom = {"s": LT.Geometry(self.N, self.in_c, self.cap), "sa": LT.Geometry(self.N, self.in_r, self.cap)}
+        # the state family's weight / dz operands belong to the critic (the actor only ever runs on the last rows of
+        # the buffer, i.e. off this path), the state-action family's to the team-reward net
+        self.lat_geom = {"s": LT.Geometry(self.N, self.in_c, self.cap, self.hid["critic"]),
+                         "sa": LT.Geometry(self.N, self.in_r, self.cap, self.hid["tr"])}
         self.lat_geom["ns"] = self.lat_geom["s"]
         self.lat_kp = {k: u8(self.lat_geom[k].kp, 1) for k in ("s", "ns", "sa")}
         self.lat_ktp = {k: u8(self.lat_geom[k].ktp, 1) for k in ("s", "sa")}

@@ -22,13 +22,13 @@ class Geometry:
     """Allocated tile counts (rt = 128-row tiles, kt = 32-deep k-tiles) of the four packed operands
     for N agents, input width in_dim and at most `cap` replay rows."""
 
-    def __init__(self, n_agents, in_dim, cap):
-        self.N, self.in_dim, self.cap = int(n_agents), int(in_dim), int(cap)
+    def __init__(self, n_agents, in_dim, cap, hid=HID):
+        self.N, self.in_dim, self.cap, self.hid = int(n_agents), int(in_dim), int(cap), int(hid)
         b_pad = cdiv(cap, 256) * 256
         self.kp = (b_pad // 128, cdiv(in_dim, 32))                    # rows = replay row, k = feature
         self.ktp = (2 * cdiv(in_dim, 256), b_pad // 32)               # rows = feature, k = replay row
-        self.wp = (cdiv(n_agents * HID, 128), cdiv(in_dim, 32))       # rows = (agent,unit), k = feature, 3 pieces
-        self.dzp = (cdiv(n_agents * HID, 128), b_pad // 32)           # rows = (agent,unit), k = replay row, 3 pieces
+        self.wp = (cdiv(n_agents * hid, 128), cdiv(in_dim, 32))       # rows = (agent,unit), k = feature, 3 pieces
+        self.dzp = (cdiv(n_agents * hid, 128), b_pad // 32)           # rows = (agent,unit), k = replay row, 3 pieces
 
     @staticmethod
     def nbytes(rt_kt, pieces):

@@ -116,14 +116,16 @@ def test_engine_run_to_run_bit_identical(labels):
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
 
 
-@pytest.mark.parametrize("n,critic_hid,H,d,rng_mode", [(5, 64, 1, 4, "device"), (12, 512, 2, 6, "device"), (5, 128, 0, 4, "numpy")])
-def test_engine_wide_critic(n, critic_hid, H, d, rng_mode):
+@pytest.mark.parametrize("n,critic_hid,H,d,rng_mode,lattice", [(5, 64, 1, 4, "device", False), (12, 512, 2, 6, "device", False),
+                                                               (5, 128, 0, 4, "numpy", False), (12, 512, 2, 6, "device", True),
+                                                               (20, 96, 1, 5, "device", "auto")])
+def test_engine_wide_critic(n, critic_hid, H, d, rng_mode, lattice):
     """BASELINE configs[4] in miniature: a critic wider than the reference's 20 units (512 in one case) takes the
     dense f32-MFMA GEMM path for local fits, TD targets, estimate consensus and start-state values; everything else
     (team-reward net, actor, rollout) stays on the 20-unit kernels.  Same oracle, same tolerances."""
     in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
     args = EC.make_args(["Cooperative"] * n, H=H, n_episodes=12, max_ep_len=10, n_ep_fixed=4, n_epochs=2, buffer_size=60, seed=51,
                         in_nodes=in_nodes, fast_lr=0.005)
-    eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, rng_mode, "cuda", None, seeds=(51, 52), critic_hid=critic_hid)
-    assert eng.wide
+    eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, rng_mode, "cuda", None, seeds=(51, 52), critic_hid=critic_hid, lattice=lattice)
+    assert eng.wide and eng.lat_active == (lattice is not False)
     EC.compare(eng, logs, o_logs, o_w)
