@@ -74,9 +74,12 @@ class Sequential:
         dense = [l for l in self.layers if isinstance(l, Dense)]
         if len(inp) != 1 or len(dense) != 3:
             raise ValueError("expected Input, Flatten and three Dense layers (main.py:59-82)")
+        # two equally wide LeakyReLU(0.1) hidden layers.  20 units (main.py:59-82) run everywhere; other widths are for
+        # critics trained through train_RPBCAC (dense-GEMM path of the engine) -- the per-agent method views
+        # (model(x), fit, ...) are compiled for 20 units and raise RcmarlError(UNSUPPORTED) otherwise
         for l in dense[:2]:
-            if not isinstance(l.activation, LeakyReLU) or abs(l.activation.alpha - 0.1) > 1e-12 or l.units != single.HID:
-                raise ValueError("hidden layers must be Dense(%d, LeakyReLU(alpha=0.1)): the HIP kernels are compiled for that" % single.HID)
+            if not isinstance(l.activation, LeakyReLU) or abs(l.activation.alpha - 0.1) > 1e-12 or l.units != dense[0].units:
+                raise ValueError("hidden layers must be two Dense(h, LeakyReLU(alpha=0.1)) of equal width h")
         if dense[2].activation not in (None, "softmax", "linear"):
             raise ValueError("output activation must be None or 'softmax'")
         self.inputs = inp

@@ -28,7 +28,14 @@ def _truthy(v):
 def train_RPBCAC(env, agents, args, exp_buffer=None, engine_hook=None):
     n_agents = env.n_agents
     labels = list(args['agent_label'])
-    cfg = EngineConfig(n_agents, labels, args['in_nodes'], H=args['H'], gamma=args['gamma'], slow_lr=args['slow_lr'],
+    # hidden widths come from the model objects (the reference builds 20-unit networks, main.py:59-82): the critic may
+    # be wider (BASELINE configs[4]: 512 units -> dense-GEMM path of the engine); actor and team-reward net stay at 20
+    widths = {attr: {int(np.shape(getattr(ag, attr).get_weights()[0])[1]) for ag in agents} for _, attr in _NETS}
+    if widths["actor"] != {20} or widths["TR"] != {20} or len(widths["critic"]) != 1:
+        raise ValueError("unsupported hidden widths %r: actor and team-reward net must have 20 hidden units and all critics "
+                         "the same width" % widths)
+    cfg = EngineConfig(n_agents, labels, args['in_nodes'], critic_hid=widths["critic"].pop(), H=args['H'], gamma=args['gamma'],
+                       slow_lr=args['slow_lr'],
                        fast_lr=args['fast_lr'], n_actions=args['n_actions'], n_states=args['n_states'],
                        max_ep_len=args['max_ep_len'], n_ep_fixed=args['n_ep_fixed'], n_epochs=args['n_epochs'],
                        buffer_size=args['buffer_size'], common_reward=_truthy(args['common_reward']), nrow=env.nrow,

@@ -229,3 +229,40 @@ def check_train_golden(golden, name, engine_hook, rtol_w=3e-4):
             scale = max(1.0, float(np.abs(want).max()))
             tol = rtol_w * scale if net != "actor" else 0.05 * args["slow_lr"] * 12 + 1e-5
             assert float(np.abs(got - want).max()) <= tol, (name, i, net, float(np.abs(got - want).max()), tol)
+
+
+def check_train_wide_critic(engine_hook, critic_hid=32, seed=5):
+    """train_RPBCAC with critic models wider than the reference's 20 units (BASELINE configs[4] in miniature): the
+    width is read off the model objects; results vs the oracle's train() on the same NumPy stream."""
+    import engine_checks as EC
+    n = 5
+    K.set_seed(seed)
+
+    def mlp(width, out, act, hid):
+        return K.Sequential([K.Input(shape=(n, width)), K.layers.Flatten(),
+                             K.layers.Dense(hid, activation=K.layers.LeakyReLU(alpha=0.1)),
+                             K.layers.Dense(hid, activation=K.layers.LeakyReLU(alpha=0.1)),
+                             K.layers.Dense(out, activation=act)])
+    agents, W = [], []
+    for i in range(n):
+        actor, critic, tr = mlp(2, 5, 'softmax', 20), mlp(2, 1, None, critic_hid), mlp(3, 1, None, 20)
+        W.append([actor.get_weights(), critic.get_weights(), tr.get_weights()])
+        agents.append(RPBCAC_agent(actor, critic, tr, slow_lr=0.002, fast_lr=0.01, gamma=0.9, H=1))
+    args = EC.make_args(["Cooperative"] * n, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=seed)
+    goals = np.array([[1, 2], [0, 0], [4, 4], [2, 3], [3, 1]])
+    np.random.seed(seed)
+    env = Grid_World(nrow=5, ncol=5, n_agents=n, desired_state=goals, initial_state=goals, randomize_state=True, scaling=True)
+    weights, df = train_RPBCAC(env, agents, args, engine_hook=engine_hook)
+    o_agents = [O.make_agent("Cooperative", [a.copy() for a in W[i][0]], [a.copy() for a in W[i][1]], [a.copy() for a in W[i][2]],
+                             0.002, 0.01, 0.9, 1) for i in range(n)]
+    np.random.seed(seed)
+    oenv = O.GridWorldOracle(5, 5, n, goals, None, True, True)
+    ow, odf = O.train(oenv, o_agents, args, rng_mode="numpy")
+    np.testing.assert_array_equal(df["True_team_returns"].to_numpy(), odf["True_team_returns"].to_numpy(dtype=np.float64))
+    np.testing.assert_allclose(df["Estimated_team_returns"].to_numpy(), odf["Estimated_team_returns"].to_numpy(dtype=np.float64),
+                               rtol=1e-4, atol=1e-5)
+    for i in range(n):
+        assert weights[i][1][0].shape == (2 * n, critic_hid)
+        for k in (1, 2):                                  # critic, team-reward net
+            for a, b in zip(weights[i][k], ow[i][k]):
+                close(a, b, 2e-4, "agent %d net %d" % (i, k))

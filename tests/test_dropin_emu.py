@@ -28,3 +28,7 @@ def test_grid_world_matches_reference_trajectories(golden):
 @pytest.mark.parametrize("name", ["malicious_H1"])
 def test_train_RPBCAC_matches_reference_golden(golden, name):
     DC.check_train_golden(golden, name, engine_hook=(emu_lib(), "cpu"))
+
+
+def test_train_RPBCAC_with_wide_critic_models():
+    DC.check_train_wide_critic(engine_hook=(emu_lib(), "cpu"))
