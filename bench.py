@@ -297,6 +297,10 @@ ROOFLINE_KIND = {
     "rcmarl_consensus_params": ("hbm", "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d). HBM-bound for "
                                 "small d (d=4: ~54% of 8 TB/s); at d=18 the 128-op min/max selection network makes it "
                                 "VALU-issue-bound (~83% of the v_min/v_max issue rate, DESIGN.md section 3)"),
+    "rcmarl_consensus_params_circulant": ("hbm", "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d); circulant "
+                                          "graph: one selection network per G consecutive agents (96/4 + 13 min/max ops per "
+                                          "agent at (18,8) instead of 128) + 18 clamps + 18 adds + the IEEE division: still "
+                                          "VALU-issue-bound at d=18, HBM-bound at d=4"),
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
                                "dz1 pieces written = 200 B; the kernel is VALU-issue-bound today (PMC: 1929 VALU + 769 SALU "
                                "instructions and 64 f32 MFMAs per wavefront), DESIGN.md section 3"),
@@ -353,7 +357,8 @@ def rooflines(tlib, ksum, workload=None):
                 "algorithmic_flops_per_launch": flops / n,
                 "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
     gemm = next((k for k in ("rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward") if k in ksum), None)
-    return (obj(dom), obj("rcmarl_consensus_params") if "rcmarl_consensus_params" in ksum else None,
+    k1 = next((k for k in ("rcmarl_consensus_params_circulant", "rcmarl_consensus_params") if k in ksum), None)
+    return (obj(dom), obj(k1) if k1 else None,
             obj(gemm) if gemm else None)
 
 

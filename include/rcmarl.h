@@ -47,6 +47,14 @@ int rcmarl_rows_per_chunk(void);                       /* replay rows per workgr
  * [S][N][ldp]) receive the clip window for bit-exact tests. */
 int rcmarl_consensus_params(const float* msg, float* theta, const int* nbr, const int* coop, int S, int N,
                             int ldp, int P_hid, int d, int H, float* lo_dbg, float* hi_dbg, void* stream);
+/* The same aggregation for a CIRCULANT in-graph, in_nodes[i] = [i, i+1, .., i+d-1 mod N] (the reference's own
+ * pattern, main.py:28; the caller guarantees it) with d == 2H+2: G consecutive agents share d-G+1 of their inputs,
+ * so one selection network over the shared values serves G agents (csrc/consensus_params.hip).  Bit-identical to
+ * rcmarl_consensus_params.  ..._supported() tells whether a kernel is compiled for (N, d, H); otherwise the call
+ * returns RCMARL_ERR_UNSUPPORTED and the general entry point must be used. */
+int rcmarl_consensus_params_circulant_supported(int N, int d, int H);
+int rcmarl_consensus_params_circulant(const float* msg, float* theta, const int* coop, int S, int N, int ldp, int P_hid,
+                                      int d, int H, float* lo_dbg, float* hi_dbg, void* stream);
 
 /* K4 layer 1 forward (shared input => one GEMM per seed), Keras Dense + LeakyReLU(0.1):
  * a1t[s][n*hid+j][b] = lrelu(sum_k x[s][b][k]*W1[s][n][k][j] + b1[s][n][j]).

@@ -28,6 +28,10 @@ SIGNATURES = {
     # msg, theta, nbr, coop, S, N, ldp, P_hid, d, H, lo_dbg, hi_dbg, stream
     "rcmarl_consensus_params": [c_f32p, c_f32p, c_i32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_f32p, c_f32p, c_stream],
+    "rcmarl_consensus_params_circulant_supported": [c_int, c_int, c_int],
+    # msg, theta, coop, S, N, ldp, P_hid, d, H, lo_dbg, hi_dbg, stream
+    "rcmarl_consensus_params_circulant": [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_f32p,
+                                          c_stream],
     # x, x_seed_stride, theta, a1t, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_layer1_forward": [c_f32p, c_long, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_stream],
@@ -155,7 +159,8 @@ SIGNATURES = {
     "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
-             "rcmarl_fit_small_partial_size", "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk"}
+             "rcmarl_fit_small_partial_size", "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
+             "rcmarl_consensus_params_circulant_supported"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",
           3: "RCMARL_ERR_UNSUPPORTED (shape outside the compiled kernels)"}

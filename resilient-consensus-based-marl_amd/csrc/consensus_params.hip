@@ -23,6 +23,7 @@
 #include "rcmarl_common.h"
 #include <stdlib.h>
 #include "selnet_generated.inc"
+#include "selmid_generated.inc"
 
 namespace {
 
@@ -215,6 +216,149 @@ __global__ __launch_bounds__(1024) void k_consensus_params_v2(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Circulant graphs (the reference's own topology: in_nodes[i] = [i, i+1, .., i+d-1 mod N], main.py:28) with
+// d == 2H+2: G consecutive agents share d-G+1 of their d inputs, so ONE selection network over the shared values
+// (SelMid: their middle G+1 order statistics) serves G agents; each agent then merges its own G-1 extra values:
+//   sorted(v_i)[H]   = min_{a=0..E} max(t[a-1], c[E-a])       E = G-1, t = the agent's sorted extras (t[-1] = -inf),
+//   sorted(v_i)[H+1] = min_{a=0..E} max(t[a-1], c[E+1-a])     c = ranks H-E .. H+1 of the shared values
+// (a lattice identity: exact for ties too).  (18, 8): 96/4 + 13 min/max ops per agent instead of 128; (66, 32):
+// 796/8 + 54 instead of 904.  Clip window and the summation order of the mean are those of aggregate_regs, so the
+// results are bit-identical to the general kernels.  Tile = [N][TC] columns in LDS (LDS-DMA double buffer as v2);
+// a wavefront holds 64/TC groups side by side.
+template <int E> struct SortSmall;
+template <> struct SortSmall<1> { static __device__ __forceinline__ void run(float (&)[1]) {} };
+template <> struct SortSmall<3> {
+  static __device__ __forceinline__ void run(float (&t)[3]) {
+    const float a = t[0], b = t[1], c = t[2];
+    t[0] = fminf(fminf(a, b), c); t[1] = __builtin_amdgcn_fmed3f(a, b, c); t[2] = fmaxf(fmaxf(a, b), c);
+  }
+};
+#define RC_CE(i, j) { const float lo_ = fminf(t[i], t[j]), hi_ = fmaxf(t[i], t[j]); t[i] = lo_; t[j] = hi_; }
+template <> struct SortSmall<5> {      // 9 comparators (optimal)
+  static __device__ __forceinline__ void run(float (&t)[5]) {
+    RC_CE(0, 1) RC_CE(3, 4) RC_CE(2, 4) RC_CE(2, 3) RC_CE(1, 4) RC_CE(0, 3) RC_CE(0, 2) RC_CE(1, 3) RC_CE(1, 2)
+  }
+};
+template <> struct SortSmall<7> {      // 16 comparators (optimal)
+  static __device__ __forceinline__ void run(float (&t)[7]) {
+    RC_CE(1, 2) RC_CE(3, 4) RC_CE(5, 6) RC_CE(0, 2) RC_CE(3, 5) RC_CE(4, 6) RC_CE(0, 1) RC_CE(4, 5)
+    RC_CE(2, 6) RC_CE(0, 4) RC_CE(1, 5) RC_CE(0, 3) RC_CE(2, 5) RC_CE(1, 3) RC_CE(2, 4) RC_CE(2, 3)
+  }
+};
+#undef RC_CE
+
+// x / D for a small integer constant D, bit-identical to the IEEE division in 3 instructions instead of ~10:
+// q0 = x*rcp, one fma residual, one fma correction (Markstein).  Checked EXHAUSTIVELY over all 2^32 inputs for
+// D in {4, 6, 10, 18, 34, 66}: the only mismatches have a subnormal quotient, which takes the true division.
+template <int D>
+__device__ __forceinline__ float rc_div_const(float x) {
+  constexpr float rcp = 1.0f / (float)D;
+  const float ax = fabsf(x);
+  if (__builtin_expect(ax < 1e-30f && ax != 0.f, 0)) return x / (float)D;
+  const float q0 = x * rcp;
+  return fmaf(fmaf(-q0, (float)D, x), rcp, q0);
+}
+
+template <int D, int H, int G, int TC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* __restrict__ msg,
+                                                                   float* __restrict__ theta,
+                                                                   const int* __restrict__ coop, int N, int ldp,
+                                                                   int P_hid, int tiles_per_seed, int total_tiles,
+                                                                   float* __restrict__ lo_dbg,
+                                                                   float* __restrict__ hi_dbg) {
+  static_assert(D == 2 * H + 2 && H >= G - 1 && 64 % TC == 0 && TC % 4 == 0, "circulant kernel: d = 2H+2, H >= G-1");
+  constexpr int E = G - 1, M = D - G + 1, U = D + G - 1, SUB = 64 / TC, RPI = 256 / TC;   // RPI: rows per LDS-DMA burst
+  RCMARL_DYN_SMEM(float, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tile_floats = N * TC, buf_floats = tile_floats + 256;
+  int* coop_s = reinterpret_cast<int*>(lds + 2 * buf_floats);
+  for (int i = threadIdx.x; i < N; i += blockDim.x) coop_s[i] = coop[i];
+  const int c = lane % TC, sub = lane / TC;
+  const int n_groups = (N + G - 1) / G, per_pass = nw * SUB, n_iter = (n_groups + per_pass - 1) / per_pass;
+  const int rows_per_wave = (N + nw - 1) / nw;
+  auto stage = [&](int t, float* buf) {
+    const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) * TC;
+    const float* m = msg + (size_t)s * N * ldp + c0;
+    const int r_begin = wave * rows_per_wave, r_end = min(N, r_begin + rows_per_wave);
+    for (int r = r_begin; r < r_end; r += RPI) {         // one instruction = RPI rows x TC*4 B = 1 KiB of LDS
+      int row = r + lane / (TC / 4);
+      row = row < N ? row : N - 1;                       // (tail lanes re-read the last row into the slack rows)
+      rc_glds16(m + (size_t)row * ldp + 4 * (lane % (TC / 4)), buf + (size_t)r * TC);
+    }
+  };
+  int t = blockIdx.x;
+  int cur = 0;
+  if (t < total_tiles) stage(t, lds);
+  for (; t < total_tiles; t += gridDim.x) {
+#ifndef RCMARL_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of tile t (see k_consensus_params_v2)
+#endif
+    __syncthreads();
+    const int tn = t + gridDim.x;
+    if (tn < total_tiles) stage(tn, lds + (cur ^ 1) * buf_floats);
+    const float* tile = lds + cur * buf_floats;
+    const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) * TC;
+    const bool col_ok = (c0 + c) < P_hid;
+    for (int j = 0; j < n_iter; ++j) {
+      const int gi = wave * SUB + sub + per_pass * j;
+      if (gi >= n_groups) continue;
+      const int i0 = gi * G;
+      float v[U];
+      if (i0 + U <= N) {                                 // no wrap: constant offsets from one base
+        const float* p0 = tile + i0 * TC + c;
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = p0[k * TC];
+      } else {
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = tile[((i0 + k) % N) * TC + c];
+      }
+      float cm[M], mid[G + 1];
+#pragma unroll
+      for (int q = 0; q < M; ++q) cm[q] = v[G - 1 + q];
+      SelMid<M, H - G + 1, G + 1>::run(cm, mid);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int agent = i0 + g;
+        if (agent >= N || !coop_s[agent]) continue;
+        float tx[E];
+#pragma unroll
+        for (int q = 0; q < E; ++q) tx[q] = (q < E - g) ? v[g + q] : v[D + q - (E - g)];
+        SortSmall<E>::run(tx);
+        float slo = mid[E], shi = mid[E + 1];
+#pragma unroll
+        for (int a = 1; a <= E; ++a) {
+          slo = fminf(slo, fmaxf(tx[a - 1], mid[E - a]));
+          shi = fminf(shi, fmaxf(tx[a - 1], mid[E + 1 - a]));
+        }
+        const float own = v[g];
+        const float lower = fminf(slo, own), upper = fmaxf(shi, own);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[g + k], lower, upper);
+        if (col_ok) {
+          const size_t o = ((size_t)s * N + agent) * ldp + c0 + c;
+          theta[o] = rc_div_const<D>(sum);
+          if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+        }
+      }
+    }
+    cur ^= 1;
+  }
+}
+
+// G per (d, H): measured choice among the generated SelMid networks (RCMARL_K1_G overrides where two exist)
+int circ_group(int d, int H) {
+  static const int forced = getenv("RCMARL_K1_G") ? atoi(getenv("RCMARL_K1_G")) : 0;
+  if (d == 4 && H == 1) return 2;
+  if (d == 6 && H == 2) return 2;
+  if (d == 10 && H == 4) return 4;
+  if (d == 18 && H == 8) return forced == 6 ? 6 : 4;
+  if (d == 34 && H == 16) return 4;
+  if (d == 66 && H == 32) return forced == 4 ? 4 : 8;
+  return 0;
+}
+
 // Any (d, H) without a generated network: order statistics by rank counting
 // out of the LDS tile (O(d^2) LDS reads).  Correct for every d >= 2H+1; slow.
 __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* __restrict__ msg,
@@ -353,4 +497,52 @@ RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const 
     RCMARL_LAUNCH(k_consensus_params_generic, grid, block, smem, stream, msg, theta, nbr, coop, N, ldp, P_hid, log2tc,
                   d, H, lo_dbg, hi_dbg);
   return rcmarl_check_launch();
+}
+
+// The same aggregation for a CIRCULANT graph, nbr[i][k] == (i + k) % N (the caller guarantees it; the reference's
+// main.py:28 pattern), d == 2H+2.  Returns RCMARL_ERR_UNSUPPORTED when no kernel is compiled for (N, d, H): use
+// rcmarl_consensus_params then.  Results are bit-identical to rcmarl_consensus_params.
+RCMARL_EXPORT int rcmarl_consensus_params_circulant_supported(int N, int d, int H) {
+  if (N <= 0 || d != 2 * H + 2 || d > N || circ_group(d, H) == 0) return 0;
+  const size_t need64 = (2 * ((size_t)N * 64 + 256) + N) * sizeof(float), need16 = (2 * ((size_t)N * 16 + 256) + N) * sizeof(float);
+  return (need64 <= 158 * 1024 || need16 <= 158 * 1024) ? 1 : 0;
+}
+
+RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* theta, const int* coop, int S, int N,
+                                                    int ldp, int P_hid, int d, int H, float* lo_dbg, float* hi_dbg,
+                                                    void* stream) {
+  if (!msg || !theta || !coop || S <= 0 || N <= 0 || d <= 0 || H < 0 || (ldp & 63) || P_hid <= 0 || P_hid > ldp ||
+      (!!lo_dbg != !!hi_dbg))
+    return RCMARL_ERR_ARG;
+  if (!rcmarl_consensus_params_circulant_supported(N, d, H)) return RCMARL_ERR_UNSUPPORTED;
+  const int G = circ_group(d, H);
+  const int TC = (2 * ((size_t)N * 64 + 256) + N) * sizeof(float) <= 158 * 1024 ? 64 : 16;
+  const size_t smem = (2 * ((size_t)N * TC + 256) + N) * sizeof(float);
+  const int tps = rc_ceil_div(P_hid, TC), tot = tps * S;
+  int wg_cu = (int)((160 * 1024) / (smem + 1024));
+  if (wg_cu > 4) wg_cu = 4;
+  if (wg_cu < 1) wg_cu = 1;
+  int nwg = 256 * wg_cu;
+#ifdef RCMARL_EMU
+  nwg = 3;
+#endif
+  if (nwg > tot) nwg = tot;
+  int rc = RCMARL_ERR_UNSUPPORTED;
+#define RC_CIRC_LAUNCH(DD, HH, GG, TT, THR)                                                                          \
+  do {                                                                                                               \
+    if (!k1_want_lds(k_consensus_params_circ<DD, HH, GG, TT, THR>, smem)) return RCMARL_ERR_LAUNCH;                   \
+    RCMARL_LAUNCH((k_consensus_params_circ<DD, HH, GG, TT, THR>), dim3(nwg), dim3(THR), smem, stream, msg, theta,     \
+                  coop, N, ldp, P_hid, tps, tot, lo_dbg, hi_dbg);                                                    \
+    rc = rcmarl_check_launch();                                                                                      \
+  } while (0)
+  // wide windows keep U = d+G-1 values plus the network's temporaries live: 512 threads (256 VGPRs) from d = 34
+#define RC_CIRC_CASE(DD, HH, GG)                                                                                     \
+  if (rc == RCMARL_ERR_UNSUPPORTED && d == DD && H == HH && G == GG) {                                               \
+    constexpr int THR = (DD >= 34) ? 512 : 1024;                                                                     \
+    if (TC == 64) RC_CIRC_LAUNCH(DD, HH, GG, 64, THR); else RC_CIRC_LAUNCH(DD, HH, GG, 16, THR);                     \
+  }
+  RCMARL_CIRC_COMBOS(RC_CIRC_CASE)
+#undef RC_CIRC_CASE
+#undef RC_CIRC_LAUNCH
+  return rc;
 }

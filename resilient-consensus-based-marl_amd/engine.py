@@ -187,6 +187,11 @@ class RPBCACEngine:
         self.seeds_dev = torch.tensor(np.asarray(seeds, dtype=np.uint64).view(np.int64), dtype=torch.int64, device=self.dev)
         # graph / roles
         self.nbr = torch.tensor(np.asarray(c.in_nodes, dtype=np.int32), **i32)
+        # circulant in-graph (the reference's own pattern, main.py:28) with d = 2H+2: K1 shares one selection
+        # network among consecutive agents (rcmarl_consensus_params_circulant; RCMARL_K1_CIRC=0 disables)
+        circ = all(row == [(i + k) % N for k in range(c.d)] for i, row in enumerate(c.in_nodes))
+        self.k1_circulant = bool(circ and os.environ.get("RCMARL_K1_CIRC", "1") not in ("0", "false")
+                                 and lib.rcmarl_consensus_params_circulant_supported(N, c.d, c.H))
         coop = np.array([1 if l == COOP else 0 for l in c.agent_label], dtype=np.int32)
         self.coop_np = coop
         self.n_coop = int(coop.sum())
@@ -290,9 +295,7 @@ class RPBCACEngine:
 
     def _consensus_wide(self, net, xkey, B):
         L, S, N, c, hid = self.lib, self.S, self.N, self.cfg, self.hid[net]
-        L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),
-                                  self.coop.data_ptr(), S, N, self.ldp[net], self.P[net] - (hid + 1), c.d, c.H, None, None,
-                                  self.stream)
+        self._k1(net, self.P[net] - (hid + 1))
         self._wide_forward(xkey, self.theta[net], net, B, a1=self.a1net[net])
         L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
                                      self.nbr.data_ptr(), self.coop.data_ptr(), None, self.w_hmat.data_ptr(),
@@ -703,15 +706,24 @@ class RPBCACEngine:
         self.lib.rcmarl_mid_value(buf.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
                                   self.S, self.N, B, self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 
+    def _k1(self, net, g_hid):
+        """hidden-layer consensus of one network family: msg -> theta (cooperative agents, columns < g_hid)"""
+        L, c = self.lib, self.cfg
+        if self.k1_circulant:
+            L.rcmarl_consensus_params_circulant(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(),
+                                                self.S, self.N, self.ldp[net], g_hid, c.d, c.H, None, None, self.stream)
+        else:
+            L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),
+                                      self.coop.data_ptr(), self.S, self.N, self.ldp[net], g_hid, c.d, c.H, None, None,
+                                      self.stream)
+
     def _consensus(self, net, xkey, B):
         """Phase II for one network family: hidden-layer consensus (K1), then estimate
         consensus + projection step of the output layer (K2+K3)."""
         if self.hid[net] != HID:
             return self._consensus_wide(net, xkey, B)
         L, S, N, c = self.lib, self.S, self.N, self.cfg
-        g_hid = self.P[net] - (HID * 1 + 1)
-        L.rcmarl_consensus_params(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.nbr.data_ptr(),
-                                  self.coop.data_ptr(), S, N, self.ldp[net], g_hid, c.d, c.H, None, None, self.stream)
+        self._k1(net, self.P[net] - (HID * 1 + 1))
         a1 = self.a1net[net]
         self._layer1(xkey, self.theta[net], net, B, buf=a1)
         L.rcmarl_consensus_head(a1.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),

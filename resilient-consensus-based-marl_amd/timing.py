@@ -22,6 +22,8 @@ WORK = {
     "rcmarl_layer1_backward_adam": lambda a: _gemm_flops(a, 7),
     # msg, theta, nbr, coop, S, N, ldp, P_hid, ...: read P_hid + write P_hid floats per (seed, agent)
     "rcmarl_consensus_params": lambda a: (0.0, 8.0 * a[4] * a[5] * a[7]),
+    # msg, theta, coop, S, N, ldp, P_hid, ...
+    "rcmarl_consensus_params_circulant": lambda a: (0.0, 8.0 * a[3] * a[4] * a[6]),
     # a1t, theta, y, partials, S, N, B, in_dim, hid: layers 2-3 fwd+bwd ~ (8 h^2 + 12 h) flops per (row, agent)
     "rcmarl_mid_fit": lambda a: (a[4] * a[5] * a[6] * (8.0 * a[8] ** 2 + 12.0 * a[8]), 8.0 * a[4] * a[5] * a[6] * a[8]),
     # lattice path: fp32-EQUIVALENT flops 2*M*N*K (the kernel executes 3x that on the bf16 matrix core)

@@ -111,6 +111,50 @@ def check_consensus_params(bk, N, d, H, P, P_hid, graph, S=2):
     np.testing.assert_array_equal(theta[:, N - 1], theta0[:, N - 1])
 
 
+def check_consensus_params_circulant(bk, N, d, H, P, P_hid, S=2):
+    """The circulant-graph kernel: same oracle checks as check_consensus_params AND bit-identical to the general kernel."""
+    assert bk.lib.rcmarl_consensus_params_circulant_supported(N, d, H) == 1
+    rng = np.random.default_rng(N * 100 + d + 1)
+    ldp = pad64(P)
+    nbr = circulant(N, d)
+    coop = np.ones(N, np.int32)
+    coop[N - 1] = 0
+    coop[min(2, N - 1)] = 0
+    base = rng.normal(size=(S, 1, ldp)).astype(np.float32)
+    msg = (base + 0.01 * rng.normal(size=(S, N, ldp))).astype(np.float32)
+    msg[:, N - 1] = 1e3                       # adversarial row
+    msg[:, :, 5] = msg[:, :1, 5]              # ties
+    msg[:, ::3, 7] = msg[:, :1, 7]            # partial ties
+    theta0 = rng.normal(size=(S, N, ldp)).astype(np.float32)
+    d_msg, d_nbr, d_coop = bk.dev(msg), bk.dev(nbr), bk.dev(coop)
+    out = []
+    for circ in (True, False):
+        d_theta = bk.dev(theta0)
+        d_lo, d_hi = bk.dev(np.zeros_like(theta0)), bk.dev(np.zeros_like(theta0))
+        if circ:
+            bk.lib.rcmarl_consensus_params_circulant(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_coop), S, N, ldp, P_hid, d, H,
+                                                     bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+        else:
+            bk.lib.rcmarl_consensus_params(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_nbr), bk.ptr(d_coop), S, N, ldp, P_hid, d,
+                                           H, bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+        out.append((bk.host(d_theta), bk.host(d_lo), bk.host(d_hi)))
+    (theta, lo, hi), (theta_g, lo_g, hi_g) = out
+    np.testing.assert_array_equal(lo, lo_g)
+    np.testing.assert_array_equal(hi, hi_g)
+    np.testing.assert_array_equal(theta, theta_g)         # same clip window, same summation order
+    for s in range(S):
+        for i in range(N):
+            if not coop[i]:
+                np.testing.assert_array_equal(theta[s, i], theta0[s, i])
+                continue
+            vals = msg[s, nbr[i], :P_hid]
+            wl, wh, _ = O.aggregation_bounds(vals, H)
+            np.testing.assert_array_equal(lo[s, i, :P_hid], wl)
+            np.testing.assert_array_equal(hi[s, i, :P_hid], wh)
+            np.testing.assert_allclose(theta[s, i, :P_hid], O.resilient_aggregate(vals, H), rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(theta[:, :, P_hid:], theta0[:, :, P_hid:])
+
+
 # ------------------------------------------------------------------------------------------
 def _layer1(bk, d_x, x_stride, d_theta, d_a1t, S, N, B, in_dim, ldp, ldb):
     bk.lib.rcmarl_layer1_forward(bk.ptr(d_x), x_stride, bk.ptr(d_theta), bk.ptr(d_a1t), S, N, B, in_dim, HID, ldp, ldb,

@@ -37,12 +37,12 @@ def test_engine_lattice_path_matches_oracle(labels, nrow, ncol):
     EC.compare(eng, logs, o_logs, o_w)
 
 
-@pytest.mark.parametrize("rng_mode,critic_hid,H,lattice", [("device", 32, 1, False), ("numpy", 24, 0, False), ("device", 40, 1, True)])
+@pytest.mark.parametrize("rng_mode,critic_hid,H,lattice", [("numpy", 24, 0, False), ("device", 40, 1, True)])
 def test_engine_wide_critic_matches_oracle(rng_mode, critic_hid, H, lattice):
     """BASELINE configs[4] in miniature: a critic wider than the reference's 20 units runs the dense-GEMM path
     (csrc/wide_kernels.hip) for its local fits, TD targets, estimate consensus and start-state values."""
-    args = EC.make_args(["Cooperative"] * 5, H=H, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=41)
-    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, rng_mode, "cpu", emu_lib(), seeds=(41, 42), critic_hid=critic_hid,
+    args = EC.make_args(["Cooperative"] * 5, H=H, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=41)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, rng_mode, "cpu", emu_lib(), seeds=(41,), critic_hid=critic_hid,
                                          lattice=lattice)
     assert eng.wide and eng.lat_active == lattice      # lattice: layer 1 of the wide critic on the bf16x3 kernels
     EC.compare(eng, logs, o_logs, o_w)

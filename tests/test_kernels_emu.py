@@ -39,6 +39,15 @@ def test_consensus_params(bk, N, d, H, P, P_hid, graph):
     KC.check_consensus_params(bk, N, d, H, P, P_hid, graph)
 
 
+@pytest.mark.parametrize("N,d,H,P,P_hid", [(5, 4, 1, 150, 130),       # G = 2, wraps in every group but the first
+                                           (13, 10, 4, 90, 70),       # G = 4, N % G != 0
+                                           (23, 18, 8, 70, 66),       # G = 4
+                                           (70, 66, 32, 40, 36),      # G = 8, 512-thread form
+                                           (700, 6, 2, 40, 30)])      # 16-column tiles (the [N][64] image exceeds the LDS)
+def test_consensus_params_circulant(bk, N, d, H, P, P_hid):
+    KC.check_consensus_params_circulant(bk, N, d, H, P, P_hid, S=2 if N < 100 else 1)
+
+
 @pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 150, 6), (1, 7, 130, 21), (1, 2, 260, 136), (2, 9, 150, 64), (1, 16, 70, 32)])
 def test_layer1_forward(bk, S, N, B, in_dim):
     KC.check_layer1_forward(bk, S, N, B, in_dim)

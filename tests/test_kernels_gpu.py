@@ -47,6 +47,13 @@ def test_consensus_params(bk, N, d, H, P, P_hid, graph):
     KC.check_consensus_params(bk, N, d, H, P, P_hid, graph)
 
 
+@pytest.mark.parametrize("N,d,H,P,P_hid,S", [(5, 4, 1, 761, 740, 300), (64, 10, 4, 3021, 3000, 2), (256, 18, 8, 1100, 1070, 2),
+                                             (256, 18, 8, 10701, 10680, 3), (37, 34, 16, 300, 280, 2), (100, 66, 32, 200, 190, 2),
+                                             (1024, 66, 32, 300, 260, 1), (1024, 18, 8, 200, 130, 2), (300, 6, 2, 700, 650, 3)])
+def test_consensus_params_circulant(bk, N, d, H, P, P_hid, S):
+    KC.check_consensus_params_circulant(bk, N, d, H, P, P_hid, S=S)
+
+
 @pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 64, 700, 128), (2, 7, 130, 21), (1, 13, 3000, 39), (2, 64, 3000, 192), (1, 256, 1000, 512), (1, 9, 150, 64)])
 def test_layer1_forward(bk, S, N, B, in_dim):
     KC.check_layer1_forward(bk, S, N, B, in_dim)

@@ -69,6 +69,10 @@ def k1(L, S=16, N=256):
                                                          ldp, P_hid, d, H, None, None, st), iters=20)
             byts = 8.0 * S * N * P_hid
             print("K1 d=%2d H=%d P_hid=%5d  %7.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (d, H, P_hid, t, byts / t / 1e3, byts / t / 1e3 / 80))
+            if L.rcmarl_consensus_params_circulant_supported(N, d, H):
+                t = timeit(lambda: L.rcmarl_consensus_params_circulant(msg.data_ptr(), theta.data_ptr(), coop.data_ptr(), S, N, ldp,
+                                                                       P_hid, d, H, None, None, st), iters=20)
+                print("   circulant kernel     %7.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (t, byts / t / 1e3, byts / t / 1e3 / 80))
 
 
 def k1_cfg5(L):
@@ -89,6 +93,10 @@ def k1_cfg5(L):
     byts = 8.0 * N * P_hid
     print("K1 cfg5 shard: N=%d d=%d H=%d P_hid/8=%d  %9.1f us  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  -> %.1f consensus-updates/s/GPU-shard"
           % (N, d, H, P_hid, t, byts / t / 1e3, byts / t / 1e3 / 80, N / (t * 1e-6)))
+    t = timeit(lambda: L.rcmarl_consensus_params_circulant(msg.data_ptr(), theta.data_ptr(), coop.data_ptr(), 1, N, ldp, P_hid, d,
+                                                           H, None, None, st), iters=5, warm=2)
+    print("   circulant kernel (G=%s): %9.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (os.environ.get("RCMARL_K1_G", "default"), t,
+                                                                                  byts / t / 1e3, byts / t / 1e3 / 80))
 
 
 def minibatch(L, S=512, N=5, B=3000):
