@@ -290,6 +290,8 @@ def main():
 
 
 BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
+BF16_SUSTAINED_TFLOPS = 1780.0  # measured on this pool: pure v_mfma_f32_32x32x16_bf16 loops on all SIMDs with operands that
+#                                 change every instruction (tools/micro/mfma_peak.hip; 2100 with constant operands)
 
 # kernel -> (bound, note).  "mfma_bf16x3": fp32-equivalent flops 2MNK against the bf16 dense peak; the kernel
 # EXECUTES 3x those flops (three exact bf16 passes per fp32 product), so its ceiling is peak/3.
@@ -347,7 +349,9 @@ def rooflines(tlib, ksum, workload=None):
                     "frac": ach / BF16_PEAK_TFLOPS, "traffic": traffic, "launches": n, "avg_us": avg_us,
                     "algorithmic_flops_per_launch": flops / n,
                     "executed": {"achieved": 3 * ach, "frac": 3 * ach / BF16_PEAK_TFLOPS,
-                                 "what": "bf16 MFMA flops actually issued = 3 x algorithmic"},
+                                 "frac_of_measured_sustained_peak": 3 * ach / BF16_SUSTAINED_TFLOPS,
+                                 "what": "bf16 MFMA flops actually issued = 3 x algorithmic; sustained peak = %.0f TFLOP/s "
+                                         "measured with tools/micro/mfma_peak.hip" % BF16_SUSTAINED_TFLOPS},
                     "note": "exact fp32 GEMM as three bf16 passes (integer-lattice operand x bf16 pieces of the fp32 "
                             "operand, v_mfma_f32_32x32x16_bf16, fp32 accumulate): achieved = fp32-equivalent 2MNK flops; "
                             "ceiling of the method = bf16 dense peak / 3 = 833 TFLOP/s; the f32-input MFMA it replaces "

@@ -19,6 +19,7 @@
 // Workgroups are numbered so that all tiles of one seed run on ONE XCD (block b -> XCD b%8): the
 // seed's small operand (K, 3 MB) stays in that XCD's L2 and the big one streams through once.
 #include "rcmarl_lattice.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -173,7 +174,9 @@ struct LatOperands {
   int art0, brt0;                                   // first 128-row tile of this workgroup on each side
 };
 
-template <int PA, int PB, int MT, int NT, int NSTAGE>
+// DBG (measurement aid, RCMARL_LAT_DBG; results are WRONG for DBG != 0): bit 0 = no LDS-DMA after the prologue,
+// bit 1 = no vmcnt wait / barrier, bit 2 = fragments read from LDS once (k-loop = matrix core only)
+template <int PA, int PB, int MT, int NT, int NSTAGE, int DBG = 0>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
                                              rc_f32x16 (&acc)[MT][NT]) {
   typedef LatCfg<PA, PB, MT, NT> C;
@@ -235,13 +238,15 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
   int cur = 0;                                        // t % NSTAGE
   for (int t = 0; t < n_ktiles; ++t) {
     // this wavefront's bursts of tile t have landed (NSTAGE 3: tile t+1's may still be in flight) ...
-    if (NSTAGE == 3 && t + 1 < n_ktiles) RC_WAIT_VMEM_N(C::GLDS); else RC_WAIT_VMEM();
-    __syncthreads();                // ... and everybody's; all reads of the buffer refilled next are done
-    if (t + NSTAGE - 1 < n_ktiles) {
+    if (!(DBG & 2) || t == 0) {
+      if (NSTAGE == 3 && t + 1 < n_ktiles) RC_WAIT_VMEM_N(C::GLDS); else RC_WAIT_VMEM();
+      __syncthreads();              // ... and everybody's; all reads of the buffer refilled next are done
+    }
+    if (t + NSTAGE - 1 < n_ktiles && !(DBG & 1)) {
       const int nb = cur == 0 ? NSTAGE - 1 : cur - 1;           // (t + NSTAGE - 1) % NSTAGE
       stage(nb, t + NSTAGE - 1);
     }
-    const unsigned char* st = lds + cur * C::STAGE_BYTES;
+    const unsigned char* st = lds + ((DBG & 4) ? 0 : cur) * C::STAGE_BYTES;
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -408,7 +413,7 @@ __device__ __forceinline__ void lat_prio(int bit) {
 }
 
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
-template <int NSTAGE>
+template <int NSTAGE, int DBG = 0>
 __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
                                                         const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                         const float* __restrict__ theta, float* __restrict__ a1t, int S,
@@ -421,7 +426,21 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   lat_decode(mtiles * ntiles, S, s, w);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
   lat_prio((stg_bit >> 8) - 1);
-  const int bn = w % ntiles, bm = w / ntiles;                      // n fastest: neighbours share the W' panel
+  // Tile order inside a seed: the n-tiles are walked in chunks of `cw` (dbg_same_tile bits 8..), m-major inside a
+  // chunk, n fastest.  The workgroups resident on an XCD (64) then share ONE chunk of the replay operand (cw x 256 KiB
+  // at 512 inputs) plus a sliding window of W' panels -- inside the 4-MiB L2 -- instead of all n-tiles (3 MiB) plus
+  // five W' panels (PMC: 2.6 GB fetched per launch for 0.3 GB of operands with the plain n-fastest order).
+  int bn, bm;
+  {
+    const int cw = dbg_same_tile >> 8;
+    if (cw <= 0 || cw >= ntiles) { bn = w % ntiles; bm = w / ntiles; }
+    else {
+      const int per_chunk = mtiles * cw, c = w / per_chunk, r = w - c * per_chunk;
+      const int wc = min(cw, ntiles - c * cw);
+      bm = r / wc; bn = c * cw + (r - bm * wc);
+    }
+    dbg_same_tile &= 0xff;
+  }
   LatOperands op;
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
   op.b = kp + (long)s * kp_rt * kp_kt * (PB * RC_PK_BLOCK); op.b_kt = kp_kt; op.brt0 = bn * C::BRT;
@@ -431,7 +450,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   }
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
-  else lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (in_dim + 31) >> 5, lds, acc);
+  else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * hid;
   const float* theta_s = theta + (long)s * N * ldp;
@@ -444,21 +463,47 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
     bias[threadIdx.x] = col < ncols ? theta_s[(long)ag * ldp + in_dim * hid + (col - ag * hid)] : 0.f;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  // Straight-line stores: the lane's 32 bias values come out of LDS in 8 ds_read_b128 up front (not one dependent
+  // ds_read_b32 per element), row bases are wave-uniform (SGPR) and the lane part of the address is ONE 32-bit
+  // offset, full tiles take no per-element predicate.  (The first version of this epilogue -- a branch, an LDS round
+  // trip and a 64-bit multiply per element -- cost as much as the k-loop of a 512-deep GEMM: 176 of 832 us.)
+  const int lane = threadIdx.x & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave >> 1, wn = wave & 1;
+  float bv[MT][16];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = bn * C::BN + wn * 32 * NT + 32 * nt + (lane & 31);
-    if (n < B) {
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = wm * 32 * MT + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int m = bm * C::BM + ml;
-          if (m < ncols) a1t_s[(long)m * ldb + n] = rc_lrelu(acc[mt][nt][r] + bias[ml]);
-        }
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + wm * 32 * MT + 32 * mt + 8 * q + 4 * half);
+      bv[mt][4 * q] = b4.x; bv[mt][4 * q + 1] = b4.y; bv[mt][4 * q + 2] = b4.z; bv[mt][4 * q + 3] = b4.w;
     }
-  }
+  const bool full_m = (bm + 1) * C::BM <= ncols;                   // workgroup-uniform
+  auto store_tile = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = bn * C::BN + wn * 32 * NT + 32 * nt + (lane & 31);
+      if (n < B) {
+        // byte offset of the lane inside its row block: 32 bits (one seed's a1t is < 4 GiB) -> saddr + voffset stores
+        const unsigned lane_byte = ((unsigned)(4 * half) * (unsigned)ldb + (unsigned)n) * 4u;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m0 = bm * C::BM + wm * 32 * MT + 32 * mt;      // wave-uniform
+          unsigned char* __restrict__ rowbase = reinterpret_cast<unsigned char*>(a1t_s + (long)m0 * ldb);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const float z = acc[mt][nt][r] + bv[mt][r];
+            const float o = fmaxf(z, RC_LEAK * z);                 // == rc_lrelu(z) bit for bit (0 < leak < 1), 2 ops not 3
+            float* __restrict__ dst = reinterpret_cast<float*>(rowbase + (long)dr * ldb * 4 + lane_byte);
+            if (DBG & 8) { if (o == 12345.678f) *dst = o; }        // DBG 8: no epilogue stores
+            else if (FULL || m0 + dr + 4 * half < ncols) *dst = o;
+          }
+        }
+      }
+    }
+  };
+  if (full_m) store_tile(std::true_type{}); else store_tile(std::false_type{});
 }
 
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
@@ -620,9 +665,24 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   const int mtiles = rc_ceil_div(N * hid, 128), ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
   if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
   const int ns = lat_stages();
-  static const int dbg = getenv("RCMARL_LAT_SAMETILE") ? atoi(getenv("RCMARL_LAT_SAMETILE")) : 0;
+  static const int dbg = (getenv("RCMARL_LAT_SAMETILE") ? (atoi(getenv("RCMARL_LAT_SAMETILE")) & 0xff) : 0) |
+                         (lat_env_int("RCMARL_LAT_NCHUNK", 0) << 8);
   const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
+  static const int dbgm = getenv("RCMARL_LAT_DBG") ? atoi(getenv("RCMARL_LAT_DBG")) : 0;
+  if (ns == 2 && dbgm != 0) {
+#define RC_DBG_CASE(M)                                                                                               \
+    if (dbgm == M) {                                                                                                 \
+      if (!lat_want_lds(k_lat_forward<2, M>, smem)) return RCMARL_ERR_LAUNCH;                                        \
+      RCMARL_LAUNCH((k_lat_forward<2, M>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,        \
+                    (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, \
+                    lat_stagger_bit(), lat_stagger_n(), hid);                                                        \
+    }
+    RC_DBG_CASE(1) RC_DBG_CASE(2) RC_DBG_CASE(3) RC_DBG_CASE(4) RC_DBG_CASE(5) RC_DBG_CASE(6) RC_DBG_CASE(7)
+    RC_DBG_CASE(8) RC_DBG_CASE(9) RC_DBG_CASE(15)
+#undef RC_DBG_CASE
+    return rcmarl_check_launch();
+  }
   if (ns == 2) {
     static const bool ok = lat_want_lds(k_lat_forward<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;

@@ -22,6 +22,7 @@
 // come in either orientation (contiguous along k, or along m/n), which covers forward (W^T x), backward-data
 // (W dz) and backward-weights (x^T dz^T) without materialising a transpose.
 #include "rcmarl_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -99,7 +100,7 @@ __device__ __forceinline__ void w_store(float* __restrict__ s, const float (&reg
 }
 
 template <bool A_KC, bool B_KC, int EPI, bool VEC>
-__global__ __launch_bounds__(256) void k_wgemm(const WArgs a) {
+__global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 workgroups per CU: <= 170 VGPRs
   __shared__ __attribute__((aligned(16))) float sA[2][WBK * WLD];
   __shared__ __attribute__((aligned(16))) float sB[2][WBK * WLD];
   const int z = blockIdx.z, s = z / a.NA, ag = z - s * a.NA;
@@ -145,28 +146,56 @@ __global__ __launch_bounds__(256) void k_wgemm(const WArgs a) {
     }
     __syncthreads();
   }
-  // epilogue: register r of tile (i, j) is C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][n0 + wn*64 + j*32 + (l&31)]
+  // epilogue: register r of tile (i, j) is C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][n0 + wn*64 + j*32 + (l&31)].
+  // Full tiles run straight-line (no per-element predicate, so the bias / activation / old-weight loads are all
+  // issued before the first dependent use); edge tiles keep the predicates.
   float* __restrict__ C = a.C + s * a.C_zs + ag * a.C_za;
   const float* __restrict__ aux = a.aux ? a.aux + s * a.aux_zs + ag * a.aux_za : nullptr;
+  const int mb = m0 + wm * 64 + 4 * (l >> 5), nb = n0 + wn * 64 + (l & 31);
+  auto tile_out = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    float bias[2][16];
+    if (EPI == WEPI_BIAS_LRELU || EPI == WEPI_BIAS) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-      if (m >= a.M) continue;
-      const float bias = (EPI == WEPI_BIAS_LRELU || EPI == WEPI_BIAS) ? aux[m] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
+          bias[i][r] = (FULL || m < a.M) ? aux[m] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (l & 31);
-        if (n >= a.N) continue;
-        const float v = acc[i][j][r];
-        float* c = C + (long)m * a.ldc + n;
-        if (EPI == WEPI_BIAS_LRELU) *c = rc_lrelu(v + bias);
-        else if (EPI == WEPI_BIAS) *c = v + bias;
-        else if (EPI == WEPI_LRELU_GRAD) *c = v * rc_lrelu_grad_from_act(aux[(long)m * a.ldaux + n]);
-        else *c = *c - a.lr * v;
+        const int n = nb + j * 32;
+        if (!FULL && n >= a.N) continue;
+        float* __restrict__ cp = C + (long)(mb + i * 32) * a.ldc + n;
+        const float* __restrict__ xp = (EPI == WEPI_LRELU_GRAD) ? aux + (long)(mb + i * 32) * a.ldaux + n : nullptr;
+        float old[16];
+        if (EPI == WEPI_LRELU_GRAD || EPI == WEPI_SGD) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            const bool ok = FULL || mb + i * 32 + dr < a.M;
+            old[r] = !ok ? 0.f : (EPI == WEPI_SGD ? cp[(long)dr * a.ldc] : xp[(long)dr * a.ldaux]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (!FULL && mb + i * 32 + dr >= a.M) continue;
+          const float v = acc[i][j][r];
+          float o;
+          if (EPI == WEPI_BIAS_LRELU) o = rc_lrelu(v + bias[i][r]);
+          else if (EPI == WEPI_BIAS) o = v + bias[i][r];
+          else if (EPI == WEPI_LRELU_GRAD) o = v * rc_lrelu_grad_from_act(old[r]);
+          else o = old[r] - a.lr * v;
+          cp[(long)dr * a.ldc] = o;
+        }
       }
-    }
+  };
+  if (m0 + WBM <= a.M && n0 + WBN <= a.N) tile_out(std::true_type{}); else tile_out(std::false_type{});
 }
 
 static inline bool w_al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
