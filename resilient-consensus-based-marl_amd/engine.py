@@ -905,18 +905,14 @@ class RPBCACEngine:
         est = self.est_hist[:n_eps].detach().cpu().numpy()
         coop = self.coop_np.astype(bool)
         E, S, N = ret.shape
-        team, adv, estm = np.zeros((E, S)), np.zeros((E, S)), np.zeros((E, S))
         n_coop = self.n_coop
-        for e in range(E):
-            for s in range(S):
-                t = a = 0
-                for i in range(N):
-                    if coop[i]:
-                        t += ret[e, s, i] / n_coop
-                    else:
-                        a += ret[e, s, i] / (N - n_coop)
-                team[e, s], adv[e, s] = t, a
-                estm[e, s] = np.mean(est[e, s][coop]) if n_coop else np.nan
+        # The reference accumulates  t += ret_i / n_coop  agent by agent in float64 (train_agents.py:168-172): np.cumsum is
+        # that strictly sequential sum (np.sum would be pairwise), so the values are bit-identical to the Python loop --
+        # which cost 25 ms per block at 16 seeds x 256 agents with the GPU idle behind it.
+        team = np.cumsum(ret[:, :, coop] / n_coop, axis=-1)[:, :, -1] if n_coop else np.zeros((E, S))
+        adv = np.cumsum(ret[:, :, ~coop] / (N - n_coop), axis=-1)[:, :, -1] if n_coop < N else np.zeros((E, S))
+        # np.mean of the cooperative agents' float32 start-state values (:173), row by row
+        estm = np.ascontiguousarray(est[:, :, coop]).mean(axis=-1).astype(np.float64) if n_coop else np.full((E, S), np.nan)
         return team, adv, estm
 
     _diverged_warned = False
