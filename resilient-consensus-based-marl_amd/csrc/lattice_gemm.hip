@@ -540,8 +540,13 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
     al[threadIdx.x] = k < in_dim ? alpha[k] : 0.f;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-  const int half = lane >> 5;
+  // Two phases per n-tile: ALL 64 old weights of the lane are requested first (independent loads, one wait), then
+  // the updates are computed and stored.  Written element by element (load, update, store the same address) the
+  // compiler had to wait for every store before the next load -- possible alias -- i.e. 128 serial memory round trips
+  // per lane, as long as the whole k-loop of the workgroup.
+  const int lane = threadIdx.x & 63, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave >> 1, wn = wave & 1;
+  const bool full_k = (bm + 1) * C::BM <= in_dim;                       // workgroup-uniform
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int cl = wn * 32 * NT + 32 * nt + (lane & 31);                 // column within the 128-wide tile
@@ -549,27 +554,37 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
     if (col < ncols) {
       const int ag = col / hid, j = col - ag * hid;
       const bool upd = mask == nullptr || mask[ag];
-      float* th = theta + ((long)s * N + ag) * ldp + j;
+      // the lane's first row: k = bm*BM + wm*32*MT + 4*half; rows of (mt, gq, e) follow at uniform distances
+      const int k0 = bm * C::BM + wm * 32 * MT + 4 * half;
+      float* th = theta + ((long)s * N + ag) * ldp + j + (long)k0 * hid;
       unsigned char* wrow = wp_out == nullptr ? nullptr
           : wp_out + (long)s * wp_rt * wp_kt * (3 * RC_PK_BLOCK) + (long)bn * wp_kt * (3 * RC_PK_BLOCK) + cl * 64 + half * 8;
       const int sw = (cl >> 2) & 3;
+      float wold[MT][16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int dk = 32 * mt + 8 * (q >> 2) + (q & 3);               // uniform
+          wold[mt][q] = (full_k || k0 + dk < in_dim) ? th[(long)dk * hid] : 0.f;
+        }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int kt = bm * (C::BM / 32) + wm * MT + mt;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
+          const float4 a4 = *reinterpret_cast<const float4*>(al + wm * 32 * MT + 32 * mt + 8 * gq + 4 * half);
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w};
           float wn4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int kl = wm * 32 * MT + 32 * mt + 8 * gq + 4 * half + e;
-            const int k = bm * C::BM + kl;
-            float w = 0.f;
-            if (k < in_dim) {
-              float* wptr = th + (long)k * hid;
-              w = *wptr;
-              if (upd) { w = w - lr * (al[kl] * acc[mt][nt][4 * gq + e]); *wptr = w; }
+            const int dk = 32 * mt + 8 * gq + e;
+            float w = wold[mt][4 * gq + e];
+            if (upd && (full_k || k0 + dk < in_dim)) {
+              w = w - lr * (av[e] * acc[mt][nt][4 * gq + e]);
+              th[(long)dk * hid] = w;
             }
-            wn4[e] = w * al[kl];
+            wn4[e] = w * av[e];
           }
           if (wrow != nullptr && kt < wp_kt) {
             unsigned h0, m0, l0, h1, m1, l1;
