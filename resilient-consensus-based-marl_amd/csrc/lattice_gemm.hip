@@ -131,19 +131,21 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
 __global__ __launch_bounds__(256) void k_dz_pack(const float* __restrict__ dz, unsigned char* __restrict__ dzp, int nrows,
                                                  int B, int ldb, int dzp_rt, int dzp_kt) {
   const int s = blockIdx.z, rt = blockIdx.y, kt = blockIdx.x;
-  const int t = threadIdx.x, r = t & 127;
-  const int row = rt * 128 + r;
-  const bool row_ok = row < nrows;
-  const float* src = dz + ((long)s * nrows + (row_ok ? row : 0)) * ldb;
+  const int t = threadIdx.x, c4 = t & 3;             // four adjacent lanes = the 128 B (32 k) of one row: coalesced both ways
   unsigned char* blk = dzp + (long)s * dzp_rt * dzp_kt * 3 * RC_PK_BLOCK + ((long)rt * dzp_kt + kt) * 3 * RC_PK_BLOCK;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int c4 = (t >> 7) + 2 * q;
+    const int r = (t >> 2) + 64 * q;
+    const int row = rt * 128 + r;
+    const bool row_ok = row < nrows;
+    const float* src = dz + ((long)s * nrows + (row_ok ? row : 0)) * ldb + kt * 32 + 8 * c4;
     float w[8];
+    if (row_ok && kt * 32 + 8 * c4 + 8 <= B) {         // ldb is a multiple of 64 floats: 16-B aligned
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+      w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = kt * 32 + 8 * c4 + e;
-      w[e] = (row_ok && k < B) ? src[k] : 0.f;
+      for (int e = 0; e < 8; ++e) w[e] = (row_ok && kt * 32 + 8 * c4 + e < B) ? src[e] : 0.f;
     }
     uint4 vh, vm, vl;
     rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
@@ -663,7 +665,9 @@ RCMARL_EXPORT int rcmarl_w1_split(const float* theta, const float* alpha, void* 
 
 RCMARL_EXPORT int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int N, int B, int hid, int ldb, int dzp_rt,
                                          int dzp_kt, void* stream) {
-  if (!dz || !dzp || S <= 0 || N <= 0 || B <= 0 || hid <= 0 || ldb < B) return RCMARL_ERR_ARG;
+  if (!dz || !dzp || S <= 0 || N <= 0 || B <= 0 || hid <= 0 || ldb < B || (ldb & 3) ||
+      (reinterpret_cast<uintptr_t>(dz) & 15))
+    return RCMARL_ERR_ARG;
   const int rts = rc_ceil_div(N * hid, 128), kts = rc_ceil_div(B, 32);
   if (dzp_rt < rts || dzp_kt < kts) return RCMARL_ERR_ARG;
   RCMARL_LAUNCH(k_dz_pack, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
