@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
             const float o = fmaxf(z, RC_LEAK * z);                 // == rc_lrelu(z) bit for bit (0 < leak < 1), 2 ops not 3
             float* __restrict__ dst = reinterpret_cast<float*>(rowbase + (long)dr * ldb * 4 + lane_byte);
             if (DBG & 8) { if (o == 12345.678f) *dst = o; }        // DBG 8: no epilogue stores
-            else if (FULL || m0 + dr + 4 * half < ncols) *dst = o;
+            else if (FULL || m0 + dr + 4 * half < ncols) RC_NT_STORE(dst, o);
           }
         }
       }

@@ -132,6 +132,13 @@ __device__ __forceinline__ void rc_wave_sum3_lane63(float& a, float& b, float& c
 
 static inline int rc_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// streaming store: data written once and not re-read by this kernel (keeps the operand panels in L2)
+#ifdef RCMARL_EMU
+#define RC_NT_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define RC_NT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 // Two fp32 lanes per register pair: v_pk_fma_f32 / v_pk_mul_f32 run 128 FMAs per wavefront instruction in the
 // 4-cycle issue slot a plain v_fma_f32 spends on 64 (the 157 TFLOP/s fp32 vector peak is the PACKED rate).
 #ifdef RCMARL_EMU
