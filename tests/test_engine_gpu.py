@@ -129,3 +129,38 @@ def test_engine_wide_critic(n, critic_hid, H, d, rng_mode, lattice):
     eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, rng_mode, "cuda", None, seeds=(51, 52), critic_hid=critic_hid, lattice=lattice)
     assert eng.wide and eng.lat_active == (lattice is not False)
     EC.compare(eng, logs, o_logs, o_w)
+
+
+def test_engine_wide_critic_cfg5_shape_paths_agree():
+    """BASELINE configs[4] shape at an eighth of the agents (128 agents, 512-unit critic, H=32, circulant d=66, 32x32 grid,
+    B = 1000..): one training block with layer 1 of the critic on the bf16x3 lattice kernels + the circulant consensus
+    kernel vs on the dense f32-MFMA GEMM + the general consensus kernel.  Independent implementations of the same
+    fp32 math: identical rollouts, weights equal to accumulated fp32 roundoff, all finite."""
+    import os
+    import numpy as np
+    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+    n, d = 128, 66
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    out = {}
+    for fast in (False, True):
+        os.environ["RCMARL_K1_CIRC"] = "1" if fast else "0"
+        try:
+            cfg = EngineConfig(n, ["Cooperative"] * n, in_nodes, H=32, max_ep_len=20, n_ep_fixed=50, n_epochs=2, buffer_size=2000,
+                               fast_lr=0.002, nrow=32, ncol=32, n_seeds=1, rng_mode="device", lattice=fast, critic_hid=512)
+            eng = RPBCACEngine(cfg, seeds=[2000])
+        finally:
+            os.environ.pop("RCMARL_K1_CIRC", None)
+        assert eng.wide and eng.k1_circulant == fast
+        eng.init_glorot(base_seed=2)
+        eng.set_goals(np.random.RandomState(7).randint(0, 5, size=(n, 2)))
+        logs = eng.train(50)
+        assert eng.lat_active == fast
+        out[fast] = (logs, {k: eng.get_all_weights(k) for k in ("critic", "tr")})
+        assert all(np.isfinite(v).all() for v in out[fast][1].values())
+    for k in ("True_team_returns", "True_adv_returns"):
+        np.testing.assert_array_equal(out[True][0][k], out[False][0][k])
+    for net in ("critic", "tr"):
+        a, b = out[True][1][net], out[False][1][net]
+        diff = np.abs(a - b)
+        assert float(diff.max()) <= 1e-3 * max(1.0, float(np.abs(b).max())) and float(diff.mean()) <= 5e-6, \
+            (net, float(diff.max()), float(diff.mean()))
