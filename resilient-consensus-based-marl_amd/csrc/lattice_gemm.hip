@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
 }
 
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
-template <int NSTAGE>
+template <int NSTAGE, int DBG = 0>
 __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
                                                              const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
                                                              const float* __restrict__ alpha, float* __restrict__ theta,
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
-  else lat_mainloop<PA, PB, MT, NT, NSTAGE>(op, (B + 31) >> 5, lds, acc);
+  else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
@@ -735,6 +735,19 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   const int ns = lat_stages();
   const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
+  static const int dbgm = getenv("RCMARL_LAT_DBG") ? atoi(getenv("RCMARL_LAT_DBG")) : 0;
+  if (ns == 2 && dbgm != 0 && dbgm < 8) {
+#define RC_DBG_CASE(M)                                                                                               \
+    if (dbgm == M) {                                                                                                 \
+      if (!lat_want_lds(k_lat_backward_sgd<2, M>, smem)) return RCMARL_ERR_LAUNCH;                                   \
+      RCMARL_LAUNCH((k_lat_backward_sgd<2, M>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, \
+                    (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles,  \
+                    ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);          \
+    }
+    RC_DBG_CASE(1) RC_DBG_CASE(2) RC_DBG_CASE(3) RC_DBG_CASE(7)
+#undef RC_DBG_CASE
+    return rcmarl_check_launch();
+  }
   if (ns == 2) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
