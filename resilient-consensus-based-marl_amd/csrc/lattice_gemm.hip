@@ -174,6 +174,7 @@ struct LatOperands {
   const unsigned char* a; const unsigned char* b;   // seed base of each packed operand
   int a_kt, b_kt;                                   // allocated k-tiles (block stride along the row-tile axis)
   int art0, brt0;                                   // first 128-row tile of this workgroup on each side
+  int pf = 0;                                       // > 0: touch the 3-piece operand's k-tile t+pf (L2 prefetch)
 };
 
 // DBG (measurement aid, RCMARL_LAT_DBG; results are WRONG for DBG != 0): bit 0 = no LDS-DMA after the prologue,
@@ -234,6 +235,19 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
     offB[nt] = C::A_KB * 1024 + (row >> 7) * PB * RC_PK_BLOCK + (row & 127) * 64;
   }
 
+  // L2 prefetch (op.pf > 0, NSTAGE 2): the 3-piece operand is streamed from HBM once per workgroup, and the LDS ring
+  // gives its loads only one k-tile of lead.  Lanes 0..191 of the workgroup each touch one 128-B line of k-tile
+  // t + pf (24 KiB, contiguous in the packed format) with a plain load whose result is never used; the DMA of that
+  // tile then finds its lines in L2.  The touch is the YOUNGEST memory instruction of its wavefront when the next
+  // k-tile starts, so the wait before the barrier is vmcnt(1) there: it never waits for the prefetch itself.
+  static_assert(PA == 3 ? C::ART == 1 : (PB != 3 || C::BRT == 1), "the 3-piece side is one 128-row tile wide");
+  const int pfd = (NSTAGE == 2 && (PA == 3 || PB == 3)) ? op.pf : 0;
+  const bool pf_wave = wave < 3;
+  const unsigned char* pf_src = (PA == 3 ? op.a + (long)op.art0 * op.a_kt * (3 * RC_PK_BLOCK)
+                                         : op.b + (long)op.brt0 * op.b_kt * (3 * RC_PK_BLOCK)) + threadIdx.x * 128;
+  float pfv = 0.f;
+  bool pf_flying = false;
+
   // ring of NSTAGE stages: tile t+NSTAGE-1 is requested right after the barrier that retires tile t-1
   stage(0, 0);
   if (NSTAGE == 3 && n_ktiles > 1) stage(1, 1);
@@ -241,13 +255,20 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
   for (int t = 0; t < n_ktiles; ++t) {
     // this wavefront's bursts of tile t have landed (NSTAGE 3: tile t+1's may still be in flight) ...
     if (!(DBG & 2) || t == 0) {
-      if (NSTAGE == 3 && t + 1 < n_ktiles) RC_WAIT_VMEM_N(C::GLDS); else RC_WAIT_VMEM();
+      if (NSTAGE == 3 && t + 1 < n_ktiles) RC_WAIT_VMEM_N(C::GLDS);
+      else if (pf_flying && pf_wave) RC_WAIT_VMEM_N(1);
+      else RC_WAIT_VMEM();
       __syncthreads();              // ... and everybody's; all reads of the buffer refilled next are done
     }
     if (t + NSTAGE - 1 < n_ktiles && !(DBG & 1)) {
       const int nb = cur == 0 ? NSTAGE - 1 : cur - 1;           // (t + NSTAGE - 1) % NSTAGE
       stage(nb, t + NSTAGE - 1);
     }
+    pf_flying = pfd > 0 && t + pfd < n_ktiles;
+#ifndef RCMARL_EMU
+    if (pf_flying && pf_wave)
+      asm volatile("global_load_dword %0, %1, off" : "=v"(pfv) : "v"(pf_src + (long)(t + pfd) * (3 * RC_PK_BLOCK)) : "memory");
+#endif
     const unsigned char* st = lds + ((DBG & 4) ? 0 : cur) * C::STAGE_BYTES;
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
 #pragma unroll
@@ -273,6 +294,12 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
     }
   }
+#ifndef RCMARL_EMU
+  if (pfd > 0) {                    // the register of the last touch must not be reused while that load is in flight
+    RC_WAIT_VMEM();
+    asm volatile("" ::"v"(pfv));
+  }
+#endif
 }
 
 // The same k-loop on a ring of FOUR half-stages (k16 each, 20 KiB; same 80 KiB of LDS): the loads of half-stage
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   int s, w;
   lat_decode(mtiles * ntiles, S, s, w);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
-  lat_prio((stg_bit >> 8) - 1);
+  lat_prio(((stg_bit >> 8) & 0xff) - 1);
   // Tile order inside a seed: the n-tiles are walked in chunks of `cw` (dbg_same_tile bits 8..), m-major inside a
   // chunk, n fastest.  The workgroups resident on an XCD (64) then share ONE chunk of the replay operand (cw x 256 KiB
   // at 512 inputs) plus a sliding window of W' panels -- inside the 4-MiB L2 -- instead of all n-tiles (3 MiB) plus
@@ -446,6 +473,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   LatOperands op;
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
   op.b = kp + (long)s * kp_rt * kp_kt * (PB * RC_PK_BLOCK); op.b_kt = kp_kt; op.brt0 = bn * C::BRT;
+  op.pf = (stg_bit >> 24) & 0xf;
   if (dbg_same_tile) {              // measurement aid only (RCMARL_LAT_SAMETILE=1): every workgroup streams ONE
     op.a = wp; op.art0 = 0;         // panel pair, i.e. the k-loop with a perfectly cached memory system
     op.b = kp; op.brt0 = 0;
@@ -523,11 +551,15 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   int s, w;
   lat_decode(mtiles * ntiles, S, s, w);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
-  lat_prio((stg_bit >> 8) - 1);
+  lat_prio(((stg_bit >> 8) & 0xff) - 1);
   const int bm = w % mtiles, bn = w / mtiles;                      // m fastest: neighbours share the dz panel
   LatOperands op;
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
+  op.pf = (stg_bit >> 24) & 0xf;
+  if (DBG & 8) {                    // measurement aid: every workgroup streams the same panel pair (all L2 hits)
+    op.a = ktp; op.art0 = 0; op.b = dzp; op.brt0 = 0;
+  }
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
   else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG>(op, (B + 31) >> 5, lds, acc);
@@ -615,7 +647,8 @@ bool lat_want_lds(K kernel, size_t smem) {
 int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 // packed scheduling knobs handed to the kernels: bits 0-7 = stagger bit + 1 (0 = off), bits 8.. = priority bit + 1
 int lat_stagger_bit() {
-  static int v = ((lat_env_int("RCMARL_LAT_PRIO_BIT", -1) + 1) << 8) | ((lat_env_int("RCMARL_LAT_STAGGER_BIT", -1) + 1) & 0xff);
+  static int v = ((lat_env_int("RCMARL_LAT_PF", 0) & 0xf) << 24) | (((lat_env_int("RCMARL_LAT_PRIO_BIT", -1) + 1) & 0xff) << 8) |
+                 ((lat_env_int("RCMARL_LAT_STAGGER_BIT", -1) + 1) & 0xff);
   return v;
 }
 int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
@@ -736,7 +769,7 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
   static const int dbgm = getenv("RCMARL_LAT_DBG") ? atoi(getenv("RCMARL_LAT_DBG")) : 0;
-  if (ns == 2 && dbgm != 0 && dbgm < 8) {
+  if (ns == 2 && dbgm != 0 && dbgm <= 8) {
 #define RC_DBG_CASE(M)                                                                                               \
     if (dbgm == M) {                                                                                                 \
       if (!lat_want_lds(k_lat_backward_sgd<2, M>, smem)) return RCMARL_ERR_LAUNCH;                                   \
@@ -744,7 +777,7 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
                     (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles,  \
                     ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);          \
     }
-    RC_DBG_CASE(1) RC_DBG_CASE(2) RC_DBG_CASE(3) RC_DBG_CASE(7)
+    RC_DBG_CASE(1) RC_DBG_CASE(2) RC_DBG_CASE(3) RC_DBG_CASE(7) RC_DBG_CASE(8)
 #undef RC_DBG_CASE
     return rcmarl_check_launch();
   }
