@@ -306,6 +306,9 @@ ROOFLINE_KIND = {
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
                                "dz1 pieces written = 200 B; the kernel is VALU-issue-bound today (PMC: 1929 VALU + 769 SALU "
                                "instructions and 64 f32 MFMAs per wavefront), DESIGN.md section 3"),
+    "rcmarl_minibatch_fit": ("mfma_f32", "the adversaries' fit(batch_size=32, epochs=10): 940 sequentially DEPENDENT SGD steps per "
+                             "network, one wavefront per network (6 us per step): bound by the latency of one step, not by a pipe; "
+                             "flops = 6 per weight per row"),
     "rcmarl_mid_fit": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 read + 20 fp32 written"),
     "rcmarl_w1_split": ("hbm", "reads W1 (4 B/weight), writes three bf16 pieces (6 B/weight)"),
     "rcmarl_layer1_forward_lattice": ("mfma_bf16x3", ""),
@@ -359,7 +362,7 @@ def rooflines(tlib, ksum, workload=None):
         return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "launches": n, "avg_us": avg_us,
                 "algorithmic_flops_per_launch": flops / n,
-                "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
+                "note": note or "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
     gemm = next((k for k in ("rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward") if k in ksum), None)
     k1 = next((k for k in ("rcmarl_consensus_params_circulant", "rcmarl_consensus_params") if k in ksum), None)
     return (obj(dom), obj(k1) if k1 else None,

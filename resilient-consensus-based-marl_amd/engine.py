@@ -201,9 +201,11 @@ class RPBCACEngine:
                          for l in c.agent_label], dtype=np.int32)
         self.fit_mode = torch.tensor(mode, **i32)
         self.episode = 0                      # global episode counter
+        self.rows_episode_aligned = True      # every replay row so far came from a full max_ep_len-step episode of ours
         self.timers = {"rollout": 0.0, "phase1": 0.0, "phase2": 0.0, "phase3": 0.0, "blocks": 0}
         self.gpow = [float(c.gamma ** j) for j in range(c.max_ep_len)]
         self._init_lattice()
+        self._term_rows = {}                  # B -> device indices of the last row of every episode
         self.initial_state = None             # used when randomize_state is False
         self.np_rngs = None                   # rng_mode='numpy': one RandomState-like object per seed
 
@@ -464,6 +466,7 @@ class RPBCACEngine:
         for k, v in (("s", s), ("ns", ns), ("a", a), ("r", r), ("sa", sa)):
             self.rp[k][seed_idx, :B] = torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
         self.B = B
+        self.rows_episode_aligned = False      # caller-supplied rows: no assumption about episode boundaries
 
     def dump_replay(self, seed_idx=0):
         B = self.B
@@ -485,7 +488,8 @@ class RPBCACEngine:
               "adam_t": self.adam_t, "cur": self.cur, "labels": list(c.agent_label), "in_nodes": c.in_nodes,
               "theta": {k: v.detach().cpu() for k, v in self.theta.items()},
               "replay": {k: v[:, :self.B].detach().cpu() for k, v in self.rp.items()},
-              "pos": self.pos[self.cur].detach().cpu(), "xs": self.xs[self.cur].detach().cpu()}
+              "pos": self.pos[self.cur].detach().cpu(), "xs": self.xs[self.cur].detach().cpu(),
+              "rows_episode_aligned": self.rows_episode_aligned}
         for k in self._CKPT_TENSORS:
             sd[k] = getattr(self, k).detach().cpu()
         if hasattr(self, "adv"):
@@ -519,6 +523,7 @@ class RPBCACEngine:
                 self.np_rngs.append(r)
         self.a1_cached["critic"] = self.a1_cached["tr"] = False
         self.lat_active = False
+        self.rows_episode_aligned = bool(sd.get("rows_episode_aligned", False))
 
     def save_checkpoint(self, path):
         torch.save(self.state_dict(), path)
@@ -717,6 +722,41 @@ class RPBCACEngine:
                                       self.coop.data_ptr(), self.S, self.N, self.ldp[net], g_hid, c.d, c.H, None, None,
                                       self.stream)
 
+    def _td_target(self, B):
+        """y = r_applied + gamma * V_critic(ns)   (agents/resilient_CAC_agents.py:114-115), all agents, all rows.
+        Inside an episode the next state of row b IS the state of row b+1 (training/train_agents.py:66-80 appends
+        s, ns step by step), and the consensus step of the previous epoch left the live critic's layer-1 activations on
+        the s rows in a1net["critic"] (hidden layers have not moved since): 19 of 20 next-state values come from those
+        activations shifted by one row; only the last step of every episode needs a forward pass of its own (1/20 of
+        the rows, f32-MFMA kernel).  Saves one forward GEMM + one W1 split per epoch."""
+        c, L, S, N = self.cfg, self.lib, self.S, self.N
+        ep = c.max_ep_len
+        ok = (self.td_shortcut and self.a1_cached["critic"] and self.rows_episode_aligned and not self.wide and ep >= 2
+              and B % ep == 0)
+        th, y, r = self.theta["critic"], self.ybuf["y_c"], self.ybuf["r_fit"]
+        if not ok:
+            self._value("ns", th, "critic", y, B, r_applied=r)
+            return
+        a1 = self.a1net["critic"]
+        # (1) rows whose successor is the next row: value head on the activations of row b+1
+        L.rcmarl_mid_value(a1.data_ptr() + 4, th.data_ptr(), r.data_ptr(), c.gamma, y.data_ptr(), S, N, B - 1, self.in_c, HID,
+                           self.ldp["critic"], self.ldb, self.stream)
+        # (2) the last step of every episode
+        idx = self._term_rows.get(B)
+        if idx is None:
+            idx = self._term_rows[B] = torch.arange(ep - 1, B, ep, device=self.dev)
+        nt = idx.numel()
+        ns_term = self.rp["ns"][:, :B].index_select(1, idx).contiguous()
+        L.rcmarl_layer1_forward(ns_term.data_ptr(), nt * self.in_c, th.data_ptr(), self.a1t.data_ptr(), S, N, nt, self.in_c, HID,
+                                self.ldp["critic"], self.ldb, self.stream)
+        v = self.ybuf["v_next"]
+        L.rcmarl_mid_value(self.a1t.data_ptr(), th.data_ptr(), None, c.gamma, v.data_ptr(), S, N, nt, self.in_c, HID,
+                           self.ldp["critic"], self.ldb, self.stream)
+        # r + gamma*v in fp32, multiply then add like the kernel (no fused multiply-add)
+        y[:, :, idx] = r[:, :, idx] + torch.mul(v[:, :, :nt], np.float32(c.gamma))
+
+    td_shortcut = os.environ.get("RCMARL_TD_SHORTCUT", "1") not in ("0", "false")
+
     def _consensus(self, net, xkey, B):
         """Phase II for one network family: hidden-layer consensus (K1), then estimate
         consensus + projection step of the output layer (K2+K3)."""
@@ -788,7 +828,7 @@ class RPBCACEngine:
                     join = torch.cuda.Event()
                     join.record(self.side_stream)
                 self.msg["critic"].copy_(self.theta["critic"])
-                self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
+                self._td_target(B)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
                 main.wait_event(join)
             else:
@@ -797,7 +837,7 @@ class RPBCACEngine:
                 # TD target first (it depends on the live critic only), so the adversaries' message generators --
                 # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
                 # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
-                self._value("ns", self.theta["critic"], "critic", self.ybuf["y_c"], B, r_applied=self.ybuf["r_fit"])
+                self._td_target(B)
                 join = self._adversary_messages_async(B)
                 self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)

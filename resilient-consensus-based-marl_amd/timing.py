@@ -34,6 +34,9 @@ WORK = {
                                          10.0 * a[7] * a[8] * a[9] * a[11]),
     # theta, alpha, wp, S, N, in_dim, hid: reads W1 (4 B), writes 3 pieces (6 B)
     "rcmarl_w1_split": lambda a: (0.0, 10.0 * a[3] * a[4] * a[5] * a[6]),
+    # x, x_seed_stride, theta, agents, n_adv, y, perm, S, N, B, in_dim, hid, ..., batch_size, epochs: whole Keras fit() of
+    # n_adv networks per seed: epochs x B rows x (forward + backward ~ 6 flops per weight)
+    "rcmarl_minibatch_fit": lambda a: (6.0 * a[7] * a[4] * a[15] * a[9] * (a[10] * a[11] + a[11] * a[11] + a[11]), 0.0),
     # wide path (csrc/wide_kernels.hip): dense per-agent GEMMs, 2*S*N*B*K*J flops
     # in, zs, za, rm, ld, theta, w_off, b_off, out, S, N, B, K, J
     "rcmarl_dense_forward": lambda a: (2.0 * a[9] * a[10] * a[11] * a[12] * a[13], 0.0),
