@@ -722,38 +722,52 @@ class RPBCACEngine:
                                       self.coop.data_ptr(), self.S, self.N, self.ldp[net], g_hid, c.d, c.H, None, None,
                                       self.stream)
 
-    def _td_target(self, B):
-        """y = r_applied + gamma * V_critic(ns)   (agents/resilient_CAC_agents.py:114-115), all agents, all rows.
-        Inside an episode the next state of row b IS the state of row b+1 (training/train_agents.py:66-80 appends
-        s, ns step by step), and the consensus step of the previous epoch left the live critic's layer-1 activations on
-        the s rows in a1net["critic"] (hidden layers have not moved since): 19 of 20 next-state values come from those
-        activations shifted by one row; only the last step of every episode needs a forward pass of its own (1/20 of
-        the rows, f32-MFMA kernel).  Saves one forward GEMM + one W1 split per epoch."""
+    def _cached_rows_ok(self, net, row0, nrows):
+        """May values of `net` on replay rows row0..row0+nrows come from the activations the consensus step left in
+        a1net[net]?  (live net unchanged since, rows are whole episodes of ours, 20-unit net)"""
+        ep = self.cfg.max_ep_len
+        return (self.td_shortcut and self.a1_cached[net] and self.rows_episode_aligned and self.hid[net] == HID and ep >= 2
+                and row0 % ep == 0 and nrows % ep == 0)
+
+    def _value_cached(self, net, out, row0, nrows, r_applied=None):
+        """out[:, :, 0:nrows] = head(a1net[net][:, :, row0:row0+nrows])  [r_applied + gamma * that]"""
+        self.lib.rcmarl_mid_value(self.a1net[net].data_ptr() + 4 * row0, self.theta[net].data_ptr(), self._p(r_applied),
+                                  self.cfg.gamma, out.data_ptr(), self.S, self.N, nrows, self.in_dim[net], HID,
+                                  self.ldp[net], self.ldb, self.stream)
+
+    def _value_next_cached(self, out, row0, nrows, r_applied, scratch):
+        """Critic values of the NEXT states of rows row0..row0+nrows (out = V, or r_applied + gamma V).  Inside an episode
+        the next state of row b IS the state of row b+1 (training/train_agents.py:66-80 appends s, ns step by step), so 19
+        of 20 values come from the cached activations of the s rows shifted by one row; only the last step of every
+        episode needs a forward pass of its own (f32-MFMA kernel on the gathered ns rows)."""
         c, L, S, N = self.cfg, self.lib, self.S, self.N
-        ep = c.max_ep_len
-        ok = (self.td_shortcut and self.a1_cached["critic"] and self.rows_episode_aligned and not self.wide and ep >= 2
-              and B % ep == 0)
-        th, y, r = self.theta["critic"], self.ybuf["y_c"], self.ybuf["r_fit"]
-        if not ok:
-            self._value("ns", th, "critic", y, B, r_applied=r)
-            return
-        a1 = self.a1net["critic"]
-        # (1) rows whose successor is the next row: value head on the activations of row b+1
-        L.rcmarl_mid_value(a1.data_ptr() + 4, th.data_ptr(), r.data_ptr(), c.gamma, y.data_ptr(), S, N, B - 1, self.in_c, HID,
-                           self.ldp["critic"], self.ldb, self.stream)
-        # (2) the last step of every episode
-        idx = self._term_rows.get(B)
+        ep, th = c.max_ep_len, self.theta["critic"]
+        L.rcmarl_mid_value(self.a1net["critic"].data_ptr() + 4 * (row0 + 1), th.data_ptr(), self._p(r_applied), c.gamma,
+                           out.data_ptr(), S, N, nrows - 1, self.in_c, HID, self.ldp["critic"], self.ldb, self.stream)
+        key = (row0, nrows)
+        idx = self._term_rows.get(key)
         if idx is None:
-            idx = self._term_rows[B] = torch.arange(ep - 1, B, ep, device=self.dev)
+            idx = self._term_rows[key] = torch.arange(ep - 1, nrows, ep, device=self.dev)
         nt = idx.numel()
-        ns_term = self.rp["ns"][:, :B].index_select(1, idx).contiguous()
+        ns_term = self.rp["ns"][:, row0:row0 + nrows].index_select(1, idx).contiguous()
         L.rcmarl_layer1_forward(ns_term.data_ptr(), nt * self.in_c, th.data_ptr(), self.a1t.data_ptr(), S, N, nt, self.in_c, HID,
                                 self.ldp["critic"], self.ldb, self.stream)
-        v = self.ybuf["v_next"]
-        L.rcmarl_mid_value(self.a1t.data_ptr(), th.data_ptr(), None, c.gamma, v.data_ptr(), S, N, nt, self.in_c, HID,
+        L.rcmarl_mid_value(self.a1t.data_ptr(), th.data_ptr(), None, c.gamma, scratch.data_ptr(), S, N, nt, self.in_c, HID,
                            self.ldp["critic"], self.ldb, self.stream)
-        # r + gamma*v in fp32, multiply then add like the kernel (no fused multiply-add)
-        y[:, :, idx] = r[:, :, idx] + torch.mul(v[:, :, :nt], np.float32(c.gamma))
+        if r_applied is None:
+            out[:, :, idx] = scratch[:, :, :nt]
+        else:        # r + gamma*v in fp32, multiply then add like the kernel (no fused multiply-add)
+            out[:, :, idx] = r_applied[:, :, idx] + torch.mul(scratch[:, :, :nt], np.float32(c.gamma))
+
+    def _td_target(self, B):
+        """y = r_applied + gamma * V_critic(ns)   (agents/resilient_CAC_agents.py:114-115), all agents, all rows: from the
+        activations the previous epoch's consensus step left behind where possible (one forward GEMM and one W1 split
+        less per epoch), else by a forward pass over the ns rows."""
+        y, r = self.ybuf["y_c"], self.ybuf["r_fit"]
+        if self._cached_rows_ok("critic", 0, B):
+            self._value_next_cached(y, 0, B, r, self.ybuf["v_next"])
+        else:
+            self._value("ns", self.theta["critic"], "critic", y, B, r_applied=r)
 
     td_shortcut = os.environ.get("RCMARL_TD_SHORTCUT", "1") not in ("0", "false")
 
@@ -864,9 +878,18 @@ class RPBCACEngine:
         c, L, S, N = self.cfg, self.lib, self.S, self.N
         nl = self.n_last
         row0 = B - nl
-        self._value("sa", self.theta["tr"], "tr", self.ybuf["v_tr"], nl, row0)
-        self._value("ns", self.theta["critic"], "critic", self.ybuf["v_next"], nl, row0)
-        self._value("s", self.theta["critic"], "critic", self.ybuf["v_cur"], nl, row0)
+        # team-average TD error (agents/resilient_CAC_agents.py:95-98): the last consensus step left the layer-1
+        # activations of the live TR net and critic on every row, so no forward GEMM is needed here
+        if self._cached_rows_ok("tr", row0, nl):
+            self._value_cached("tr", self.ybuf["v_tr"], row0, nl)
+        else:
+            self._value("sa", self.theta["tr"], "tr", self.ybuf["v_tr"], nl, row0)
+        if self._cached_rows_ok("critic", row0, nl):
+            self._value_next_cached(self.ybuf["v_next"], row0, nl, None, self.ybuf["delta"])
+            self._value_cached("critic", self.ybuf["v_cur"], row0, nl)
+        else:
+            self._value("ns", self.theta["critic"], "critic", self.ybuf["v_next"], nl, row0)
+            self._value("s", self.theta["critic"], "critic", self.ybuf["v_cur"], nl, row0)
         L.rcmarl_td_error(self.ybuf["v_tr"].data_ptr(), self.ybuf["v_next"].data_ptr(), self.ybuf["v_cur"].data_ptr(),
                           c.gamma, self.ybuf["delta"].data_ptr(), S * N * self.ldb, self.stream)
         aptr, astride = self._x("a", row0)
