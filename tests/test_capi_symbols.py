@@ -52,7 +52,32 @@ def test_argument_validation_needs_no_gpu():
         ("rcmarl_mid_fit_lattice", (None, None, None, None, None, 0, 0, 1, 5, 100, 10, 20, 704, 128, None)),
         ("rcmarl_shuffle_perms", (None, None, 1, 1, 100, None, 1, None)),
         ("rcmarl_mid_fit", (None, None, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
+        ("rcmarl_consensus_params_circulant", (None, None, None, 1, 5, 64, 40, 4, 1, None, None, None)),
+        ("rcmarl_lattice_pack_dz", (None, None, 1, 5, 100, 20, 128, 1, 4, None)),
+        ("rcmarl_dense_forward", (None, 0, 0, 1, 10, None, 0, 200, None, 1, 5, 100, 10, 32, 1472, 128, None)),
+        ("rcmarl_dense_backward_data", (None, None, 0, None, None, 1, 5, 100, 32, 32, 1472, 128, None)),
+        ("rcmarl_dense_backward_sgd", (None, 0, 0, 1, 10, None, None, 0, None, 1, 5, 100, 10, 32, 1472, 128, 0.01, None)),
+        ("rcmarl_wide_head_value", (None, None, None, 0.9, None, 1, 5, 100, 10, 32, 1472, 128, None)),
+        ("rcmarl_wide_head_fit", (None, None, None, None, None, None, 1, 5, 100, 10, 32, 1472, 128, None)),
+        ("rcmarl_wide_bias_grad", (None, None, 1, 5, 100, 32, 128, None)),
+        ("rcmarl_wide_small_sgd", (None, None, None, None, None, 1, 5, 100, 10, 32, 1472, 0.01, None)),
+        ("rcmarl_wide_consensus_head", (None, None, None, None, None, None, None, None, None, None, None, None, 1, 5, 100, 10, 32,
+                                        1472, 128, 4, 1, None)),
+        ("rcmarl_wide_head_apply", (None, None, None, 1, 5, 100, 10, 32, 1472, None)),
     ]
     for name, args in bad:
         with pytest.raises(capi.RcmarlError, match="RCMARL_ERR_ARG|RCMARL_ERR_UNSUPPORTED"):
             getattr(lib, name)(*args)
+
+
+def test_circulant_kernel_coverage_query():
+    """Host-only query: which (N, d, H) the circulant consensus kernel serves (d = 2H+2 with a generated shared network,
+    tile image within the LDS); everything else must go through the general entry point."""
+    from rcmarl_amd import build, capi
+    lib = capi.CLib(build.build_hip())
+    q = lib.rcmarl_consensus_params_circulant_supported
+    assert q(256, 18, 8) == 1 and q(5, 4, 1) == 1 and q(1024, 66, 32) == 1 and q(64, 10, 4) == 1
+    assert q(256, 18, 1) == 0          # d != 2H+2
+    assert q(256, 20, 9) == 0          # no generated network
+    assert q(3, 4, 1) == 0             # d > N
+    assert q(5000, 18, 8) == 0         # [N][16] tile image exceeds the LDS
