@@ -869,6 +869,8 @@ class RPBCACEngine:
         # IV) trim the replay buffer (after the update, train_agents.py:158-163)
         if B > c.buffer_size:
             q = B - c.buffer_size
+            if q % c.max_ep_len:                   # the buffer no longer starts at an episode boundary
+                self.rows_episode_aligned = False
             for k in self.rp:
                 self.rp[k][:, :c.buffer_size] = self.rp[k][:, q:B].clone()
             self.B = c.buffer_size

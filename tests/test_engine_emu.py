@@ -78,3 +78,12 @@ def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
     for net in ("actor", "critic", "tr"):
         np.testing.assert_array_equal(a.get_all_weights(net), c.get_all_weights(net))
     np.testing.assert_array_equal(a.adam_m.numpy(), c.adam_m.numpy())
+
+
+def test_engine_buffer_not_a_multiple_of_the_episode_length():
+    """The replay trim may cut an episode in two (buffer_size % max_ep_len != 0): the TD-target shortcut that reads the
+    next state's value from the following row must switch itself off; results still match the oracle."""
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=6, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=7, seed=61)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(61,))
+    assert not eng.rows_episode_aligned
+    EC.compare(eng, logs, o_logs, o_w)
