@@ -41,14 +41,24 @@ __device__ __forceinline__ void load_a1(const float* __restrict__ a1t, long row0
 template <int HID>
 __device__ __forceinline__ void layer2(const float* __restrict__ th, const NetGeom& g, const float (&a1)[HID],
                                        float (&a2)[HID]) {
+  // two output units per instruction (v_pk_fma_f32; the weight pair is two consecutive floats of a W2 row, a scalar
+  // operand): every unit keeps its own fmaf chain over j, so the values are those of the scalar form bit for bit
+  static_assert(HID % 2 == 0, "units are processed in pairs");
+  rc_f2 acc[HID / 2];
 #pragma unroll
-  for (int k = 0; k < HID; ++k) a2[k] = 0.f;
+  for (int q = 0; q < HID / 2; ++q) acc[q] = rc_bcast2(0.f);
 #pragma unroll
-  for (int j = 0; j < HID; ++j)
+  for (int j = 0; j < HID; ++j) {
+    const rc_f2 aj = rc_bcast2(a1[j]);
 #pragma unroll
-    for (int k = 0; k < HID; ++k) a2[k] = fmaf(a1[j], th[g.o_W2 + j * HID + k], a2[k]);
+    for (int q = 0; q < HID / 2; ++q)
+      acc[q] = rc_fma2(aj, rc_f2{th[g.o_W2 + j * HID + 2 * q], th[g.o_W2 + j * HID + 2 * q + 1]}, acc[q]);
+  }
 #pragma unroll
-  for (int k = 0; k < HID; ++k) a2[k] = rc_lrelu(a2[k] + th[g.o_b2 + k]);
+  for (int q = 0; q < HID / 2; ++q) {
+    a2[2 * q] = rc_lrelu(acc[q].x + th[g.o_b2 + 2 * q]);
+    a2[2 * q + 1] = rc_lrelu(acc[q].y + th[g.o_b2 + 2 * q + 1]);
+  }
 }
 
 template <int HID>
