@@ -408,8 +408,7 @@ __device__ __forceinline__ void lat_mainloop_half(const LatOperands& op, int n_k
 }
 
 // workgroup id -> (seed, tile w within the seed); all tiles of a seed on one XCD when S % 8 == 0
-__device__ __forceinline__ void lat_decode(int per_seed, int S, int& seed, int& w) {
-  const int g = blockIdx.x;
+__device__ __forceinline__ void lat_decode(int g, int per_seed, int S, int& seed, int& w) {
   if ((S & 7) == 0) {
     const int xcd = g & 7, q = g >> 3;
     seed = xcd + 8 * (q / per_seed);
@@ -451,24 +450,25 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   constexpr int PA = 3, PB = 1, MT = 2, NT = 4;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
-  int s, w;
-  lat_decode(mtiles * ntiles, S, s, w);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
   lat_prio(((stg_bit >> 8) & 0xff) - 1);
+  const int cw = dbg_same_tile >> 8;
+  dbg_same_tile &= 0xff;
+  // persistent form (RCMARL_LAT_PERSIST): the grid is one resident wave of workgroups, each walks tiles g, g + grid, ..
+  // (g & 7 stays the XCD, so a seed's tiles stay on one XCD); otherwise the grid covers the tiles and this runs once
+  for (int g = blockIdx.x; g < S * mtiles * ntiles; g += gridDim.x) {
+  int s, w;
+  lat_decode(g, mtiles * ntiles, S, s, w);
   // Tile order inside a seed: the n-tiles are walked in chunks of `cw` (dbg_same_tile bits 8..), m-major inside a
   // chunk, n fastest.  The workgroups resident on an XCD (64) then share ONE chunk of the replay operand (cw x 256 KiB
   // at 512 inputs) plus a sliding window of W' panels -- inside the 4-MiB L2 -- instead of all n-tiles (3 MiB) plus
   // five W' panels (PMC: 2.6 GB fetched per launch for 0.3 GB of operands with the plain n-fastest order).
   int bn, bm;
-  {
-    const int cw = dbg_same_tile >> 8;
-    if (cw <= 0 || cw >= ntiles) { bn = w % ntiles; bm = w / ntiles; }
-    else {
-      const int per_chunk = mtiles * cw, c = w / per_chunk, r = w - c * per_chunk;
-      const int wc = min(cw, ntiles - c * cw);
-      bm = r / wc; bn = c * cw + (r - bm * wc);
-    }
-    dbg_same_tile &= 0xff;
+  if (cw <= 0 || cw >= ntiles) { bn = w % ntiles; bm = w / ntiles; }
+  else {
+    const int per_chunk = mtiles * cw, c = w / per_chunk, r = w - c * per_chunk;
+    const int wc = min(cw, ntiles - c * cw);
+    bm = r / wc; bn = c * cw + (r - bm * wc);
   }
   LatOperands op;
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
@@ -534,6 +534,8 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
     }
   };
   if (full_m) store_tile(std::true_type{}); else store_tile(std::false_type{});
+  __syncthreads();                  // (persistent form: the bias words share LDS with the next tile's first stage)
+  }
 }
 
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
@@ -548,10 +550,11 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
-  int s, w;
-  lat_decode(mtiles * ntiles, S, s, w);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
   lat_prio(((stg_bit >> 8) & 0xff) - 1);
+  for (int g = blockIdx.x; g < S * mtiles * ntiles; g += gridDim.x) {     // persistent form: see k_lat_forward
+  int s, w;
+  lat_decode(g, mtiles * ntiles, S, s, w);
   const int bm = w % mtiles, bn = w / mtiles;                      // m fastest: neighbours share the dz panel
   LatOperands op;
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
@@ -633,6 +636,8 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
       }
     }
   }
+  __syncthreads();                  // (persistent form: the alpha words share LDS with the next tile's first stage)
+  }
 }
 
 template <class K>
@@ -650,6 +655,17 @@ int lat_stagger_bit() {
   static int v = ((lat_env_int("RCMARL_LAT_PF", 0) & 0xf) << 24) | (((lat_env_int("RCMARL_LAT_PRIO_BIT", -1) + 1) & 0xff) << 8) |
                  ((lat_env_int("RCMARL_LAT_STAGGER_BIT", -1) + 1) & 0xff);
   return v;
+}
+// RCMARL_LAT_PERSIST=k (tuning knob, default 0 = one workgroup per tile): launch k resident waves of workgroups
+// (k x 256 CUs x workgroups per CU) and let each walk several tiles
+int lat_grid(int tiles, int ns) {
+  static const int k = lat_env_int("RCMARL_LAT_PERSIST", 0);
+#ifdef RCMARL_EMU
+  return k > 0 ? (tiles < 3 ? tiles : 3) : tiles;
+#else
+  const int resident = 256 * (ns == 3 ? 1 : 2) * k;
+  return (k > 0 && resident < tiles) ? resident : tiles;
+#endif
 }
 int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
 
@@ -720,7 +736,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   static const int dbg = (getenv("RCMARL_LAT_SAMETILE") ? (atoi(getenv("RCMARL_LAT_SAMETILE")) & 0xff) : 0) |
                          (lat_env_int("RCMARL_LAT_NCHUNK", 0) << 8);
   const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
-  const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
+  const dim3 grid((unsigned)lat_grid(S * mtiles * ntiles, ns)), block(256);
   static const int dbgm = getenv("RCMARL_LAT_DBG") ? atoi(getenv("RCMARL_LAT_DBG")) : 0;
   if (ns == 2 && dbgm != 0) {
 #define RC_DBG_CASE(M)                                                                                               \
@@ -767,7 +783,7 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   if (wp_out && (wp_rt < ntiles || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
   const int ns = lat_stages();
   const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
-  const dim3 grid((unsigned)(S * mtiles * ntiles)), block(256);
+  const dim3 grid((unsigned)lat_grid(S * mtiles * ntiles, ns)), block(256);
   static const int dbgm = getenv("RCMARL_LAT_DBG") ? atoi(getenv("RCMARL_LAT_DBG")) : 0;
   if (ns == 2 && dbgm != 0 && dbgm <= 8) {
 #define RC_DBG_CASE(M)                                                                                               \
