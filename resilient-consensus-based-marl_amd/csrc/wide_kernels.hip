@@ -23,6 +23,7 @@
 // (W dz) and backward-weights (x^T dz^T) without materialising a transpose.
 #include "rcmarl_common.h"
 #include <type_traits>
+#include "selnet_generated.inc"
 
 namespace {
 
@@ -393,6 +394,35 @@ __global__ __launch_bounds__(WSEL_ROWS) void k_wselect(const float* __restrict__
   if (agg_out) agg_out[o] = agg;
 }
 
+// the same with the generated selection network of (D, H) on registers (selnet_generated.inc) instead of rank counting
+template <int D, int H>
+__global__ __launch_bounds__(WSEL_ROWS) void k_wselect_net(const float* __restrict__ est, const float* __restrict__ phi,
+                                                           const int* __restrict__ coop, float* __restrict__ ebuf,
+                                                           float* __restrict__ agg_out, int N, int B, int hid, int ldb) {
+  const int s = blockIdx.z, i = blockIdx.y;
+  if (!coop[i]) return;
+  const int b = blockIdx.x * WSEL_ROWS + threadIdx.x;
+  if (b >= B) return;
+  const float* __restrict__ e0 = est + ((long)s * N + i) * (D + 1) * ldb + b;
+  float v[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) v[k] = e0[(long)k * ldb];
+  const float* __restrict__ col = phi + ((long)s * N + i) * hid * ldb + b;
+  float nrm = 0.f;
+  for (int k = 0; k < hid; ++k) { const float p = col[(long)k * ldb]; nrm = fmaf(p, p, nrm); }
+  nrm += 1.0f;
+  float lo, hi;
+  SelNet<D, H>::run(v, lo, hi);
+  const float lower = fminf(lo, v[0]), upper = fmaxf(hi, v[0]);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[k], lower, upper);
+  const float agg = sum / (float)D;
+  const long o = ((long)s * N + i) * ldb + b;
+  ebuf[o] = (agg - e0[(long)D * ldb]) / nrm;
+  if (agg_out) agg_out[o] = agg;
+}
+
 // residual toward a caller-supplied aggregate (critic_update_team(s, agg), :60-71): e = (agg - V_live)/(|phi|^2+1)
 __global__ __launch_bounds__(256) void k_wresidual(const float* __restrict__ phi, const float* __restrict__ theta,
                                                    const float* __restrict__ agg_in, const int* __restrict__ coop,
@@ -553,8 +583,18 @@ RCMARL_EXPORT int rcmarl_wide_consensus_head(const float* phi, const float* thet
     a.M = d + 1; a.N = B; a.K = hid; a.NA = N;
     const int rc = w_launch<true, false, WEPI_BIAS>(a, S, stream);
     if (rc != RCMARL_OK) return rc;
-    RCMARL_LAUNCH(k_wselect, dim3(rc_ceil_div(B, WSEL_ROWS), N, S), dim3(WSEL_ROWS), (size_t)d * WSEL_ROWS * sizeof(float),
-                  stream, (const float*)est, phi, coop, ebuf, agg_out, N, B, hid, ldb, d, H);
+    bool done = false;
+#define RC_WSEL_CASE(DD, HH)                                                                                        \
+    if (!done && d == DD && H == HH) {                                                                               \
+      RCMARL_LAUNCH((k_wselect_net<DD, HH>), dim3(rc_ceil_div(B, WSEL_ROWS), N, S), dim3(WSEL_ROWS), 0, stream,      \
+                    (const float*)est, phi, coop, ebuf, agg_out, N, B, hid, ldb);                                    \
+      done = true;                                                                                                   \
+    }
+    RCMARL_SELNET_COMBOS(RC_WSEL_CASE)
+#undef RC_WSEL_CASE
+    if (!done)
+      RCMARL_LAUNCH(k_wselect, dim3(rc_ceil_div(B, WSEL_ROWS), N, S), dim3(WSEL_ROWS), (size_t)d * WSEL_ROWS * sizeof(float),
+                    stream, (const float*)est, phi, coop, ebuf, agg_out, N, B, hid, ldb, d, H);
   }
   RCMARL_LAUNCH((k_wrows<WROW_DOT>), dim3(rc_ceil_div(hid + 1, 4), N, S), block, 0, stream, const_cast<float*>(phi),
                 (const float*)ebuf, (const float*)nullptr, coop, grads, 0, N, B, in_dim, hid, ldp, ldb);

@@ -133,6 +133,7 @@ def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
     WC.check_wide_fit(bk, S, N, B, in_dim, hid, steps=2, masked_agent=masked)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 72, 10, 32, 4, 1, "circ"), (1, 8, 140, 16, 24, 7, 2, "rand")])
+@pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 72, 10, 32, 4, 1, "circ"), (1, 8, 140, 16, 24, 7, 2, "rand"),
+                                                        (1, 24, 40, 8, 24, 23, 5, "rand")])     # no generated network: rank counting
 def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
