@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (it re-executes
+under torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1); a mismatch between --gpus and the
+ranks that actually joined aborts -- the line never reports a GPU count it did not run on.
+
 One "step" = one training block of the reference loop (training/train_agents.py:
 46-163): n_ep_fixed=50 episodes x max_ep_len=20 environment steps of rollout for
 every seed and agent, followed by the full update block (10 epochs of local
@@ -13,7 +17,9 @@ networks, on-device grid-world); arithmetic fp32 like the reference.
 
 Prints ONE JSON line (rank 0): metric = agent-steps/s (whole loop), plus
 consensus-updates/s, the per-kernel breakdown, `roofline` for the dominant
-kernel, `roofline_consensus` for the consensus kernel and `cpu_baseline`.
+kernel, `roofline_consensus` for the consensus kernel, `cpu_baseline`, and (N=1) `extra`: short runs of the
+other workloads in the same process, among them the north-star target shape whose consensus-kernel roofline is
+`roofline_consensus_target`.
 """
 import argparse
 import json
@@ -180,7 +186,60 @@ def cpu_baseline(w, budget_s=25.0):
 
 
 # --------------------------------------------------------------------------------------------
-def main():
+class StubEngine:
+    """Test double for the CONTROL path of this script (tests/test_bench_launcher.py): same surface as
+    RPBCACEngine as far as main() touches it, no GPU, no HIP library.  Selected with --stub-engine only; a
+    bench line produced with it says so in `data` and is not a measurement."""
+
+    class _Cfg:
+        n_ep_fixed, max_ep_len, n_epochs, fast_lr, slow_lr, critic_hid = 50, 20, 10, 0.01, 0.002, 20
+
+    def __init__(self, w, S, seeds):
+        self.cfg, self.S, self.N, self.seeds = self._Cfg(), S, w["N"], list(seeds)
+        self.n_coop, self.cap, self.blocks = w["N"], 3000, 0
+        self.timers = {"rollout": 0.0, "phase1": 0.0, "phase2": 0.0, "phase3": 0.0, "blocks": 0}
+        self.theta = {k: torch.zeros(1) for k in ("actor", "critic", "tr")}
+        self.profile_phases = False
+
+    def run_block(self):
+        time.sleep(0.01)
+        self.blocks += 1
+        if self.profile_phases:
+            for k in ("rollout", "phase1", "phase2", "phase3"):
+                self.timers[k] += 0.0025
+        E = self.cfg.n_ep_fixed
+        team = np.tile(-np.asarray(self.seeds, np.float64)[None, :], (E, 1))      # return of seed s == -s
+        return team, np.zeros_like(team), team + 1.0
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves
+    (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) and become that launcher.
+    The reference has no counterpart -- it runs one SGE job per seed (.../seed=100/job.sh:4)."""
+    if not args.stub_engine:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench: --gpus %d requested but only %d GPU(s) visible; refusing to report a %d-GPU number "
+                             "from fewer devices" % (args.gpus, have, args.gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -189,65 +248,149 @@ def main():
     ap.add_argument("--seeds-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other workloads (`extra`)")
+    ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY: CPU stub engine + gloo, exercises the launcher/"
+                    "barrier/all-reduce control path without a GPU")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from rcmarl_amd import capi
-    from rcmarl_amd.timing import TimedLib
+def time_blocks(eng, steps, warmup, barrier, S, dev, tlib=None, want_kernels=True):
+    """W untimed blocks, then exactly K timed blocks bracketed by barrier + synchronize; returns
+    (seconds on this rank, mean return curve over ALL ranks' seeds)."""
     from rcmarl_amd.parallel import allreduce_curves
-    w = WORKLOADS[args.workload]
-    S = args.seeds_per_gpu or w["S"]
-    seeds = [1000 + rank * S + k for k in range(S)]                # disjoint seed shards per rank
-    tlib = TimedLib(capi.load())
-    eng = make_engine(w, S, seeds, tlib)
-    N = w["N"]
-    c = eng.cfg
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.run_block()
     barrier()
-    tlib.enabled = not args.no_kernel_timing
-    tlib.reset()
+    if tlib is not None:
+        tlib.enabled = want_kernels
+        tlib.reset()
     curves = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         team, adv, est = eng.run_block()
         curves.append(np.stack([team.sum(1), adv.sum(1), est.sum(1)], axis=1))   # per-episode sums over local seeds
-    curve = allreduce_curves(np.concatenate(curves, 0), S, device=torch.device("cuda", local_rank))  # C1: RCCL all-reduce
+    curve = allreduce_curves(np.concatenate(curves, 0), S, device=dev)            # C1: the path's only collective
     barrier()
     dt = time.perf_counter() - t0
-    tlib.enabled = False
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    B_steady = eng.cap
+    if tlib is not None:
+        tlib.enabled = False
+    return dt, curve
 
-    # per-kernel breakdown of the timed region (HIP events on the launch stream)
-    ksum = tlib.summary()
-    # one extra, untimed block with phase synchronisation for the phase split
+
+def phase_split(eng):
+    """one extra, untimed block with a synchronisation at every phase boundary"""
     eng.profile_phases = True
     for k in eng.timers:
         eng.timers[k] = 0.0
     eng.run_block()
-    ph = dict(eng.timers)
     eng.profile_phases = False
+    return dict(eng.timers)
+
+
+def extra_workloads(main_name, tlib, barrier, dev):
+    """Short driver-timed runs of the OTHER workloads in the same process (1 warm-up + 2 timed blocks each), so the one
+    bench line also carries BASELINE configs[1], [2], [4] and the north-star target shape; K1's roofline on the target
+    shape is measured here with HIP events (`roofline_consensus_target`)."""
+    out, k1_target = {}, None
+    for name in ("target_N256_H1", "cfg3", "cfg2_batched", "cfg1_batched", "cfg5_1gpu"):
+        if name == main_name:
+            continue
+        w = WORKLOADS[name]
+        try:
+            S = w["S"]
+            t_setup = time.perf_counter()
+            eng = make_engine(w, S, [1000 + k for k in range(S)], tlib)
+            t_setup = time.perf_counter() - t_setup
+            steps = 2
+            dt, _ = time_blocks(eng, steps, 1, barrier, S, dev, tlib, want_kernels=True)
+            ksum = tlib.summary()
+            finite = all(bool(torch.isfinite(eng.theta[k]).all().item()) for k in ("actor", "critic", "tr"))
+            c = eng.cfg
+            env_steps = c.n_ep_fixed * c.max_ep_len
+            rec = {"description": w["desc"], "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 1,
+                   "agent_steps_per_s": S * w["N"] * env_steps * steps / dt,
+                   "consensus_updates_per_s": S * eng.n_coop * c.n_epochs * steps / dt,
+                   "weights_finite": finite, "fast_lr": c.fast_lr, "setup_s": round(t_setup, 2)}
+            if ksum:
+                tot_ms = sum(v[1] for v in ksum.values())
+                top = sorted(ksum.items(), key=lambda kv: -kv[1][1])[:4]
+                rec["top_kernels"] = {k.replace("rcmarl_", ""): {"avg_us": round(v[2], 2), "frac": round(v[1] / tot_ms, 4)}
+                                      for k, v in top}
+                _, k1, _ = rooflines(tlib, ksum, name)
+                if k1:
+                    rec["roofline_consensus"] = {k: k1[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_us",
+                                                                    "launches", "algorithmic_bytes_per_launch",
+                                                                    "traffic", "traffic_source")}
+                    if name == "target_N256_H1":
+                        k1_target = k1
+            out[name] = rec
+            del eng
+            torch.cuda.empty_cache()
+        except Exception as e:                                  # an extra must never kill the bench line
+            out[name] = {"error": repr(e)}
+    return out, k1_target
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args)                                       # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    import torch.distributed as dist
+    stub = args.stub_engine
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    if not stub:
+        torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if stub:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)           # "nccl" IS RCCL on ROCm
+        joined = dist.get_world_size()
+        if joined != args.gpus:
+            raise SystemExit("bench: %d ranks joined, --gpus %d" % (joined, args.gpus))
+        comm = {"backend": dist.get_backend(), "world_size": joined,
+                "rccl_version": None if stub else ".".join(str(v) for v in torch.cuda.nccl.version())}
+
+    w = WORKLOADS[args.workload]
+    S = args.seeds_per_gpu or w["S"]
+    seeds = [1000 + rank * S + k for k in range(S)]                # disjoint seed shards per rank
+    N = w["N"]
+    if stub:
+        tlib, eng = None, StubEngine(w, S, seeds)
+    else:
+        from rcmarl_amd import capi
+        from rcmarl_amd.timing import TimedLib
+        tlib = TimedLib(capi.load())
+        eng = make_engine(w, S, seeds, tlib)
+    c = eng.cfg
+
+    def barrier():
+        if not stub:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if not stub:
+            torch.cuda.synchronize()
+
+    dt, curve = time_blocks(eng, args.steps, args.warmup, barrier, S, dev, tlib, want_kernels=not args.no_kernel_timing)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                # the slowest rank's clock
+    dt = float(tmax.item())
+    B_steady = eng.cap
+
+    ksum = tlib.summary() if tlib is not None else {}              # per-kernel HIP-event times of the timed region
+    roof = rooflines(tlib, ksum, args.workload) if ksum else None  # (before the extras reset the counters)
+    ph = phase_split(eng)
 
     finite = all(bool(torch.isfinite(eng.theta[k]).all().item()) for k in ("actor", "critic", "tr"))
     if not finite:
@@ -261,31 +404,44 @@ def main():
             "metric": "agent-steps/sec (whole RPBCAC training loop; + consensus-updates/sec)",
             "value": agent_steps / dt, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not stub else "STUB ENGINE (control-path test, not a measurement)",
             "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
                        "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady, "fast_lr": c.fast_lr, "slow_lr": c.slow_lr, "weights_finite": finite,
                        "env_steps_per_block": env_steps, "n_epochs": c.n_epochs, "hidden": 20, "critic_hidden": c.critic_hid,
                        "parallelism": "seed-sharded, %d seeds/GPU x %d GPU, one all-reduce of return curves" % (S, world)},
+            "comm": comm,
             "consensus_updates_per_s": cons_updates / dt,
             "consensus_updates_per_s_phase2_only": (S * eng.n_coop * c.n_epochs) / ph["phase2"] if ph["phase2"] > 0 else None,
             "phase_seconds_per_block": {k: ph[k] for k in ("rollout", "phase1", "phase2", "phase3")},
             "phase_fraction": {k: ph[k] / ph_total for k in ("rollout", "phase1", "phase2", "phase3")} if ph_total > 0 else None,
             "mean_team_return_last_block": float(curve[-c.n_ep_fixed:, 0].mean()),
         }
+        if abs(c.fast_lr - 0.01) > 1e-12:
+            out["deviation"] = {"fast_lr": c.fast_lr, "reference": 0.01,
+                                "why": "the reference's plain full-batch SGD local fit diverges to NaN at this input width "
+                                       "with its logged fast_lr (the oracle reproduces it); work per step is unchanged"}
         if ksum:
             tot_ms = sum(v[1] for v in ksum.values())
             out["kernels"] = {k.replace("rcmarl_", ""): {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[2], 2),
                                                         "frac": round(v[1] / tot_ms, 4)} for k, v in
                               sorted(ksum.items(), key=lambda kv: -kv[1][1])}
-            out["roofline"], out["roofline_consensus"], out["roofline_gemm"] = rooflines(tlib, ksum, args.workload)
-        if not args.no_cpu_baseline and world == 1:
+            out["roofline"], out["roofline_consensus"], out["roofline_gemm"] = roof
+        if world == 1 and not stub and not args.no_extra:
+            del eng
+            torch.cuda.empty_cache()
+            out["extra"], k1t = extra_workloads(args.workload, tlib, barrier, dev)
+            if k1t is not None:
+                out["roofline_consensus_target"] = k1t
+        if not args.no_cpu_baseline and world == 1 and not stub:
             try:
                 out["cpu_baseline"] = cpu_baseline(w)
                 out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:                                     # the baseline must never kill the bench line
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -325,7 +481,9 @@ def _pmc_traffic(workload):
         return {}
     try:
         with open(files[-1]) as f:
-            return json.load(f).get("traffic_bytes_per_launch", {})
+            t = dict(json.load(f).get("traffic_bytes_per_launch", {}))
+        t["__source__"] = "profiles/" + os.path.basename(files[-1])
+        return t
     except Exception:
         return {}
 
@@ -341,15 +499,18 @@ def rooflines(tlib, ksum, workload=None):
         flops, byts = work.get(name, (0.0, 0.0))
         kind, note = ROOFLINE_KIND.get(name, ("mfma_f32", ""))
         traffic = pmc.get(name.replace("rcmarl_", ""))
+        # `traffic` is NOT measured by this process: it is replayed from the committed rocprofv3 PMC passes of the same
+        # command (tools/gpu_pmc_bench.sh); traffic_source names the file (null: no committed pass for this workload)
+        src = pmc.get("__source__") if traffic is not None else None
         if kind == "hbm":
             ach = byts / (tot_ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches": n, "avg_us": avg_us,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                     "algorithmic_bytes_per_launch": byts / n, "note": note}
         ach = flops / (tot_ms * 1e-3) / 1e12
         if kind == "mfma_bf16x3":
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / BF16_PEAK_TFLOPS, "traffic": traffic, "launches": n, "avg_us": avg_us,
+                    "frac": ach / BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                     "algorithmic_flops_per_launch": flops / n,
                     "executed": {"achieved": 3 * ach, "frac": 3 * ach / BF16_PEAK_TFLOPS,
                                  "frac_of_measured_sustained_peak": 3 * ach / BF16_SUSTAINED_TFLOPS,
@@ -360,7 +521,7 @@ def rooflines(tlib, ksum, workload=None):
                             "ceiling of the method = bf16 dense peak / 3 = 833 TFLOP/s; the f32-input MFMA it replaces "
                             "peaks at 157.3"}
         return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "launches": n, "avg_us": avg_us,
+                "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                 "algorithmic_flops_per_launch": flops / n,
                 "note": note or "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
     gemm = next((k for k in ("rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward") if k in ksum), None)
