@@ -1014,4 +1014,6 @@ class RPBCACEngine:
             logs["True_adv_returns"].append(adv)
             logs["Estimated_team_returns"].append(est)
             done += n
+        if not done:                            # n_episodes = 0: the reference's loop body never runs (train_agents.py:46)
+            return {k: np.zeros((0, self.S)) for k in logs}
         return {k: np.concatenate(v, axis=0) for k, v in logs.items()}

@@ -30,28 +30,28 @@ def _json_or_str(v):
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description='Provide parameters for training consensus AC agents')
-    parser.add_argument('--n_agents', help='total number of agents', type=int, default=5)
+    parser = argparse.ArgumentParser(description='RPBCAC training on one MI355X (flag names and defaults of the reference main.py)')
+    parser.add_argument('--n_agents', help='agents in the team (adversaries included)', type=int, default=5)
     parser.add_argument('--agent_label', help='classification of each agent (Cooperative,Malicious,Faulty,Greedy), JSON list',
                         type=_json_or_str, default=['Cooperative'] * 5)
     parser.add_argument('--in_nodes', help='in-neighbourhood of each agent, own index first, JSON list of lists',
                         type=_json_or_str, default=[[0, 1, 2, 3], [1, 2, 3, 4], [2, 3, 4, 0], [3, 4, 0, 1], [4, 0, 1, 2]])
-    parser.add_argument('--n_actions', help='size of action space of each agent', type=int, default=5)
-    parser.add_argument('--n_states', help='state dimension of each agent', type=int, default=2)
-    parser.add_argument('--n_episodes', help='Total number of episodes', type=int, default=7000)
-    parser.add_argument('--max_ep_len', help='Number of steps per episode', type=int, default=20)
-    parser.add_argument('--n_ep_fixed', help='Number of episodes under a fixed policy', type=int, default=50)
-    parser.add_argument('--n_epochs', help='Number of updates in the policy evaluation', type=int, default=10)
-    parser.add_argument('--slow_lr', help='actor network learning rate', type=float, default=0.01)
-    parser.add_argument('--fast_lr', help='critic network learning rate', type=float, default=0.01)
+    parser.add_argument('--n_actions', help='discrete actions per agent (the grid-world has 5)', type=int, default=5)
+    parser.add_argument('--n_states', help='coordinates per agent (the grid-world has 2)', type=int, default=2)
+    parser.add_argument('--n_episodes', help='episodes to run', type=int, default=7000)
+    parser.add_argument('--max_ep_len', help='environment steps in one episode', type=int, default=20)
+    parser.add_argument('--n_ep_fixed', help='episodes rolled out between two update blocks', type=int, default=50)
+    parser.add_argument('--n_epochs', help='local-fit + consensus rounds per update block', type=int, default=10)
+    parser.add_argument('--slow_lr', help='Adam step size of the actors', type=float, default=0.01)
+    parser.add_argument('--fast_lr', help='SGD step size of critic and team-reward nets', type=float, default=0.01)
     parser.add_argument('--batch_size', help='batch size for policy evaluation (unused, as in the reference)', type=int, default=200)
-    parser.add_argument('--buffer_size', help='size of experience replay buffer', type=int, default=2000)
-    parser.add_argument('--gamma', help='discount factor', type=float, default=0.9)
-    parser.add_argument('--H', help='max number of adversaries in the local neighborhood', type=int, default=0)
-    parser.add_argument('--common_reward', help='Set to True if the agents receive the team-average reward', default=False)
-    parser.add_argument('--summary_dir', help='Create a directory to save simulation results', default='./simulation_results/')
-    parser.add_argument('--pretrained_agents', help='Set to True if the agents have been pretrained', default=False)
-    parser.add_argument('--random_seed', help='Set random seed for the random number generator', type=int, default=300)
+    parser.add_argument('--buffer_size', help='replay rows kept after an update block', type=int, default=2000)
+    parser.add_argument('--gamma', help='discount', type=float, default=0.9)
+    parser.add_argument('--H', help='values trimmed on each side by the resilient aggregation', type=int, default=0)
+    parser.add_argument('--common_reward', help='any non-empty value: cooperative agents fit on the team-average reward', default=False)
+    parser.add_argument('--summary_dir', help='kept for CLI compatibility (unused, as in the reference)', default='./simulation_results/')
+    parser.add_argument('--pretrained_agents', help='any non-empty value: warm start from ./pretrained_weights.npy and ./desired_state.npy', default=False)
+    parser.add_argument('--random_seed', help='seed of the NumPy stream, the weight init and the shuffles', type=int, default=300)
     parser.add_argument('--nrow', type=int, default=5)
     parser.add_argument('--ncol', type=int, default=5)
     parser.add_argument('--rng_mode', choices=['numpy', 'device'], default='numpy')
@@ -108,7 +108,8 @@ def save_weights(path, agent_weights):
     np.save(path, obj, allow_pickle=True)
 
 
-def main(argv=None):
+def main(argv=None, engine_hook=None):
+    """engine_hook: (lib, device) handed to train_RPBCAC -- tests inject the hipemu build; None = the product library on cuda."""
     args = vars(build_parser().parse_args(argv))
     np.random.seed(args['random_seed'])
     keras.set_seed(args['random_seed'])
@@ -123,7 +124,7 @@ def main(argv=None):
     print(args, s_desired)
     env = Grid_World(nrow=args['nrow'], ncol=args['ncol'], n_agents=args['n_agents'], desired_state=s_desired,
                      initial_state=s_initial, randomize_state=True, scaling=True)
-    agent_weights, sim_data = training.train_RPBCAC(env, agents, args)
+    agent_weights, sim_data = training.train_RPBCAC(env, agents, args, engine_hook=engine_hook)
     sim_data.to_pickle("sim_data.pkl")
     save_weights('pretrained_weights.npy', agent_weights)
     np.save('desired_state.npy', s_desired, allow_pickle=True)

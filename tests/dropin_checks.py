@@ -266,3 +266,98 @@ def check_train_wide_critic(engine_hook, critic_hid=32, seed=5):
         for k in (1, 2):                                  # critic, team-reward net
             for a, b in zip(weights[i][k], ow[i][k]):
                 close(a, b, 2e-4, "agent %d net %d" % (i, k))
+
+
+def write_reference_artifacts(golden, directory, tag="mal_H1_s300"):
+    """`pretrained_weights.npy` + `desired_state.npy` in the reference's OWN on-disk format (main.py:119-121: object array
+    [agent][net][six Keras arrays], 4 nets for a Malicious agent), rebuilt from the shipped run
+    simulation_results/raw_data/malicious/H=1/seed=300 carried in tests/golden (art/*)."""
+    import os
+    n = 5
+    obj = np.empty(n, dtype=object)
+    for i in range(n):
+        nets = []
+        for net in ("actor", "critic", "tr", "critic_local"):
+            key = "art/%s/weights/%d/%s" % (tag, i, net)
+            if key in golden.files:
+                nets.append(helpers.unflatten(golden[key], *helpers.net_dims(n, "critic" if net == "critic_local" else net)))
+        obj[i] = nets
+    np.save(os.path.join(directory, "pretrained_weights.npy"), obj, allow_pickle=True)
+    np.save(os.path.join(directory, "desired_state.npy"), golden["art/%s/desired_state" % tag], allow_pickle=True)
+    return obj
+
+
+def check_main_roundtrip(golden, tmp_path, engine_hook, n_episodes=100, n_ep_fixed=50, max_ep_len=20, n_epochs=3, buffer_size=2000):
+    """rcmarl_amd.main against the reference's artefact contract (main.py:52-54 load, :119-121 save):
+    1. warm start from the reference's SHIPPED weights of its malicious run (--pretrained_agents True), train, and
+       compare with the oracle's train() warm-started from the same file on the same NumPy stream;
+    2. the artefacts it writes have the reference's format;
+    3. save -> --pretrained_agents load -> save (zero episodes) reproduces the weight file bit for bit."""
+    import json
+    import os
+    import pandas as pd
+    from rcmarl_amd import main as RM
+    labels = ["Cooperative"] * 4 + ["Malicious"]
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path))
+    try:
+        shipped = write_reference_artifacts(golden, ".")
+        argv = ["--pretrained_agents", "True", "--agent_label", json.dumps(labels), "--H", "1", "--slow_lr", "0.002",
+                "--fast_lr", "0.01", "--random_seed", "300", "--n_episodes", str(n_episodes), "--n_ep_fixed", str(n_ep_fixed),
+                "--max_ep_len", str(max_ep_len), "--n_epochs", str(n_epochs), "--buffer_size", str(buffer_size),
+                "--rng_mode", "numpy"]
+        weights, df = RM.main(argv, engine_hook=engine_hook)
+        # ---- 2. artefact formats
+        saved = np.load("pretrained_weights.npy", allow_pickle=True)
+        assert saved.dtype == object and saved.shape == (5,)
+        assert [len(saved[i]) for i in range(5)] == [3, 3, 3, 3, 4]
+        for i in range(5):
+            for k in range(len(saved[i])):
+                assert [np.shape(a) for a in saved[i][k]] == [np.shape(a) for a in shipped[i][k]]
+                for a, b in zip(saved[i][k], weights[i][k]):
+                    np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.load("desired_state.npy", allow_pickle=True), golden["art/mal_H1_s300/desired_state"])
+        sim = pd.read_pickle("sim_data.pkl")
+        assert list(sim.columns) == ["True_team_returns", "True_adv_returns", "Estimated_team_returns"] and len(sim) == n_episodes
+        # ---- 1. the same warm start in the oracle (main.py:46-49 draws s_desired, s_initial before the file replaces s_desired)
+        np.random.seed(300)
+        np.random.randint(0, 5, size=(5, 2))
+        np.random.randint(0, 5, size=(5, 2))
+        desired = golden["art/mal_H1_s300/desired_state"]
+        o_agents = []
+        for i, lab in enumerate(labels):
+            w = [[np.array(a, np.float32) for a in net] for net in shipped[i]]
+            ag = O.make_agent(lab, w[0], w[1], w[2], 0.002, 0.01, 0.9, 1)
+            if lab == "Malicious":
+                ag.critic_local = w[3]
+            o_agents.append(ag)
+        args = {"n_agents": 5, "agent_label": labels, "in_nodes": IN_NODES, "n_actions": 5, "n_states": 2, "n_episodes": n_episodes,
+                "max_ep_len": max_ep_len, "n_ep_fixed": n_ep_fixed, "n_epochs": n_epochs, "slow_lr": 0.002, "fast_lr": 0.01,
+                "batch_size": 200, "buffer_size": buffer_size, "gamma": 0.9, "H": 1, "common_reward": False, "random_seed": 300}
+        oenv = O.GridWorldOracle(5, 5, 5, desired, None, True, True)
+        ow, odf = O.train(oenv, o_agents, args, rng_mode="numpy")
+        np.testing.assert_array_equal(df["True_team_returns"].to_numpy(), odf["True_team_returns"].to_numpy(dtype=np.float64))
+        np.testing.assert_array_equal(df["True_adv_returns"].to_numpy(), odf["True_adv_returns"].to_numpy(dtype=np.float64))
+        np.testing.assert_allclose(df["Estimated_team_returns"].to_numpy(), odf["Estimated_team_returns"].to_numpy(dtype=np.float64),
+                                   rtol=1e-4, atol=1e-5)
+        for i in range(5):
+            for k in (1, 2) + ((3,) if len(ow[i]) == 4 else ()):
+                for a, b in zip(weights[i][k], ow[i][k]):
+                    close(a, b, 5e-4, "agent %d net %d after warm start" % (i, k))
+        # a policy trained for 8000 episodes by the reference: its first block (before any update of ours) must already be good
+        first = float(df["True_team_returns"].to_numpy()[:n_ep_fixed].mean())
+        assert first > -6.5, "shipped policy's return on the new engine: %.3f (reference phase-2 band: -5.3 .. -5.6)" % first
+        # ---- 3. save -> load -> save identity
+        before = np.load("pretrained_weights.npy", allow_pickle=True)
+        argv0 = list(argv)
+        argv0[argv0.index("--n_episodes") + 1] = "0"
+        w0, df0 = RM.main(argv0, engine_hook=engine_hook)
+        assert len(df0) == 0
+        after = np.load("pretrained_weights.npy", allow_pickle=True)
+        for i in range(5):
+            assert len(before[i]) == len(after[i])
+            for k in range(len(before[i])):
+                for a, b in zip(before[i][k], after[i][k]):
+                    np.testing.assert_array_equal(a, b)
+    finally:
+        os.chdir(cwd)

@@ -25,26 +25,20 @@ def init_weights(rng, n_agents, critic_hid=20):
     return out
 
 
-def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3, lattice="auto", critic_hid=20):
-    """Run the oracle (one run per seed) and the engine (all seeds batched); return both results."""
+def make_inputs(args, nrow, seeds, weight_seed=3, critic_hid=20):
+    """Initial weights and goals of every seed (shared by the oracle run and the engine run)."""
     n = args["n_agents"]
-    S = len(seeds)
     wrng = np.random.default_rng(weight_seed)
-    W = [init_weights(wrng, n, critic_hid) for _ in range(S)]
-    goals = [np.random.default_rng(100 + s).integers(0, min(5, nrow), size=(n, 2)) for s in range(S)]
-    cfg = EngineConfig(n, args["agent_label"], args["in_nodes"], H=args["H"], gamma=args["gamma"], slow_lr=args["slow_lr"],
-                       fast_lr=args["fast_lr"], max_ep_len=args["max_ep_len"], n_ep_fixed=args["n_ep_fixed"],
-                       n_epochs=args["n_epochs"], buffer_size=args["buffer_size"], common_reward=args["common_reward"],
-                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode, lattice=lattice, critic_hid=critic_hid)
-    eng = RPBCACEngine(cfg, seeds=list(seeds), device=device, lib=lib)
-    for s in range(S):
-        for i in range(n):
-            for net in ("actor", "critic", "tr"):
-                eng.set_weights(s, i, net, W[s][i][net])
-    eng.set_goals(np.stack(goals))
-    # --- oracle
+    W = [init_weights(wrng, n, critic_hid) for _ in seeds]
+    goals = [np.random.default_rng(100 + s).integers(0, min(5, nrow), size=(n, 2)) for s in range(len(seeds))]
+    return W, goals
+
+
+def run_oracle(args, nrow, ncol, rng_mode, seeds, W, goals):
+    """oracle.train, one run per seed -> (per-seed DataFrames, per-seed weight lists)."""
+    n = args["n_agents"]
     o_logs, o_weights = [], []
-    for s in range(S):
+    for s in range(len(seeds)):
         a = dict(args)
         a["random_seed"] = int(seeds[s])
         agents = [O.make_agent(lab, W[s][i]["actor"], W[s][i]["critic"], W[s][i]["tr"], a["slow_lr"], a["fast_lr"], a["gamma"], a["H"])
@@ -58,7 +52,25 @@ def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3
             w, df = O.train(env, agents, a, rng_mode="device")
         o_logs.append(df)
         o_weights.append(w)
-    # --- engine
+    return o_logs, o_weights
+
+
+def run_engine(args, nrow, ncol, rng_mode, device, lib, seeds, W, goals, lattice="auto", critic_hid=20, tweak=None):
+    """The batched engine on all seeds from the same weights/goals.  tweak(eng): instance-level switches
+    (e.g. eng.td_shortcut = False) applied before training."""
+    n, S = args["n_agents"], len(seeds)
+    cfg = EngineConfig(n, args["agent_label"], args["in_nodes"], H=args["H"], gamma=args["gamma"], slow_lr=args["slow_lr"],
+                       fast_lr=args["fast_lr"], max_ep_len=args["max_ep_len"], n_ep_fixed=args["n_ep_fixed"],
+                       n_epochs=args["n_epochs"], buffer_size=args["buffer_size"], common_reward=args["common_reward"],
+                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode=rng_mode, lattice=lattice, critic_hid=critic_hid)
+    eng = RPBCACEngine(cfg, seeds=list(seeds), device=device, lib=lib)
+    for s in range(S):
+        for i in range(n):
+            for net in ("actor", "critic", "tr"):
+                eng.set_weights(s, i, net, W[s][i][net])
+    eng.set_goals(np.stack(goals))
+    if tweak is not None:
+        tweak(eng)
     if rng_mode == "numpy":
         eng.np_rngs = []
         for s in range(S):
@@ -66,6 +78,14 @@ def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3
             r.randint([0, 0], [nrow, ncol], size=(n, 2))       # the env constructor's reset() draw (grid_world.py:28)
             eng.np_rngs.append(r)
     logs = eng.train(args["n_episodes"])
+    return eng, logs
+
+
+def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3, lattice="auto", critic_hid=20):
+    """Run the oracle (one run per seed) and the engine (all seeds batched); return both results."""
+    W, goals = make_inputs(args, nrow, seeds, weight_seed, critic_hid)
+    o_logs, o_weights = run_oracle(args, nrow, ncol, rng_mode, seeds, W, goals)
+    eng, logs = run_engine(args, nrow, ncol, rng_mode, device, lib, seeds, W, goals, lattice, critic_hid)
     return eng, logs, o_logs, o_weights
 
 

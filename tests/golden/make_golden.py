@@ -86,6 +86,20 @@ def gen_hidden_consensus_fixture(out):
         out[f"hid/H{H}/tr_after"] = np.stack(res_t)
 
 
+def gen_shipped_artifacts(out):
+    """The reference's shipped artefacts of one run in full (main.py:119-121 wrote them): every agent's actor / critic /
+    team-reward weights (+ the Malicious agent's private critic) and the desired state, so that tests on the GPU box can
+    rebuild `pretrained_weights.npy` / `desired_state.npy` in the reference's own on-disk format and warm-start from them
+    (main.py:52-54)."""
+    d = os.path.join(ref_harness.REF_ROOT, "simulation_results/raw_data/malicious/H=1/seed=300")
+    W = np.load(os.path.join(d, "pretrained_weights2.npy"), allow_pickle=True)
+    names = ("actor", "critic", "tr", "critic_local")
+    for i in range(len(W)):
+        for k, net in enumerate(W[i]):
+            out[f"art/mal_H1_s300/weights/{i}/{names[k]}"] = flat_net(net)
+    out["art/mal_H1_s300/desired_state"] = np.asarray(np.load(os.path.join(d, "desired_state.npy"), allow_pickle=True), np.int64)
+
+
 def gen_env(out):
     """Grid_World stepped with a random action stream."""
     for name, (nrow, ncol, n) in {"g5": (5, 5, 5), "g16": (16, 16, 12)}.items():
@@ -193,6 +207,7 @@ if __name__ == "__main__":
     out = {}
     gen_aggregation(out)
     gen_hidden_consensus_fixture(out)
+    gen_shipped_artifacts(out)
     gen_env(out)
     gen_training(out)
     path = os.path.join(HERE, "reference_golden.npz")

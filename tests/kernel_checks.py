@@ -839,3 +839,81 @@ def check_lattice_vs_f32(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01):
     assert np.abs(d_f).max() > 0
     err = float(np.abs(d_l - d_f).max())
     assert err <= 2e-4 * float(np.abs(d_f).max()), (err, float(np.abs(d_f).max()))
+
+
+# ------------------------------------------------------------------------------------------
+def check_consensus_on_shipped_weights(bk, golden):
+    """K1 and K2 on the `hid/*` fixture -- the messages are the reference's SHIPPED
+    weights of its malicious run (simulation_results/raw_data/malicious/H=1/seed=300/pretrained_weights2.npy; agent 4
+    is the Malicious one) and `hid/H*/{critic,tr}_after` were produced by executing the reference's own
+    resilient_consensus_{critic,TR}_hidden (agents/resilient_CAC_agents.py:142-166) on them
+    (tests/golden/make_golden.py).  K1: clip window bit-exact vs the oracle, aggregated rows vs the REFERENCE's output
+    to 1e-6 (summation order), general and circulant kernel.  K2: estimate consensus on the same messages."""
+    in_nodes = np.asarray(golden["hid/in_nodes"], np.int32)
+    N, d = in_nodes.shape
+    coop = np.array([1, 1, 1, 1, 0], np.int32)
+    for net, key, in_dim in (("critic", "hid/critic_msgs", 2 * N), ("tr", "hid/tr_msgs", 3 * N)):
+        msgs = np.asarray(golden[key], np.float32)
+        P, P_hid = geom(in_dim, 1)
+        assert msgs.shape == (N, P)
+        ldp = pad64(P)
+        S = 3                                        # the same instance in every seed slot (the kernels batch over seeds)
+        msg = np.zeros((S, N, ldp), np.float32)
+        msg[:, :, :P] = msgs
+        for H in (0, 1):
+            after = np.asarray(golden["hid/H%d/%s_after" % (H, net)], np.float32)        # [4][P], reference output
+            kernels = ["general"]
+            if bk.lib.rcmarl_consensus_params_circulant_supported(N, d, H) == 1 and \
+                    all(list(in_nodes[i]) == [(i + k) % N for k in range(d)] for i in range(N)):
+                kernels.append("circulant")
+            for kern in kernels:
+                d_msg, d_theta = bk.dev(msg), bk.dev(msg.copy())       # live net == own message (make_golden.py:79-80)
+                d_nbr, d_coop = bk.dev(in_nodes), bk.dev(coop)
+                d_lo, d_hi = bk.dev(np.zeros_like(msg)), bk.dev(np.zeros_like(msg))
+                if kern == "general":
+                    bk.lib.rcmarl_consensus_params(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_nbr), bk.ptr(d_coop), S, N, ldp,
+                                                   P_hid, d, H, bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+                else:
+                    bk.lib.rcmarl_consensus_params_circulant(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_coop), S, N, ldp, P_hid,
+                                                             d, H, bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+                theta, lo, hi = bk.host(d_theta), bk.host(d_lo), bk.host(d_hi)
+                for s in range(S):
+                    for i in range(4):
+                        wl, wh, _ = O.aggregation_bounds(msgs[in_nodes[i], :P_hid], H)
+                        np.testing.assert_array_equal(lo[s, i, :P_hid], wl, err_msg="%s %s H=%d lower" % (net, kern, H))
+                        np.testing.assert_array_equal(hi[s, i, :P_hid], wh, err_msg="%s %s H=%d upper" % (net, kern, H))
+                        ref = after[i]
+                        err = np.abs(theta[s, i, :P_hid] - ref[:P_hid])
+                        assert float((err / np.maximum(1.0, np.abs(ref[:P_hid]))).max()) <= 1e-6, (net, kern, H, i, float(err.max()))
+                        # aggregated W3,b3 are discarded (agents/resilient_CAC_agents.py:150-153): output layer untouched
+                        np.testing.assert_array_equal(theta[s, i, P_hid:P], msgs[i, P_hid:])
+                        np.testing.assert_array_equal(ref[P_hid:], msgs[i, P_hid:])
+                    np.testing.assert_array_equal(theta[s, 4], msg[s, 4])               # the Malicious agent's row
+    # K2 on the critic messages: every cooperative agent evaluates its neighbours' heads on its own (post-K1) features
+    H, in_dim = 1, 2 * N
+    msgs = np.asarray(golden["hid/critic_msgs"], np.float32)
+    after = np.asarray(golden["hid/H1/critic_after"], np.float32)
+    P, P_hid = geom(in_dim, 1)
+    ldp, B = pad64(P), 300
+    ldb = pad64(B)
+    rng = np.random.default_rng(5)
+    x = ((rng.integers(0, 5, size=(1, B, in_dim)) - 2.0) / np.sqrt(2.0)).astype(np.float32)    # z-scored 5x5 grid states
+    theta = np.zeros((1, N, ldp), np.float32)
+    theta[0, :4, :P] = after
+    theta[0, 4, :P] = msgs[4]
+    msg = np.zeros((1, N, ldp), np.float32)
+    msg[0, :, :P] = msgs
+    nchunk = (B + 255) // 256
+    d_x, d_th, d_msg, d_nbr, d_coop = bk.dev(x), bk.dev(theta), bk.dev(msg), bk.dev(in_nodes), bk.dev(coop)
+    d_a = bk.dev(np.zeros((1, N * HID, ldb), np.float32))
+    d_part = bk.dev(np.zeros((1, N, nchunk, HID + 1), np.float32))
+    d_agg = bk.dev(np.zeros((1, N, ldb), np.float32))
+    _layer1(bk, d_x, B * in_dim, d_th, d_a, 1, N, B, in_dim, ldp, ldb)
+    bk.lib.rcmarl_consensus_head(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_msg), bk.ptr(d_nbr), bk.ptr(d_coop), bk.ptr(d_part),
+                                 bk.ptr(d_agg), 1, N, B, in_dim, HID, ldp, ldb, d, H, bk.stream)
+    agg = bk.host(d_agg)
+    for i in range(4):
+        live = unpack_row(theta[0, i], in_dim, 1)
+        ag = O.CoopAgent(M.init_mlp(rng, in_dim, HID, 5), live, live, 0.002, 0.01, 0.9, H)
+        want = ag.consensus_estimates_critic(x[0], [unpack_row(msgs[j], in_dim, 1) for j in in_nodes[i]])
+        rel_close(agg[0, i, :B], want[:, 0], 5e-6, "estimate aggregate on shipped weights, agent %d" % i)

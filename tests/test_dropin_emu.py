@@ -32,3 +32,7 @@ def test_train_RPBCAC_matches_reference_golden(golden, name):
 
 def test_train_RPBCAC_with_wide_critic_models():
     DC.check_train_wide_critic(engine_hook=(emu_lib(), "cpu"))
+
+
+def test_main_roundtrip_and_warm_start_from_shipped_reference_weights(golden, tmp_path):
+    DC.check_main_roundtrip(golden, tmp_path, (emu_lib(), "cpu"), n_episodes=4, n_ep_fixed=2, max_ep_len=3, n_epochs=1, buffer_size=9)

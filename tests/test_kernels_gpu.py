@@ -77,6 +77,10 @@ def test_actor_step(bk, S, N, B, in_dim):
     KC.check_actor_step(bk, S, N, B, in_dim, steps=3)
 
 
+def test_consensus_on_shipped_reference_weights(bk, golden):
+    KC.check_consensus_on_shipped_weights(bk, golden)
+
+
 def test_reward_helpers(bk):
     KC.check_reward_helpers(bk, 2, 5, 1000)
     KC.check_reward_helpers(bk, 1, 64, 3000)

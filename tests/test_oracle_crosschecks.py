@@ -85,7 +85,7 @@ def test_fixtures_regenerate_from_live_reference(tmp_path):
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys, numpy as np; sys.argv=['x']; sys.path.insert(0, %r); import runpy;"
             "ns = runpy.run_path(%r, run_name='gen');"
-            "out = {}; [ns[f](out) for f in ('gen_aggregation','gen_hidden_consensus_fixture','gen_env','gen_training')];"
+            "out = {}; [ns[f](out) for f in ('gen_aggregation','gen_hidden_consensus_fixture','gen_shipped_artifacts','gen_env','gen_training')];"
             "np.savez(%r, **out)") % (here, os.path.join(here, "golden", "make_golden.py"), str(tmp_path / "g.npz"))
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, cwd=os.path.dirname(here))
     new = np.load(tmp_path / "g.npz")
