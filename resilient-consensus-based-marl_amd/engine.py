@@ -120,8 +120,6 @@ class RPBCACEngine:
         self.in_dim_x = {"s": self.in_c, "ns": self.in_c, "sa": self.in_r}      # width of each replay tensor
         self.ldp = {k: pad64(v) for k, v in self.P.items()}
         self.n_last = c.max_ep_len * c.n_ep_fixed
-        self.cap = c.buffer_size + self.n_last
-        self.ldb = pad64(self.cap)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.theta = {k: torch.zeros(S, N, self.ldp[k], **f32) for k in ("actor", "critic", "tr")}
         if MALICIOUS in c.agent_label:
@@ -134,28 +132,15 @@ class RPBCACEngine:
         self.adam_m = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_t = 0
-        self.a1t = torch.zeros(S, N * HID, self.ldb, **f32)          # scratch layer-1 activations
-        # per-net activation buffers: the consensus step leaves layer-1 activations of the live nets on the
-        # fit inputs there, which are exactly what step 0 of the next epoch's local fit needs (the fit starts
-        # from a copy of the live net and only W3,b3 moved since) -> one forward GEMM per net per epoch saved
-        self.a1net = {k: torch.zeros(S, N * self.hid[k], self.ldb, **f32) for k in ("critic", "tr")}
         self.a1_cached = {"critic": False, "tr": False}
-        self._init_wide()
-        self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
-        self.rcoop = torch.zeros(S, self.ldb, **f32)
-        nchunk_max = (self.cap + 255) // 256
-        psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
         # networks with at most 32 inputs (the reference's 5-agent scenarios): one fused launch per local-fit step
         # (measured slower than the three small kernels it replaces -- 1.72 vs 1.42 ms per step at 512 seeds x 5
         # agents: two workgroups per CU and a long dependent chain -- so it is opt-in: RCMARL_SMALL_FUSED=1)
         self.small_fused = self.in_r <= 32 and os.environ.get("RCMARL_SMALL_FUSED", "0") not in ("0", "false")
-        if self.small_fused:
-            psz = max(psz, lib.rcmarl_fit_small_partial_size(HID, self.in_r))
-        self.partials = torch.zeros(S * N * nchunk_max * psz, **f32)
         self.partials_side = None             # second record buffer, allocated when the two local fits overlap
         self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
-        # replay buffers [S][cap][w*N]
-        self.rp = {k: torch.zeros(S, self.cap, w * N, **f32) for k, w in (("s", 2), ("ns", 2), ("sa", 3), ("a", 1), ("r", 1))}
+        self.rp, self.ybuf = None, {k: None for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
+        self._alloc_row_buffers(c.buffer_size + self.n_last)
         self.B = 0
         # environment
         i32 = dict(dtype=torch.int32, device=self.dev)
@@ -204,10 +189,54 @@ class RPBCACEngine:
         self.rows_episode_aligned = True      # every replay row so far came from a full max_ep_len-step episode of ours
         self.timers = {"rollout": 0.0, "phase1": 0.0, "phase2": 0.0, "phase3": 0.0, "blocks": 0}
         self.gpow = [float(c.gamma ** j) for j in range(c.max_ep_len)]
-        self._init_lattice()
-        self._term_rows = {}                  # B -> device indices of the last row of every episode
         self.initial_state = None             # used when randomize_state is False
         self.np_rngs = None                   # rng_mode='numpy': one RandomState-like object per seed
+
+    # ---- everything sized by the replay capacity ---------------------------------------------------
+    def _alloc_row_buffers(self, cap):
+        """(Re)allocate every buffer whose size follows the replay capacity `cap` (rows per seed): the replay tensors
+        (contents kept), per-row vectors, activation scratch, gradient records, lattice operands, wide-critic scratch."""
+        c, S, N, lib = self.cfg, self.S, self.N, self.lib
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        old_rp, old_B = self.rp, getattr(self, "B", 0)
+        self.cap = int(cap)
+        self.ldb = pad64(self.cap)
+        self.a1t = torch.zeros(S, N * HID, self.ldb, **f32)          # scratch layer-1 activations
+        # per-net activation buffers: the consensus step leaves layer-1 activations of the live nets on the
+        # fit inputs there, which are exactly what step 0 of the next epoch's local fit needs (the fit starts
+        # from a copy of the live net and only W3,b3 moved since) -> one forward GEMM per net per epoch saved
+        self.a1net = {k: torch.zeros(S, N * self.hid[k], self.ldb, **f32) for k in ("critic", "tr")}
+        self.a1_cached["critic"] = self.a1_cached["tr"] = False
+        self._init_wide()
+        self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in self.ybuf}
+        self.rcoop = torch.zeros(S, self.ldb, **f32)
+        nchunk_max = (self.cap + 255) // 256
+        psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
+        if self.small_fused:
+            psz = max(psz, lib.rcmarl_fit_small_partial_size(HID, self.in_r))
+        self.partials = torch.zeros(S * N * nchunk_max * psz, **f32)
+        if self.partials_side is not None:
+            self.partials_side = torch.zeros_like(self.partials)
+        # replay buffers [S][cap][w*N]
+        self.rp = {k: torch.zeros(S, self.cap, w * N, **f32) for k, w in (("s", 2), ("ns", 2), ("sa", 3), ("a", 1), ("r", 1))}
+        if old_rp is not None and old_B:
+            for k in self.rp:
+                self.rp[k][:, :old_B] = old_rp[k][:, :old_B]
+        self._init_lattice()
+        self._term_rows = {}                  # (row0, nrows) -> device indices of the last row of every episode
+        if hasattr(self, "adv"):
+            self.adv.a1t = torch.zeros_like(self.a1t)
+
+    def _reserve_rows(self, n_new):
+        """The reference's replay lists grow to any length before the post-update trim (train_agents.py:76-80,158-163): a
+        caller-supplied exp_buffer, trailing episodes of a previous train() call or a second train() on the same engine
+        can push B + n_new past buffer_size + n_ep_fixed*max_ep_len.  Grow the row-sized buffers instead of failing."""
+        self._ensure_cap(self.B + int(n_new))
+
+    def _ensure_cap(self, need):
+        if need > self.cap:
+            self.sync()
+            self._alloc_row_buffers(need)
 
     # ---- wide critic (hid != 20): dense-GEMM path, csrc/wide_kernels.hip ---------------------
     def _init_wide(self):
@@ -376,11 +405,11 @@ class RPBCACEngine:
     # ---- plumbing -------------------------------------------------------------------------
     @property
     def stream(self):
-        return torch.cuda.current_stream().cuda_stream if self.dev.type == "cuda" else None
+        return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else None
 
     def sync(self):
         if self.dev.type == "cuda":
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(self.dev)
 
     @staticmethod
     def _p(t, offset_elems=0):
@@ -416,7 +445,11 @@ class RPBCACEngine:
         self.adam_m[seed_idx, agent, :n] = torch.from_numpy(np.asarray(m, np.float32)).to(self.dev)
         self.adam_v[seed_idx, agent, :n] = torch.from_numpy(np.asarray(v, np.float32)).to(self.dev)
         if self.cfg.agent_label[agent] == COOP:
-            self.adam_t = int(t)
+            loaded = getattr(self, "_adam_t_loaded", None)
+            if loaded is not None and loaded != int(t):
+                raise ValueError("cooperative actors disagree on their Adam step count (%d vs %d): the batched engine steps "
+                                 "all of them together and keeps one bias-correction factor" % (loaded, int(t)))
+            self._adam_t_loaded = self.adam_t = int(t)
         else:
             self._require_adversary_support()
             self.adv.adam_t = int(t)
@@ -455,9 +488,9 @@ class RPBCACEngine:
     def load_replay(self, states, nstates, actions, rewards, seed_idx=0):
         """exp_buffer of the reference API (train_agents.py:36-40): lists of per-step arrays."""
         B = len(states)
-        assert B <= self.cap
         if B == 0:
             return
+        self._ensure_cap(B + self.n_last)         # room for the rows of the next block (rows of other seeds are kept)
         s = np.asarray(states, np.float32).reshape(B, -1)
         ns = np.asarray(nstates, np.float32).reshape(B, -1)
         a = np.asarray(actions, np.float32).reshape(B, -1)
@@ -494,15 +527,35 @@ class RPBCACEngine:
             sd[k] = getattr(self, k).detach().cpu()
         if hasattr(self, "adv"):
             sd["adv"] = self.adv.state_dict()
-        if self.np_rngs is not None:
-            sd["np_rngs"] = [r.get_state() for r in self.np_rngs]
+        sd["shape"] = {"H": c.H, "critic_hid": c.critic_hid, "buffer_size": c.buffer_size, "n_ep_fixed": c.n_ep_fixed,
+                       "max_ep_len": c.max_ep_len, "nrow": c.nrow, "ncol": c.ncol, "rng_mode": c.rng_mode}
+        if self.np_rngs is not None:          # plain tensors / numbers only, so the file loads with weights_only=True
+            sd["np_rngs"] = []
+            for r in self.np_rngs:
+                name, keys, pos, has_gauss, cached = r.get_state()
+                sd["np_rngs"].append({"name": str(name), "keys": torch.from_numpy(np.asarray(keys, np.uint32).astype(np.int64)),
+                                      "pos": int(pos), "has_gauss": int(has_gauss), "cached": float(cached)})
         return sd
 
     def load_state_dict(self, sd):
-        if sd.get("format") != 1 or sd["S"] != self.S or sd["N"] != self.N or list(sd["labels"]) != list(self.cfg.agent_label):
+        c = self.cfg
+        if sd.get("format") != 1 or sd["S"] != self.S or sd["N"] != self.N or list(sd["labels"]) != list(c.agent_label):
             raise ValueError("checkpoint does not match this engine (format/S/N/agent labels)")
+        if [list(map(int, r)) for r in sd["in_nodes"]] != c.in_nodes:
+            raise ValueError("checkpoint was written for a different communication graph")
+        mine = {"H": c.H, "critic_hid": c.critic_hid, "buffer_size": c.buffer_size, "n_ep_fixed": c.n_ep_fixed,
+                "max_ep_len": c.max_ep_len, "nrow": c.nrow, "ncol": c.ncol, "rng_mode": c.rng_mode}
+        theirs = sd.get("shape", mine)
+        diff = {k: (theirs.get(k), v) for k, v in mine.items() if theirs.get(k) != v}
+        if diff:
+            raise ValueError("checkpoint does not match this engine: %r (checkpoint, engine)" % diff)
+        for k, v in sd["theta"].items():
+            if k not in self.theta or tuple(v.shape) != tuple(self.theta[k].shape):
+                raise ValueError("checkpoint parameter matrix %r has shape %r, engine expects %r"
+                                 % (k, tuple(v.shape), tuple(self.theta[k].shape) if k in self.theta else None))
         self.seeds = [int(x) for x in sd["seeds"]]
         self.seeds_dev.copy_(torch.tensor(np.asarray(self.seeds, dtype=np.uint64).view(np.int64), dtype=torch.int64))
+        self._ensure_cap(int(sd["B"]))
         self.episode, self.B, self.adam_t, self.cur = int(sd["episode"]), int(sd["B"]), int(sd["adam_t"]), int(sd["cur"])
         for k, v in sd["theta"].items():
             self.theta[k].copy_(v)
@@ -519,7 +572,8 @@ class RPBCACEngine:
             self.np_rngs = []
             for st in sd["np_rngs"]:
                 r = np.random.RandomState()
-                r.set_state(st)
+                r.set_state((st["name"], st["keys"].numpy().astype(np.uint32), int(st["pos"]), int(st["has_gauss"]),
+                             float(st["cached"])))
                 self.np_rngs.append(r)
         self.a1_cached["critic"] = self.a1_cached["tr"] = False
         self.lat_active = False
@@ -529,7 +583,8 @@ class RPBCACEngine:
         torch.save(self.state_dict(), path)
 
     def load_checkpoint(self, path):
-        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+        # tensors, numbers, strings and containers of them only: nothing in the file is unpickled into code
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
 
     # ---- rollout (train_agents.py:46-80) ---------------------------------------------------
     def _reset(self, host_positions=None):
@@ -547,7 +602,10 @@ class RPBCACEngine:
     def rollout_episode(self, ep_in_block):
         """One episode for all seeds; appends max_ep_len rows to the replay buffers."""
         c, L, S, N = self.cfg, self.lib, self.S, self.N
+        self._reserve_rows(c.max_ep_len)
         if c.rng_mode == "numpy":
+            if self.np_rngs is None:          # one legacy stream per seed, seeded like main.py:46 seeds the global one
+                self.np_rngs = [np.random.RandomState(int(sd) & 0xFFFFFFFF) for sd in self.seeds]
             if c.randomize_state:                                     # env.reset(): grid_world.py:39-40
                 host_pos = np.stack([rng.randint([0, 0], [c.nrow, c.ncol], size=(N, 2)) for rng in self.np_rngs])
             else:
@@ -602,6 +660,7 @@ class RPBCACEngine:
         land exactly where the sequential loop (train_agents.py:46-80) would have put them."""
         c, L, S, N, EP = self.cfg, self.lib, self.S, self.N, self.EP
         assert c.rng_mode == "device" and n_eps <= c.n_ep_fixed
+        self._reserve_rows(c.max_ep_len * n_eps)
         pin = None
         if not c.randomize_state:
             pin = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(self.initial_state, dtype=np.int32),
@@ -832,7 +891,7 @@ class RPBCACEngine:
             if self._overlap_ok():
                 # the two local fits are independent until the consensus step: TR on a side stream, critic on the
                 # main one (the VALU/LDS-bound mid kernels of one net fill the gaps of the other's matrix-core GEMMs)
-                main = torch.cuda.current_stream()
+                main = torch.cuda.current_stream(self.dev)
                 fork = torch.cuda.Event()
                 fork.record(main)
                 with torch.cuda.stream(self.side_stream):
@@ -856,7 +915,7 @@ class RPBCACEngine:
                 self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
                 if join is not None:
-                    torch.cuda.current_stream().wait_event(join)
+                    torch.cuda.current_stream(self.dev).wait_event(join)
             t0 = self._timed("phase1", t0)
             # II) resilient consensus (cooperative agents)
             self._consensus("critic", "s", B)
@@ -931,7 +990,7 @@ class RPBCACEngine:
             return None
         if getattr(self, "adv_stream", None) is None:
             self.adv_stream = torch.cuda.Stream(device=self.dev)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.dev)
         fork = torch.cuda.Event()
         fork.record(main)
         with torch.cuda.stream(self.adv_stream):

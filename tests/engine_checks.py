@@ -111,3 +111,48 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4):
                 for a, b in zip(got, o_weights[s][i][3]):
                     scale = max(1.0, float(np.abs(b).max()))
                     assert float(np.abs(a - b).max()) <= rtol_w * scale, (s, i, "critic_local")
+
+
+def check_checkpoint_resume(labels, rng_mode, device, lib, path, n=5, nrow=5, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9,
+                            S=2, blocks=(1, 2), lattice=True, d=4):
+    """Train blocks[0]+blocks[1] blocks straight vs blocks[0] -> save -> FRESH engine -> load -> blocks[1]: same logs, same
+    bits (weights, Adam slots and step counts, replay rows, agent positions, RNG position all travel in the file)."""
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+
+    def make():
+        cfg = EngineConfig(n, labels, in_nodes, H=1, max_ep_len=max_ep_len, n_ep_fixed=n_ep_fixed, n_epochs=n_epochs,
+                           buffer_size=buffer_size, nrow=nrow, ncol=nrow, n_seeds=S, rng_mode=rng_mode, lattice=lattice)
+        eng = RPBCACEngine(cfg, seeds=[7 + s for s in range(S)], device=device, lib=lib)
+        eng.init_glorot(base_seed=3)
+        eng.set_goals(np.random.default_rng(9).integers(0, min(5, nrow), size=(n, 2)))
+        if rng_mode == "numpy":
+            eng.np_rngs = [np.random.RandomState(70 + s) for s in range(S)]
+        return eng
+    e1, e2 = blocks[0] * n_ep_fixed, blocks[1] * n_ep_fixed
+    a = make()
+    la = a.train(e1 + e2)
+    b = make()
+    lb1 = b.train(e1)
+    b.save_checkpoint(path)
+    c = make()
+    c.init_glorot(base_seed=99)                       # different weights: everything must come from the file
+    c.load_checkpoint(path)
+    lc = c.train(e2)
+    for k in la:
+        np.testing.assert_array_equal(la[k], np.concatenate([lb1[k], lc[k]], axis=0))
+    for net in a.theta:
+        np.testing.assert_array_equal(a.get_all_weights(net), c.get_all_weights(net))
+    np.testing.assert_array_equal(a.adam_m.cpu().numpy(), c.adam_m.cpu().numpy())
+    np.testing.assert_array_equal(a.adam_v.cpu().numpy(), c.adam_v.cpu().numpy())
+    for k in a.rp:
+        np.testing.assert_array_equal(a.rp[k][:, :a.B].cpu().numpy(), c.rp[k][:, :c.B].cpu().numpy())
+    # a checkpoint of a different scenario is refused, not silently loaded
+    other = EngineConfig(n, labels, in_nodes, H=0, max_ep_len=max_ep_len, n_ep_fixed=n_ep_fixed, n_epochs=n_epochs,
+                         buffer_size=buffer_size, nrow=nrow, ncol=nrow, n_seeds=S, rng_mode=rng_mode, lattice=lattice)
+    wrong = RPBCACEngine(other, seeds=[7 + s for s in range(S)], device=device, lib=lib)
+    try:
+        wrong.load_checkpoint(path)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("a checkpoint written with H=1 loaded into an H=0 engine")

@@ -50,34 +50,7 @@ def test_engine_wide_critic_matches_oracle(rng_mode, critic_hid, H, lattice):
 
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])
 def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
-    """Train 3 blocks straight vs 1 block -> save -> fresh engine -> load -> 2 blocks: same logs, same bits
-    (weights, Adam slots, replay rows, RNG position all travel in the checkpoint)."""
-    import numpy as np
-    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
-
-    def make():
-        cfg = EngineConfig(5, labels, EC.CIRC5, H=1, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, nrow=5, ncol=5,
-                           n_seeds=2, rng_mode=rng_mode, lattice=True)
-        eng = RPBCACEngine(cfg, seeds=[7, 8], device="cpu", lib=emu_lib())
-        eng.init_glorot(base_seed=3)
-        eng.set_goals(np.array([[1, 2], [0, 0], [4, 4], [2, 3], [3, 1]]))
-        if rng_mode == "numpy":
-            eng.np_rngs = [np.random.RandomState(70 + s) for s in range(2)]
-        return eng
-    a = make()
-    la = a.train(6)
-    b = make()
-    lb1 = b.train(2)
-    b.save_checkpoint(str(tmp_path / "ck.pt"))
-    c = make()
-    c.init_glorot(base_seed=99)                       # different weights: everything must come from the file
-    c.load_checkpoint(str(tmp_path / "ck.pt"))
-    lc = c.train(4)
-    for k in la:
-        np.testing.assert_array_equal(la[k], np.concatenate([lb1[k], lc[k]], axis=0))
-    for net in ("actor", "critic", "tr"):
-        np.testing.assert_array_equal(a.get_all_weights(net), c.get_all_weights(net))
-    np.testing.assert_array_equal(a.adam_m.numpy(), c.adam_m.numpy())
+    EC.check_checkpoint_resume(labels, rng_mode, "cpu", emu_lib(), str(tmp_path / "ck.pt"))
 
 
 def test_engine_buffer_not_a_multiple_of_the_episode_length():
@@ -87,3 +60,36 @@ def test_engine_buffer_not_a_multiple_of_the_episode_length():
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(61,))
     assert not eng.rows_episode_aligned
     EC.compare(eng, logs, o_logs, o_w)
+
+
+def test_replay_grows_past_the_steady_state_capacity():
+    """The reference's replay lists have no capacity (training/train_agents.py:76-80; the trim to buffer_size happens after
+    an update, :158-163): trailing episodes of one train() call stay in the buffer, and a second call on the same state
+    pushes B past buffer_size + n_ep_fixed*max_ep_len.  The engine grows its row-sized buffers; results follow the oracle
+    run with the same carried-over exp_buffer."""
+    import numpy as np
+    from oracle import rpbcac_oracle as O
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=5, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=71)
+    seeds = (71,)
+    W, goals = EC.make_inputs(args, 5, seeds)
+    # oracle: two calls, the replay lists and the agents carried over
+    a1, a2 = dict(args), dict(args, n_episodes=4)
+    agents = [O.make_agent("Cooperative", W[0][i]["actor"], W[0][i]["critic"], W[0][i]["tr"], 0.002, 0.01, 0.9, 1) for i in range(5)]
+    np.random.seed(71)
+    env = O.GridWorldOracle(5, 5, 5, goals[0], None, True, True)
+    buf = ([], [], [], [])
+    _, df1 = O.train(env, agents, a1, exp_buffer=buf, rng_mode="numpy")
+    rows_after_first = len(buf[0])
+    ow, df2 = O.train(env, agents, a2, exp_buffer=buf, rng_mode="numpy")
+    # engine: two train() calls on one engine
+    caps = []
+
+    def tweak(eng):
+        caps.append(eng.cap)
+    eng, l1 = EC.run_engine(args, 5, 5, "numpy", "cpu", emu_lib(), seeds, W, goals, tweak=tweak)
+    assert eng.B == rows_after_first and eng.B > args["buffer_size"]            # trailing episode: untrimmed rows
+    l2 = eng.train(4)
+    assert eng.cap > caps[0]                                                        # 12 + 6 rows > 9 + 6
+    logs = {k: np.concatenate([l1[k], l2[k]], axis=0) for k in l1}
+    import pandas as pd
+    EC.compare(eng, logs, [pd.concat([df1, df2], ignore_index=True)], [ow])

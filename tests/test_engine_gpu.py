@@ -164,3 +164,13 @@ def test_engine_wide_critic_cfg5_shape_paths_agree():
         diff = np.abs(a - b)
         assert float(diff.max()) <= 1e-3 * max(1.0, float(np.abs(b).max())) and float(diff.mean()) <= 5e-6, \
             (net, float(diff.max()), float(diff.mean()))
+
+
+@pytest.mark.parametrize("labels,rng_mode,n", [(["Cooperative"] * 4 + ["Malicious"], "device", 5), (["Cooperative"] * 5, "numpy", 5),
+                                               (["Cooperative"] * 19 + ["Greedy"], "device", 20)])
+def test_checkpoint_resume_is_bit_identical(labels, rng_mode, n, tmp_path):
+    """Mid-run checkpoint on the GPU (the reference only saves final weights, main.py:119-121): 2 blocks -> save -> fresh
+    engine -> load -> 2 blocks equals 4 blocks straight, bit for bit; n = 20 runs the lattice GEMMs and the TD shortcut."""
+    EC.check_checkpoint_resume(labels, rng_mode, "cuda", None, str(tmp_path / "ck.pt"), n=n, nrow=5 if n == 5 else 8,
+                               max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=300, S=3, blocks=(2, 2),
+                               lattice=True if n == 5 else "auto")
