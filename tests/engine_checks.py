@@ -89,8 +89,14 @@ def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3
     return eng, logs, o_logs, o_weights
 
 
-def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4):
+def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4, actor="strict"):
+    """actor="strict": every actor parameter within 5 % of an Adam step per update.  actor="stat" (hundreds of agents):
+    Adam turns a gradient of magnitude ~eps into anything in [-lr, lr] and a pre-activation within rounding of 0 flips its
+    LeakyReLU slope, so among millions of parameters a few legitimately differ by more between any two fp32 summation
+    orders: bulk within 5 % of a step, at most 1e-4 of the entries beyond, none beyond two full steps (the bar of
+    kernel_checks.check_actor_step)."""
     S, n = eng.S, eng.N
+    steps = max(1, eng.adam_t)
     for s in range(S):
         df = o_logs[s]
         # identical action streams -> bit-identical float64 returns
@@ -98,19 +104,29 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4):
         np.testing.assert_array_equal(logs["True_adv_returns"][:, s], df["True_adv_returns"].to_numpy(dtype=np.float64))
         np.testing.assert_allclose(logs["Estimated_team_returns"][:, s], df["Estimated_team_returns"].to_numpy(dtype=np.float64),
                                    rtol=1e-4, atol=1e-5)
+        actor_err = []
         for i in range(n):
             for k, net in enumerate(("actor", "critic", "tr")):
                 got = eng.get_weights(s, i, net)
                 for a, b in zip(got, o_weights[s][i][k]):
                     scale = max(1.0, float(np.abs(b).max()))
-                    tol = rtol_w * scale if net != "actor" else 0.05 * eng.cfg.slow_lr * max(1, eng.adam_t) + 1e-5
                     err = float(np.abs(a - b).max())
+                    if net == "actor" and actor == "stat":
+                        actor_err.append(np.abs(a - b).ravel())
+                        continue
+                    tol = rtol_w * scale if net != "actor" else 0.05 * eng.cfg.slow_lr * steps + 1e-5
                     assert err <= tol, (s, i, net, err, tol)
             if len(o_weights[s][i]) == 4:                       # Malicious: private critic (adversarial:180-182)
                 got = eng.get_weights(s, i, "critic_local")
                 for a, b in zip(got, o_weights[s][i][3]):
                     scale = max(1.0, float(np.abs(b).max()))
                     assert float(np.abs(a - b).max()) <= rtol_w * scale, (s, i, "critic_local")
+        if actor_err:
+            e = np.concatenate(actor_err)
+            lr = eng.cfg.slow_lr
+            assert e.max() <= 2.0 * lr * steps + 1e-6, ("actor", float(e.max()))
+            frac = float(np.mean(e > 0.05 * lr * steps + 1e-5))
+            assert frac <= 1e-4, ("actor outliers", frac, float(e.max()))
 
 
 def check_checkpoint_resume(labels, rng_mode, device, lib, path, n=5, nrow=5, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9,

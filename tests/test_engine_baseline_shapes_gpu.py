@@ -25,7 +25,7 @@ def test_engine_cfg3_shape_vs_oracle():
                         seed=64, in_nodes=_random_regular(n, 10, 5), fast_lr=0.005)
     eng, logs, o_logs, o_w = EC.run_pair(args, 16, 16, "device", "cuda", None, seeds=(64, 65))
     assert eng.lat_active and not eng.k1_circulant
-    EC.compare(eng, logs, o_logs, o_w)
+    EC.compare(eng, logs, o_logs, o_w, actor="stat")
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +53,7 @@ def test_engine_cfg4_shape_vs_oracle(cfg4_oracle, shortcut):
     assert eng.lat_active and eng.k1_circulant
     for df in o_logs:
         assert np.isfinite(df["Estimated_team_returns"].to_numpy()).all()
-    EC.compare(eng, logs, o_logs, o_w)
+    EC.compare(eng, logs, o_logs, o_w, actor="stat")       # 2.8 M actor parameters: statistical bar, see EC.compare
 
 
 def test_engine_wide_critic_d66_vs_oracle():
@@ -63,4 +63,4 @@ def test_engine_wide_critic_d66_vs_oracle():
                         seed=77, in_nodes=in_nodes, fast_lr=0.004)
     eng, logs, o_logs, o_w = EC.run_pair(args, 8, 8, "device", "cuda", None, seeds=(77,), critic_hid=128)
     assert eng.wide and eng.lat_active and eng.k1_circulant
-    EC.compare(eng, logs, o_logs, o_w)
+    EC.compare(eng, logs, o_logs, o_w, actor="stat")

@@ -8,7 +8,7 @@ TAG=${2:-r01}
 mkdir -p $R/gpurun_out/pmcb
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb -o ${W}_$c -- python $R/bench.py --steps 1 --warmup 1 --workload $W --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/pmcb/${W}_$c.log 2>&1
+  timeout 400 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmcb -o ${W}_$c -- python $R/bench.py --steps 1 --warmup 1 --workload $W --no-cpu-baseline --no-kernel-timing --no-extra > $R/gpurun_out/pmcb/${W}_$c.log 2>&1
   tail -1 $R/gpurun_out/pmcb/${W}_$c.log | cut -c1-200
 done
 python - <<PY
