@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
                                                              const int* __restrict__ mask, int S, int N, int B,
                                                              int in_dim, int ldp, float lr, int mtiles, int ntiles,
                                                              unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt,
-                                                             int stg_bit, int stg_n, int hid) {
+                                                             int stg_bit, int stg_n, int hid, int wp_fit) {
   constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
   typedef LatCfg<PA, PB, MT, NT> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
@@ -594,9 +594,12 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
       // the lane's first row: k = bm*BM + wm*32*MT + 4*half; rows of (mt, gq, e) follow at uniform distances
       const int k0 = bm * C::BM + wm * 32 * MT + 4 * half;
       float* th = theta + ((long)s * N + ag) * ldp + j + (long)k0 * hid;
+      // row of this column in the forward operand: natural order (column tile bn, row cl), or the fit order of the
+      // fused local-fit kernel (wp_fit; rcmarl_lattice.h)
+      const int wr = wp_fit ? rc_fit_row(ag, j) : col;
       unsigned char* wrow = wp_out == nullptr ? nullptr
-          : wp_out + (long)s * wp_rt * wp_kt * (3 * RC_PK_BLOCK) + (long)bn * wp_kt * (3 * RC_PK_BLOCK) + cl * 64 + half * 8;
-      const int sw = (cl >> 2) & 3;
+          : wp_out + (long)s * wp_rt * wp_kt * (3 * RC_PK_BLOCK) + (long)(wr >> 7) * wp_kt * (3 * RC_PK_BLOCK) + (wr & 127) * 64 + half * 8;
+      const int sw = (wr >> 2) & 3;
       float wold[MT][16];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -770,17 +773,20 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   return rcmarl_check_launch();
 }
 
-RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
+static int backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
                                                      int dzp_kt, const float* alpha, float* theta, const int* mask,
                                                      int S, int N, int B, int in_dim, int hid, int ldp, float lr,
-                                                     void* wp_out, int wp_rt, int wp_kt, void* stream) {
+                                                     void* wp_out, int wp_rt, int wp_kt, void* stream, int wp_fit) {
   if (!ktp || !dzp || !alpha || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) ||
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
   if (hid <= 0) return RCMARL_ERR_ARG;
   const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * hid, 128), ktiles = rc_ceil_div(B, 32);
   if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
-  if (wp_out && (wp_rt < ntiles || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
+  if (wp_fit && hid != 20) return RCMARL_ERR_UNSUPPORTED;
+  if (wp_out && ((long)wp_rt * 128 < (wp_fit ? (long)rc_ceil_div(N, RC_FIT_AGENTS) * RC_FIT_ROWS : (long)ntiles * 128) ||
+                 wp_kt < rc_ceil_div(in_dim, 32)))
+    return RCMARL_ERR_ARG;
   const int ns = lat_stages();
   const size_t smem = (size_t)(ns == 4 ? 2 : ns) * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
   const dim3 grid((unsigned)lat_grid(S * mtiles * ntiles, ns)), block(256);
@@ -791,7 +797,7 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
       if (!lat_want_lds(k_lat_backward_sgd<2, M>, smem)) return RCMARL_ERR_LAUNCH;                                   \
       RCMARL_LAUNCH((k_lat_backward_sgd<2, M>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, \
                     (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles,  \
-                    ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);          \
+                    ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);          \
     }
     RC_DBG_CASE(1) RC_DBG_CASE(2) RC_DBG_CASE(3) RC_DBG_CASE(7) RC_DBG_CASE(8)
 #undef RC_DBG_CASE
@@ -802,19 +808,36 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<2>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
   } else if (ns == 4) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<4>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<4>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
   } else {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<3>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<3>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid);
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
   }
   return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
+                                                     int dzp_kt, const float* alpha, float* theta, const int* mask,
+                                                     int S, int N, int B, int in_dim, int hid, int ldp, float lr,
+                                                     void* wp_out, int wp_rt, int wp_kt, void* stream) {
+  return backward_sgd_lattice(ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, wp_out,
+                              wp_rt, wp_kt, stream, 0);
+}
+
+// the same step; wp_out receives the split of the updated W1 in FIT ORDER (the A operand of rcmarl_fit_fused_lattice)
+RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice_fit(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
+                                                         int dzp_kt, const float* alpha, float* theta, const int* mask,
+                                                         int S, int N, int B, int in_dim, int hid, int ldp, float lr,
+                                                         void* wpf_out, int wpf_rt, int wpf_kt, void* stream) {
+  return backward_sgd_lattice(ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, wpf_out,
+                              wpf_rt, wpf_kt, stream, 1);
 }

@@ -149,3 +149,89 @@ typedef float rc_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ rc_f2 rc_fma2(rc_f2 a, rc_f2 b, rc_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 __device__ __forceinline__ rc_f2 rc_bcast2(float v) { return rc_f2{v, v}; }
+#ifdef RCMARL_EMU
+__device__ __forceinline__ rc_f2 rc_add2(rc_f2 a, rc_f2 b) { return rc_f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ rc_f2 rc_sub2(rc_f2 a, rc_f2 b) { return rc_f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ rc_f2 rc_mul2(rc_f2 a, rc_f2 b) { return rc_f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ rc_f2 rc_max2(rc_f2 a, rc_f2 b) { return rc_f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+#else
+__device__ __forceinline__ rc_f2 rc_add2(rc_f2 a, rc_f2 b) { return a + b; }
+__device__ __forceinline__ rc_f2 rc_sub2(rc_f2 a, rc_f2 b) { return a - b; }
+__device__ __forceinline__ rc_f2 rc_mul2(rc_f2 a, rc_f2 b) { return a * b; }
+__device__ __forceinline__ rc_f2 rc_max2(rc_f2 a, rc_f2 b) { return __builtin_elementwise_max(a, b); }
+#endif
+// LeakyReLU of two values at once: max(z, leak*z) == rc_lrelu(z) bit for bit (0 < leak < 1)
+__device__ __forceinline__ rc_f2 rc_lrelu2(rc_f2 z) { return rc_max2(z, rc_mul2(z, rc_bcast2(RC_LEAK))); }
+
+// Sums over the lanes of each 32-lane HALF of the wavefront, three values at once; results in lanes 31 and 63
+// (five fused-DPP adds per value: the wave-wide rc_wave_sum3_lane63 without its last step).
+__device__ __forceinline__ void rc_half_sum3_lane31(float& a, float& b, float& c) {
+#ifdef RCMARL_EMU
+  float all[64], *vals[3] = {&a, &b, &c};
+  for (int q = 0; q < 3; ++q) {
+    __hipemu_gather64(*vals[q], all);
+    const int base = hipemu::lane() & 32;
+    float nxt[32], cur[32];
+    for (int l = 0; l < 32; ++l) cur[l] = all[base + l];
+    for (int m = 1; m < 32; m <<= 1) {                 // xor butterfly, lowest distance first (as the DPP sequence)
+      for (int l = 0; l < 32; ++l) nxt[l] = cur[l] + cur[l ^ m];
+      for (int l = 0; l < 32; ++l) cur[l] = nxt[l];
+    }
+    *vals[q] = cur[hipemu::lane() & 31];
+  }
+#else
+#define RC_DPP3(mod)                          \
+  "v_add_f32_dpp %0, %0, %0 " mod "\n\t"      \
+  "v_add_f32_dpp %1, %1, %1 " mod "\n\t"      \
+  "v_add_f32_dpp %2, %2, %2 " mod "\n\t"
+  asm volatile("s_nop 1\n\t"
+               RC_DPP3("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+               RC_DPP3("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+               RC_DPP3("row_half_mirror row_mask:0xf bank_mask:0xf")
+               RC_DPP3("row_mirror row_mask:0xf bank_mask:0xf")
+               RC_DPP3("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               "s_nop 1"
+               : "+v"(a), "+v"(b), "+v"(c));
+#undef RC_DPP3
+#endif
+}
+
+// Scheduling fence: hipcc's scheduler otherwise hoists every independent LDS read of a fully unrolled loop to its top
+// (100 ds_read_b128 of weights = 400 live registers -> spills); nothing moves across this point.
+#ifdef RCMARL_EMU
+#define RC_SCHED_FENCE() ((void)0)
+#else
+#define RC_SCHED_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+
+// A condition that is always true but opaque to the compiler: `if (RC_OPAQUE_TRUE()) { ... }` puts its body into a
+// basic block of its own (one s_cmp + s_cbranch at run time).  Instruction selection and scheduling work per basic
+// block, so this bounds how far hipcc can reorder a long fully unrolled computation (see lattice_fit.hip: left as one
+// block, all weight reads are scheduled first and the FMAs that consume them last -> 2000 spilled registers).
+#ifdef RCMARL_EMU
+#define RC_OPAQUE_TRUE() (true)
+#else
+#define RC_OPAQUE_TRUE() ([]() __attribute__((always_inline)) { int c_ = 1; asm volatile("" : "+s"(c_)); return c_ != 0; }())
+#endif
+
+// Ties a pointer to a value computed earlier (an empty asm that "modifies" both): loads through the pointer cannot be
+// started before that value exists.  Keeps hipcc from hoisting ALL weight reads of a fully unrolled chain of FMAs
+// above the chain (it then spills them: 100 ds_read_b128 = 400 registers).
+#ifdef RCMARL_EMU
+#define RC_TIE(ptr, val) ((void)0)
+#else
+#define RC_TIE(ptr, val) asm volatile("" : "+v"(ptr), "+v"(val))
+#endif
+
+// Ordering point for data exchanged through LDS among the lanes of ONE wavefront (no workgroup barrier): the LDS
+// executes a wavefront's instructions in order, so this only has to stop the compiler from moving accesses across it.
+#ifdef RCMARL_EMU
+#define RC_WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define RC_WAVE_SYNC()                                         \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
+#endif

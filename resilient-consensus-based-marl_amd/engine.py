@@ -372,6 +372,15 @@ class RPBCACEngine:
         self.lat_wp_f = {"sa": u8(self.lat_geom["sa"].wp, 3), "s": u8(self.lat_geom["s"].wp, 3)}
         self.lat_dzp_f = {"sa": u8(self.lat_geom["sa"].dzp, 3), "s": u8(self.lat_geom["s"].dzp, 3)}
         self.lat_wp_f["ns"] = self.lat_wp_f["s"]
+        # fused local-fit step (csrc/lattice_fit.hip, 20-unit nets): its forward operand is W' in "fit order"
+        self.fit_fused = os.environ.get("RCMARL_FIT_FUSED", "1") not in ("0", "false")
+        self.lat_wpf_geom, self.lat_wpf = {}, {}
+        if self.fit_fused:
+            for k, net in (("sa", "tr"), ("s", "critic")):
+                if self.hid[net] == HID:
+                    rt_kt = (LT.cdiv(self.lib.rcmarl_fit_rows(self.N), 128), LT.cdiv(self.in_dim[net], 32))
+                    self.lat_wpf_geom[k] = rt_kt
+                    self.lat_wpf[k] = u8(rt_kt, 3)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.lat_alpha = {"s": torch.tensor(LT.column_alpha(self.N, 2, c.nrow, c.ncol, c.scaling), **f32),
                           "sa": torch.tensor(LT.column_alpha(self.N, 3, c.nrow, c.ncol, c.scaling), **f32)}
@@ -732,6 +741,26 @@ class RPBCACEngine:
                 L.rcmarl_small_sgd_full(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
                                         self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
                                         self.ldp[net], self.cfg.fast_lr, self.stream)
+            self.a1_cached[net] = False
+            return
+        if lat and xkey in self.lat_wpf:
+            # one launch per step for layer 1 forward + layers 2-3 + the way back to dz1 (no a1t round trip through HBM)
+            wpf, (frt, fkt) = self.lat_wpf[xkey], self.lat_wpf_geom[xkey]
+            kp, alpha = self.lat_kp[xkey], self.lat_alpha[xkey]
+            for step in range(self.cfg.local_fit_steps):
+                if step == 0:                  # later steps: the backward epilogue leaves the split of the updated W1
+                    L.rcmarl_w1_split_fit(msg.data_ptr(), alpha.data_ptr(), wpf.data_ptr(), S, N, self.in_dim[net], HID,
+                                          self.ldp[net], frt, fkt, self.stream)
+                L.rcmarl_fit_fused_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wpf.data_ptr(), frt, fkt, msg.data_ptr(),
+                                           y.data_ptr(), partials.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B,
+                                           self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+                L.rcmarl_small_sgd(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+                                   self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
+                                   self.ldp[net], self.cfg.fast_lr, self.stream)
+                L.rcmarl_layer1_backward_sgd_lattice_fit(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
+                                                         g.dzp[0], g.dzp[1], alpha.data_ptr(), msg.data_ptr(),
+                                                         mask.data_ptr(), S, N, B, self.in_dim[net], HID, self.ldp[net],
+                                                         self.cfg.fast_lr, wpf.data_ptr(), frt, fkt, self.stream)
             self.a1_cached[net] = False
             return
         wp_fresh = False

@@ -141,3 +141,8 @@ def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
                                                         (1, 24, 40, 8, 24, 23, 5, "rand")])     # no generated network: rank counting
 def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(1, 5, 70, 2, 5, 5, None), (2, 11, 300, 3, 8, 6, 3)])
+def test_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, masked):
+    KC.check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)

@@ -172,3 +172,11 @@ def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
                                                         (1, 70, 300, 140, 512, 66, 32, "circ"), (1, 30, 300, 60, 64, 23, 5, "rand")])
 def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (2, 11, 300, 3, 8, 6, 3), (1, 64, 3000, 3, 16, 16, 5),
+                                                          (2, 256, 1000, 2, 32, 32, None), (1, 256, 3000, 3, 32, 32, 100),
+                                                          (1, 20, 777, 2, 7, 9, None)])
+def test_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, masked):
+    """The fused local-fit step (csrc/lattice_fit.hip) vs the unfused pair (dz1 bit-identical) and vs the oracle's fit."""
+    KC.check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, masked_agent=masked)

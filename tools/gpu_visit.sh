@@ -33,6 +33,10 @@ prof:*)
   ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$W -o $W -- python $R/bench.py --steps 3 --warmup 2 --workload $W --no-cpu-baseline --no-extra > $R/gpurun_out/${TAG}_prof_$W.log 2>&1 )
   f=$(ls gpurun_out/prof_${TAG}_$W/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f gpurun_out/${TAG}_kernel_stats_$W.csv && head -12 $f | cut -c1-160 ;;
+kbench:*)
+  timeout 300 python tools/kbench.py ${what#kbench:} 2>&1 | tail -30 ;;
+env:*)
+  export ${what#env:} ;;
 pmc:*)
   W=${what#pmc:}
   bash tools/gpu_pmc_bench.sh $W $TAG | tail -12 ;;
