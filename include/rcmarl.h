@@ -121,11 +121,12 @@ int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y,
  *   rcmarl_fit_fused_lattice = rcmarl_layer1_forward_lattice + rcmarl_mid_fit_lattice in ONE launch -- the layer-1
  * activations stay in registers between the GEMM's k-loop and layers 2-3 (no a1t round trip through HBM).  Same
  * outputs: dzp (dz1 as three exact bf16 pieces, bit-identical to rcmarl_mid_fit_lattice) and
- * partials[S][N][ceil(B/256)][rcmarl_fit_partial_size(hid)] for rcmarl_small_sgd.  Replaces one full-batch step of the
+ * partials[S][N][rcmarl_fit_fused_chunks(B)][rcmarl_fit_partial_size(hid)] for rcmarl_small_sgd_chunks.  Replaces one full-batch step of the
  * Keras fit at agents/resilient_CAC_agents.py:118,136.  Its A operand wpf is W' in FIT ORDER (rows permuted so that
  * every lane ends the k-loop with whole agents; rcmarl_fit_rows(N) rows): produced by rcmarl_w1_split_fit, or by
  * rcmarl_layer1_backward_sgd_lattice_fit from the previous step's update. */
 int rcmarl_fit_rows(int n_agents);
+int rcmarl_fit_fused_chunks(int B);      /* records per (seed, agent) it writes: apply with rcmarl_small_sgd_chunks */
 int rcmarl_w1_split_fit(const float* theta, const float* alpha, void* wpf, int S, int N, int in_dim, int hid, int ldp,
                         int wpf_rt, int wpf_kt, void* stream);
 int rcmarl_fit_fused_lattice(const void* kp, int kp_rt, int kp_kt, const void* wpf, int wpf_rt, int wpf_kt,
@@ -157,6 +158,9 @@ int rcmarl_shuffle_perms(const void* seeds, const int* calls, int n, int epochs,
 /* reduce the partials over chunks and apply SGD to b1,W2,b2,W3,b3; loss_out[S][N] (or NULL) = MSE. */
 int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
                      int B, int in_dim, int hid, int ldp, float lr, void* stream);
+/* the same for partials[S][N][nchunk][..] with an explicit nchunk (producers whose chunk is not 256 replay rows) */
+int rcmarl_small_sgd_chunks(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
+                            int B, int in_dim, int hid, int ldp, float lr, int nchunk, void* stream);
 
 /* K6: out[s][n][b] = head(a1t) (r_applied NULL), or the TD target r_applied + gamma*V
  * (local_TD_target, agents/resilient_CAC_agents.py:114-115).  Also serves r_team, V, nV of :95-97. */

@@ -63,6 +63,9 @@ SIGNATURES = {
                                c_int, c_int, c_stream],
     # fused local-fit step of the lattice path, csrc/lattice_fit.hip
     "rcmarl_fit_rows": [c_int],
+    "rcmarl_fit_fused_chunks": [c_int],
+    # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, nchunk, stream
+    "rcmarl_small_sgd_chunks": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_stream],
     # theta, alpha, wpf, S, N, in_dim, hid, ldp, wpf_rt, wpf_kt, stream
     "rcmarl_w1_split_fit": [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # kp, kp_rt, kp_kt, wpf, wpf_rt, wpf_kt, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
@@ -167,7 +170,7 @@ SIGNATURES = {
     # grads, theta, coop, S, N, B, in_dim, hid, ldp, stream
     "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_rows", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_rows", "rcmarl_fit_fused_chunks", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
              "rcmarl_fit_small_partial_size", "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
              "rcmarl_consensus_params_circulant_supported"}
 

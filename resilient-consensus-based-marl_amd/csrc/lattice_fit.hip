@@ -31,7 +31,12 @@ constexpr int HID = 20, H2 = HID / 2;
 constexpr int FAG = RC_FIT_AGENTS;            // agents per workgroup
 constexpr int FBM = RC_FIT_ROWS;              // W' rows per workgroup
 constexpr int FMB = FBM / 32;                 // 32-row MFMA blocks
-constexpr int NW = 8;                         // wavefronts per workgroup
+#ifndef RC_FIT_NW
+#define RC_FIT_NW 4
+#endif
+constexpr int NW = RC_FIT_NW;                 // wavefronts per workgroup (4: two workgroups per CU, one in its k-loop while
+                                              // the other is in its epilogue; 8: one workgroup per CU)
+constexpr int NB_MAX = (30 + NW - 1) / NW;    // LDS-DMA bursts per wavefront and stage (the last wavefronts issue one less)
 constexpr int FWN = 32;                       // replay rows per wavefront (one MFMA column block)
 constexpr int FBN = NW * FWN;                 // replay rows per workgroup = the chunk of a partial record
 constexpr int A_PIECE = FBM * 64;             // bytes of one piece of one k32 stage
@@ -44,35 +49,18 @@ constexpr int P_GW2 = 0, P_GB2 = HID * HID, P_GW3 = P_GB2 + HID, P_GB3 = P_GW3 +
 constexpr int W_B1 = 0, W_W2 = HID, W_B2 = W_W2 + HID * HID, W_W3 = W_B2 + HID, W_B3 = W_W3 + HID, W_W2T = 464;
 constexpr int WS = W_W2T + HID * HID;         // floats per agent: b1(20) | W2(400) | b2(20) | W3(20) | b3 | pad | W2^T(400)
 constexpr int PLD = FWN + 1;                  // panel row stride (floats): (unit*33 + row) % 32 distinct over units
-constexpr int PA_ROWS = HID + 2, PB_ROWS = HID + 1;                      // a1 | ones | zeros ;  dz2 | zeros
+// panels of the reduction product G = A^T B over the wavefront's 32 rows (one half's agent at a time), 32 x 32:
+//   A rows: a1[0..19] | ones | a2[0..10]*dv          B rows: dz2[0..19] | ones | dv | diff^2 | a2[11..19]*dv
+//   G[i<20][j<20] = gW2, G[20][j<20] = gb2, G[21+i][20] = gW3[i], G[20][21] = gb3, G[20][22] = loss, G[20][23+i] = gW3[11+i]
+constexpr int PA_ROWS = 32, PB_ROWS = 32, GW3_IN_A = 11;
 constexpr int PANEL = ((PA_ROWS + PB_ROWS) * PLD + 63) / 64 * 64;        // floats per wavefront
 constexpr int LDS_WTS = 0, LDS_PANELS = FAG * WS * 4, LDS_STAGING = LDS_PANELS + NW * PANEL * 4;
 static_assert(LDS_STAGING >= 2 * A_STAGE, "the k-loop stages lie inside the weights + panels area");
-constexpr int LDS_TOTAL = LDS_STAGING + NW * 2 * P_SIZE * 4;             // ~102 KiB: one 8-wavefront workgroup per CU
+static_assert(NW == 4 || NW == 8, "4 or 8 wavefronts");
+constexpr int P_STRIDE = P_SIZE + 64 + 2;     // a staged record + one dump word per lane (elements of the 32x32 tile outside the record)
+constexpr int LDS_TOTAL = LDS_STAGING + NW * 2 * P_STRIDE * 4;           // ~126 KiB: one 8-wavefront workgroup per CU
 
-typedef unsigned rc_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_u4(const unsigned char* p) { return *reinterpret_cast<const uint4*>(p); }
-
-// B-operand fragment straight from global memory (L2): 16 B per lane, wave-uniform base + 32-bit lane offset.
-// Issued as inline asm so that the loads stay where they are written (one k16 step ahead of their use) instead of
-// being sunk to the use by the register-pressure scheduler; RC_WAIT_B orders them.
-#ifdef RCMARL_EMU
-typedef uint4 rc_bfrag;
-__device__ __forceinline__ void ldg_b(rc_bfrag& dst, const unsigned char* sbase, unsigned voff) { dst = ld_u4(sbase + voff); }
-__device__ __forceinline__ uint4 as_u4(const rc_bfrag& v) { return v; }
-#define RC_WAIT_B(n, x) ((void)0)
-#else
-typedef rc_u4 rc_bfrag;
-__device__ __forceinline__ void ldg_b(rc_bfrag& dst, const unsigned char* sbase, unsigned voff) {
-  // (s_nop 4: the base may come straight out of an SALU add; an SGPR written by the SALU needs wait states before a
-  // vector-memory instruction reads it, and hipcc pads nothing inside an asm statement)
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ uint4 as_u4(const rc_bfrag& v) { return __builtin_bit_cast(uint4, v); }
-// wait until at most n vector-memory operations of this wavefront are outstanding; x is the register the caller is
-// about to read (the dependency keeps its uses behind the wait)
-#define RC_WAIT_B(n, x) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(n) : "memory")
-#endif
 
 // workgroup id -> (seed, tile within the seed); all tiles of a seed on one XCD when S % 8 == 0 (as lattice_gemm.hip)
 __device__ __forceinline__ void fit_decode(int g, int per_seed, int S, int& seed, int& w) {
@@ -86,12 +74,12 @@ __device__ __forceinline__ void fit_decode(int g, int per_seed, int S, int& seed
   }
 }
 
-__global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict__ wpf, int wpf_rt, int wpf_kt,
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lat_fit(const unsigned char* __restrict__ wpf, int wpf_rt, int wpf_kt,
                                                  const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                  const float* __restrict__ theta, const float* __restrict__ y,
                                                  float* __restrict__ partials, unsigned char* __restrict__ dzp,
                                                  int dzp_rt, int dzp_kt, int S, int N, int B, int in_dim, int ldp,
-                                                 int ldb, int mtiles, int ntiles) {
+                                                 int ldb, int mtiles, int ntiles, int dbg) {
   RCMARL_DYN_SMEM(unsigned char, lds);
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -99,6 +87,16 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
   fit_decode(blockIdx.x, mtiles * ntiles, S, s, w);
   const int bn = w % ntiles, bm = w / ntiles;        // n fastest: the workgroups resident together share W' panels
   const int n_ktiles = (in_dim + 31) >> 5;
+#ifndef RCMARL_EMU
+  // De-phasing (pure scheduling, no effect on results): the two workgroups that share a CU would start together and
+  // run their k-loops (matrix core) and their epilogues (VALU, f32 MFMA, stores) in lockstep.  In the first round of
+  // residency the workgroup that got the UPPER LDS allocation sleeps about half a tile (dbg bits 8-15 x ~3.4 us), so
+  // one workgroup's epilogue runs beside the other's k-loop; later workgroups inherit the offset.
+  if ((dbg >> 8) & 0xff) {
+    if (blockIdx.x < 512u && (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) & 0xff) != 0)        // HW_REG_LDS_ALLOC.LDS_BASE
+      for (int i = 0; i < ((dbg >> 8) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   // ---- k-loop ------------------------------------------------------------------------------------------------
   rc_f32x16 acc[FMB];
@@ -109,10 +107,10 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
   {
     // A: burst q = piece*10 + j covers rows 16j..16j+15 of one piece; wavefront `wave` issues bursts wave, wave+8, ..
     const unsigned char* wp_s = wpf + (long)s * wpf_rt * wpf_kt * (3 * RC_PK_BLOCK);
-    const unsigned char* gsrc[4];
-    unsigned gdst[4];
+    const unsigned char* gsrc[NB_MAX];
+    unsigned gdst[NB_MAX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB_MAX; ++i) {
       int q = wave + NW * i;
       if (q >= A_BURSTS) q = A_BURSTS - 1;          // (not issued: see n_bursts)
       const int p = q / 10, j = q - 10 * p;
@@ -120,13 +118,13 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
       gsrc[i] = wp_s + ((long)(R >> 7) * wpf_kt * 3 + p) * RC_PK_BLOCK + (R & 127) * 64;
       gdst[i] = p * A_PIECE + j * 1024;
     }
-    const int n_bursts = wave < A_BURSTS - 3 * NW ? 4 : 3;          // 30 bursts over 8 wavefronts
+    const bool last_burst = wave < A_BURSTS - (NB_MAX - 1) * NW;    // 30 bursts over NW wavefronts
     const unsigned lane16 = lane * 16;
     const rc_lds_t lds0 = rc_lds_addr(lds);
     auto stage = [&](int buf, int t) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) RC_GLDS16S(gsrc[i] + (long)t * (3 * RC_PK_BLOCK), lane16, lds0 + buf * A_STAGE + gdst[i]);
-      if (n_bursts == 4) RC_GLDS16S(gsrc[3] + (long)t * (3 * RC_PK_BLOCK), lane16, lds0 + buf * A_STAGE + gdst[3]);
+      for (int i = 0; i < NB_MAX - 1; ++i) RC_GLDS16S(gsrc[i] + (long)t * (3 * RC_PK_BLOCK), lane16, lds0 + buf * A_STAGE + gdst[i]);
+      if (last_burst) RC_GLDS16S(gsrc[NB_MAX - 1] + (long)t * (3 * RC_PK_BLOCK), lane16, lds0 + buf * A_STAGE + gdst[NB_MAX - 1]);
     };
     // A fragment: row m = 32*mb + l31, chunk (2*ks + half) ^ ((m>>2)&3)
     const int swa = (l31 >> 2) & 3;
@@ -136,7 +134,7 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
     for (int mb = 0; mb < FMB; ++mb) offA[mb] = (32 * mb + l31) * 64;
     // B fragment: replay row r = row0 + l31, 16 B at chunk (2*ks + half) ^ ((r>>2)&3) of k-tile t
     const unsigned char* kp_s = kp + (long)s * kp_rt * kp_kt * RC_PK_BLOCK;
-    unsigned offB0, offB1;
+    unsigned offB0, offB1;                             // (32-bit: one seed's K image is a few MB)
     {
       const int r = bn * FBN + wave * FWN + l31;
       const unsigned base = (unsigned)((r >> 7) * kp_kt) * RC_PK_BLOCK + (r & 127) * 64;
@@ -144,9 +142,14 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
       offB0 = base + (((0 + half) ^ sw) << 4);
       offB1 = base + (((2 + half) ^ sw) << 4);
     }
-    rc_bfrag b0, b1;                                   // fragments of ks = 0 / ks = 1
+    // B fragments are PLAIN loads (hipcc counts them; the LDS-DMA bursts it cannot see only make its vmcnt waits
+    // conservative), each pinned one k16 step ahead of its use by a scheduling fence.  (Hand-issued asm loads with a
+    // separate asm wait were tried first: hipcc placed register copies of the not-yet-landed destination BEFORE the
+    // wait on two of three paths -- intermittently stale fragments at 24 k-tiles.)
+    uint4 b0, b1;                                      // fragments of ks = 0 / ks = 1
     stage(0, 0);
-    ldg_b(b0, kp_s, offB0);
+    b0 = ld_u4(kp_s + offB0);
+    RC_SCHED_FENCE();
     auto kstep = [&](const unsigned char* st, int co, const uint4 bf) {
 #pragma unroll
       for (int p = 2; p >= 0; --p) {                   // smallest pieces first (as lattice_gemm.hip: same fp32 sums)
@@ -157,26 +160,32 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
         for (int mb = 0; mb < FMB; ++mb) acc[mb] = rc_mfma_bf16(af[mb], bf, acc[mb]);
       }
     };
-    for (int t = 0; t < n_ktiles; ++t) {
+    for (int t = 0; t < ((dbg & 2) ? 1 : n_ktiles); ++t) {          // (dbg 2: one k-tile only = the epilogue's time)
       const int cur = t & 1;
-      RC_WAIT_B(0, b0);                                // this wavefront's A bursts of tile t and B(t, ks 0) have landed
+      RC_WAIT_VMEM();                                  // this wavefront's A bursts of tile t (and B(t, ks 0)) have landed
       __syncthreads();                                 // ... everybody's bursts; all reads of the other stage are done
       const bool more = t + 1 < n_ktiles;
-      ldg_b(b1, kp_s + (long)t * RC_PK_BLOCK, offB1);
+      b1 = ld_u4(kp_s + (long)t * RC_PK_BLOCK + offB1);
+      RC_SCHED_FENCE();
       if (more) stage(cur ^ 1, t + 1);
       const unsigned char* st = lds + cur * A_STAGE;
-      kstep(st, coa0, as_u4(b0));
-      if (more) {
-        ldg_b(b0, kp_s + (long)(t + 1) * RC_PK_BLOCK, offB0);
-        // B(t, ks 1) is older than the bursts of tile t+1 and the load just issued
-        if (n_bursts == 4) RC_WAIT_B(5, b1); else RC_WAIT_B(4, b1);
-      } else {
-        RC_WAIT_B(0, b1);
-      }
-      kstep(st, coa1, as_u4(b1));
+      kstep(st, coa0, b0);
+      RC_SCHED_FENCE();
+      if (more) b0 = ld_u4(kp_s + (long)(t + 1) * RC_PK_BLOCK + offB0);
+      RC_SCHED_FENCE();
+      kstep(st, coa1, b1);
     }
   }
 
+  if (dbg & 1) {                                       // measurement aid (RCMARL_FIT_DBG=1): k-loop only, results WRONG
+    float t = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < FMB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += acc[mb][i];
+    if (t == 12345.678f) partials[0] = t;
+    return;
+  }
   // ---- epilogue ----------------------------------------------------------------------------------------------
   __syncthreads();                                     // all fragment reads done: the stage area becomes scratch
   float* wts = reinterpret_cast<float*>(lds + LDS_WTS);
@@ -197,11 +206,10 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
         wts[a8 * WS + W_W2T + k * HID + j] = v;
       }
     }
-    // constant rows of this wavefront's panels: ones (-> gb2), zeros (padding of the 32x32 tile)
+    // constant rows of this wavefront's panels: the ones row of A (-> column sums of B) and of B (-> row sums of A)
     if (lane < FWN) {
       sA[HID * PLD + lane] = 1.f;
-      sA[(HID + 1) * PLD + lane] = 0.f;
-      sB[HID * PLD + lane] = 0.f;
+      sB[HID * PLD + lane] = 1.f;
     }
   }
   __syncthreads();
@@ -212,6 +220,19 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
   const unsigned dz_lane = (unsigned)(row_l >> 5) * (3 * RC_PK_BLOCK) + ((((unsigned)row_l & 31u) >> 3) << 4) + ((unsigned)row_l & 7u) * 2;
   unsigned char* dzp_s = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK);
   const int nchunk = ntiles;
+  // where element q of this lane's 32x32 result tile D[i = (q&3) + 8*(q>>2) + 4*half][j = l31] goes inside a staged record
+  // (layout of the product: see PA_ROWS above); elements outside the record go to the lane's dump word.  Same for every
+  // agent: computed once, sixteen registers.
+  int rec_idx[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = (q & 3) + 8 * (q >> 2) + 4 * half, j = l31;
+    int idx = -1;
+    if (i < HID) idx = j < HID ? i * HID + j : -1;
+    else if (i == HID) idx = j < HID ? P_GB2 + j : (j == HID + 1 ? P_GB3 : (j == HID + 2 ? P_LOSS : (j >= HID + 3 ? P_GW3 + GW3_IN_A + (j - HID - 3) : -1)));
+    else idx = j == HID ? P_GW3 + (i - HID - 1) : -1;
+    rec_idx[q] = idx >= 0 ? idx : P_SIZE + lane;
+  }
 
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -219,8 +240,8 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
     const int agent = bm * FAG + a8;                   // differs between the two halves of the wavefront
     const bool agent_ok = agent < N;
     const float* wl = wts + a8 * WS;
-    float* st_w = staging + wave * (2 * P_SIZE);
-    // ---- layer 1: a1 = lrelu(z1 + b1)
+    float* st_w = staging + wave * (2 * P_STRIDE);
+    // ---- layer 1: a1 = lrelu(z1 + b1), row per lane (the lane's own agent)
     float a1[HID];
 #pragma unroll
     for (int q = 0; q < HID / 4; ++q) {
@@ -233,69 +254,62 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
         a1[4 * q + e] = fmaxf(z, RC_LEAK * z);
       }
     }
-    // ---- layer 2 forward: z2[k] = sum_j a1[j] W2[j][k] (j ascending), a2 = lrelu(z2 + b2).  Plain v_fma_f32: the
-    // packed form has the same throughput on this VALU and costs extra beside MFMAs (MI355X_MICROARCH.md).  Two rows of
-    // W2 per basic block (RC_OPAQUE_TRUE: keeps the weight reads next to the FMAs that consume them).
+    // ---- layer 2 forward on the f32 matrix core, TRANSPOSED so that the result lands row-per-lane again:
+    //   Z_b[unit i][row j] = sum_m W2_b[m][i] * a1_b[row j][m]     (block b = the half's agent; two-block 32x32x1 MFMA)
+    // A operand: lane (i, b) reads W2_b[m][i] from LDS (units >= 20 read finite neighbours: unused rows of Z);
+    // B operand: lane (row, b) supplies ITS OWN register a1[m].  20 instructions, m ascending = the fmaf chain of the
+    // VALU form bit for bit.  Lane (row, h) then holds units e + 8q + 4h of BOTH agents (registers 16b + 4q + e);
+    // twelve v_permlane32_swap hand the other agent's values across: afterwards unit e + 8q of the lane's own agent
+    // is in register 4q + e and unit e + 8q + 4 in register 16 + 4q + e, for both halves alike.
     float z2[HID];
+    {
+      rc_f32x32 zz;
 #pragma unroll
-    for (int k = 0; k < HID; ++k) z2[k] = 0.f;
+      for (int r = 0; r < 32; ++r) zz[r] = 0.f;
+      const float* wcol = wl + W_W2 + l31;
+      if (!(dbg & 32))
 #pragma unroll
-    for (int jj = 0; jj < HID; jj += 2) {
-      if (RC_OPAQUE_TRUE()) {
+      for (int m = 0; m < HID; ++m) zz = __builtin_amdgcn_mfma_f32_32x32x1f32(wcol[m * HID], a1[m], zz, 0, 0, 0);
 #pragma unroll
-        for (int j = jj; j < jj + 2; ++j) {
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-          for (int q4 = 0; q4 < HID / 4; ++q4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wl + W_W2 + j * HID + 4 * q4);
-            z2[4 * q4 + 0] = fmaf(a1[j], w4.x, z2[4 * q4 + 0]);
-            z2[4 * q4 + 1] = fmaf(a1[j], w4.y, z2[4 * q4 + 1]);
-            z2[4 * q4 + 2] = fmaf(a1[j], w4.z, z2[4 * q4 + 2]);
-            z2[4 * q4 + 3] = fmaf(a1[j], w4.w, z2[4 * q4 + 3]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          float lo = zz[4 * q + e], hi = zz[16 + 4 * q + e];
+          rc_swap32(lo, hi);
+          z2[8 * q + e] = lo;
+          if (8 * q + 4 + e < HID) z2[8 * q + 4 + e] = hi;
         }
-      }
     }
+    // ---- a2 = lrelu(z2 + b2); head v = a2 . W3 + b3 (k ascending); MSE gradient
     float a2[HID], w3[HID];
     float v = 0.f;
-    if (RC_OPAQUE_TRUE()) {
 #pragma unroll
-      for (int q4 = 0; q4 < HID / 4; ++q4) {
-        const float4 b4 = *reinterpret_cast<const float4*>(wl + W_B2 + 4 * q4);
-        const float4 w4 = *reinterpret_cast<const float4*>(wl + W_W3 + 4 * q4);
-        a2[4 * q4 + 0] = rc_lrelu(z2[4 * q4 + 0] + b4.x);
-        a2[4 * q4 + 1] = rc_lrelu(z2[4 * q4 + 1] + b4.y);
-        a2[4 * q4 + 2] = rc_lrelu(z2[4 * q4 + 2] + b4.z);
-        a2[4 * q4 + 3] = rc_lrelu(z2[4 * q4 + 3] + b4.w);
-        w3[4 * q4] = w4.x; w3[4 * q4 + 1] = w4.y; w3[4 * q4 + 2] = w4.z; w3[4 * q4 + 3] = w4.w;
-      }
-#pragma unroll
-      for (int k = 0; k < HID; ++k) v = fmaf(a2[k], w3[k], v);
-      v += wl[W_B3];
+    for (int q4 = 0; q4 < HID / 4; ++q4) {
+      const float4 b4 = *reinterpret_cast<const float4*>(wl + W_B2 + 4 * q4);
+      const float4 w4 = *reinterpret_cast<const float4*>(wl + W_W3 + 4 * q4);
+      a2[4 * q4 + 0] = rc_lrelu(z2[4 * q4 + 0] + b4.x);
+      a2[4 * q4 + 1] = rc_lrelu(z2[4 * q4 + 1] + b4.y);
+      a2[4 * q4 + 2] = rc_lrelu(z2[4 * q4 + 2] + b4.z);
+      a2[4 * q4 + 3] = rc_lrelu(z2[4 * q4 + 3] + b4.w);
+      w3[4 * q4] = w4.x; w3[4 * q4 + 1] = w4.y; w3[4 * q4 + 2] = w4.z; w3[4 * q4 + 3] = w4.w;
     }
-    // ---- MSE gradient
+#pragma unroll
+    for (int k = 0; k < HID; ++k) v = fmaf(a2[k], w3[k], v);
+    v += wl[W_B3];
     const bool row_ok = agent_ok && valid;
     const float yv = row_ok ? y[((long)s * N + agent) * ldb + row_l] : 0.f;
     const float diff = row_ok ? v - yv : 0.f;
     const float dv = (2.0f * diff) / fb;
-    // ---- dz2[k] = dv * W3[k] * lrelu'(z2[k]); the row sums that need a2: gW3[k] = sum a2[k]*dv, gb3 = sum dv
-    float dz2[HID];
-    {
-      float sm[HID + 1];
+    // ---- dz2[k] = dv * W3[k] * lrelu'(z2[k]); g3[k] = a2[k]*dv (summed over rows = gW3)
+    float dz2[HID], g3[HID];
 #pragma unroll
-      for (int k = 0; k < HID; ++k) {
-        sm[k] = a2[k] * dv;
-        dz2[k] = dv * w3[k] * rc_lrelu_grad_from_act(a2[k]);
-      }
-      sm[HID] = dv;
-      static_assert((HID + 1) % 3 == 0, "sums are reduced three at a time");
-#pragma unroll
-      for (int q = 0; q < (HID + 1) / 3; ++q) rc_half_sum3_lane31(sm[3 * q], sm[3 * q + 1], sm[3 * q + 2]);
-      if (l31 == 31) {
-#pragma unroll
-        for (int k = 0; k < HID + 1; ++k) st_w[half * P_SIZE + P_GW3 + k] = sm[k];     // gW3[0..19], gb3
-      }
+    for (int k = 0; k < HID; ++k) {
+      g3[k] = a2[k] * dv;
+      dz2[k] = dv * w3[k] * rc_lrelu_grad_from_act(a2[k]);
     }
-    // ---- gW2 = a1^T dz2, gb2 = 1^T dz2 of this wavefront's 32 rows: f32 matrix core, one half's agent at a time
+    // ---- everything summed over the wavefront's 32 rows except gb1: ONE 32x32 product per agent on the f32 matrix core
+    // (panel layout above), one half's agent at a time through the wavefront's panel buffer
+    if (!(dbg & 16))
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       RC_WAVE_SYNC();                                  // the previous product's fragment reads are done
@@ -305,77 +319,80 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
           sA[k * PLD + l31] = a1[k];
           sB[k * PLD + l31] = dz2[k];
         }
+#pragma unroll
+        for (int i = 0; i < GW3_IN_A; ++i) sA[(HID + 1 + i) * PLD + l31] = g3[i];
+        sB[(HID + 1) * PLD + l31] = dv;
+        sB[(HID + 2) * PLD + l31] = diff * diff;
+#pragma unroll
+        for (int i = 0; i < HID - GW3_IN_A; ++i) sB[(HID + 3 + i) * PLD + l31] = g3[GW3_IN_A + i];
       }
       RC_WAVE_SYNC();
       rc_f32x16 g1;
 #pragma unroll
       for (int q = 0; q < 16; ++q) g1[q] = 0.f;
-      const int ia = (l31 < HID + 1 ? l31 : HID + 1) * PLD + half;      // A rows: a1 units | ones | zeros
-      const int ib = (l31 < HID ? l31 : HID) * PLD + half;              // B rows: dz2 units | zeros
+      const int ia = l31 * PLD + half, ib = l31 * PLD + half;
 #pragma unroll
       for (int m = 0; m < FWN / 2; ++m) g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib + 2 * m], g1, 0, 0, 0);
-      // D[row = (q&3) + 8*(q>>2) + 4*half][col = l31] -> gW2[row][col] (row < 20), gb2[col] (row == 20)
-      if (l31 < HID) {
+      float* rec = st_w + hh * P_STRIDE;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
-          if (row <= HID) st_w[hh * P_SIZE + row * HID + l31] = g1[q];      // row 20 lands on P_GB2 + col
-        }
-      }
+      for (int q = 0; q < 16; ++q) rec[rec_idx[q]] = g1[q];
     }
-    // ---- layer 2 backward: dz1[j] = (sum_k dz2[k] W2[j][k]) * lrelu'(z1[j]), k ascending (rows of W2^T)
+    // ---- layer 2 backward, same transposed form:  DA_b[unit j][row] = sum_k W2_b[j][k] * dz2_b[row][k]  (k ascending)
     float da[HID];
+    {
+      rc_f32x32 dd;
 #pragma unroll
-    for (int j = 0; j < HID; ++j) da[j] = 0.f;
+      for (int r = 0; r < 32; ++r) dd[r] = 0.f;
+      const float* wtcol = wl + W_W2T + l31;           // W2^T[k][j]: lane j reads a conflict-free column
+      if (!(dbg & 32))
 #pragma unroll
-    for (int kk = 0; kk < HID; kk += 2) {
-      if (RC_OPAQUE_TRUE()) {
+      for (int k = 0; k < HID; ++k) dd = __builtin_amdgcn_mfma_f32_32x32x1f32(wtcol[k * HID], dz2[k], dd, 0, 0, 0);
 #pragma unroll
-        for (int k = kk; k < kk + 2; ++k) {
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-          for (int q4 = 0; q4 < HID / 4; ++q4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wl + W_W2T + k * HID + 4 * q4);
-            da[4 * q4 + 0] = fmaf(dz2[k], w4.x, da[4 * q4 + 0]);
-            da[4 * q4 + 1] = fmaf(dz2[k], w4.y, da[4 * q4 + 1]);
-            da[4 * q4 + 2] = fmaf(dz2[k], w4.z, da[4 * q4 + 2]);
-            da[4 * q4 + 3] = fmaf(dz2[k], w4.w, da[4 * q4 + 3]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          float lo = dd[4 * q + e], hi = dd[16 + 4 * q + e];
+          rc_swap32(lo, hi);
+          da[8 * q + e] = lo;
+          if (8 * q + 4 + e < HID) da[8 * q + 4 + e] = hi;
         }
-      }
     }
-    // dz1 leaves as three exact bf16 pieces (packed rows = (agent, unit) in NATURAL order, k = replay row) and joins
-    // gb1[j] = sum dz1[j]; loss = sum diff^2
+    // ---- dz1[j] = da[j] * lrelu'(z1[j]) leaves as three exact bf16 pieces (packed rows = (agent, unit) in NATURAL
+    // order, k = replay row) and joins gb1[j] = sum dz1[j]
     {
       float sm[HID + 1];
+      const unsigned dz_agent = agent_ok ? (unsigned)agent * HID : 0u;
 #pragma unroll
       for (int q = 0; q < H2; ++q) {
         const float d0 = da[2 * q] * rc_lrelu_grad_from_act(a1[2 * q]);
         const float d1 = da[2 * q + 1] * rc_lrelu_grad_from_act(a1[2 * q + 1]);
         sm[2 * q] = d0;
         sm[2 * q + 1] = d1;
-        if (agent_ok) {
-          unsigned ph, pm, pl;
-          rc_split3_pair(d0, d1, ph, pm, pl);                      // bits 0-15: unit 2q, bits 16-31: unit 2q+1
+        unsigned ph, pm, pl;
+        rc_split3_pair(d0, d1, ph, pm, pl);                        // bits 0-15: unit 2q, bits 16-31: unit 2q+1
+        if (agent_ok && !(dbg & 4)) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int R = agent * HID + 2 * q + u;
-            const unsigned roff = (unsigned)(R >> 7) * (unsigned)dzp_kt * (3 * RC_PK_BLOCK) + (unsigned)(R & 127) * 64;
-            const unsigned sw = (unsigned)(((R >> 2) & 3) << 4);
-            unsigned char* p = dzp_s + roff + (dz_lane ^ sw);
-            *reinterpret_cast<unsigned short*>(p) = (unsigned short)(u ? ph >> 16 : ph);
-            *reinterpret_cast<unsigned short*>(p + RC_PK_BLOCK) = (unsigned short)(u ? pm >> 16 : pm);
-            *reinterpret_cast<unsigned short*>(p + 2 * RC_PK_BLOCK) = (unsigned short)(u ? pl >> 16 : pl);
+            const unsigned R = dz_agent + 2 * q + u;
+            // 32-bit offset from the seed's wave-uniform base (one seed's dz image is < 4 GiB): saddr + voffset stores
+            const unsigned off = ((R >> 7) * (unsigned)dzp_kt * (3 * RC_PK_BLOCK) + (R & 127u) * 64u + (dz_lane ^ (((R >> 2) & 3u) << 4)));
+            *reinterpret_cast<unsigned short*>(dzp_s + off) = (unsigned short)(u ? ph >> 16 : ph);
+            *reinterpret_cast<unsigned short*>(dzp_s + (off + RC_PK_BLOCK)) = (unsigned short)(u ? pm >> 16 : pm);
+            *reinterpret_cast<unsigned short*>(dzp_s + (off + 2 * RC_PK_BLOCK)) = (unsigned short)(u ? pl >> 16 : pl);
           }
         }
       }
-      sm[HID] = diff * diff;
+      sm[HID] = 0.f;
+      static_assert((HID + 1) % 3 == 0, "sums are reduced three at a time");
+      if (!(dbg & 8))
 #pragma unroll
       for (int q = 0; q < (HID + 1) / 3; ++q) rc_half_sum3_lane31(sm[3 * q], sm[3 * q + 1], sm[3 * q + 2]);
       if (l31 == 31) {
 #pragma unroll
-        for (int k = 0; k < HID + 1; ++k) st_w[half * P_SIZE + P_GB1 + k] = sm[k];     // gb1[0..19], loss
+        for (int k = 0; k < HID; ++k) st_w[half * P_STRIDE + P_GB1 + k] = sm[k];
       }
     }
+    if (dbg & 64) continue;
     __syncthreads();
     // ---- the eight wavefronts' records, summed in a fixed order -> partials[s][agent][bn]
     for (int e = threadIdx.x; e < 2 * P_SIZE; e += 64 * NW) {
@@ -384,9 +401,10 @@ __global__ __launch_bounds__(512) void k_lat_fit(const unsigned char* __restrict
       if (ag < N) {
         float r[NW];
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) r[ww] = staging[ww * 2 * P_SIZE + e];
-        partials[(((long)s * N + ag) * nchunk + bn) * P_SIZE + idx] =
-            ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int ww = 0; ww < NW; ++ww) r[ww] = staging[(ww * 2 + hh) * P_STRIDE + idx];
+        float tot = (r[0] + r[1]) + (r[2] + r[3]);
+        if constexpr (NW == 8) tot += (r[4] + r[5]) + (r[6] + r[7]);
+        partials[(((long)s * N + ag) * nchunk + bn) * P_SIZE + idx] = tot;
       }
     }
     __syncthreads();
@@ -442,6 +460,8 @@ bool fit_want_lds() {
 }  // namespace
 
 RCMARL_EXPORT int rcmarl_fit_rows(int n_agents) { return rc_ceil_div(n_agents, RC_FIT_AGENTS) * RC_FIT_ROWS; }
+// partial records per (seed, agent) rcmarl_fit_fused_lattice writes for B replay rows (one per workgroup row tile)
+RCMARL_EXPORT int rcmarl_fit_fused_chunks(int B) { return rc_ceil_div(B, FBN); }
 
 RCMARL_EXPORT int rcmarl_w1_split_fit(const float* theta, const float* alpha, void* wpf, int S, int N, int in_dim, int hid,
                                       int ldp, int wpf_rt, int wpf_kt, void* stream) {
@@ -462,12 +482,15 @@ RCMARL_EXPORT int rcmarl_fit_fused_lattice(const void* kp, int kp_rt, int kp_kt,
     return RCMARL_ERR_ARG;
   if (hid != HID) return RCMARL_ERR_UNSUPPORTED;
   const int mtiles = rc_ceil_div(N, FAG), ntiles = rc_ceil_div(B, FBN), ktiles = rc_ceil_div(in_dim, 32);
-  if ((long)wpf_rt * 128 < (long)mtiles * FBM || kp_rt < 2 * ntiles || wpf_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
+  if ((long)wpf_rt * 128 < (long)mtiles * FBM || kp_rt * 128 < ntiles * FBN || wpf_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
   if (dzp_rt < rc_ceil_div(N * HID, 128) || dzp_kt < ntiles * (FBN / 32)) return RCMARL_ERR_ARG;
   if (!fit_want_lds()) return RCMARL_ERR_LAUNCH;
+  // bits 0-7: measurement aids (0 in production); bits 8-15: de-phasing sleep of the second workgroup of a CU
+  static const int dbg = (getenv("RCMARL_FIT_DBG") ? atoi(getenv("RCMARL_FIT_DBG")) & 0xff : 0) |
+                         ((getenv("RCMARL_FIT_STAGGER") ? atoi(getenv("RCMARL_FIT_STAGGER")) & 0xff : 0) << 8);
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(64 * NW);
   RCMARL_LAUNCH(k_lat_fit, grid, block, LDS_TOTAL, stream, (const unsigned char*)wpf, wpf_rt, wpf_kt, (const unsigned char*)kp,
                 kp_rt, kp_kt, theta, y, partials, (unsigned char*)dzp, dzp_rt, dzp_kt, S, N, B, in_dim, ldp, ldb, mtiles,
-                ntiles);
+                ntiles, dbg);
   return rcmarl_check_launch();
 }

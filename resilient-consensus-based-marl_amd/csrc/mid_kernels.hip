@@ -977,6 +977,17 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   return rcmarl_check_launch();
 }
 
+// the same with an explicit number of records per (seed, agent): producers whose chunk is not 256 rows
+// (rcmarl_fit_fused_lattice: rcmarl_fit_fused_chunks(B) records)
+RCMARL_EXPORT int rcmarl_small_sgd_chunks(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
+                                          int B, int in_dim, int hid, int ldp, float lr, int nchunk, void* stream) {
+  if (!partials || !theta || S <= 0 || N <= 0 || B <= 0 || nchunk <= 0) return RCMARL_ERR_ARG;
+  const dim3 grid(N, S), block(256);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
+                                   in_dim, ldp, nchunk, lr, (int)FitPart<HID_>::SIZE));
+  return rcmarl_check_launch();
+}
+
 RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out,
                                    int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream) {
   if (!partials || !theta || S <= 0 || N <= 0 || B <= 0) return RCMARL_ERR_ARG;

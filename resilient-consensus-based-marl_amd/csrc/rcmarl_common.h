@@ -25,6 +25,7 @@
 #define RCMARL_EXPORT extern "C"
 typedef floatx16 rc_f32x16;
 typedef floatx4 rc_f32x4;
+typedef floatx32 rc_f32x32;
 #else
 // hipGetLastError() is sticky across the whole runtime (PyTorch's own calls included):
 // drop any stale error first so rcmarl_check_launch() reports THIS launch only.
@@ -36,6 +37,7 @@ typedef floatx4 rc_f32x4;
 #define RCMARL_EXPORT extern "C" __attribute__((visibility("default")))
 typedef float rc_f32x16 __attribute__((ext_vector_type(16)));
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
+typedef float rc_f32x32 __attribute__((ext_vector_type(32)));
 #endif
 
 static inline int rcmarl_check_launch() {
@@ -222,6 +224,13 @@ __device__ __forceinline__ void rc_half_sum3_lane31(float& a, float& b, float& c
 #else
 #define RC_TIE(ptr, val) asm volatile("" : "+v"(ptr), "+v"(val))
 #endif
+
+// v_permlane32_swap on two floats: lanes 32-63 of `a` swap with lanes 0-31 of `b`
+__device__ __forceinline__ void rc_swap32(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
 
 // Ordering point for data exchanged through LDS among the lanes of ONE wavefront (no workgroup barrier): the LDS
 // executes a wavefront's instructions in order, so this only has to stop the compiler from moving accesses across it.

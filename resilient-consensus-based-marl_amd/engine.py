@@ -210,7 +210,7 @@ class RPBCACEngine:
         self._init_wide()
         self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in self.ybuf}
         self.rcoop = torch.zeros(S, self.ldb, **f32)
-        nchunk_max = (self.cap + 255) // 256
+        nchunk_max = max((self.cap + 255) // 256, lib.rcmarl_fit_fused_chunks(self.cap))
         psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
         if self.small_fused:
             psz = max(psz, lib.rcmarl_fit_small_partial_size(HID, self.in_r))
@@ -372,8 +372,11 @@ class RPBCACEngine:
         self.lat_wp_f = {"sa": u8(self.lat_geom["sa"].wp, 3), "s": u8(self.lat_geom["s"].wp, 3)}
         self.lat_dzp_f = {"sa": u8(self.lat_geom["sa"].dzp, 3), "s": u8(self.lat_geom["s"].dzp, 3)}
         self.lat_wp_f["ns"] = self.lat_wp_f["s"]
-        # fused local-fit step (csrc/lattice_fit.hip, 20-unit nets): its forward operand is W' in "fit order"
-        self.fit_fused = os.environ.get("RCMARL_FIT_FUSED", "1") not in ("0", "false")
+        # fused local-fit step (csrc/lattice_fit.hip, 20-unit nets): its forward operand is W' in "fit order".  Opt-in
+        # (RCMARL_FIT_FUSED=1): bit-identical dz1, but measured no faster than the unfused pair it replaces (1.73 vs
+        # 1.76 ms per step at the cfg-4 critic shape) and the unfused path can skip the step-0
+        # forward GEMM of every fit (activations left by the consensus step), so a block is 361 vs 297 ms.
+        self.fit_fused = os.environ.get("RCMARL_FIT_FUSED", "0") not in ("0", "false")
         self.lat_wpf_geom, self.lat_wpf = {}, {}
         if self.fit_fused:
             for k, net in (("sa", "tr"), ("s", "critic")):
@@ -754,9 +757,9 @@ class RPBCACEngine:
                 L.rcmarl_fit_fused_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wpf.data_ptr(), frt, fkt, msg.data_ptr(),
                                            y.data_ptr(), partials.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B,
                                            self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
-                L.rcmarl_small_sgd(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
-                                   self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
-                                   self.ldp[net], self.cfg.fast_lr, self.stream)
+                L.rcmarl_small_sgd_chunks(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+                                          self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
+                                          self.ldp[net], self.cfg.fast_lr, L.rcmarl_fit_fused_chunks(B), self.stream)
                 L.rcmarl_layer1_backward_sgd_lattice_fit(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
                                                          g.dzp[0], g.dzp[1], alpha.data_ptr(), msg.data_ptr(),
                                                          mask.data_ptr(), S, N, B, self.in_dim[net], HID, self.ldp[net],

@@ -143,6 +143,42 @@ inline floatx16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, floatx16 
   hipemu::wave_barrier();
   return d;
 }
+// two-block form: block b = lane>>5 on the input side; lane l supplies A_b[i=l&31][k=0], B_b[k=0][j=l&31];
+// D_b[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] in register 16*b + r  (r = 0..15) -- every lane holds both blocks.
+struct floatx32 { float v[32]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+inline floatx32 __builtin_amdgcn_mfma_f32_32x32x1f32(float a, float b, floatx32 c, int, int, int) {
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  s.xch_f[((size_t)w * 64 + l) * 2 + 0] = a;
+  s.xch_f[((size_t)w * 64 + l) * 2 + 1] = b;
+  hipemu::wave_barrier();
+  floatx32 d = c;
+  int col = l & 31;
+  for (int blk = 0; blk < 2; ++blk)
+    for (int r = 0; r < 16; ++r) {
+      int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      float av = s.xch_f[((size_t)w * 64 + row + 32 * blk) * 2 + 0];
+      float bv = s.xch_f[((size_t)w * 64 + col + 32 * blk) * 2 + 1];
+      d[16 * blk + r] = fmaf(av, bv, d[16 * blk + r]);
+    }
+  hipemu::wave_barrier();
+  return d;
+}
+// v_permlane32_swap: lanes 32-63 of `vdst` swap with lanes 0-31 of `src` (the other two halves stay); returns {vdst', src'}
+struct __hipemu_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline __hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  s.xch_u[(size_t)w * 64 + l] = ((unsigned long long)vdst << 32) | src;
+  hipemu::wave_barrier();
+  unsigned long long other = s.xch_u[(size_t)w * 64 + (l ^ 32)];
+  hipemu::wave_barrier();
+  __hipemu_u2 r;
+  if (l < 32) { r.v[0] = vdst; r.v[1] = (unsigned)(other >> 32); }           // lower: keeps vdst, src <- upper's vdst
+  else { r.v[0] = (unsigned)(other & 0xffffffffu); r.v[1] = src; }              // upper: vdst <- lower's src, keeps src
+  return r;
+}
+
 inline floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, floatx4 c, int, int, int) {
   // lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=(l>>4)*4+r][col=l&15]
   auto& s = hipemu::st();

@@ -941,7 +941,7 @@ def check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, lr=0.01, ga
     mask = np.ones(N, np.int32)
     if masked_agent is not None:
         mask[masked_agent] = 0
-    nchunk = (B + 255) // 256
+    nchunk, nchunk_f = (B + 255) // 256, bk.lib.rcmarl_fit_fused_chunks(B)
     psz = bk.lib.rcmarl_fit_partial_size(HID)
     lb = LatticeBuffers(bk, S, N, in_dim, B)
     g = lb.g
@@ -951,7 +951,7 @@ def check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, lr=0.01, ga
     d_x, d_al, d_y, d_mask = bk.dev(x), bk.dev(alpha), bk.dev(y), bk.dev(mask)
     d_msg = bk.dev(theta.copy())
     d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
-    d_part = bk.dev(np.full((S, N, nchunk, psz), np.nan, np.float32))
+    d_part = bk.dev(np.full((S, N, nchunk_f, psz), np.nan, np.float32))
     d_part2 = bk.dev(np.full((S, N, nchunk, psz), np.nan, np.float32))
     d_loss = bk.dev(np.zeros((S, N), np.float32))
     L = bk.lib
@@ -972,12 +972,12 @@ def check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, lr=0.01, ga
             for pc in range(3):
                 idx = LT.pk_element_index(N * HID, kpad, g.dzp[1], 3, pc)
                 np.testing.assert_array_equal(dz_f[s_][idx], dz_u[s_][idx], err_msg="dz1 piece %d, step %d" % (pc, st))
-        pf, pu = bk.host(d_part), bk.host(d_part2)
+        pf, pu = bk.host(d_part).sum(axis=2), bk.host(d_part2).sum(axis=2)        # the chunkings differ: compare the sums
         assert np.isfinite(pf).all()
-        scale = np.maximum(np.abs(pu).max(axis=(2, 3), keepdims=True), 1e-6)
+        scale = np.maximum(np.abs(pu).max(axis=2, keepdims=True), 1e-6)
         assert float((np.abs(pf - pu) / scale).max()) <= 2e-5, ("partial records", st, float((np.abs(pf - pu) / scale).max()))
-        L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
-                           in_dim, HID, ldp, lr, bk.stream)
+        L.rcmarl_small_sgd_chunks(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
+                                  in_dim, HID, ldp, lr, nchunk_f, bk.stream)
         L.rcmarl_layer1_backward_sgd_lattice_fit(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
                                                  bk.ptr(d_al), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
                                                  bk.ptr(d_wpf), frt, fkt, bk.stream)

@@ -93,3 +93,13 @@ def test_replay_grows_past_the_steady_state_capacity():
     logs = {k: np.concatenate([l1[k], l2[k]], axis=0) for k in l1}
     import pandas as pd
     EC.compare(eng, logs, [pd.concat([df1, df2], ignore_index=True)], [ow])
+
+
+def test_engine_fused_local_fit_matches_oracle(monkeypatch):
+    """RCMARL_FIT_FUSED=1: the local fits run through rcmarl_fit_fused_lattice (one launch for layer-1 GEMM + layers 2-3 +
+    the way back to dz1) -> same oracle, same tolerances."""
+    monkeypatch.setenv("RCMARL_FIT_FUSED", "1")
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=33)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(33, 34), lattice=True)
+    assert eng.lat_active and eng.fit_fused and "s" in eng.lat_wpf
+    EC.compare(eng, logs, o_logs, o_w)

@@ -174,3 +174,15 @@ def test_checkpoint_resume_is_bit_identical(labels, rng_mode, n, tmp_path):
     EC.check_checkpoint_resume(labels, rng_mode, "cuda", None, str(tmp_path / "ck.pt"), n=n, nrow=5 if n == 5 else 8,
                                max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=300, S=3, blocks=(2, 2),
                                lattice=True if n == 5 else "auto")
+
+
+def test_engine_fused_local_fit_matches_oracle(monkeypatch):
+    """The opt-in fused local-fit step (RCMARL_FIT_FUSED=1, csrc/lattice_fit.hip) end to end vs the oracle, 20 agents."""
+    monkeypatch.setenv("RCMARL_FIT_FUSED", "1")
+    n = 20
+    in_nodes = [[(i + k) % n for k in range(6)] for i in range(n)]
+    args = EC.make_args(["Cooperative"] * n, H=2, n_episodes=20, max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=300,
+                        seed=43, in_nodes=in_nodes)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 16, 12, "device", "cuda", None, seeds=(43, 44))
+    assert eng.lat_active and eng.fit_fused and "s" in eng.lat_wpf
+    EC.compare(eng, logs, o_logs, o_w)

@@ -161,7 +161,7 @@ def lattice(L, S=16, N=256, B=3000):
         kp, ktp, wp, dzp = u8(g.kp, 1), u8(g.ktp, 1), u8(g.wp, 3), u8(g.dzp, 3)
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         nchunk = (B + 255) // 256
-        part = torch.zeros(S * N * nchunk * L.rcmarl_fit_partial_size(HID), device="cuda")
+        part = torch.zeros(S * N * max(nchunk, L.rcmarl_fit_fused_chunks(B)) * L.rcmarl_fit_partial_size(HID), device="cuda")
         flops = 2.0 * S * N * HID * B * in_dim
         t = timeit(lambda: L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0],
                                                    g.kp[1], ktp.data_ptr(), g.ktp[0], g.ktp[1], flag.data_ptr(), st))
