@@ -37,3 +37,118 @@ def allreduce_curves(local_sums, n_local_seeds, device=None, sq_sums=None):
         return mean
     var = np.maximum(out[k:2 * k].reshape(local_sums.shape) / n - mean ** 2, 0.0)
     return mean, np.sqrt(var)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C2: ONE instance sharded over the ranks (BASELINE configs[4]: 1024 agents x 512-unit critic)
+#
+# Phase I (local fits) is independent per AGENT, phase II-b (hidden-layer consensus, K1) is independent per parameter
+# COLUMN: every output column needs all d neighbour rows of that column and nothing else.  So an agent-sharded phase I
+# followed by a column-sharded K1 needs exactly one exchange each way -- an all-to-all transpose of the message matrix
+# [N, P_hid] (each rank sends the (its agents) x (peer's columns) block to every peer) and the reverse transpose of the
+# aggregated hidden parameters.  This replaces the reference's in-process gather
+# `[critic_weights[i] for i in in_nodes[node]]` (training/train_agents.py:129-130).  On xGMI the all-to-all is direct
+# (7 links per GPU used in parallel), not a ring: cfg 5 sends 7 x 84 MB per GPU per net per epoch.
+# K1 per column is the SAME kernel launch on a narrower matrix, so the sharded result equals the unsharded one bit for
+# bit (tests/test_sharded_consensus_gloo.py).
+def agent_range(n_agents, rank, world):
+    """Contiguous block of agents owned by `rank` (phase I / III shard)."""
+    base, rem = divmod(int(n_agents), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def column_ranges(n_cols, world, align=64):
+    """`world` contiguous column ranges covering [0, n_cols), boundaries on multiples of `align` (K1 walks 64-column
+    tiles and 16-byte loads want aligned rows); trailing ranks may get an empty range when n_cols is small."""
+    tiles = (int(n_cols) + align - 1) // align
+    out = []
+    for r in range(world):
+        base, rem = divmod(tiles, world)
+        t0 = r * base + min(r, rem)
+        t1 = t0 + base + (1 if r < rem else 0)
+        out.append((min(t0 * align, n_cols), min(t1 * align, n_cols)))
+    return out
+
+
+class ShardedConsensus:
+    """Column-sharded K1 for one network family of ONE instance whose agents are sharded over the ranks.
+
+        sc = ShardedConsensus(lib, S, N, P_hid, d, H, in_nodes, coop, device)        # after init_process_group
+        msg_cols = sc.exchange(msg_local)          # [S][N_loc][ldp]  ->  [S][N][ldc]   (all-to-all #1)
+        sc.consensus(msg_cols)                     # K1 on this rank's columns -> sc.theta_cols
+        sc.gather(theta_local)                     # [S][N][ldc] -> columns < P_hid of [S][N_loc][ldp]   (all-to-all #2)
+
+    Rows of non-cooperative agents are never aggregated (agents/resilient_CAC_agents.py is the cooperative agent's
+    class); gather() leaves them as they are."""
+
+    def __init__(self, lib, S, N, P_hid, d, H, in_nodes, coop, device, stream=None, group=None):
+        self.lib, self.S, self.N, self.P_hid, self.d, self.H = lib, int(S), int(N), int(P_hid), int(d), int(H)
+        self.dev, self.stream, self.group = torch.device(device), stream, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.a_lo, self.a_hi = agent_range(N, self.rank, self.world)
+        self.agents = [agent_range(N, r, self.world) for r in range(self.world)]
+        self.cols = column_ranges(P_hid, self.world)
+        self.c_lo, self.c_hi = self.cols[self.rank]
+        self.width = self.c_hi - self.c_lo
+        self.ldc = max(64, (self.width + 63) // 64 * 64)
+        nodes = np.asarray(in_nodes, dtype=np.int32)
+        self.circulant = bool(all(list(nodes[i]) == [(i + k) % N for k in range(d)] for i in range(N)) and
+                              lib.rcmarl_consensus_params_circulant_supported(N, d, H) == 1)
+        self.nbr = torch.tensor(nodes, dtype=torch.int32, device=self.dev)
+        self.coop = torch.tensor(np.asarray(coop, dtype=np.int32), dtype=torch.int32, device=self.dev)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.msg_cols = torch.zeros(self.S, self.N, self.ldc, **f32)
+        self.theta_cols = torch.zeros(self.S, self.N, self.ldc, **f32)
+
+    def _a2a(self, send_blocks, recv_shapes):
+        """all-to-all of one block per peer (flattened, unequal sizes); returns the received blocks."""
+        if self.world == 1:
+            return [send_blocks[0]]
+        send = torch.cat([b.reshape(-1) for b in send_blocks])
+        sizes_in = [int(b.numel()) for b in send_blocks]
+        sizes_out = [int(np.prod(sh)) for sh in recv_shapes]
+        recv = torch.empty(sum(sizes_out), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
+        out, o = [], 0
+        for sh, n in zip(recv_shapes, sizes_out):
+            out.append(recv[o:o + n].view(*sh))
+            o += n
+        return out
+
+    def exchange(self, msg_local):
+        """msg_local [S][N_loc][ldp] (this rank's agents, all columns) -> self.msg_cols [S][N][ldc] (all agents, this
+        rank's columns)."""
+        n_loc = self.a_hi - self.a_lo
+        assert msg_local.shape[0] == self.S and msg_local.shape[1] == n_loc
+        send = [msg_local[:, :, c0:c1].contiguous() for (c0, c1) in self.cols]
+        shapes = [(self.S, a1 - a0, self.width) for (a0, a1) in self.agents]
+        for (a0, a1), blk in zip(self.agents, self._a2a(send, shapes)):
+            self.msg_cols[:, a0:a1, :self.width] = blk
+        return self.msg_cols
+
+    def consensus(self, msg_cols=None):
+        """K1 (agents/resilient_CAC_agents.py:142-166) on this rank's columns; same launch as the unsharded step."""
+        msg = self.msg_cols if msg_cols is None else msg_cols
+        if self.width == 0:
+            return self.theta_cols
+        if self.circulant:
+            self.lib.rcmarl_consensus_params_circulant(msg.data_ptr(), self.theta_cols.data_ptr(), self.coop.data_ptr(), self.S,
+                                                       self.N, self.ldc, self.width, self.d, self.H, None, None, self.stream)
+        else:
+            self.lib.rcmarl_consensus_params(msg.data_ptr(), self.theta_cols.data_ptr(), self.nbr.data_ptr(),
+                                             self.coop.data_ptr(), self.S, self.N, self.ldc, self.width, self.d, self.H, None,
+                                             None, self.stream)
+        return self.theta_cols
+
+    def gather(self, theta_local):
+        """self.theta_cols [S][N][ldc] -> columns < P_hid of theta_local [S][N_loc][ldp], cooperative agents only."""
+        send = [self.theta_cols[:, a0:a1, :self.width].contiguous() for (a0, a1) in self.agents]
+        n_loc = self.a_hi - self.a_lo
+        shapes = [(self.S, n_loc, c1 - c0) for (c0, c1) in self.cols]
+        mine = self.coop[self.a_lo:self.a_hi].bool()
+        for (c0, c1), blk in zip(self.cols, self._a2a(send, shapes)):
+            if c1 > c0:
+                theta_local[:, :, c0:c1] = torch.where(mine[None, :, None], blk, theta_local[:, :, c0:c1])
+        return theta_local
