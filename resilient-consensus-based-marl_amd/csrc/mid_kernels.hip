@@ -519,6 +519,203 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
   }  // chunk loop
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_mid_fit, fifth form ("v5"): every product on the f32 matrix core, the VALU keeps only the element-wise work.
+// v3 is bound by instruction issue and dependent latency (1200 VALU + 340 LDS instructions per wavefront-chunk against
+// 400 packed FMAs of real work, 12.8k SIMD cycles per 64 rows); here a wavefront-chunk is 72 MFMAs (4.6k cycles of the
+// matrix pipe, which the lattice path leaves idle in this kernel) and ~600 other instructions:
+//   * layer 2 forward/backward as TRANSPOSED products in the two-block form v_mfma_f32_32x32x1_2b_f32,
+//       Z_b[unit i][row j] = sum_m W2[m][i] * a1[row 32b + j][m]        (b = half of the wavefront)
+//     the B operand of lane (j, b) is ITS OWN register a1[m] (row-per-lane data needs no transposition), the A operand
+//     W2[m][i] one conflict-free ds_read_b32; m ascending = the fmaf chain of the VALU form bit for bit.  The result
+//     has units 8q+4h+e of both row blocks in lane (j, h); twelve v_permlane32_swap put it back row-per-lane;
+//   * everything summed over rows except gb1 comes out of ONE 32x32 reduction product per 32 rows,
+//       A = [a1 | 1 | a2[0..10]*dv]^T,  B = [dz2 | 1 | dv | diff^2 | a2[11..19]*dv]
+//     (G[i<20][j<20] = gW2, G[20][j<20] = gb2, G[21+i][20] = gW3[i], G[20][21] = gb3, G[20][22] = loss,
+//     G[20][23+i] = gW3[11+i]); gb1 = sum dz1 by six fused-DPP adds per value.
+// Same arithmetic as v3 (dz1 bit-identical, records to summation order).  EMIT as in v3.
+template <int HID, bool EMIT>
+__global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restrict__ a1t, const float* __restrict__ theta,
+                                                       const float* __restrict__ y, float* __restrict__ partials, int N,
+                                                       int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
+                                                       unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt, int stagger) {
+  static_assert(HID == 20, "panel layout of the reduction product is written for 20 units");
+  typedef FitPart<HID> PT;
+  constexpr int WLD = 32, PLD = 33, GA = 11;           // padded weight rows; panel row stride; gW3 values in the A panel
+  constexpr int PANEL = 2 * 32 * PLD;                  // floats per wavefront: A panel | B panel (later: its record)
+  __shared__ float sW2[HID * WLD];                     // W2[m][i]   (i >= HID: zeros)
+  __shared__ float sW2T[HID * WLD];                    // W2[j][k] stored as [k][j]
+  __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];         // b2 | W3 | b3
+  __shared__ float sPn[4 * PANEL];
+  static_assert(PANEL >= PT::SIZE + 64, "a staged record (+ one dump word per lane) fits the panel area");
+  const int s = blockIdx.z, i = blockIdx.y;
+  const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
+  const int r = threadIdx.x;
+  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  for (int e = r; e < HID * WLD; e += ROWS) {
+    const int m = e / WLD, c = e - m * WLD;
+    sW2[e] = c < HID ? th[g.o_W2 + m * HID + c] : 0.f;
+    sW2T[e] = c < HID ? th[g.o_W2 + c * HID + m] : 0.f;
+  }
+  if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];
+  float* sA = sPn + wave * PANEL;
+  float* sB = sA + 32 * PLD;
+  // where element q of the lane's result tile D[(q&3) + 8*(q>>2) + 4*half][l31] goes inside a record (else: dump word)
+  int rec_idx[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int ii = (q & 3) + 8 * (q >> 2) + 4 * half, jj = l31;
+    int idx = -1;
+    if (ii < HID) idx = jj < HID ? ii * HID + jj : -1;
+    else if (ii == HID) idx = jj < HID ? PT::gb2 + jj : (jj == HID + 1 ? PT::gb3 : (jj == HID + 2 ? PT::loss : (jj >= HID + 3 ? PT::gW3 + GA + (jj - HID - 3) : -1)));
+    else idx = jj == HID ? PT::gW3 + (ii - HID - 1) : -1;
+    rec_idx[q] = idx >= 0 ? idx : PT::SIZE + lane;
+  }
+  const float* yrow = y + ((long)s * N + i) * ldb;
+  __syncthreads();
+#ifndef RCMARL_EMU
+  // de-phasing aid (pure scheduling): the workgroups resident on a CU start together and run identical instruction
+  // streams; every second one of the first round waits `stagger` x ~3.4 us so that matrix-core and VALU phases interleave
+  if (stagger > 0 && blockIdx.y < 64u && (blockIdx.y & 1u))
+    for (int q = 0; q < stagger; ++q) __builtin_amdgcn_s_sleep(127);
+#endif
+  // (requesting the activations of chunk c+1 while chunk c is processed, as v3 does, costs 20 registers = one wavefront
+  // per SIMD of occupancy here and measured slower: 919 vs 857 us)
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int b = chunk * ROWS + r;
+    const bool valid = b < B;
+    float a1[HID];
+    load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+    const float ycur = valid ? yrow[b] : 0.f;
+    // ---- layer 2 forward
+    float z2[HID];
+    {
+      rc_f32x32 zz;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) zz[q] = 0.f;
+#pragma unroll
+      for (int m = 0; m < HID; ++m) zz = __builtin_amdgcn_mfma_f32_32x32x1f32(sW2[m * WLD + l31], a1[m], zz, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = zz[4 * q + e], hi = zz[16 + 4 * q + e];
+          rc_swap32(lo, hi);
+          z2[8 * q + e] = lo;
+          if (8 * q + 4 + e < HID) z2[8 * q + 4 + e] = hi;
+        }
+    }
+    float a2[HID];
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) a2[k] = rc_lrelu(z2[k] + sV[k]);
+#pragma unroll
+    for (int k = 0; k < HID; ++k) v = fmaf(a2[k], sV[HID + k], v);
+    v += sV[2 * HID];
+    const float diff = valid ? v - ycur : 0.f;
+    const float dv = (2.0f * diff) / (float)B;
+    float dz2[HID], g3[HID];
+#pragma unroll
+    for (int k = 0; k < HID; ++k) {
+      g3[k] = a2[k] * dv;
+      dz2[k] = dv * sV[HID + k] * rc_lrelu_grad_from_act(a2[k]);
+    }
+    // ---- the reduction product over this wavefront's 64 rows, 32 rows (one half) at a time through its panels
+    rc_f32x16 g1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g1[q] = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      RC_WAVE_SYNC();                                  // earlier fragment reads / record reads of this area are done
+      if (half == hh) {
+#pragma unroll
+        for (int k = 0; k < HID; ++k) {
+          sA[k * PLD + l31] = a1[k];
+          sB[k * PLD + l31] = dz2[k];
+        }
+        sA[HID * PLD + l31] = 1.f;
+        sB[HID * PLD + l31] = 1.f;
+#pragma unroll
+        for (int q = 0; q < GA; ++q) sA[(HID + 1 + q) * PLD + l31] = g3[q];
+        sB[(HID + 1) * PLD + l31] = dv;
+        sB[(HID + 2) * PLD + l31] = diff * diff;
+#pragma unroll
+        for (int q = 0; q < HID - GA; ++q) sB[(HID + 3 + q) * PLD + l31] = g3[GA + q];
+      }
+      RC_WAVE_SYNC();
+      const int ia = l31 * PLD + half;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ia + 2 * m], g1, 0, 0, 0);
+    }
+    // ---- layer 2 backward
+    float dz1[HID];
+    {
+      rc_f32x32 dd;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) dd[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < HID; ++k) dd = __builtin_amdgcn_mfma_f32_32x32x1f32(sW2T[k * WLD + l31], dz2[k], dd, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float lo = dd[4 * q + e], hi = dd[16 + 4 * q + e];
+          rc_swap32(lo, hi);
+          dz1[8 * q + e] = lo * rc_lrelu_grad_from_act(a1[8 * q + e]);
+          if (8 * q + 4 + e < HID) dz1[8 * q + 4 + e] = hi * rc_lrelu_grad_from_act(a1[8 * q + 4 + e]);
+        }
+    }
+    if (EMIT) {
+      // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + j (uniform), k = b (lane), as k_mid_fit_v3
+      unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + (long)(chunk * (ROWS / 32)) * (3 * RC_PK_BLOCK);
+      const unsigned lane_off = (unsigned)(r >> 5) * (3 * RC_PK_BLOCK) + (((r & 31) >> 3) << 4) + (r & 7) * 2;
+      const unsigned lane_off1 = lane_off + RC_PK_BLOCK, lane_off2 = lane_off + 2 * RC_PK_BLOCK;
+#pragma unroll
+      for (int q = 0; q < HID / 2; ++q) {
+        unsigned h, m, l;
+        rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = i * HID + 2 * q + u;
+          unsigned char* p = base + (long)(row >> 7) * dzp_kt * (3 * RC_PK_BLOCK) + (row & 127) * 64;
+          const unsigned sw = (unsigned)(((row >> 2) & 3) << 4);
+          *reinterpret_cast<unsigned short*>(p + (lane_off ^ sw)) = (unsigned short)(u ? h >> 16 : h);
+          *reinterpret_cast<unsigned short*>(p + (lane_off1 ^ sw)) = (unsigned short)(u ? m >> 16 : m);
+          *reinterpret_cast<unsigned short*>(p + (lane_off2 ^ sw)) = (unsigned short)(u ? l >> 16 : l);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < HID; ++j)
+        if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];
+    }
+    // ---- gb1[j] = sum over the 64 rows of dz1[j]
+    {
+      float sm[HID + 1];
+#pragma unroll
+      for (int j = 0; j < HID; ++j) sm[j] = dz1[j];
+      sm[HID] = 0.f;
+      static_assert((HID + 1) % 3 == 0, "sums are reduced three at a time");
+#pragma unroll
+      for (int q = 0; q < (HID + 1) / 3; ++q) rc_wave_sum3_lane63(sm[3 * q], sm[3 * q + 1], sm[3 * q + 2]);
+      RC_WAVE_SYNC();                                  // this wavefront's panel reads are done: the area takes its record
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sA[rec_idx[q]] = g1[q];
+      if (lane == 63) {
+#pragma unroll
+        for (int j = 0; j < HID; ++j) sA[PT::gb1 + j] = sm[j];
+      }
+    }
+    __syncthreads();
+    float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
+    for (int e = r; e < PT::SIZE; e += ROWS) out[e] = (sPn[e] + sPn[PANEL + e]) + (sPn[2 * PANEL + e] + sPn[3 * PANEL + e]);
+    __syncthreads();                                   // records read out before the next chunk's panels land
+  }
+}
+
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B.
 // rec_size > FitPart::SIZE: the record also carries gW1 (fused layer 1) and W1 is updated too.
 template <int HID>
@@ -898,13 +1095,13 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
   if (t < n_total) delta[t] = r_team[t] + gamma * v_next[t] - v_cur[t];
 }
 
+int midfit_stagger() { const char* e = getenv("RCMARL_MIDFIT_STAGGER"); return e ? atoi(e) : 0; }
+
 int midfit_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("RCMARL_MIDFIT");
-    v = e ? atoi(e) : 2;
-    if (v < 0 || v > 2) v = 2;
-  }
+  // read at every call (a getenv per launch is nothing next to the launch; tests switch variants inside one process)
+  const char* e = getenv("RCMARL_MIDFIT");
+  int v = e ? atoi(e) : 2;                   // (5 = v5, all products on the matrix core: opt-in until measured)
+  if (v != 5 && (v < 0 || v > 2)) v = 2;
   return v;
 }
 
@@ -942,7 +1139,12 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(nchunk, N, S), block(ROWS);
   const int variant = midfit_variant();   // RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 (default) v3
-  if (variant == 2) {
+  if (variant == 5) {
+    const int cpw = midfit_cpw(nchunk);
+    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, midfit_stagger()));
+  } else if (variant == 2) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 0>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
@@ -964,7 +1166,12 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   const int nchunk = rc_ceil_div(B, ROWS);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(nchunk, N, S), block(ROWS);
-  if (midfit_variant() == 2) {
+  if (midfit_variant() == 5) {
+    const int cpw = midfit_cpw(nchunk);
+    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, midfit_stagger()));
+  } else if (midfit_variant() == 2) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true, 0>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,

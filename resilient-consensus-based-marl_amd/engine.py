@@ -314,7 +314,8 @@ class RPBCACEngine:
                 L.rcmarl_lattice_pack_dz(dz1.data_ptr(), dzp.data_ptr(), S, N, B, hid, ldb, g.dzp[0], g.dzp[1], st)
                 L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
                                                      g.dzp[0], g.dzp[1], self.lat_alpha[xkey].data_ptr(), msg.data_ptr(),
-                                                     mask.data_ptr(), S, N, B, in_dim, hid, ldp, lr, wp.data_ptr(), g.wp[0],
+                                                     mask.data_ptr(), S, N, B, in_dim, hid, ldp, lr,
+                                                     None if step == self.cfg.local_fit_steps - 1 else wp.data_ptr(), g.wp[0],
                                                      g.wp[1], st)
                 wp_fresh = True           # the epilogue left the split of the updated W1 in lat_wp
             else:
@@ -763,7 +764,9 @@ class RPBCACEngine:
                 L.rcmarl_layer1_backward_sgd_lattice_fit(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
                                                          g.dzp[0], g.dzp[1], alpha.data_ptr(), msg.data_ptr(),
                                                          mask.data_ptr(), S, N, B, self.in_dim[net], HID, self.ldp[net],
-                                                         self.cfg.fast_lr, wpf.data_ptr(), frt, fkt, self.stream)
+                                                         self.cfg.fast_lr,
+                                                         None if step == self.cfg.local_fit_steps - 1 else wpf.data_ptr(),
+                                                         frt, fkt, self.stream)
             self.a1_cached[net] = False
             return
         wp_fresh = False
@@ -781,11 +784,14 @@ class RPBCACEngine:
                                self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
                                self.ldp[net], self.cfg.fast_lr, self.stream)
             if lat:
+                # the epilogue also leaves the bf16x3 split of the updated W1 for the NEXT step's forward -- except after
+                # the last step, whose weights only travel as a message (252 / 378 MB of writes per fit at cfg 4)
+                last = step == self.cfg.local_fit_steps - 1
                 L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1],
                                                      dzp.data_ptr(), g.dzp[0], g.dzp[1],
                                                      self.lat_alpha[xkey].data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N,
                                                      B, self.in_dim[net], HID, self.ldp[net], self.cfg.fast_lr,
-                                                     wp.data_ptr(), g.wp[0], g.wp[1], self.stream)
+                                                     None if last else wp.data_ptr(), g.wp[0], g.wp[1], self.stream)
                 wp_fresh = True           # the epilogue left the split of the updated W1 in lat_wp
             else:
                 L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,

@@ -146,3 +146,14 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(1, 5, 70, 2, 5, 5, None), (2, 11, 300, 3, 8, 6, 3)])
 def test_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, masked):
     KC.check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)
+
+
+@pytest.mark.parametrize("lattice", [False, True])
+def test_mid_fit_v5_matrix_core_form(bk, lattice, monkeypatch):
+    """RCMARL_MIDFIT=5: k_mid_fit_v5 (layer 2 forward/backward and every row reduction on the f32 matrix core) behind the
+    same two entry points, against the same oracle fits."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "5")
+    if lattice:
+        KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
+    else:
+        KC.check_sgd_fit(bk, 2, 5, 130, 10, steps=2, masked_agent=1)

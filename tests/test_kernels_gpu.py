@@ -182,3 +182,44 @@ def test_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, masked):
     # N = 256: fast_lr 0.0025 as everywhere at that size (0.01 is on the edge of divergence at 512/768 unscaled inputs and
     # amplifies fp32 roundoff between any two summation orders; bench.py header)
     KC.check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, masked_agent=masked, lr=0.0025 if N >= 256 else 0.01)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (2, 5, 3000, 15, 4), (1, 64, 1000, 192, 5), (1, 128, 333, 256, None)])
+def test_mid_fit_v5_sgd_fit(bk, S, N, B, in_dim, masked, monkeypatch):
+    """RCMARL_MIDFIT=5: the all-matrix-core form of the mid kernel behind rcmarl_mid_fit, same oracle fits as test_sgd_fit."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "5")
+    KC.check_sgd_fit(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (1, 64, 1000, 3, 16, 16, 5), (8, 32, 700, 2, 16, 16, 2), (1, 20, 777, 2, 7, 9, 3)])
+def test_mid_fit_v5_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
+    monkeypatch.setenv("RCMARL_MIDFIT", "5")
+    KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
+
+
+def test_mid_fit_v5_bit_identical_dz_to_v3(bk, monkeypatch):
+    """Same fmaf chains in both forms: the dz1 pieces of v5 equal those of v3 bit for bit (records: summation order)."""
+    import torch
+    rng = np.random.default_rng(3)
+    S, N, B, in_dim = 2, 6, 700, 12
+    P, _ = KC.geom(in_dim, 1)
+    ldp, ldb = KC.pad64(P), KC.pad64(B)
+    theta = KC.pack_rows(KC.random_params(rng, S, N, in_dim, 1), ldp)
+    a1 = np.maximum(rng.normal(size=(S, N * 20, ldb)), 0.1 * rng.normal(size=(S, N * 20, ldb))).astype(np.float32)
+    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    from rcmarl_amd import lattice as LT
+    g = LT.Geometry(N, in_dim, B)
+    nchunk, psz = (B + 255) // 256, bk.lib.rcmarl_fit_partial_size(20)
+    out = {}
+    for var in ("2", "5"):
+        monkeypatch.setenv("RCMARL_MIDFIT", var)
+        d_a, d_th, d_y = bk.dev(a1), bk.dev(theta), bk.dev(y)
+        d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+        d_dzp = bk.dev(np.zeros(S * LT.Geometry.nbytes(g.dzp, 3) // 2, np.uint16))
+        bk.lib.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(d_dzp), g.dzp[0], g.dzp[1], S, N, B,
+                                      in_dim, 20, ldp, ldb, bk.stream)
+        out[var] = (bk.host(d_dzp).copy(), bk.host(d_part).copy())
+    np.testing.assert_array_equal(out["5"][0], out["2"][0])
+    pu, pf = out["2"][1], out["5"][1]
+    scale = np.maximum(np.abs(pu).max(axis=(2, 3), keepdims=True), 1e-6)
+    assert float((np.abs(pf - pu) / scale).max()) <= 2e-5
