@@ -1097,11 +1097,14 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
 
 int midfit_stagger() { const char* e = getenv("RCMARL_MIDFIT_STAGGER"); return e ? atoi(e) : 0; }
 
-int midfit_variant() {
-  // read at every call (a getenv per launch is nothing next to the launch; tests switch variants inside one process)
+// RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 v3, 5 v5 (every product on the f32 matrix core).
+// Default: v5 behind rcmarl_mid_fit (fp32 dz1 in place: 857 vs 935 us at the cfg-4 shape, cfg1_batched 120.9 vs 126.0 ms
+// per block), v3 behind rcmarl_mid_fit_lattice (bf16-piece stores: 985 vs 1004 us, within the noise).
+// Read at every call (a getenv per launch is nothing next to the launch; tests switch variants inside one process).
+int midfit_variant(bool lattice = false) {
   const char* e = getenv("RCMARL_MIDFIT");
-  int v = e ? atoi(e) : 2;                   // (5 = v5, all products on the matrix core: opt-in until measured)
-  if (v != 5 && (v < 0 || v > 2)) v = 2;
+  int v = e ? atoi(e) : (lattice ? 2 : 5);
+  if (v != 5 && (v < 0 || v > 2)) v = lattice ? 2 : 5;
   return v;
 }
 
@@ -1138,7 +1141,7 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(nchunk, N, S), block(ROWS);
-  const int variant = midfit_variant();   // RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 (default) v3
+  const int variant = midfit_variant();
   if (variant == 5) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
@@ -1166,12 +1169,12 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   const int nchunk = rc_ceil_div(B, ROWS);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(nchunk, N, S), block(ROWS);
-  if (midfit_variant() == 5) {
+  if (midfit_variant(true) == 5) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
                                      partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, midfit_stagger()));
-  } else if (midfit_variant() == 2) {
+  } else if (midfit_variant(true) == 2) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true, 0>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,

@@ -157,3 +157,9 @@ def test_mid_fit_v5_matrix_core_form(bk, lattice, monkeypatch):
         KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
     else:
         KC.check_sgd_fit(bk, 2, 5, 130, 10, steps=2, masked_agent=1)
+
+
+def test_mid_fit_v3_still_reachable(bk, monkeypatch):
+    """RCMARL_MIDFIT=2 keeps the VALU form (k_mid_fit_v3) behind rcmarl_mid_fit, which defaults to v5 now."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "2")
+    KC.check_sgd_fit(bk, 1, 5, 130, 10, steps=2, masked_agent=1)

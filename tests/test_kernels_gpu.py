@@ -223,3 +223,10 @@ def test_mid_fit_v5_bit_identical_dz_to_v3(bk, monkeypatch):
     pu, pf = out["2"][1], out["5"][1]
     scale = np.maximum(np.abs(pu).max(axis=(2, 3), keepdims=True), 1e-6)
     assert float((np.abs(pf - pu) / scale).max()) <= 2e-5
+
+
+@pytest.mark.parametrize("variant", ["2", "1", "0"])
+def test_mid_fit_older_variants(bk, variant, monkeypatch):
+    """The earlier forms of the mid kernel stay selectable (RCMARL_MIDFIT) and correct."""
+    monkeypatch.setenv("RCMARL_MIDFIT", variant)
+    KC.check_sgd_fit(bk, 2, 5, 1000, 10, steps=3, masked_agent=None)
