@@ -1,8 +1,8 @@
 """Long-horizon check of the learning behaviour on the CPU oracle (TEST INFRASTRUCTURE; see profiles/learning_r02a_oracle_check.json).
-    python tools/oracle_long_horizon.py SEED EPISODES_PER_PHASE {Malicious|Faulty|Greedy|Cooperative} H
+    python tests/oracle_long_horizon.py SEED EPISODES_PER_PHASE {Malicious|Faulty|Greedy|Cooperative} H
 """
 import sys, time, json
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; _T = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, os.path.dirname(_T)); sys.path.insert(0, _T)
 import numpy as np
 from oracle import rpbcac_oracle as O, mlp_np as M
 seed=int(sys.argv[1]); n_ep=int(sys.argv[2]); scen=sys.argv[3]; H=int(sys.argv[4])
