@@ -43,7 +43,7 @@ constexpr int A_PIECE = FBM * 64;             // bytes of one piece of one k32 s
 constexpr int A_STAGE = 3 * A_PIECE;          // 30720
 constexpr int A_BURSTS = A_STAGE / 1024;      // 30 LDS-DMA bursts of 1 KiB per stage
 // record layout = FitPart<20> of mid_kernels.hip
-constexpr int P_GW2 = 0, P_GB2 = HID * HID, P_GW3 = P_GB2 + HID, P_GB3 = P_GW3 + HID, P_GB1 = P_GB3 + 1,
+constexpr int P_GB2 = HID * HID, P_GW3 = P_GB2 + HID, P_GB3 = P_GW3 + HID, P_GB1 = P_GB3 + 1,
               P_LOSS = P_GB1 + HID, P_SIZE = P_LOSS + 1;                  // 462 floats
 // epilogue LDS (aliases the k-loop stages): weights of the 8 agents | per-wavefront panels | staging area
 constexpr int W_B1 = 0, W_W2 = HID, W_B2 = W_W2 + HID * HID, W_W3 = W_B2 + HID, W_B3 = W_W3 + HID, W_W2T = 464;

@@ -270,11 +270,10 @@ __global__ __launch_bounds__(256) void k_minibatch_train(MbArgs a) {
 constexpr int WP_W = 864, WP_W2T = 404, WP_LD = 33, WP_A = 32 * WP_LD, WP_B = 22 * WP_LD;
 constexpr int WP_FLOATS = WP_W + WP_W2T + 2 * WP_A + WP_B;  // LDS floats per wavefront (16.4 KiB)
 
+// (RC_WAVE_SYNC: rcmarl_common.h)
 #ifdef RCMARL_EMU
-#define RC_WAVE_SYNC() hipemu::wave_barrier()
 __device__ __forceinline__ float rc_other_half(float v) { return __shfl_xor(v, 32, 64); }
 #else
-#define RC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // value of the same row's lane in the other half (lane ^ 32): v_permlane32_swap_b32 exchanges lanes 32-63 of its
 // first operand with lanes 0-31 of its second -- one VALU instruction + a select instead of a trip through the
 // LDS crossbar (ds_bpermute)
