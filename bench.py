@@ -348,7 +348,9 @@ def main(argv=None):
     if not stub:
         torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    # RCMARL_BENCH_FORCE_PG=1: create the process group even for ONE rank (exercises the RCCL plumbing on a 1-GPU box)
+    use_pg = world > 1 or (os.environ.get("RCMARL_BENCH_FORCE_PG") == "1" and "RANK" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if stub:
             dist.init_process_group(backend="gloo")
@@ -376,14 +378,14 @@ def main(argv=None):
     def barrier():
         if not stub:
             torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         if not stub:
             torch.cuda.synchronize()
 
     dt, curve = time_blocks(eng, args.steps, args.warmup, barrier, S, dev, tlib, want_kernels=not args.no_kernel_timing)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                # the slowest rank's clock
     dt = float(tmax.item())
     B_steady = eng.cap
@@ -440,7 +442,7 @@ def main(argv=None):
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 
