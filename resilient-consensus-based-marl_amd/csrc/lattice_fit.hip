@@ -93,7 +93,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_lat_fit(const unsi
   // residency the workgroup that got the UPPER LDS allocation sleeps about half a tile (dbg bits 8-15 x ~3.4 us), so
   // one workgroup's epilogue runs beside the other's k-loop; later workgroups inherit the offset.
   if ((dbg >> 8) & 0xff) {
-    if (blockIdx.x < 512u && (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) & 0xff) != 0)        // HW_REG_LDS_ALLOC.LDS_BASE
+    // dbg bit 16 selects WHO sleeps: 0 = the workgroup whose LDS allocation is the upper one (HW_REG_LDS_ALLOC.LDS_BASE != 0),
+    // 1 = workgroups 256..511 (the second round of the dispatcher over the 256 CUs)
+    const bool second = (dbg >> 16) & 1 ? (blockIdx.x >= 256u && blockIdx.x < 512u)
+                                        : (blockIdx.x < 512u && (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) & 0xff) != 0);
+    if (second)
       for (int i = 0; i < ((dbg >> 8) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
   }
 #endif
@@ -487,7 +491,8 @@ RCMARL_EXPORT int rcmarl_fit_fused_lattice(const void* kp, int kp_rt, int kp_kt,
   if (!fit_want_lds()) return RCMARL_ERR_LAUNCH;
   // bits 0-7: measurement aids (0 in production); bits 8-15: de-phasing sleep of the second workgroup of a CU
   static const int dbg = (getenv("RCMARL_FIT_DBG") ? atoi(getenv("RCMARL_FIT_DBG")) & 0xff : 0) |
-                         ((getenv("RCMARL_FIT_STAGGER") ? atoi(getenv("RCMARL_FIT_STAGGER")) & 0xff : 0) << 8);
+                         ((getenv("RCMARL_FIT_STAGGER") ? atoi(getenv("RCMARL_FIT_STAGGER")) & 0xff : 0) << 8) |
+                         ((getenv("RCMARL_FIT_STAGGER_MODE") ? atoi(getenv("RCMARL_FIT_STAGGER_MODE")) & 1 : 0) << 16);
   const dim3 grid((unsigned)(S * mtiles * ntiles)), block(64 * NW);
   RCMARL_LAUNCH(k_lat_fit, grid, block, LDS_TOTAL, stream, (const unsigned char*)wpf, wpf_rt, wpf_kt, (const unsigned char*)kp,
                 kp_rt, kp_kt, theta, y, partials, (unsigned char*)dzp, dzp_rt, dzp_kt, S, N, B, in_dim, ldp, ldb, mtiles,
