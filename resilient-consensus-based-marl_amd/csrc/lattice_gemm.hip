@@ -160,14 +160,15 @@ __global__ __launch_bounds__(256) void k_dz_pack(const float* __restrict__ dz, u
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int PA, int PB, int MT, int NT> struct LatCfg {
-  static_assert(MT % 2 == 0 && NT % 2 == 0, "block tile sides are multiples of 128");
-  static constexpr int BM = 64 * MT, BN = 64 * NT;
-  static constexpr int ART = MT / 2, BRT = NT / 2;                  // 128-row tiles per block side
+// WM x WN wavefronts per workgroup (default 2 x 2), each owning MT x NT accumulator blocks of 32 x 32
+template <int PA, int PB, int MT, int NT, int WM = 2, int WN = 2> struct LatCfg {
+  static constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NWV = WM * WN;
+  static_assert(BM % 128 == 0 && BN % 128 == 0, "block tile sides are multiples of 128");
+  static constexpr int ART = BM / 128, BRT = BN / 128;              // 128-row tiles per block side
   static constexpr int A_KB = ART * PA * 8, B_KB = BRT * PB * 8;    // KiB per k-tile stage
   static constexpr int STAGE_KB = A_KB + B_KB, STAGE_BYTES = STAGE_KB * 1024;
-  static constexpr int GLDS = STAGE_KB / 4;                         // 1-KiB bursts per wavefront per stage
-  static_assert(STAGE_KB % 4 == 0, "stage splits evenly over 4 wavefronts");
+  static constexpr int GLDS = STAGE_KB / NWV;                       // 1-KiB bursts per wavefront per stage
+  static_assert(STAGE_KB % NWV == 0, "stage splits evenly over the wavefronts");
 };
 
 struct LatOperands {
@@ -179,14 +180,14 @@ struct LatOperands {
 
 // DBG (measurement aid, RCMARL_LAT_DBG; results are WRONG for DBG != 0): bit 0 = no LDS-DMA after the prologue,
 // bit 1 = no vmcnt wait / barrier, bit 2 = fragments read from LDS once (k-loop = matrix core only)
-template <int PA, int PB, int MT, int NT, int NSTAGE, int DBG = 0>
+template <int PA, int PB, int MT, int NT, int NSTAGE, int DBG = 0, int WM = 2, int WN = 2>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
                                              rc_f32x16 (&acc)[MT][NT]) {
-  typedef LatCfg<PA, PB, MT, NT> C;
+  typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   static_assert(NSTAGE == 2 || NSTAGE == 3, "LDS ring depth");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -200,7 +201,7 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
   int gstep[C::GLDS];
 #pragma unroll
   for (int i = 0; i < C::GLDS; ++i) {
-    const int q = wave + 4 * i;
+    const int q = wave + C::NWV * i;
     if (q < C::A_KB) {
       const int seg = q / (PA * 8), off = q - seg * (PA * 8);
       gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * (PA * RC_PK_BLOCK) + off * 1024;
@@ -217,7 +218,7 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
   auto stage = [&](int buf, int t) {
     const rc_lds_t dst = lds0 + buf * C::STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < C::GLDS; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, dst + i * 4096);
+    for (int i = 0; i < C::GLDS; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, dst + i * (C::NWV * 1024));
   };
 
   // fragment addresses: row = lane&31 (+ tile offsets), chunk = 2*kstep + lane>>5, XOR (row>>2)&3
@@ -441,14 +442,16 @@ __device__ __forceinline__ void lat_prio(int bit) {
 }
 
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
-template <int NSTAGE, int DBG = 0>
-__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
+// W8: eight wavefronts per workgroup (2 x 4, each 64 x 64) on the SAME 128 x 256 block tile and LDS stages: 64 instead of
+// 128 accumulator registers per wavefront, i.e. four instead of two wavefronts per SIMD at two workgroups per CU
+template <int NSTAGE, int DBG = 0, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt,
                                                         const unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                         const float* __restrict__ theta, float* __restrict__ a1t, int S,
                                                         int N, int B, int in_dim, int ldp, int ldb, int mtiles,
                                                         int ntiles, int dbg_same_tile, int stg_bit, int stg_n, int hid) {
-  constexpr int PA = 3, PB = 1, MT = 2, NT = 4;
-  typedef LatCfg<PA, PB, MT, NT> C;
+  constexpr int PA = 3, PB = 1, MT = 2, NT = W8 ? 2 : 4, WM = 2, WN = W8 ? 4 : 2;
+  typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
   lat_prio(((stg_bit >> 8) & 0xff) - 1);
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   }
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
-  else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG>(op, (in_dim + 31) >> 5, lds, acc);
+  else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG, WM, WN>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * hid;
   const float* theta_s = theta + (long)s * N * ldp;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
   // offset, full tiles take no per-element predicate.  (The first version of this epilogue -- a branch, an LDS round
   // trip and a 64-bit multiply per element -- cost as much as the k-loop of a 512-deep GEMM: 176 of 832 us.)
   const int lane = threadIdx.x & 63, half = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave / WN, wn = wave % WN;
   float bv[MT][16];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -539,16 +542,24 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_forward(const 
 }
 
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
-template <int NSTAGE, int DBG = 0>
-__global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
+// (explicit work-group size + waves per SIMD: with __launch_bounds__(512, 2) hipcc allots 129 registers to the W8 form,
+// one too many for the four wavefronts per SIMD that two 8-wavefront workgroups per CU need)
+#ifdef RCMARL_EMU
+#define RC_LAT_OCC(threads, waves)
+#else
+#define RC_LAT_OCC(threads, waves) __attribute__((amdgpu_flat_work_group_size(threads, threads), amdgpu_waves_per_eu(waves)))
+#endif
+template <int NSTAGE, int DBG = 0, bool W8 = false>
+__global__ RC_LAT_OCC(W8 ? 512 : 256, NSTAGE == 3 ? 1 : (W8 ? 4 : 2))
+void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
                                                              const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
                                                              const float* __restrict__ alpha, float* __restrict__ theta,
                                                              const int* __restrict__ mask, int S, int N, int B,
                                                              int in_dim, int ldp, float lr, int mtiles, int ntiles,
                                                              unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt,
                                                              int stg_bit, int stg_n, int hid, int wp_fit) {
-  constexpr int PA = 1, PB = 3, MT = 4, NT = 2;
-  typedef LatCfg<PA, PB, MT, NT> C;
+  constexpr int PA = 1, PB = 3, MT = W8 ? 2 : 4, NT = 2, WM = W8 ? 4 : 2, WN = 2;
+  typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
   lat_prio(((stg_bit >> 8) & 0xff) - 1);
@@ -565,14 +576,14 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   }
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
-  else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG>(op, (B + 31) >> 5, lds, acc);
+  else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG, WM, WN>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
   const int ncols = N * hid;
   __syncthreads();
   float* al = reinterpret_cast<float*>(lds);
-  {
+  if (threadIdx.x < C::BM) {
     const int k = bm * C::BM + threadIdx.x;
     al[threadIdx.x] = k < in_dim ? alpha[k] : 0.f;
   }
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(256, NSTAGE == 3 ? 1 : 2) void k_lat_backward_sgd(c
   // compiler had to wait for every store before the next load -- possible alias -- i.e. 128 serial memory round trips
   // per lane, as long as the whole k-loop of the workgroup.
   const int lane = threadIdx.x & 63, half = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave / WN, wn = wave % WN;
   const bool full_k = (bm + 1) * C::BM <= in_dim;                       // workgroup-uniform
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -671,6 +682,12 @@ int lat_grid(int tiles, int ns) {
 #endif
 }
 int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
+// Eight wavefronts of 64 x 64 per workgroup instead of four of 64 x 128 / 128 x 64 (four instead of two wavefronts per
+// SIMD on the same tiles and LDS stages).  Measured at cfg 4: forward 749 / 988 us against 776 / 1037 (critic / TR shape),
+// backward 780 / 1103 against 756 / 1103 -- twice the occupancy buys 3-5 % on one kernel and nothing on the other: the
+// k-loops are bound by operand delivery into the CU, not by latency.  Default: forward on, backward off;
+// RCMARL_LAT_W8=0 / 1 forces both (read at every call).
+bool lat_w8(bool forward) { const char* e = getenv("RCMARL_LAT_W8"); return e ? atoi(e) != 0 : forward; }
 
 // LDS ring of the lattice GEMMs: 2 full k32 stages (80 KiB, two workgroups per CU), 3 (120 KiB, one workgroup per
 // CU, a tile more of load lead; measured slower) or 4 HALF stages (80 KiB, 1.5 tiles of lead, counted vmcnt).
@@ -754,7 +771,12 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
 #undef RC_DBG_CASE
     return rcmarl_check_launch();
   }
-  if (ns == 2) {
+  if (ns == 2 && lat_w8(true)) {
+    static const bool ok = lat_want_lds(k_lat_forward<2, 0, true>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_forward<2, 0, true>), grid, dim3(512), smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
+                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n(), hid);
+  } else if (ns == 2) {
     static const bool ok = lat_want_lds(k_lat_forward<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_forward<2>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
@@ -803,7 +825,13 @@ static int backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const v
 #undef RC_DBG_CASE
     return rcmarl_check_launch();
   }
-  if (ns == 2) {
+  if (ns == 2 && lat_w8(false)) {
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<2, 0, true>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<2, 0, true>), grid, dim3(512), smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
+  } else if (ns == 2) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<2>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<2>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,

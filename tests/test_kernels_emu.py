@@ -163,3 +163,9 @@ def test_mid_fit_v3_still_reachable(bk, monkeypatch):
     """RCMARL_MIDFIT=2 keeps the VALU form (k_mid_fit_v3) behind rcmarl_mid_fit, which defaults to v5 now."""
     monkeypatch.setenv("RCMARL_MIDFIT", "2")
     KC.check_sgd_fit(bk, 1, 5, 130, 10, steps=2, masked_agent=1)
+
+
+@pytest.mark.parametrize("w8", ["0", "1"])
+def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
+    monkeypatch.setenv("RCMARL_LAT_W8", w8)
+    KC.check_lattice_sgd_fit(bk, 1, 7, 130, 2, 5, 5, steps=2, masked_agent=2)

@@ -230,3 +230,12 @@ def test_mid_fit_older_variants(bk, variant, monkeypatch):
     """The earlier forms of the mid kernel stay selectable (RCMARL_MIDFIT) and correct."""
     monkeypatch.setenv("RCMARL_MIDFIT", variant)
     KC.check_sgd_fit(bk, 2, 5, 1000, 10, steps=3, masked_agent=None)
+
+
+@pytest.mark.parametrize("w8", ["0", "1"])
+def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
+    """RCMARL_LAT_W8: the lattice GEMMs as four wavefronts of 64x128 / 128x64 or eight of 64x64 per workgroup -- same
+    products, same k order: the same oracle fit either way (forward defaults to eight, backward to four)."""
+    monkeypatch.setenv("RCMARL_LAT_W8", w8)
+    KC.check_lattice_sgd_fit(bk, 2, 20, 777, 3, 7, 9, steps=3, masked_agent=4)
+    KC.check_lattice_forward(bk, 1, 64, 1000, 2, 16, 16)
