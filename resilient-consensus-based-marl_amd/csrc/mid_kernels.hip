@@ -541,8 +541,13 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
                                                        unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt, int stagger) {
   static_assert(HID == 20, "panel layout of the reduction product is written for 20 units");
   typedef FitPart<HID> PT;
-  constexpr int WLD = 32, PLD = 33, GA = 11;           // padded weight rows; panel row stride; gW3 values in the A panel
-  constexpr int PANEL = 2 * 32 * PLD;                  // floats per wavefront: A panel | B panel (later: its record)
+// (rows per pass of the reduction product: 32; 16 halves the panels -- 22.7 instead of 39 KiB of LDS per workgroup --
+// and measured slower, 877 / 1071 against 857 / 985 us: occupancy is not limited by the LDS here)
+#ifndef RC_V5_PLD
+#define RC_V5_PLD 33
+#endif
+  constexpr int WLD = 32, PLD = RC_V5_PLD, GA = 11;    // padded weight rows; panel row stride (rows per pass + 1); gW3 values in the A panel
+  constexpr int PANEL = (2 * 32 * PLD > 528 ? 2 * 32 * PLD : 528);   // floats per wavefront: A panel | B panel (later: its record)
   __shared__ float sW2[HID * WLD];                     // W2[m][i]   (i >= HID: zeros)
   __shared__ float sW2T[HID * WLD];                    // W2[j][k] stored as [k][j]
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];         // b2 | W3 | b3
@@ -623,32 +628,34 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
       g3[k] = a2[k] * dv;
       dz2[k] = dv * sV[HID + k] * rc_lrelu_grad_from_act(a2[k]);
     }
-    // ---- the reduction product over this wavefront's 64 rows, 32 rows (one half) at a time through its panels
+    // ---- the reduction product over this wavefront's 64 rows, QR rows at a time through its panels
     rc_f32x16 g1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) g1[q] = 0.f;
+    constexpr int QR = PLD - 1;                        // rows per pass (16 or 32)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int pp = 0; pp < 64 / QR; ++pp) {
       RC_WAVE_SYNC();                                  // earlier fragment reads / record reads of this area are done
-      if (half == hh) {
+      if (lane / QR == pp) {
+        const int c = lane % QR;
 #pragma unroll
         for (int k = 0; k < HID; ++k) {
-          sA[k * PLD + l31] = a1[k];
-          sB[k * PLD + l31] = dz2[k];
+          sA[k * PLD + c] = a1[k];
+          sB[k * PLD + c] = dz2[k];
         }
-        sA[HID * PLD + l31] = 1.f;
-        sB[HID * PLD + l31] = 1.f;
+        sA[HID * PLD + c] = 1.f;
+        sB[HID * PLD + c] = 1.f;
 #pragma unroll
-        for (int q = 0; q < GA; ++q) sA[(HID + 1 + q) * PLD + l31] = g3[q];
-        sB[(HID + 1) * PLD + l31] = dv;
-        sB[(HID + 2) * PLD + l31] = diff * diff;
+        for (int q = 0; q < GA; ++q) sA[(HID + 1 + q) * PLD + c] = g3[q];
+        sB[(HID + 1) * PLD + c] = dv;
+        sB[(HID + 2) * PLD + c] = diff * diff;
 #pragma unroll
-        for (int q = 0; q < HID - GA; ++q) sB[(HID + 3 + q) * PLD + l31] = g3[GA + q];
+        for (int q = 0; q < HID - GA; ++q) sB[(HID + 3 + q) * PLD + c] = g3[GA + q];
       }
       RC_WAVE_SYNC();
       const int ia = l31 * PLD + half;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ia + 2 * m], g1, 0, 0, 0);
+      for (int m = 0; m < QR / 2; ++m) g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ia + 2 * m], g1, 0, 0, 0);
     }
     // ---- layer 2 backward
     float dz1[HID];
