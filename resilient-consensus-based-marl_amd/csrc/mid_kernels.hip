@@ -1105,13 +1105,15 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
 int midfit_stagger() { const char* e = getenv("RCMARL_MIDFIT_STAGGER"); return e ? atoi(e) : 0; }
 
 // RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 v3, 5 v5 (every product on the f32 matrix core).
-// Default: v5 behind rcmarl_mid_fit (fp32 dz1 in place: 857 vs 935 us at the cfg-4 shape, cfg1_batched 120.9 vs 126.0 ms
-// per block), v3 behind rcmarl_mid_fit_lattice (bf16-piece stores: 985 vs 1004 us, within the noise).
+// Default: v5 behind both entry points (fp32 dz1 in place: 857 vs 935 us at the cfg-4 shape, cfg1_batched 120.9 vs 126.0 ms
+// per block; bf16-piece stores: 985 vs 1004 and 1006 vs 1048 us on two boxes).  A "v6" -- v5 with layer 2 back on the
+// VALU as in v3 -- measured 958 / 1094 us against 891 / 1006 for v5 on the same box and was dropped.
 // Read at every call (a getenv per launch is nothing next to the launch; tests switch variants inside one process).
 int midfit_variant(bool lattice = false) {
   const char* e = getenv("RCMARL_MIDFIT");
-  int v = e ? atoi(e) : (lattice ? 2 : 5);
-  if (v != 5 && (v < 0 || v > 2)) v = lattice ? 2 : 5;
+  (void)lattice;
+  int v = e ? atoi(e) : 5;
+  if (v != 5 && (v < 0 || v > 2)) v = 5;
   return v;
 }
 
