@@ -462,8 +462,10 @@ ROOFLINE_KIND = {
                                           "agent at (18,8) instead of 128) + 18 clamps + 18 adds + the IEEE division: still "
                                           "VALU-issue-bound at d=18, HBM-bound at d=4"),
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
-                               "dz1 pieces written = 200 B; the kernel is VALU-issue-bound today (PMC: 1929 VALU + 769 SALU "
-                               "instructions and 64 f32 MFMAs per wavefront), DESIGN.md section 3"),
+                               "dz1 pieces written = 200 B; k_mid_fit_v5: layer 2 and the row reductions on the f32 matrix core "
+                               "(72 MFMAs = 4.6k cycles + 630 VALU + 157 LDS instructions per 64 rows); bound by instruction "
+                               "issue on a SIMD whose matrix-core and VALU time add up (tools/micro/pipe_overlap.hip), "
+                               "DESIGN.md section 5"),
     "rcmarl_minibatch_fit": ("mfma_f32", "the adversaries' fit(batch_size=32, epochs=10): 940 sequentially DEPENDENT SGD steps per "
                              "network, one wavefront per network (6 us per step): bound by the latency of one step, not by a pipe; "
                              "flops = 6 per weight per row"),
