@@ -551,7 +551,8 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
   __shared__ float sW2[HID * WLD];                     // W2[m][i]   (i >= HID: zeros)
   __shared__ float sW2T[HID * WLD];                    // W2[j][k] stored as [k][j]
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];         // b2 | W3 | b3
-  __shared__ float sPn[4 * PANEL];
+  __shared__ __attribute__((aligned(16))) float sPn[4 * PANEL];
+  static_assert(!EMIT || (PANEL * 4 >= HID * 3 * 64 * 2 && PANEL % 4 == 0), "the dz transpose (HID x 3 pieces x 64 rows of bf16) fits the panel area");
   static_assert(PANEL >= PT::SIZE + 64, "a staged record (+ one dump word per lane) fits the panel area");
   const int s = blockIdx.z, i = blockIdx.y;
   const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
         }
     }
     if (EMIT) {
-      // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + j (uniform), k = b (lane), as k_mid_fit_v3
+#ifdef RC_V5_DZ_DIRECT
       unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + (long)(chunk * (ROWS / 32)) * (3 * RC_PK_BLOCK);
       const unsigned lane_off = (unsigned)(r >> 5) * (3 * RC_PK_BLOCK) + (((r & 31) >> 3) << 4) + (r & 7) * 2;
       const unsigned lane_off1 = lane_off + RC_PK_BLOCK, lane_off2 = lane_off + 2 * RC_PK_BLOCK;
@@ -694,6 +695,44 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
           *reinterpret_cast<unsigned short*>(p + (lane_off2 ^ sw)) = (unsigned short)(u ? l >> 16 : l);
         }
       }
+#else
+      // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + j, k = replay row.  A lane owns ONE replay row, i.e. 2 bytes of
+      // every (unit, piece) row of the packed image: stored directly that is 120 two-byte store instructions per
+      // wavefront.  Instead the wavefront transposes its 64 rows x 60 (unit, piece) values through its (now idle) panel
+      // area and writes 16-byte chunks = 8 consecutive replay rows of one (unit, piece): 8 store instructions.
+      unsigned short* stg = reinterpret_cast<unsigned short*>(sA);          // [60 (unit, piece)][64 rows] bf16 = 7680 B
+      RC_WAVE_SYNC();                                  // the reduction product's fragment reads are done
+#pragma unroll
+      for (int q = 0; q < HID / 2; ++q) {
+        unsigned h, m, l;
+        rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);              // bits 0-15: unit 2q, bits 16-31: unit 2q+1
+        stg[((2 * q) * 3 + 0) * 64 + lane] = (unsigned short)h;
+        stg[((2 * q) * 3 + 1) * 64 + lane] = (unsigned short)m;
+        stg[((2 * q) * 3 + 2) * 64 + lane] = (unsigned short)l;
+        stg[((2 * q + 1) * 3 + 0) * 64 + lane] = (unsigned short)(h >> 16);
+        stg[((2 * q + 1) * 3 + 1) * 64 + lane] = (unsigned short)(m >> 16);
+        stg[((2 * q + 1) * 3 + 2) * 64 + lane] = (unsigned short)(l >> 16);
+      }
+      RC_WAVE_SYNC();
+      unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK);
+      const int k0 = chunk * ROWS + wave * 64;         // first replay row of this wavefront (a multiple of 64: two k-tiles)
+#pragma unroll
+      for (int it = 0; it < (HID * 3 * 8 + 63) / 64; ++it) {
+        const int c = it * 64 + lane;                  // chunk index: (unit, piece) = c >> 3, rows 8*(c&7) .. +7
+        if (c < HID * 3 * 8) {
+          const int up = c >> 3, c8 = c & 7;
+          const int unit = up / 3, piece = up - 3 * unit;
+          const int R = i * HID + unit;
+          const int kt = (k0 >> 5) + (c8 >> 2), c4 = c8 & 3;
+          if (kt < dzp_kt) {
+            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 64 + 8 * c8);
+            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 3 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
+                                 (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
+            *reinterpret_cast<uint4*>(base + off) = v4;
+          }
+        }
+      }
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < HID; ++j)

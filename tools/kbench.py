@@ -192,6 +192,31 @@ def lattice(L, S=16, N=256, B=3000):
                                                                                                    3 * flops / t / 1e6))
 
 
+def mid_ab(L, S=16, N=256, B=3000):
+    """A/B of rcmarl_mid_fit_lattice between the product library and RCMARL_KBENCH_LIB_B (a variant build), interleaved."""
+    from rcmarl_amd import lattice as LT
+    LB = capi.CLib(os.environ["RCMARL_KBENCH_LIB_B"])
+    st = torch.cuda.current_stream().cuda_stream
+    in_dim = 2 * N
+    P = in_dim * HID + HID + HID * HID + HID + HID + 1
+    ldp, ldb = pad64(P), pad64(B)
+    g = LT.Geometry(N, in_dim, B)
+    theta = torch.randn(S, N, ldp, device="cuda") * 0.05
+    a1t = torch.randn(S, N * HID, ldb, device="cuda")
+    y = torch.randn(S, N, ldb, device="cuda")
+    dzp = torch.zeros(S * LT.Geometry.nbytes(g.dzp, 3), dtype=torch.uint8, device="cuda")
+    part = torch.zeros(S * N * ((B + 255) // 256) * L.rcmarl_fit_partial_size(HID), device="cuda")
+    outs = {}
+    for rnd in range(4):
+        for name, lib in (("product", L), ("variant", LB)):
+            dzp.zero_()
+            t = timeit(lambda: lib.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
+                                                          g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st), iters=20)
+            outs[name] = dzp.clone()
+            print("round %d  %-8s %8.1f us" % (rnd, name, t))
+    print("dz images identical:", bool(torch.equal(outs["product"], outs["variant"])))
+
+
 def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
     """the dense-GEMM path at the cfg-5 shape (1024 agents x 512-wide critic, here a 64-agent slice)"""
     st = torch.cuda.current_stream().cuda_stream
@@ -239,4 +264,4 @@ if __name__ == "__main__":
     L = capi.load()
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "mid_ab": mid_ab, "minibatch": minibatch, "wide": wide}[what](L)
