@@ -252,6 +252,12 @@ template <> struct SortSmall<7> {      // 16 comparators (optimal)
 // q0 = x*rcp, one fma residual, one fma correction (Markstein).  Checked EXHAUSTIVELY over all 2^32 inputs for
 // D in {4, 6, 10, 18, 34, 66}: the only mismatches have a subnormal quotient, which takes the true division.
 template <int D>
+__device__ __forceinline__ float rc_div_fast(float x) {           // rc_div_const without its subnormal-quotient guard
+  constexpr float rcp = 1.0f / (float)D;
+  const float q0 = x * rcp;
+  return fmaf(fmaf(-q0, (float)D, x), rcp, q0);
+}
+template <int D>
 __device__ __forceinline__ float rc_div_const(float x) {
   constexpr float rcp = 1.0f / (float)D;
   const float ax = fabsf(x);
@@ -270,23 +276,34 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
   static_assert(D == 2 * H + 2 && H >= G - 1 && 64 % TC == 0 && TC % 4 == 0, "circulant kernel: d = 2H+2, H >= G-1");
   constexpr int E = G - 1, M = D - G + 1, U = D + G - 1, SUB = 64 / TC, RPI = 256 / TC;   // RPI: rows per LDS-DMA burst
   RCMARL_DYN_SMEM(float, lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int tile_floats = N * TC, buf_floats = tile_floats + 256;
-  int* coop_s = reinterpret_cast<int*>(lds + 2 * buf_floats);
-  for (int i = threadIdx.x; i < N; i += blockDim.x) coop_s[i] = coop[i];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = THREADS >> 6;   // wave: an SGPR
+  // the tile carries the first U-1 rows a second time after row N-1: a group's window never wraps
+  const int NR = N + U - 1, tile_floats = NR * TC, buf_floats = tile_floats + 256;
   const int c = lane % TC, sub = lane / TC;
   const int n_groups = (N + G - 1) / G, per_pass = nw * SUB, n_iter = (n_groups + per_pass - 1) / per_pass;
-  const int rows_per_wave = (N + nw - 1) / nw;
+  const int rows_per_wave = (NR + nw - 1) / nw;
   auto stage = [&](int t, float* buf) {
     const int s = t / tiles_per_seed, c0 = (t - s * tiles_per_seed) * TC;
     const float* m = msg + (size_t)s * N * ldp + c0;
-    const int r_begin = wave * rows_per_wave, r_end = min(N, r_begin + rows_per_wave);
+    const int r_begin = wave * rows_per_wave, r_end = min(NR, r_begin + rows_per_wave);
     for (int r = r_begin; r < r_end; r += RPI) {         // one instruction = RPI rows x TC*4 B = 1 KiB of LDS
       int row = r + lane / (TC / 4);
-      row = row < N ? row : N - 1;                       // (tail lanes re-read the last row into the slack rows)
+      row = row < NR ? row : NR - 1;                     // (tail lanes re-read the last row into the slack rows)
+      if (row >= N) row -= N;
+      if (row >= N) row -= N;                            // (U - 1 < 2N)
       rc_glds16(m + (size_t)row * ldp + 4 * (lane % (TC / 4)), buf + (size_t)r * TC);
     }
   };
+  // the groups a lane serves are the same for every tile: their "exists and is cooperative" flags, G bits per pass
+  static_assert(G % 2 == 0, "agents are finished in pairs");
+  unsigned long long okmask = 0;
+  for (int j = 0; j < n_iter; ++j) {
+    const int gi = wave * SUB + sub + per_pass * j;
+    for (int g = 0; g < G; ++g) {
+      const int agent = gi * G + g;
+      if (gi < n_groups && agent < N && coop[agent]) okmask |= 1ull << (j * G + g);
+    }
+  }
   int t = blockIdx.x;
   int cur = 0;
   if (t < total_tiles) stage(t, lds);
@@ -305,22 +322,18 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
       if (gi >= n_groups) continue;
       const int i0 = gi * G;
       float v[U];
-      if (i0 + U <= N) {                                 // no wrap: constant offsets from one base
-        const float* p0 = tile + i0 * TC + c;
+      const float* p0 = tile + i0 * TC + c;              // constant offsets from one base
 #pragma unroll
-        for (int k = 0; k < U; ++k) v[k] = p0[k * TC];
-      } else {
-#pragma unroll
-        for (int k = 0; k < U; ++k) v[k] = tile[((i0 + k) % N) * TC + c];
-      }
+      for (int q = 0; q < U; ++q) v[q] = p0[q * TC];
       float cm[M], mid[G + 1];
 #pragma unroll
       for (int q = 0; q < M; ++q) cm[q] = v[G - 1 + q];
       SelMid<M, H - G + 1, G + 1>::run(cm, mid);
+      // bounds of the G agents, then clip + mean for two agents at a time: the D dependent additions of a mean are the
+      // reference's summation order, and two agents' chains ride in one v_pk_add_f32
+      float lower[G], upper[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const int agent = i0 + g;
-        if (agent >= N || !coop_s[agent]) continue;
         float tx[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) tx[q] = (q < E - g) ? v[g + q] : v[D + q - (E - g)];
@@ -332,14 +345,44 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
           shi = fminf(shi, fmaxf(tx[a - 1], mid[E + 1 - a]));
         }
         const float own = v[g];
-        const float lower = fminf(slo, own), upper = fmaxf(shi, own);
-        float sum = 0.f;
+        lower[g] = fminf(slo, own);
+        upper[g] = fmaxf(shi, own);
+      }
+      float res[G];
 #pragma unroll
-        for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[g + k], lower, upper);
-        if (col_ok) {
-          const size_t o = ((size_t)s * N + agent) * ldp + c0 + c;
-          theta[o] = rc_div_const<D>(sum);
-          if (lo_dbg) { lo_dbg[o] = lower; hi_dbg[o] = upper; }
+      for (int g = 0; g < G; g += 2) {
+        rc_f2 sum = rc_bcast2(0.f);
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+          sum = rc_add2(sum, rc_f2{__builtin_amdgcn_fmed3f(v[g + k], lower[g], upper[g]),
+                                   __builtin_amdgcn_fmed3f(v[g + 1 + k], lower[g + 1], upper[g + 1])});
+        res[g] = sum.x;
+        res[g + 1] = sum.y;
+      }
+      // x / D by reciprocal + two fma corrections (rc_div_const); its only inexact cases have a subnormal quotient, and
+      // those take the true division on a wavefront-uniform branch that real weights never enter
+      bool tiny = false;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float ax = fabsf(res[g]);
+        tiny |= (ax < 1e-30f && ax != 0.f);
+      }
+      float q[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) q[g] = rc_div_fast<D>(res[g]);
+      if (__builtin_expect(rc_any(tiny), 0)) {
+        RC_NO_SPECULATE();                             // (keeps the IEEE division's ~10 instructions out of the fast path)
+#pragma unroll
+        for (int g = 0; g < G; ++g) q[g] = res[g] / (float)D;
+      }
+      const unsigned ok = col_ok ? (unsigned)(okmask >> (j * G)) : 0u;       // bit g: agent i0+g exists and is cooperative
+      const size_t o0 = ((size_t)s * N + i0) * ldp + c0 + c;
+      float* tp = theta + o0;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if ((ok >> g) & 1u) {
+          tp[(size_t)g * ldp] = q[g];
+          if (lo_dbg) { lo_dbg[o0 + (size_t)g * ldp] = lower[g]; hi_dbg[o0 + (size_t)g * ldp] = upper[g]; }
         }
       }
     }
@@ -358,6 +401,9 @@ int circ_group(int d, int H) {
   if (d == 66 && H == 32) return forced == 4 ? 4 : 8;
   return 0;
 }
+
+// LDS of the circulant kernel: two tiles of N + (d+G-2) rows (the wrapped rows twice) + one DMA burst of slack each
+size_t circ_smem(int N, int d, int G, int TC) { return 2 * ((size_t)(N + d + G - 2) * TC + 256) * sizeof(float); }
 
 // Any (d, H) without a generated network: order statistics by rank counting
 // out of the LDS tile (O(d^2) LDS reads).  Correct for every d >= 2H+1; slow.
@@ -504,8 +550,7 @@ RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const 
 // rcmarl_consensus_params then.  Results are bit-identical to rcmarl_consensus_params.
 RCMARL_EXPORT int rcmarl_consensus_params_circulant_supported(int N, int d, int H) {
   if (N <= 0 || d != 2 * H + 2 || d > N || circ_group(d, H) == 0) return 0;
-  const size_t need64 = (2 * ((size_t)N * 64 + 256) + N) * sizeof(float), need16 = (2 * ((size_t)N * 16 + 256) + N) * sizeof(float);
-  return (need64 <= 158 * 1024 || need16 <= 158 * 1024) ? 1 : 0;
+  return circ_smem(N, d, circ_group(d, H), 16) <= 158 * 1024 ? 1 : 0;
 }
 
 RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* theta, const int* coop, int S, int N,
@@ -516,8 +561,8 @@ RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* the
     return RCMARL_ERR_ARG;
   if (!rcmarl_consensus_params_circulant_supported(N, d, H)) return RCMARL_ERR_UNSUPPORTED;
   const int G = circ_group(d, H);
-  const int TC = (2 * ((size_t)N * 64 + 256) + N) * sizeof(float) <= 158 * 1024 ? 64 : 16;
-  const size_t smem = (2 * ((size_t)N * TC + 256) + N) * sizeof(float);
+  const int TC = circ_smem(N, d, G, 64) <= 158 * 1024 ? 64 : 16;
+  const size_t smem = circ_smem(N, d, G, TC);
   const int tps = rc_ceil_div(P_hid, TC), tot = tps * S;
   int wg_cu = (int)((160 * 1024) / (smem + 1024));
   if (wg_cu > 4) wg_cu = 4;

@@ -198,6 +198,24 @@ __device__ __forceinline__ void rc_half_sum3_lane31(float& a, float& b, float& c
 #endif
 }
 
+// True if `v` holds for any active lane of the wavefront (one v_cmp + one scalar test).  Used to put a rare slow path
+// on a wavefront-uniform branch; both sides of such a branch must give the same result for a lane whose own `v` is false
+// (the host emulation decides per lane).
+__device__ __forceinline__ bool rc_any(bool v) {
+#ifdef RCMARL_EMU
+  return v;
+#else
+  return __builtin_amdgcn_ballot_w64(v) != 0ull;
+#endif
+}
+
+// Placed first in a rarely taken block: the compiler may not hoist ("speculate") the block's arithmetic above the branch
+#ifdef RCMARL_EMU
+#define RC_NO_SPECULATE() ((void)0)
+#else
+#define RC_NO_SPECULATE() asm volatile("" ::: "memory")
+#endif
+
 // Scheduling fence: hipcc's scheduler otherwise hoists every independent LDS read of a fully unrolled loop to its top
 // (100 ds_read_b128 of weights = 400 live registers -> spills); nothing moves across this point.
 #ifdef RCMARL_EMU

@@ -56,8 +56,11 @@ def gemm(L, S=16, N=256, B=3000):
 
 def k1(L, S=16, N=256):
     st = torch.cuda.current_stream().cuda_stream
+    only = os.environ.get("RCMARL_KBENCH_ONLY")       # e.g. "18": just the d=18, H=8 critic case (for counter runs)
     for d, H in ((4, 1), (10, 4), (18, 8), (18, 1)):
-        for in_dim in (2 * N, 3 * N):
+        if only and (d != int(only) or 2 * H + 2 != d):
+            continue
+        for in_dim in ((2 * N,) if only else (2 * N, 3 * N)):
             P = in_dim * HID + HID + HID * HID + HID + HID + 1
             P_hid = P - 21
             ldp = pad64(P)
