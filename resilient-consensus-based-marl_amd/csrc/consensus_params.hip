@@ -361,29 +361,33 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
       }
       // x / D by reciprocal + two fma corrections (rc_div_const); its only inexact cases have a subnormal quotient, and
       // those take the true division on a wavefront-uniform branch that real weights never enter
-      bool tiny = false;
+      // (a zero sum also takes it: same result, and only all-zero columns such as fresh biases have one)
+      float amin = fabsf(res[0]);
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float ax = fabsf(res[g]);
-        tiny |= (ax < 1e-30f && ax != 0.f);
-      }
+      for (int g = 1; g < G; ++g) amin = fminf(amin, fabsf(res[g]));
       float q[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) q[g] = rc_div_fast<D>(res[g]);
-      if (__builtin_expect(rc_any(tiny), 0)) {
+      if (__builtin_expect(rc_any(amin < 1e-30f), 0)) {
         RC_NO_SPECULATE();                             // (keeps the IEEE division's ~10 instructions out of the fast path)
 #pragma unroll
         for (int g = 0; g < G; ++g) q[g] = res[g] / (float)D;
       }
-      const unsigned ok = col_ok ? (unsigned)(okmask >> (j * G)) : 0u;       // bit g: agent i0+g exists and is cooperative
+      const unsigned ok = col_ok ? (unsigned)(okmask >> (j * G)) & ((1u << G) - 1u) : 0u;   // bit g: agent i0+g exists and is cooperative
       const size_t o0 = ((size_t)s * N + i0) * ldp + c0 + c;
       float* tp = theta + o0;
+      if (rc_all(ok == (1u << G) - 1u)) {                // the usual case: no per-agent predicates
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if ((ok >> g) & 1u) {
-          tp[(size_t)g * ldp] = q[g];
-          if (lo_dbg) { lo_dbg[o0 + (size_t)g * ldp] = lower[g]; hi_dbg[o0 + (size_t)g * ldp] = upper[g]; }
-        }
+        for (int g = 0; g < G; ++g) tp[(size_t)g * ldp] = q[g];
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if ((ok >> g) & 1u) tp[(size_t)g * ldp] = q[g];
+      }
+      if (lo_dbg) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if ((ok >> g) & 1u) { lo_dbg[o0 + (size_t)g * ldp] = lower[g]; hi_dbg[o0 + (size_t)g * ldp] = upper[g]; }
       }
     }
     cur ^= 1;
@@ -561,12 +565,19 @@ RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* the
     return RCMARL_ERR_ARG;
   if (!rcmarl_consensus_params_circulant_supported(N, d, H)) return RCMARL_ERR_UNSUPPORTED;
   const int G = circ_group(d, H);
-  const int TC = circ_smem(N, d, G, 64) <= 158 * 1024 ? 64 : 16;
+  static const int tc_env = getenv("RCMARL_K1_TC") ? atoi(getenv("RCMARL_K1_TC")) : 0;
+  // 32 columns = one 128-byte line per row and two resident workgroups per CU up to N ~ 580 (measured best: 64-column
+  // tiles leave one workgroup per CU and coarser tile counts); 16 columns only when nothing wider fits
+  int TC = circ_smem(N, d, G, 32) <= 158 * 1024 ? 32 : 16;
+  if ((tc_env == 64 || tc_env == 16) && circ_smem(N, d, G, tc_env) <= 158 * 1024) TC = tc_env;
   const size_t smem = circ_smem(N, d, G, TC);
   const int tps = rc_ceil_div(P_hid, TC), tot = tps * S;
   int wg_cu = (int)((160 * 1024) / (smem + 1024));
-  if (wg_cu > 4) wg_cu = 4;
+  const int wg_threads = d >= 34 ? 512 : 1024;        // (RC_CIRC_CASE below)
+  if (wg_cu > 2048 / wg_threads) wg_cu = 2048 / wg_threads;          // resident workgroups only: the tile loop is persistent
   if (wg_cu < 1) wg_cu = 1;
+  static const int wgcu_env = getenv("RCMARL_K1_WGCU") ? atoi(getenv("RCMARL_K1_WGCU")) : 0;     // (tuning aid)
+  if (wgcu_env > 0) wg_cu = wgcu_env;
   int nwg = 256 * wg_cu;
 #ifdef RCMARL_EMU
   nwg = 3;
@@ -584,7 +595,8 @@ RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* the
 #define RC_CIRC_CASE(DD, HH, GG)                                                                                     \
   if (rc == RCMARL_ERR_UNSUPPORTED && d == DD && H == HH && G == GG) {                                               \
     constexpr int THR = (DD >= 34) ? 512 : 1024;                                                                     \
-    if (TC == 64) RC_CIRC_LAUNCH(DD, HH, GG, 64, THR); else RC_CIRC_LAUNCH(DD, HH, GG, 16, THR);                     \
+    if (TC == 64) RC_CIRC_LAUNCH(DD, HH, GG, 64, THR); else if (TC == 32) RC_CIRC_LAUNCH(DD, HH, GG, 32, THR);        \
+    else RC_CIRC_LAUNCH(DD, HH, GG, 16, THR);                                                                        \
   }
   RCMARL_CIRC_COMBOS(RC_CIRC_CASE)
 #undef RC_CIRC_CASE

@@ -209,6 +209,16 @@ __device__ __forceinline__ bool rc_any(bool v) {
 #endif
 }
 
+// True if `v` holds for every active lane (for a fast path without per-lane predicates; the other path must be correct
+// for any lane, and the host emulation decides per lane)
+__device__ __forceinline__ bool rc_all(bool v) {
+#ifdef RCMARL_EMU
+  return v;
+#else
+  return __builtin_amdgcn_ballot_w64(!v) == 0ull;
+#endif
+}
+
 // Placed first in a rarely taken block: the compiler may not hoist ("speculate") the block's arithmetic above the branch
 #ifdef RCMARL_EMU
 #define RC_NO_SPECULATE() ((void)0)
