@@ -378,7 +378,7 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
       float* tp = theta + o0;
       if (rc_all(ok == (1u << G) - 1u)) {                // the usual case: no per-agent predicates
 #pragma unroll
-        for (int g = 0; g < G; ++g) tp[(size_t)g * ldp] = q[g];
+        for (int g = 0; g < G; ++g) RC_NT_STORE(tp + (size_t)g * ldp, q[g]);
       } else {
 #pragma unroll
         for (int g = 0; g < G; ++g)
