@@ -294,7 +294,10 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
       rc_glds16(m + (size_t)row * ldp + 4 * (lane % (TC / 4)), buf + (size_t)r * TC);
     }
   };
-  // the groups a lane serves are the same for every tile: their "exists and is cooperative" flags, G bits per pass
+  int t = blockIdx.x;
+  int cur = 0;
+  if (t < total_tiles) stage(t, lds);
+  // (while the first tile is in flight) the groups a lane serves are the same for every tile: their "exists and is cooperative" flags, G bits per pass
   static_assert(G % 2 == 0, "agents are finished in pairs");
   unsigned long long okmask = 0;
   for (int j = 0; j < n_iter; ++j) {
@@ -304,9 +307,6 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
       if (gi < n_groups && agent < N && coop[agent]) okmask |= 1ull << (j * G + g);
     }
   }
-  int t = blockIdx.x;
-  int cur = 0;
-  if (t < total_tiles) stage(t, lds);
   for (; t < total_tiles; t += gridDim.x) {
 #ifndef RCMARL_EMU
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of tile t (see k_consensus_params_v2)
