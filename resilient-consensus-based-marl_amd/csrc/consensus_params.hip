@@ -27,6 +27,18 @@
 
 namespace {
 
+// x / D for a small integer constant D, bit-identical to the IEEE division in 3 instructions instead of ~10:
+// q0 = x*rcp, one fma residual, one fma correction (Markstein).  Checked EXHAUSTIVELY over all 2^32 inputs for every
+// D in 2..66 (tools/micro/check_div_const.c): the only mismatches have a subnormal quotient (|x| < 2.4e-38 * D), and
+// the callers send |x| < 1e-30 to the true division on a wavefront-uniform branch (rc_any) that real weights never
+// enter -- an if-converted IEEE division costs ~10 instructions per value.
+template <int D>
+__device__ __forceinline__ float rc_div_fast(float x) {
+  constexpr float rcp = 1.0f / (float)D;
+  const float q0 = x * rcp;
+  return fmaf(fmaf(-q0, (float)D, x), rcp, q0);
+}
+
 template <int D, int H>
 __device__ __forceinline__ float aggregate_regs(const float (&v)[D], float& lower, float& upper) {
   float lo, hi;
@@ -36,7 +48,12 @@ __device__ __forceinline__ float aggregate_regs(const float (&v)[D], float& lowe
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[k], lower, upper);  // clamp
-  return sum / (float)D;
+  float q = rc_div_fast<D>(sum);
+  if (__builtin_expect(rc_any(fabsf(sum) < 1e-30f), 0)) {
+    RC_NO_SPECULATE();
+    q = sum / (float)D;
+  }
+  return q;
 }
 
 // Software-pipelined tile staging: a workgroup walks a strided sequence of (seed, column-tile)
@@ -248,24 +265,6 @@ template <> struct SortSmall<7> {      // 16 comparators (optimal)
 };
 #undef RC_CE
 
-// x / D for a small integer constant D, bit-identical to the IEEE division in 3 instructions instead of ~10:
-// q0 = x*rcp, one fma residual, one fma correction (Markstein).  Checked EXHAUSTIVELY over all 2^32 inputs for
-// D in {4, 6, 10, 18, 34, 66}: the only mismatches have a subnormal quotient, which takes the true division.
-template <int D>
-__device__ __forceinline__ float rc_div_fast(float x) {           // rc_div_const without its subnormal-quotient guard
-  constexpr float rcp = 1.0f / (float)D;
-  const float q0 = x * rcp;
-  return fmaf(fmaf(-q0, (float)D, x), rcp, q0);
-}
-template <int D>
-__device__ __forceinline__ float rc_div_const(float x) {
-  constexpr float rcp = 1.0f / (float)D;
-  const float ax = fabsf(x);
-  if (__builtin_expect(ax < 1e-30f && ax != 0.f, 0)) return x / (float)D;
-  const float q0 = x * rcp;
-  return fmaf(fmaf(-q0, (float)D, x), rcp, q0);
-}
-
 template <int D, int H, int G, int TC, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* __restrict__ msg,
                                                                    float* __restrict__ theta,
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
         res[g] = sum.x;
         res[g + 1] = sum.y;
       }
-      // x / D by reciprocal + two fma corrections (rc_div_const); its only inexact cases have a subnormal quotient, and
+      // x / D by reciprocal + two fma corrections (rc_div_fast); its only inexact cases have a subnormal quotient, and
       // those take the true division on a wavefront-uniform branch that real weights never enter
       // (a zero sum also takes it: same result, and only all-zero columns such as fresh biases have one)
       float amin = fabsf(res[0]);

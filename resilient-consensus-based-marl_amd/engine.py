@@ -12,6 +12,7 @@ the hot path runs in csrc/*.hip.  There is no CPU fallback: the constructor
 raises if the HIP library or a GPU is missing (tests inject the hipemu build
 explicitly via ``lib=``/``device='cpu'``).
 """
+import contextlib
 import math
 import time
 
@@ -191,6 +192,8 @@ class RPBCACEngine:
         self.gpow = [float(c.gamma ** j) for j in range(c.max_ep_len)]
         self.initial_state = None             # used when randomize_state is False
         self.np_rngs = None                   # rng_mode='numpy': one RandomState-like object per seed
+        self.shard = None                     # shard_agents(): ONE instance over several GPUs (wide critic)
+        self._windowed = False
 
     # ---- everything sized by the replay capacity ---------------------------------------------------
     def _alloc_row_buffers(self, cap):
@@ -325,11 +328,19 @@ class RPBCACEngine:
                                     self.loss[net].data_ptr() if step == 0 else None, S, N, B, in_dim, hid, ldp, lr, st)
         self.a1_cached[net] = False
 
-    def _consensus_wide(self, net, xkey, B):
+    def _consensus_wide(self, net, xkey, B, msg_all=None):
+        if self.shard is not None and not self._windowed:
+            # the neighbours' output layers (W3, b3 of their messages) come from all ranks; everything else is per agent
+            o = self.P[net] - (self.hid[net] + 1)
+            self._allgather_rows(self.msg[net], o, self.P[net])
+            msg_all = self.msg[net]
+            with self._critic_window():
+                return self._consensus_wide(net, xkey, B, msg_all)
         L, S, N, c, hid = self.lib, self.S, self.N, self.cfg, self.hid[net]
+        msg_all = self.msg[net] if msg_all is None else msg_all      # rows indexed by GLOBAL agent (in_nodes)
         self._k1(net, self.P[net] - (hid + 1))
         self._wide_forward(xkey, self.theta[net], net, B, a1=self.a1net[net])
-        L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
+        L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), msg_all.data_ptr(),
                                      self.nbr.data_ptr(), self.coop.data_ptr(), None, self.w_hmat.data_ptr(),
                                      self.w_hb.data_ptr(), self.w_est.data_ptr(), self.w_ebuf.data_ptr(),
                                      self.w_grads.data_ptr(), None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb,
@@ -343,6 +354,129 @@ class RPBCACEngine:
         self.lib.rcmarl_wide_head_value(self.w_a2.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma,
                                         out.data_ptr(), self.S, self.N, B, self.in_dim[net], self.hid[net], self.ldp[net],
                                         self.ldb, self.stream)
+
+    # ---- ONE instance over several GPUs (C2, SURVEY.md 8e / BASELINE configs[4]) ---------------------------------
+    def shard_agents(self, rank=None, world=None, group=None, comm=None):
+        """Shard the wide critic of this (single-seed) instance over the ranks of `group`: rank r owns a contiguous block of
+        agents for everything that is independent per agent (TD targets, local fits, estimate consensus + projection,
+        values) and a block of parameter COLUMNS for the hidden-layer consensus K1; two all-to-all transposes of the
+        message matrix per epoch (parallel.ShardedConsensus) replace the reference's in-process gather
+        `[critic_weights[i] for i in in_nodes[node]]` (training/train_agents.py:129-130), one small all-gather carries
+        the neighbours' output layers (hid+1 floats per agent) and one the critic values the actors need.  The 20-unit
+        nets (team reward, actors), the environment and the replay buffer stay replicated: they are a few per cent of a
+        wide-critic block and every rank computes them bit-identically.  Results equal the unsharded engine bit for bit
+        (tests/test_sharded_engine_gloo.py).  Call after torch.distributed.init_process_group; world 1 = no-op.
+        comm: the collectives (parallel.TorchComm over `group` by default; parallel.ThreadComm in the one-GPU test)."""
+        from .parallel import ShardedConsensus, TorchComm, agent_range
+        if comm is None and world is None:
+            comm = TorchComm(group)
+        if comm is not None:
+            rank, world = comm.rank, comm.world
+        if world == 1:
+            self.shard = None
+            return self
+        if self.S != 1 or not self.wide:
+            raise ValueError("agent sharding is for ONE instance (n_seeds == 1) with a wide critic; independent seeds shard "
+                             "over ranks without any exchange (parallel.shard_seeds)")
+        if self.N % world:
+            raise ValueError("n_agents must be a multiple of the number of ranks")
+        a0, a1 = agent_range(self.N, rank, world)
+        hid = self.hid["critic"]
+        if self.lat_enabled and ((a1 - a0) * hid) % 128:
+            raise ValueError("agents per rank x critic width must be a multiple of 128 (packed operand row tiles)")
+
+        class _Shard:
+            pass
+        sh = _Shard()
+        sh.rank, sh.world, sh.a0, sh.a1, sh.n_loc, sh.N = rank, world, a0, a1, a1 - a0, self.N
+        sh.comm = TorchComm(group) if comm is None else comm
+        assert (sh.comm.rank, sh.comm.world) == (rank, world), "rank/world do not match the communicator"
+        sh.sc = ShardedConsensus(self.lib, 1, self.N, self.P["critic"] - (hid + 1), self.cfg.d, self.cfg.H, self.cfg.in_nodes,
+                                 self.coop_np, self.dev, comm=sh.comm)
+        self.shard = sh
+        return self
+
+    def _wv(self, t):
+        """this rank's agents of a per-agent tensor ([N] or [1][N][...])"""
+        if t is None or self.shard is None:
+            return t
+        sh = self.shard
+        return t[sh.a0:sh.a1] if t.dim() == 1 else t[:, sh.a0:sh.a1]
+
+    @contextlib.contextmanager
+    def _critic_window(self):
+        """Inside, every per-agent buffer the wide-critic code touches IS its slice for this rank's agents and self.N the
+        number of those agents: with one seed an agent range is a contiguous piece of every [S][N][...] tensor (and a
+        range of 128-row tiles of the packed lattice operands), so the kernels run unchanged on (pointer, N_local)."""
+        sh = self.shard
+        if sh is None or self._windowed:
+            yield
+            return
+        a0, a1, hid = sh.a0, sh.a1, self.hid["critic"]
+        rows = lambda t: t[:, a0:a1]
+        units = lambda t: t[:, a0 * hid:a1 * hid]
+        saved = []
+
+        def swap_attr(name, fn):
+            full = getattr(self, name)
+            saved.append((self, name, full, False))
+            setattr(self, name, fn(full))
+
+        def swap_item(dname, key, value):
+            d_ = getattr(self, dname)
+            saved.append((d_, key, d_[key], True))
+            d_[key] = value
+
+        for name in ("w_a1", "w_a2", "w_dz1"):
+            swap_attr(name, units)
+        for name in ("w_dz3", "w_ebuf", "w_v", "w_grads", "w_losspart", "w_hmat", "w_hb", "w_est"):
+            swap_attr(name, rows)
+        swap_attr("coop", lambda t: t[a0:a1])
+        swap_attr("nbr", lambda t: t[a0:a1])
+        for dname in ("theta", "msg", "loss"):
+            swap_item(dname, "critic", rows(getattr(self, dname)["critic"]))
+        swap_item("a1net", "critic", units(self.a1net["critic"]))
+        for key in ("y_c", "r_fit", "v_next", "v_cur"):
+            swap_item("ybuf", key, rows(self.ybuf[key]))
+        if self.lat_enabled:
+            g_full = self.lat_geom["s"]
+            g_loc = LT.Geometry(sh.n_loc, self.in_c, self.cap, hid)
+            rt0 = a0 * hid // 128
+            for dname, rk_full, rk_loc in (("lat_wp_f", g_full.wp, g_loc.wp), ("lat_dzp_f", g_full.dzp, g_loc.dzp)):
+                per_rt = rk_full[1] * 3 * LT.PK_BLOCK
+                view = getattr(self, dname)["s"][rt0 * per_rt:(rt0 + rk_loc[0]) * per_rt]
+                swap_item(dname, "s", view)
+                if "ns" in getattr(self, dname):
+                    swap_item(dname, "ns", view)
+            swap_item("lat_geom", "s", g_loc)
+            swap_item("lat_geom", "ns", g_loc)
+        swap_attr("N", lambda n: sh.n_loc)
+        self._windowed = True
+        try:
+            yield
+        finally:
+            self._windowed = False
+            for obj, key, full, is_item in reversed(saved):
+                if is_item:
+                    obj[key] = full
+                else:
+                    setattr(obj, key, full)
+
+    def _allgather_rows(self, full, c0, c1):
+        """full [1][N][...]: every rank holds its own agents' rows of columns c0..c1; afterwards all rows everywhere"""
+        sh = self.shard
+        send = full[0, sh.a0:sh.a1, c0:c1].contiguous()
+        recv = [torch.empty_like(send) for _ in range(sh.world)]
+        sh.comm.all_gather(recv, send)
+        for r, blk in enumerate(recv):
+            if r != sh.rank:
+                full[0, r * sh.n_loc:(r + 1) * sh.n_loc, c0:c1] = blk
+
+    def sync_shards(self):
+        """all critic parameters on every rank (checkpoints, get_weights, the end of train()); no-op when not sharded"""
+        if self.shard is not None:
+            self._allgather_rows(self.theta["critic"], 0, self.ldp["critic"])
+            self._allgather_rows(self.loss["critic"].unsqueeze(-1), 0, 1)
 
     # ---- lattice (exact bf16x3) layer-1 path: csrc/lattice_gemm.hip, lattice.py ------------
     def _init_lattice(self):
@@ -530,6 +664,7 @@ class RPBCACEngine:
         agent positions, goals and the RNG position (device mode: the episode counter of the counter-based
         Philox stream; numpy mode: the per-seed RandomState states)."""
         c = self.cfg
+        self.sync_shards()
         sd = {"format": 1, "S": self.S, "N": self.N, "seeds": list(self.seeds), "episode": self.episode, "B": self.B,
               "adam_t": self.adam_t, "cur": self.cur, "labels": list(c.agent_label), "in_nodes": c.in_nodes,
               "theta": {k: v.detach().cpu() for k, v in self.theta.items()},
@@ -628,7 +763,10 @@ class RPBCACEngine:
             self._reset(None if c.randomize_state else np.broadcast_to(np.asarray(self.initial_state), (S, N, 2)))
         # expected returns at the start state (train_agents.py:60-62)
         if self.wide:
-            self._value_wide(None, self.theta["critic"], "critic", self.w_v, 1, x=(self.xs[self.cur].data_ptr(), 2 * N, 1, 2 * N))
+            with self._critic_window():
+                self._value_wide(None, self.theta["critic"], "critic", self.w_v, 1, x=(self.xs[self.cur].data_ptr(), 2 * N, 1, 2 * N))
+            if self.shard is not None:
+                self._allgather_rows(self.w_v, 0, 1)
             self.est.copy_(self.w_v[:, :, 0])
         else:
             L.rcmarl_value_rows(self.xs[self.cur].data_ptr(), self.theta["critic"].data_ptr(), self.est.data_ptr(), S, N,
@@ -682,7 +820,10 @@ class RPBCACEngine:
                                     self.episode, self.posT[0].data_ptr(), self.xsT[0].data_ptr(), self.retT.data_ptr(),
                                     S, N, n_eps, EP, self.stream)
         if self.wide:      # start states are episode-minor xsT[S][2N][EP]: a feature-major layer-1 input
-            self._value_wide(None, self.theta["critic"], "critic", self.w_v, n_eps, x=(self.xsT[0].data_ptr(), 2 * N * EP, 0, EP))
+            with self._critic_window():
+                self._value_wide(None, self.theta["critic"], "critic", self.w_v, n_eps, x=(self.xsT[0].data_ptr(), 2 * N * EP, 0, EP))
+            if self.shard is not None:
+                self._allgather_rows(self.w_v, 0, n_eps)
             self.est_hist[:n_eps].copy_(self.w_v[:, :, :n_eps].permute(2, 0, 1))
         else:
             L.rcmarl_value_rows_episodes(self.xsT[0].data_ptr(), self.theta["critic"].data_ptr(), self.est_hist.data_ptr(), S, N,
@@ -728,6 +869,10 @@ class RPBCACEngine:
     def _local_fit(self, net, xkey, y, B, mask, partials=None):
         """5 full-batch SGD steps on the message copy (agents/resilient_CAC_agents.py:118,136)."""
         if self.hid[net] != HID:
+            if self.shard is not None and not self._windowed:
+                y, mask = self._wv(y), self._wv(mask)
+                with self._critic_window():
+                    return self._local_fit_wide(net, xkey, y, B, mask)
             return self._local_fit_wide(net, xkey, y, B, mask)
         L, S, N = self.lib, self.S, self.N
         msg = self.msg[net]
@@ -798,10 +943,18 @@ class RPBCACEngine:
                                              self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
         self.a1_cached[net] = False
 
-    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None):
+    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None, gather=False):
         """scratch: private activation buffer of a caller that may run beside the main stream (the adversaries); such a
-        caller also stays off the lattice path, whose packed-operand scratch belongs to the main stream."""
+        caller also stays off the lattice path, whose packed-operand scratch belongs to the main stream.
+        gather (agent-sharded instance only): the caller needs the values of ALL agents, not just this rank's."""
         if self.hid[net] != HID:
+            if self.shard is not None and not self._windowed:
+                th, o, r = self._wv(theta), self._wv(out), self._wv(r_applied)
+                with self._critic_window():
+                    self._value_wide(xkey, th, net, o, B, row0, r)
+                if gather:
+                    self._allgather_rows(out, 0, B)
+                return
             return self._value_wide(xkey, theta, net, out, B, row0, r_applied)
         buf = self.a1t if scratch is None else scratch
         self._layer1(xkey, theta, net, B, row0, buf=buf, lattice=scratch is None)
@@ -811,6 +964,14 @@ class RPBCACEngine:
     def _k1(self, net, g_hid):
         """hidden-layer consensus of one network family: msg -> theta (cooperative agents, columns < g_hid)"""
         L, c = self.lib, self.cfg
+        if self._windowed:          # agent-sharded instance: all-to-all, K1 on this rank's parameter columns, all-to-all back
+            sc = self.shard.sc
+            assert g_hid == sc.P_hid
+            sc.stream = self.stream
+            sc.exchange(self.msg[net])
+            sc.consensus()
+            sc.gather(self.theta[net])
+            return
         if self.k1_circulant:
             L.rcmarl_consensus_params_circulant(self.msg[net].data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(),
                                                 self.S, self.N, self.ldp[net], g_hid, c.d, c.H, None, None, self.stream)
@@ -938,13 +1099,15 @@ class RPBCACEngine:
                     self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop, partials=self.partials_side)
                     join = torch.cuda.Event()
                     join.record(self.side_stream)
-                self.msg["critic"].copy_(self.theta["critic"])
+                with self._critic_window():
+                    self.msg["critic"].copy_(self.theta["critic"])
                 self._td_target(B)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
                 main.wait_event(join)
             else:
                 self.msg["tr"].copy_(self.theta["tr"])
-                self.msg["critic"].copy_(self.theta["critic"])
+                with self._critic_window():
+                    self.msg["critic"].copy_(self.theta["critic"])
                 # TD target first (it depends on the live critic only), so the adversaries' message generators --
                 # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
                 # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
@@ -987,8 +1150,8 @@ class RPBCACEngine:
             self._value_next_cached(self.ybuf["v_next"], row0, nl, None, self.ybuf["delta"])
             self._value_cached("critic", self.ybuf["v_cur"], row0, nl)
         else:
-            self._value("ns", self.theta["critic"], "critic", self.ybuf["v_next"], nl, row0)
-            self._value("s", self.theta["critic"], "critic", self.ybuf["v_cur"], nl, row0)
+            self._value("ns", self.theta["critic"], "critic", self.ybuf["v_next"], nl, row0, gather=True)
+            self._value("s", self.theta["critic"], "critic", self.ybuf["v_cur"], nl, row0, gather=True)
         L.rcmarl_td_error(self.ybuf["v_tr"].data_ptr(), self.ybuf["v_next"].data_ptr(), self.ybuf["v_cur"].data_ptr(),
                           c.gamma, self.ybuf["delta"].data_ptr(), S * N * self.ldb, self.stream)
         aptr, astride = self._x("a", row0)
@@ -1111,6 +1274,7 @@ class RPBCACEngine:
             logs["True_adv_returns"].append(adv)
             logs["Estimated_team_returns"].append(est)
             done += n
+        self.sync_shards()
         if not done:                            # n_episodes = 0: the reference's loop body never runs (train_agents.py:46)
             return {k: np.zeros((0, self.S)) for k in logs}
         return {k: np.concatenate(v, axis=0) for k, v in logs.items()}

@@ -71,6 +71,56 @@ def column_ranges(n_cols, world, align=64):
     return out
 
 
+class TorchComm:
+    """The two collectives of the sharded instance over a torch.distributed group (RCCL on GPUs, gloo in CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_gather(self, recv_list, send):
+        dist.all_gather(recv_list, send, group=self.group)
+
+    def all_to_all_single(self, recv, send, out_sizes, in_sizes):
+        dist.all_to_all_single(recv, send, output_split_sizes=out_sizes, input_split_sizes=in_sizes, group=self.group)
+
+
+class ThreadComm:
+    """The same two collectives among THREADS of one process, each driving its own engine on the same device (same
+    stream, so plain copies are ordered): lets a single-GPU box run the sharded instance's kernels on real hardware
+    (tests/test_sharded_engine_gpu.py).  make(world) returns one endpoint per rank."""
+
+    def __init__(self, rank, world, shared):
+        self.rank, self.world, self.group, self._sh = rank, world, None, shared
+
+    @staticmethod
+    def make(world):
+        import threading
+        shared = {"slot": [None] * world, "barrier": threading.Barrier(world, timeout=300)}   # a failed peer breaks it
+        return [ThreadComm(r, world, shared) for r in range(world)]
+
+    def all_gather(self, recv_list, send):
+        sh = self._sh
+        sh["slot"][self.rank] = send
+        sh["barrier"].wait()
+        for r in range(self.world):
+            recv_list[r].copy_(sh["slot"][r])
+        sh["barrier"].wait()
+
+    def all_to_all_single(self, recv, send, out_sizes, in_sizes):
+        sh = self._sh
+        sh["slot"][self.rank] = (send, list(in_sizes))
+        sh["barrier"].wait()
+        o = 0
+        for r in range(self.world):
+            peer, sizes = sh["slot"][r]
+            start = sum(sizes[:self.rank])
+            recv[o:o + out_sizes[r]].copy_(peer[start:start + sizes[self.rank]])
+            o += out_sizes[r]
+        sh["barrier"].wait()
+
+
 class ShardedConsensus:
     """Column-sharded K1 for one network family of ONE instance whose agents are sharded over the ranks.
 
@@ -82,11 +132,11 @@ class ShardedConsensus:
     Rows of non-cooperative agents are never aggregated (agents/resilient_CAC_agents.py is the cooperative agent's
     class); gather() leaves them as they are."""
 
-    def __init__(self, lib, S, N, P_hid, d, H, in_nodes, coop, device, stream=None, group=None):
+    def __init__(self, lib, S, N, P_hid, d, H, in_nodes, coop, device, stream=None, group=None, comm=None):
         self.lib, self.S, self.N, self.P_hid, self.d, self.H = lib, int(S), int(N), int(P_hid), int(d), int(H)
         self.dev, self.stream, self.group = torch.device(device), stream, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.comm = TorchComm(group) if comm is None else comm
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.a_lo, self.a_hi = agent_range(N, self.rank, self.world)
         self.agents = [agent_range(N, r, self.world) for r in range(self.world)]
         self.cols = column_ranges(P_hid, self.world)
@@ -110,7 +160,7 @@ class ShardedConsensus:
         sizes_in = [int(b.numel()) for b in send_blocks]
         sizes_out = [int(np.prod(sh)) for sh in recv_shapes]
         recv = torch.empty(sum(sizes_out), dtype=send.dtype, device=send.device)
-        dist.all_to_all_single(recv, send, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
+        self.comm.all_to_all_single(recv, send, sizes_out, sizes_in)
         out, o = [], 0
         for sh, n in zip(recv_shapes, sizes_out):
             out.append(recv[o:o + n].view(*sh))
