@@ -66,6 +66,13 @@ WORKLOADS = {
     "cfg5_1gpu": dict(N=1024, nrow=32, ncol=32, H=32, d=66, S=1, graph="circulant", fast_lr=0.0005, critic_hid=512,
                       desc="BASELINE configs[4] on one GPU: 1024 agents, 512-unit critic (dense f32-MFMA GEMM path), 20-unit "
                            "team-reward net and actor, 32x32 grid, H=32, circulant in-degree d=66 (=2H+2), one instance"),
+    # the same instance sharded over ALL ranks of the job (strong scaling): agents for the per-agent phases, parameter
+    # columns for the hidden-layer consensus, two all-to-all transposes per epoch (RPBCACEngine.shard_agents)
+    "cfg5_shard": dict(N=1024, nrow=32, ncol=32, H=32, d=66, S=1, graph="circulant", fast_lr=0.0005, critic_hid=512,
+                       shard_instance=True,
+                       desc="BASELINE configs[4] as ONE instance over all ranks: 1024 agents, 512-unit critic sharded by agent "
+                            "(fits, estimate consensus) and by parameter column (hidden-layer consensus); 20-unit nets, "
+                            "environment and replay replicated"),
 }
 
 
@@ -364,7 +371,8 @@ def main(argv=None):
 
     w = WORKLOADS[args.workload]
     S = args.seeds_per_gpu or w["S"]
-    seeds = [1000 + rank * S + k for k in range(S)]                # disjoint seed shards per rank
+    one_instance = bool(w.get("shard_instance"))                   # every rank works on the SAME instance (strong scaling)
+    seeds = [1000 + (0 if one_instance else rank * S) + k for k in range(S)]      # else: disjoint seed shards per rank
     N = w["N"]
     if stub:
         tlib, eng = None, StubEngine(w, S, seeds)
@@ -373,7 +381,10 @@ def main(argv=None):
         from rcmarl_amd.timing import TimedLib
         tlib = TimedLib(capi.load())
         eng = make_engine(w, S, seeds, tlib)
+        if one_instance and world > 1:
+            eng.shard_agents()                                     # over the default process group
     c = eng.cfg
+    jobs = 1 if one_instance else world                            # independent instances of the workload in the job
 
     def barrier():
         if not stub:
@@ -399,18 +410,21 @@ def main(argv=None):
         raise SystemExit("bench invalid: non-finite network weights after the timed region (diverged training)")
     if rank == 0:
         env_steps = c.n_ep_fixed * c.max_ep_len
-        agent_steps = world * S * N * env_steps * args.steps
-        cons_updates = world * S * eng.n_coop * c.n_epochs * args.steps
+        agent_steps = jobs * S * N * env_steps * args.steps
+        cons_updates = jobs * S * eng.n_coop * c.n_epochs * args.steps
         ph_total = ph["rollout"] + ph["phase1"] + ph["phase2"] + ph["phase3"]
         out = {
             "metric": "agent-steps/sec (whole RPBCAC training loop; + consensus-updates/sec)",
             "value": agent_steps / dt, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong" if one_instance else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not stub else "STUB ENGINE (control-path test, not a measurement)",
             "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
                        "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady, "fast_lr": c.fast_lr, "slow_lr": c.slow_lr, "weights_finite": finite,
                        "env_steps_per_block": env_steps, "n_epochs": c.n_epochs, "hidden": 20, "critic_hidden": c.critic_hid,
-                       "parallelism": "seed-sharded, %d seeds/GPU x %d GPU, one all-reduce of return curves" % (S, world)},
+                       "parallelism": ("one instance over %d GPU: agent-sharded critic phases, column-sharded K1, two all-to-all "
+                                       "per epoch" % world) if one_instance else
+                                      "seed-sharded, %d seeds/GPU x %d GPU, one all-reduce of return curves" % (S, world)},
             "comm": comm,
             "consensus_updates_per_s": cons_updates / dt,
             "consensus_updates_per_s_phase2_only": (S * eng.n_coop * c.n_epochs) / ph["phase2"] if ph["phase2"] > 0 else None,
