@@ -92,8 +92,11 @@ class EngineConfig:
                 raise ValueError("unknown agent label %r" % lab)
         if self.critic_hid < 1:
             raise ValueError("critic_hid must be positive")
-        if self.critic_hid != HID and any(lab != COOP for lab in self.agent_label):
-            raise ValueError("a wide critic (critic_hid != 20) is supported for cooperative agents only")
+        if self.critic_hid != HID and any(lab not in (COOP, FAULTY) for lab in self.agent_label):
+            # Faulty agents never fit their critic / team-reward net (adversarial_CAC_agents.py:45-55 transmit the frozen
+            # weights; only their 20-unit actor learns), so they run beside a wide critic as they are; Greedy / Malicious
+            # agents would need the mini-batch message generators (csrc/minibatch_fit.hip) at the wide width
+            raise ValueError("a wide critic (critic_hid != 20) is supported with Cooperative and Faulty agents only")
 
     @property
     def d(self):
@@ -329,13 +332,6 @@ class RPBCACEngine:
         self.a1_cached[net] = False
 
     def _consensus_wide(self, net, xkey, B, msg_all=None):
-        if self.shard is not None and not self._windowed:
-            # the neighbours' output layers (W3, b3 of their messages) come from all ranks; everything else is per agent
-            o = self.P[net] - (self.hid[net] + 1)
-            self._allgather_rows(self.msg[net], o, self.P[net])
-            msg_all = self.msg[net]
-            with self._critic_window():
-                return self._consensus_wide(net, xkey, B, msg_all)
         L, S, N, c, hid = self.lib, self.S, self.N, self.cfg, self.hid[net]
         msg_all = self.msg[net] if msg_all is None else msg_all      # rows indexed by GLOBAL agent (in_nodes)
         self._k1(net, self.P[net] - (hid + 1))
@@ -380,6 +376,8 @@ class RPBCACEngine:
                              "over ranks without any exchange (parallel.shard_seeds)")
         if self.N % world:
             raise ValueError("n_agents must be a multiple of the number of ranks")
+        if self.n_coop != self.N:
+            raise ValueError("the agent-sharded instance is built for all-cooperative teams")
         a0, a1 = agent_range(self.N, rank, world)
         hid = self.hid["critic"]
         if self.lat_enabled and ((a1 - a0) * hid) % 128:
@@ -391,10 +389,20 @@ class RPBCACEngine:
         sh.rank, sh.world, sh.a0, sh.a1, sh.n_loc, sh.N = rank, world, a0, a1, a1 - a0, self.N
         sh.comm = TorchComm(group) if comm is None else comm
         assert (sh.comm.rank, sh.comm.world) == (rank, world), "rank/world do not match the communicator"
-        sh.sc = ShardedConsensus(self.lib, 1, self.N, self.P["critic"] - (hid + 1), self.cfg.d, self.cfg.H, self.cfg.in_nodes,
-                                 self.coop_np, self.dev, comm=sh.comm)
+        # the 20-unit team-reward net is sharded the same way whenever its packed lattice operands split on 128-row tiles
+        # (32 agents per rank); otherwise it stays replicated like the actors (a few per cent of a wide-critic block)
+        sh.shard_tr = (not self.lat_enabled) or ((a1 - a0) * HID) % 128 == 0
+        sh.sc = {}
+        for net in ("critic", "tr") if sh.shard_tr else ("critic",):
+            sh.sc[net] = ShardedConsensus(self.lib, 1, self.N, self.P[net] - (self.hid[net] + 1), self.cfg.d, self.cfg.H,
+                                          self.cfg.in_nodes, self.coop_np, self.dev, comm=sh.comm)
         self.shard = sh
         return self
+
+    def _sharded(self, net):
+        """is this network family's per-agent work split over the ranks (and are we not already inside a window)?"""
+        sh = self.shard
+        return sh is not None and not self._windowed and (net == "critic" or (net == "tr" and sh.shard_tr))
 
     def _wv(self, t):
         """this rank's agents of a per-agent tensor ([N] or [1][N][...])"""
@@ -404,10 +412,11 @@ class RPBCACEngine:
         return t[sh.a0:sh.a1] if t.dim() == 1 else t[:, sh.a0:sh.a1]
 
     @contextlib.contextmanager
-    def _critic_window(self):
-        """Inside, every per-agent buffer the wide-critic code touches IS its slice for this rank's agents and self.N the
+    def _agent_window(self):
+        """Inside, every per-agent buffer of the sharded network families IS its slice for this rank's agents and self.N the
         number of those agents: with one seed an agent range is a contiguous piece of every [S][N][...] tensor (and a
-        range of 128-row tiles of the packed lattice operands), so the kernels run unchanged on (pointer, N_local)."""
+        range of 128-row tiles of the packed lattice operands), so the kernels run unchanged on (pointer, N_local).
+        (Scratch that is only ever indexed from its base -- a1t, partials -- needs no slice.)"""
         sh = self.shard
         if sh is None or self._windowed:
             yield
@@ -433,23 +442,25 @@ class RPBCACEngine:
             swap_attr(name, rows)
         swap_attr("coop", lambda t: t[a0:a1])
         swap_attr("nbr", lambda t: t[a0:a1])
-        for dname in ("theta", "msg", "loss"):
-            swap_item(dname, "critic", rows(getattr(self, dname)["critic"]))
-        swap_item("a1net", "critic", units(self.a1net["critic"]))
-        for key in ("y_c", "r_fit", "v_next", "v_cur"):
+        families = [("critic", hid, ("s", "ns"), self.in_c)] + ([("tr", HID, ("sa",), self.in_r)] if sh.shard_tr else [])
+        for net, h_, xkeys, in_dim in families:
+            for dname in ("theta", "msg", "loss"):
+                swap_item(dname, net, rows(getattr(self, dname)[net]))
+            swap_item("a1net", net, self.a1net[net][:, a0 * h_:a1 * h_])
+            if self.lat_enabled:
+                g_full = self.lat_geom[xkeys[0]]
+                g_loc = LT.Geometry(sh.n_loc, in_dim, self.cap, h_)
+                rt0 = a0 * h_ // 128
+                for dname, rk_full, rk_loc in (("lat_wp_f", g_full.wp, g_loc.wp), ("lat_dzp_f", g_full.dzp, g_loc.dzp)):
+                    per_rt = rk_full[1] * 3 * LT.PK_BLOCK
+                    view = getattr(self, dname)[xkeys[0]][rt0 * per_rt:(rt0 + rk_loc[0]) * per_rt]
+                    for xk in xkeys:
+                        if xk in getattr(self, dname):
+                            swap_item(dname, xk, view)
+                for xk in xkeys:
+                    swap_item("lat_geom", xk, g_loc)
+        for key in ("y_c", "r_fit", "v_next", "v_cur", "v_tr"):
             swap_item("ybuf", key, rows(self.ybuf[key]))
-        if self.lat_enabled:
-            g_full = self.lat_geom["s"]
-            g_loc = LT.Geometry(sh.n_loc, self.in_c, self.cap, hid)
-            rt0 = a0 * hid // 128
-            for dname, rk_full, rk_loc in (("lat_wp_f", g_full.wp, g_loc.wp), ("lat_dzp_f", g_full.dzp, g_loc.dzp)):
-                per_rt = rk_full[1] * 3 * LT.PK_BLOCK
-                view = getattr(self, dname)["s"][rt0 * per_rt:(rt0 + rk_loc[0]) * per_rt]
-                swap_item(dname, "s", view)
-                if "ns" in getattr(self, dname):
-                    swap_item(dname, "ns", view)
-            swap_item("lat_geom", "s", g_loc)
-            swap_item("lat_geom", "ns", g_loc)
         swap_attr("N", lambda n: sh.n_loc)
         self._windowed = True
         try:
@@ -475,8 +486,9 @@ class RPBCACEngine:
     def sync_shards(self):
         """all critic parameters on every rank (checkpoints, get_weights, the end of train()); no-op when not sharded"""
         if self.shard is not None:
-            self._allgather_rows(self.theta["critic"], 0, self.ldp["critic"])
-            self._allgather_rows(self.loss["critic"].unsqueeze(-1), 0, 1)
+            for net in self.shard.sc:
+                self._allgather_rows(self.theta[net], 0, self.ldp[net])
+                self._allgather_rows(self.loss[net].unsqueeze(-1), 0, 1)
 
     # ---- lattice (exact bf16x3) layer-1 path: csrc/lattice_gemm.hip, lattice.py ------------
     def _init_lattice(self):
@@ -763,7 +775,7 @@ class RPBCACEngine:
             self._reset(None if c.randomize_state else np.broadcast_to(np.asarray(self.initial_state), (S, N, 2)))
         # expected returns at the start state (train_agents.py:60-62)
         if self.wide:
-            with self._critic_window():
+            with self._agent_window():
                 self._value_wide(None, self.theta["critic"], "critic", self.w_v, 1, x=(self.xs[self.cur].data_ptr(), 2 * N, 1, 2 * N))
             if self.shard is not None:
                 self._allgather_rows(self.w_v, 0, 1)
@@ -820,7 +832,7 @@ class RPBCACEngine:
                                     self.episode, self.posT[0].data_ptr(), self.xsT[0].data_ptr(), self.retT.data_ptr(),
                                     S, N, n_eps, EP, self.stream)
         if self.wide:      # start states are episode-minor xsT[S][2N][EP]: a feature-major layer-1 input
-            with self._critic_window():
+            with self._agent_window():
                 self._value_wide(None, self.theta["critic"], "critic", self.w_v, n_eps, x=(self.xsT[0].data_ptr(), 2 * N * EP, 0, EP))
             if self.shard is not None:
                 self._allgather_rows(self.w_v, 0, n_eps)
@@ -868,11 +880,11 @@ class RPBCACEngine:
 
     def _local_fit(self, net, xkey, y, B, mask, partials=None):
         """5 full-batch SGD steps on the message copy (agents/resilient_CAC_agents.py:118,136)."""
+        if self._sharded(net):
+            y, mask = self._wv(y), self._wv(mask)
+            with self._agent_window():
+                return self._local_fit(net, xkey, y, B, mask, partials)
         if self.hid[net] != HID:
-            if self.shard is not None and not self._windowed:
-                y, mask = self._wv(y), self._wv(mask)
-                with self._critic_window():
-                    return self._local_fit_wide(net, xkey, y, B, mask)
             return self._local_fit_wide(net, xkey, y, B, mask)
         L, S, N = self.lib, self.S, self.N
         msg = self.msg[net]
@@ -947,14 +959,14 @@ class RPBCACEngine:
         """scratch: private activation buffer of a caller that may run beside the main stream (the adversaries); such a
         caller also stays off the lattice path, whose packed-operand scratch belongs to the main stream.
         gather (agent-sharded instance only): the caller needs the values of ALL agents, not just this rank's."""
+        if self._sharded(net) and scratch is None:
+            th, o, r = self._wv(theta), self._wv(out), self._wv(r_applied)
+            with self._agent_window():
+                self._value(xkey, th, net, o, B, row0, r)
+            if gather:
+                self._allgather_rows(out, 0, B)
+            return
         if self.hid[net] != HID:
-            if self.shard is not None and not self._windowed:
-                th, o, r = self._wv(theta), self._wv(out), self._wv(r_applied)
-                with self._critic_window():
-                    self._value_wide(xkey, th, net, o, B, row0, r)
-                if gather:
-                    self._allgather_rows(out, 0, B)
-                return
             return self._value_wide(xkey, theta, net, out, B, row0, r_applied)
         buf = self.a1t if scratch is None else scratch
         self._layer1(xkey, theta, net, B, row0, buf=buf, lattice=scratch is None)
@@ -965,7 +977,7 @@ class RPBCACEngine:
         """hidden-layer consensus of one network family: msg -> theta (cooperative agents, columns < g_hid)"""
         L, c = self.lib, self.cfg
         if self._windowed:          # agent-sharded instance: all-to-all, K1 on this rank's parameter columns, all-to-all back
-            sc = self.shard.sc
+            sc = self.shard.sc[net]
             assert g_hid == sc.P_hid
             sc.stream = self.stream
             sc.exchange(self.msg[net])
@@ -989,6 +1001,11 @@ class RPBCACEngine:
 
     def _value_cached(self, net, out, row0, nrows, r_applied=None):
         """out[:, :, 0:nrows] = head(a1net[net][:, :, row0:row0+nrows])  [r_applied + gamma * that]"""
+        if self._sharded(net):
+            o, r = self._wv(out), self._wv(r_applied)
+            with self._agent_window():
+                self._value_cached(net, o, row0, nrows, r)
+            return self._allgather_rows(out, 0, nrows)
         self.lib.rcmarl_mid_value(self.a1net[net].data_ptr() + 4 * row0, self.theta[net].data_ptr(), self._p(r_applied),
                                   self.cfg.gamma, out.data_ptr(), self.S, self.N, nrows, self.in_dim[net], HID,
                                   self.ldp[net], self.ldb, self.stream)
@@ -1029,16 +1046,25 @@ class RPBCACEngine:
 
     td_shortcut = os.environ.get("RCMARL_TD_SHORTCUT", "1") not in ("0", "false")
 
-    def _consensus(self, net, xkey, B):
+    def _consensus(self, net, xkey, B, msg_all=None):
         """Phase II for one network family: hidden-layer consensus (K1), then estimate
-        consensus + projection step of the output layer (K2+K3)."""
+        consensus + projection step of the output layer (K2+K3).
+        msg_all: the message matrix whose rows the in_nodes table indexes (GLOBAL agents; default: self.msg[net])."""
+        if self._sharded(net):
+            # the neighbours' output layers (W3, b3 of their messages) come from all ranks; everything else is per agent
+            o = self.P[net] - (self.hid[net] + 1)
+            self._allgather_rows(self.msg[net], o, self.P[net])
+            msg_all = self.msg[net]
+            with self._agent_window():
+                return self._consensus(net, xkey, B, msg_all)
         if self.hid[net] != HID:
-            return self._consensus_wide(net, xkey, B)
+            return self._consensus_wide(net, xkey, B, msg_all)
         L, S, N, c = self.lib, self.S, self.N, self.cfg
+        msg_all = self.msg[net] if msg_all is None else msg_all
         self._k1(net, self.P[net] - (HID * 1 + 1))
         a1 = self.a1net[net]
         self._layer1(xkey, self.theta[net], net, B, buf=a1)
-        L.rcmarl_consensus_head(a1.data_ptr(), self.theta[net].data_ptr(), self.msg[net].data_ptr(),
+        L.rcmarl_consensus_head(a1.data_ptr(), self.theta[net].data_ptr(), msg_all.data_ptr(),
                                 self.nbr.data_ptr(), self.coop.data_ptr(), self.partials.data_ptr(), None, S, N, B,
                                 self.in_dim[net], HID, self.ldp[net], self.ldb, c.d, c.H, self.stream)
         self.a1_cached[net] = self.reuse_activations       # hidden layers of the live net do not move until the next K1
@@ -1061,7 +1087,7 @@ class RPBCACEngine:
         want = self.overlap_fits
         if want is None:
             want = os.environ.get("RCMARL_OVERLAP", "0") not in ("0", "", "false")
-        if not (want and self.dev.type == "cuda" and not hasattr(self, "adv")):
+        if not (want and self.dev.type == "cuda" and not hasattr(self, "adv")) or self.shard is not None:
             return False
         if self.partials_side is None:
             self.partials_side = torch.zeros_like(self.partials)
@@ -1099,14 +1125,17 @@ class RPBCACEngine:
                     self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop, partials=self.partials_side)
                     join = torch.cuda.Event()
                     join.record(self.side_stream)
-                with self._critic_window():
+                with self._agent_window():
                     self.msg["critic"].copy_(self.theta["critic"])
                 self._td_target(B)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
                 main.wait_event(join)
             else:
-                self.msg["tr"].copy_(self.theta["tr"])
-                with self._critic_window():
+                if self.shard is not None and not self.shard.shard_tr:
+                    self.msg["tr"].copy_(self.theta["tr"])
+                with self._agent_window():
+                    if self.shard is None or self.shard.shard_tr:
+                        self.msg["tr"].copy_(self.theta["tr"])
                     self.msg["critic"].copy_(self.theta["critic"])
                 # TD target first (it depends on the live critic only), so the adversaries' message generators --
                 # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
@@ -1145,7 +1174,7 @@ class RPBCACEngine:
         if self._cached_rows_ok("tr", row0, nl):
             self._value_cached("tr", self.ybuf["v_tr"], row0, nl)
         else:
-            self._value("sa", self.theta["tr"], "tr", self.ybuf["v_tr"], nl, row0)
+            self._value("sa", self.theta["tr"], "tr", self.ybuf["v_tr"], nl, row0, gather=True)
         if self._cached_rows_ok("critic", row0, nl):
             self._value_next_cached(self.ybuf["v_next"], row0, nl, None, self.ybuf["delta"])
             self._value_cached("critic", self.ybuf["v_cur"], row0, nl)

@@ -48,6 +48,20 @@ def test_engine_wide_critic_matches_oracle(rng_mode, critic_hid, H, lattice):
     EC.compare(eng, logs, o_logs, o_w)
 
 
+def test_engine_wide_critic_with_faulty_agent_matches_oracle():
+    """A Faulty agent (frozen critic / team-reward net, learning actor: adversarial_CAC_agents.py:5-55) beside a wide critic:
+    its frozen wide message enters every neighbour's aggregation, its actor takes the mini-batch Adam steps from TD errors
+    of its own (wide) critic."""
+    args = EC.make_args(["Cooperative"] * 4 + ["Faulty"], H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9,
+                        seed=43)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(43,), critic_hid=24, lattice=False)
+    assert eng.wide and hasattr(eng, "adv")
+    EC.compare(eng, logs, o_logs, o_w)
+    from rcmarl_amd.engine import EngineConfig
+    with pytest.raises(ValueError, match="Cooperative and Faulty"):
+        EngineConfig(5, ["Cooperative"] * 4 + ["Greedy"], args["in_nodes"], H=1, critic_hid=24)
+
+
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])
 def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
     EC.check_checkpoint_resume(labels, rng_mode, "cpu", emu_lib(), str(tmp_path / "ck.pt"))

@@ -131,6 +131,22 @@ def test_engine_wide_critic(n, critic_hid, H, d, rng_mode, lattice):
     EC.compare(eng, logs, o_logs, o_w)
 
 
+@pytest.mark.parametrize("n,critic_hid,lattice", [(6, 64, False), (16, 512, True)])
+def test_engine_wide_critic_with_faulty_agents(n, critic_hid, lattice):
+    """Faulty agents (frozen critic / team-reward messages, learning actor: adversarial_CAC_agents.py:5-55) beside a wide
+    critic: the frozen wide message enters its neighbours' aggregations, the Faulty actors take their mini-batch Adam steps
+    from TD errors of their own wide critic."""
+    d = 4
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    labels = ["Cooperative"] * n
+    labels[2] = labels[n - 1] = "Faulty"
+    args = EC.make_args(labels, H=1, n_episodes=12, max_ep_len=10, n_ep_fixed=4, n_epochs=2, buffer_size=60, seed=57,
+                        in_nodes=in_nodes, fast_lr=0.005)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, "device", "cuda", None, seeds=(57, 58), critic_hid=critic_hid, lattice=lattice)
+    assert eng.wide and hasattr(eng, "adv") and eng.lat_active == lattice
+    EC.compare(eng, logs, o_logs, o_w)
+
+
 def test_engine_wide_critic_cfg5_shape_paths_agree():
     """BASELINE configs[4] shape at an eighth of the agents (128 agents, 512-unit critic, H=32, circulant d=66, 32x32 grid,
     B = 1000..): one training block with layer 1 of the critic on the bf16x3 lattice kernels + the circulant consensus

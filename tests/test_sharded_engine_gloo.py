@@ -39,28 +39,35 @@ def _run(case, lib, shard):
     args = EC.make_args(["Cooperative"] * n, H=H, n_episodes=5, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=17,
                         in_nodes=nodes)
     W, goals = EC.make_inputs(args, 5, (17,), critic_hid=hid)
-    calls = {"exchange": 0, "rows": []}
+    calls = {"exchange": {}, "rows": []}
 
     def tweak(eng):
         eng.shard_agents()
-        exchange, fit = eng.shard.sc.exchange, eng._local_fit_wide
+        assert eng.shard.shard_tr == (not lattice)           # 2 agents x 20 units do not fill a 128-row tile of the packed operands
+        fit = eng._local_fit_wide
 
-        def counted_exchange(msg_local):
-            calls["exchange"] += 1
-            return exchange(msg_local)
+        def count(net, exchange):
+            def counted_exchange(msg_local):
+                calls["exchange"][net] = calls["exchange"].get(net, 0) + 1
+                assert msg_local.shape[1] == n // 2
+                return exchange(msg_local)
+            return counted_exchange
+        for net, sc in eng.shard.sc.items():
+            sc.exchange = count(net, sc.exchange)
 
         def counted_fit(net, xkey, y, B, mask):
             calls["rows"].append((eng.N, y.shape[1], eng.msg[net].shape[1]))      # inside the window: this rank's agents only
             return fit(net, xkey, y, B, mask)
-        eng.shard.sc.exchange, eng._local_fit_wide = counted_exchange, counted_fit
+        eng._local_fit_wide = counted_fit
     eng, logs = EC.run_engine(args, 5, 5, rng_mode, "cpu", lib, (17,), W, goals, lattice=lattice, critic_hid=hid,
                               tweak=tweak if shard else None)
     assert eng.wide and eng.lat_active == lattice and (eng.shard is not None) == shard and not eng._windowed
     if shard:           # 2 update blocks x 2 epochs: one transpose each way per epoch, fits on half of the agents
-        assert calls["exchange"] == 4 and calls["rows"] == [(n // 2, n // 2, n // 2)] * 4, calls
+        assert calls["exchange"] == ({"critic": 4} if lattice else {"critic": 4, "tr": 4}), calls
+        assert calls["rows"] == [(n // 2, n // 2, n // 2)] * 4, calls
     out = {"theta_" + k: v.numpy().copy() for k, v in eng.theta.items()}
     out.update({"adam_m": eng.adam_m.numpy().copy(), "adam_v": eng.adam_v.numpy().copy(),
-                "loss_critic": eng.loss["critic"].numpy().copy()})
+                "loss_critic": eng.loss["critic"].numpy().copy(), "loss_tr": eng.loss["tr"].numpy().copy()})
     out.update({"rp_" + k: v[:, :eng.B].numpy().copy() for k, v in eng.rp.items()})
     out.update({"log_" + k: np.asarray(v) for k, v in logs.items()})
     return out

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 # (agents, d, H, graph, critic width, lattice path)
 CASES = [(8, 4, 1, "circ", 64, True),          # packed bf16x3 layer 1: 4 agents x 64 units = two 128-row tiles per rank
          (8, 3, 1, "rand", 128, False),        # dense f32-MFMA path, general K1 kernel
-         (16, 6, 2, "circ", 512, True)]        # the cfg-5 critic width
+         (16, 6, 2, "circ", 512, True),        # the cfg-5 critic width
+         (64, 6, 2, "circ", 64, True)]         # 32 agents per rank: the 20-unit team-reward net is sharded too (packed operands)
 
 
 def _setup(case):
@@ -35,7 +36,8 @@ def _setup(case):
 
 def _snapshot(eng, logs):
     out = {"theta_" + k: v.cpu().numpy() for k, v in eng.theta.items()}
-    out.update({"adam_m": eng.adam_m.cpu().numpy(), "loss_critic": eng.loss["critic"].cpu().numpy()})
+    out.update({"adam_m": eng.adam_m.cpu().numpy(), "loss_critic": eng.loss["critic"].cpu().numpy(),
+                "loss_tr": eng.loss["tr"].cpu().numpy()})
     out.update({"rp_" + k: v[:, :eng.B].cpu().numpy() for k, v in eng.rp.items()})
     out.update({"log_" + k: np.asarray(v) for k, v in logs.items()})
     return out
@@ -58,6 +60,9 @@ def test_agent_sharded_wide_critic_two_ranks_on_one_gpu(case):
             eng, logs = EC.run_engine(args, 6, 6, "device", "cuda", lib, (23,), W, goals, lattice=lattice, critic_hid=hid,
                                       tweak=lambda e: e.shard_agents(comm=comms[r]))
             assert eng.shard is not None and eng.shard.n_loc == case[0] // world and not eng._windowed
+            # the team-reward net joins whenever its packed operands split on 128-row tiles (or are not used)
+            assert eng.shard.shard_tr == ((not lattice) or (eng.shard.n_loc * 20) % 128 == 0)
+            assert sorted(eng.shard.sc) == (["critic", "tr"] if eng.shard.shard_tr else ["critic"])
             results[r] = _snapshot(eng, logs)
         except BaseException as e:            # noqa: BLE001 -- reported below; the peer's barrier breaks by timeout/abort
             errors.append((r, repr(e)))
