@@ -71,8 +71,8 @@ WORKLOADS = {
     "cfg5_shard": dict(N=1024, nrow=32, ncol=32, H=32, d=66, S=1, graph="circulant", fast_lr=0.0005, critic_hid=512,
                        shard_instance=True,
                        desc="BASELINE configs[4] as ONE instance over all ranks: 1024 agents, 512-unit critic sharded by agent "
-                            "(fits, estimate consensus) and by parameter column (hidden-layer consensus); 20-unit nets, "
-                            "environment and replay replicated"),
+                            "(fits, estimate consensus) and by parameter column (hidden-layer consensus), the team-reward net "
+                            "alike; actors, environment and replay replicated"),
 }
 
 
