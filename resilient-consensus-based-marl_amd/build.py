@@ -38,8 +38,19 @@ def _stamp():
     return h.hexdigest()
 
 
+def generate_sources(verbose=True):
+    """The selection networks of the resilient aggregation are generated, not tracked (csrc/gen_selnet.py)."""
+    sys.path.insert(0, CSRC)
+    try:
+        import gen_selnet
+        return gen_selnet.ensure_generated(CSRC, verbose)
+    finally:
+        sys.path.remove(CSRC)
+
+
 def build_hip(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
+    generate_sources(verbose)
     stamp_file = os.path.join(LIBDIR, ".stamp")
     stamp = _stamp()
     if not force and os.path.exists(lib_path()) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:

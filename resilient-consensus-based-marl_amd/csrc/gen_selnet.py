@@ -11,8 +11,14 @@ principle (exhaustive up to D=16, random beyond) and emits one
 `SelNet<D,H>::run` specialisation of fminf/fmaxf in SSA form, so every value
 lives in a VGPR.
 
-    python gen_selnet.py > selnet_generated.inc
+    python gen_selnet.py > selnet_generated.inc          (--mid: selmid_generated.inc, the circulant kernel's shared networks)
+
+Both files are BUILD PRODUCTS (git-ignored): rcmarl_amd.build and the hipemu test build call ensure_generated(), which
+writes them next to this script when they are missing or older than it (about a minute, deterministic).
 """
+import contextlib
+import io
+import os
 import itertools
 import random
 import sys
@@ -184,6 +190,29 @@ def main():
     sys.stderr.write("generated %d networks; ops: %s\n" % (
         len(table), {f"{d},{h}": n_ops(prune(merge_exchange(d), d, sorted({h, d - h - 1}))) for d, h in table
                      if (d, h) in [(4, 1), (10, 4), (18, 8), (18, 1), (34, 16), (66, 32)]}))
+
+
+def ensure_generated(csrc_dir=None, verbose=True):
+    """Write selnet_generated.inc / selmid_generated.inc into csrc_dir unless they exist and are newer than this script."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc_dir = here if csrc_dir is None else csrc_dir
+    me = os.path.getmtime(os.path.abspath(__file__))
+    made = []
+    for name, fn in (("selnet_generated.inc", main), ("selmid_generated.inc", main_mid)):
+        path = os.path.join(csrc_dir, name)
+        if os.path.exists(path) and os.path.getmtime(path) >= me:
+            continue
+        if verbose:
+            sys.stderr.write("generating %s (selection networks, verified by the 0-1 principle) ...\n" % name)
+        out, err = io.StringIO(), io.StringIO()
+        with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+            fn()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as f:
+            f.write(out.getvalue())
+        os.replace(tmp, path)                  # atomic: concurrent builds (pytest workers) never see half a file
+        made.append(name)
+    return made
 
 
 if __name__ == "__main__":

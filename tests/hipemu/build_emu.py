@@ -16,6 +16,13 @@ FLAGS = ["-O1", "-g0", "-std=c++17", "-fPIC", "-DRCMARL_EMU", "-x", "c++", "-Wno
 
 
 def build_emu(force=False):
+    import sys
+    sys.path.insert(0, CSRC)
+    try:
+        import gen_selnet
+        gen_selnet.ensure_generated(CSRC)          # generated sources (selection networks) are not tracked
+    finally:
+        sys.path.remove(CSRC)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     h = hashlib.sha256()
     for p in srcs + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + \
