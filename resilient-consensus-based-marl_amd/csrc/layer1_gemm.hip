@@ -321,11 +321,16 @@ RCMARL_EXPORT int rcmarl_layer1_forward(const float* x, long x_seed_stride, cons
   if (bad_common(x, theta, a1t, S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
   const int var = gemm_variant();
   if (hid == 20 && in_dim <= 32 && small_enabled()) {
-    const dim3 grid(rc_ceil_div(B, small::SROWS), N, S), block(256);
+    // chunks per workgroup: all of them once S*N workgroups fill the chip several times over, else one (short rows x few nets)
+    const int nchunk = rc_ceil_div(B, small::SROWS);
+    static const int cpw_env = getenv("RCMARL_SMALL_FWD_CPW") ? atoi(getenv("RCMARL_SMALL_FWD_CPW")) : 0;
+    int cpw = cpw_env > 0 ? cpw_env : ((long)S * N >= 2048 ? nchunk : ((long)S * N >= 512 ? (nchunk + 3) / 4 : 1));
+    if (cpw > nchunk) cpw = nchunk;
+    const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(256);
     if (in_dim <= 16) {
-      RCMARL_LAUNCH((small::k_fwd<16>), grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
+      RCMARL_LAUNCH((small::k_fwd<16>), grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb, cpw);
     } else {
-      RCMARL_LAUNCH((small::k_fwd<32>), grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
+      RCMARL_LAUNCH((small::k_fwd<32>), grid, block, 0, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb, cpw);
     }
     return rcmarl_check_launch();
   }
