@@ -303,6 +303,98 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
 #endif
 }
 
+// The backward GEMM's k-loop with its THREE-PIECE operand (dz, the B side) loaded straight from global memory into
+// registers: the packed image already lies in fragment order (the LDS stage was a verbatim copy of it), so a lane's
+// fragment of (row tile, k-tile, piece, k16 step) is one 16-byte load.  LDS then carries only the one-piece operand:
+// 16 KiB of LDS-DMA + 32 KiB of fragment reads per workgroup and k-tile instead of 40 + 80 (the
+// long k-loop of the backward is limited by operand delivery into the CU, not by the matrix core).  The two wavefronts
+// that share a dz row block both load it (the second hits L1/L2).  Fragments of k-tile t+1 are requested into the
+// registers a k16 step has just freed, i.e. half a k-tile to a full k-tile ahead of their use; they are PLAIN loads
+// (hipcc counts them itself; the asm LDS-DMA it cannot see only makes its vmcnt waits conservative).
+template <int MT, int NT, int WM, int WN>
+__device__ __forceinline__ void lat_mainloop_bdirect(const LatOperands& op, int n_ktiles, unsigned char* lds,
+                                                     rc_f32x16 (&acc)[MT][NT]) {
+  constexpr int PB = 3, NWV = WM * WN, BM = 32 * MT * WM, ART = BM / 128, A_KB = ART * 8, GLDS = A_KB / NWV;
+  constexpr int STAGE_BYTES = A_KB * 1024;
+  static_assert(BM % 128 == 0 && A_KB % NWV == 0 && 32 * NT * WN == 128, "tile shape of the B-direct k-loop");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+  const unsigned char* gsrc[GLDS];
+#pragma unroll
+  for (int i = 0; i < GLDS; ++i) {
+    const int q = wave + NWV * i, seg = q / 8, off = q - seg * 8;
+    gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * RC_PK_BLOCK + off * 1024;
+  }
+  const unsigned lane16 = lane * 16;
+  const rc_lds_t lds0 = rc_lds_addr(lds) + wave * 1024;
+  auto stage = [&](int buf, int t) {
+    const rc_lds_t dst = lds0 + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < GLDS; ++i) RC_GLDS16S(gsrc[i] + (long)t * RC_PK_BLOCK, lane16, dst + i * (NWV * 1024));
+  };
+  const int sw = (l31 >> 2) & 3;
+  const int co0 = ((0 + half) ^ sw) << 4, co1 = ((2 + half) ^ sw) << 4;
+  int offA[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = wm * 32 * MT + 32 * mt + l31;
+    offA[mt] = (row >> 7) * RC_PK_BLOCK + (row & 127) * 64;
+  }
+  // this lane's rows of the dz tile (one 128-row tile wide); k-tile t, piece p, k16 step ks at  t*3*8 KiB + p*8 KiB + co_ks
+  const unsigned char* gB = op.b + (long)op.brt0 * op.b_kt * (PB * RC_PK_BLOCK);
+  unsigned offB[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) offB[nt] = (unsigned)(wn * 32 * NT + 32 * nt + l31) * 64;
+  uint4 b0[NT][PB], b1[NT][PB];
+  auto loadB = [&](uint4 (&b)[NT][PB], int t, int co) {
+    const unsigned char* base = gB + (long)t * (PB * RC_PK_BLOCK) + co;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int p = 0; p < PB; ++p) b[nt][p] = ld_u4(base + p * RC_PK_BLOCK + offB[nt]);
+  };
+  auto kstep = [&](const unsigned char* st, int co, const uint4 (&b)[NT][PB]) {
+    uint4 af[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = ld_u4(st + offA[mt] + co);
+#pragma unroll
+    for (int pb = PB - 1; pb >= 0; --pb)            // smallest pieces first, as lat_mainloop: the same fp32 sums
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = rc_mfma_bf16(af[mt], b[nt][pb], acc[mt][nt]);
+  };
+  stage(0, 0);
+  loadB(b0, 0, co0);
+  loadB(b1, 0, co1);
+  RC_SCHED_FENCE();
+  for (int t = 0; t < n_ktiles; ++t) {
+    const int cur = t & 1;
+    // the A bursts of tile t are older than the (at most) 2 x NT x PB fragment loads issued after them
+    RC_WAIT_VMEM_N(2 * NT * PB);
+    __syncthreads();                                  // everybody's bursts landed; all reads of the other stage are done
+    const bool more = t + 1 < n_ktiles;
+    if (more) stage(cur ^ 1, t + 1);
+    const unsigned char* st = lds + cur * STAGE_BYTES;
+    kstep(st, co0, b0);
+    RC_SCHED_FENCE();
+    if (more) loadB(b0, t + 1, co0);
+    RC_SCHED_FENCE();
+    kstep(st, co1, b1);
+    RC_SCHED_FENCE();
+    if (more) loadB(b1, t + 1, co1);
+    RC_SCHED_FENCE();
+  }
+}
+
 // The same k-loop on a ring of FOUR half-stages (k16 each, 20 KiB; same 80 KiB of LDS): the loads of half-stage
 // h+3 are requested while half-stage h is computed, i.e. 1.5 k-tiles of lead instead of 1, and the wait before a
 // barrier is a COUNTED vmcnt that leaves the two youngest half-stages in flight.  A half-stage takes the 32-byte
@@ -576,6 +668,7 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   }
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
+  else if constexpr (NSTAGE == 5) lat_mainloop_bdirect<MT, NT, WM, WN>(op, (B + 31) >> 5, lds, acc);
   else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG, WM, WN>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
@@ -701,6 +794,8 @@ int lat_stages() {
   }
   return v;
 }
+// backward only: RCMARL_LAT_BDIRECT=1 loads the three-piece dz fragments global -> registers (lat_mainloop_bdirect)
+bool lat_bdirect() { return lat_env_int("RCMARL_LAT_BDIRECT", 0) != 0; }      // (read per call: tests switch it)
 
 }  // namespace
 
@@ -825,7 +920,14 @@ static int backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const v
 #undef RC_DBG_CASE
     return rcmarl_check_launch();
   }
-  if (ns == 2 && lat_w8(false)) {
+  if (lat_bdirect()) {
+    const size_t smem5 = 2 * 16 * 1024;                 // two stages of the one-piece operand only
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<5>, smem5);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<5>), dim3((unsigned)(S * mtiles * ntiles)), block, smem5, stream, (const unsigned char*)ktp,
+                  ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles,
+                  ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
+  } else if (ns == 2 && lat_w8(false)) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<2, 0, true>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<2, 0, true>), grid, dim3(512), smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
