@@ -171,13 +171,13 @@ def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
     KC.check_lattice_sgd_fit(bk, 1, 7, 130, 2, 5, 5, steps=2, masked_agent=2)
 
 
-@pytest.mark.parametrize("S,N,B,width", [(2, 20, 777, 3), (1, 40, 300, 2)])
+@pytest.mark.parametrize("S,N,B,width", [(1, 14, 300, 2)])
 def test_lattice_backward_dz_fragments_from_global_bit_identical(bk, S, N, B, width, monkeypatch):
     """RCMARL_LAT_BDIRECT=1: the backward GEMM loads its three-piece operand's fragments global -> registers instead of
     staging them through LDS (lat_mainloop_bdirect).  Same products in the same order: the same oracle fit, and weights
     and next-step operand pieces equal to the LDS-staged kernel's bit for bit."""
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=3, masked_agent=4)
+    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=2, masked_agent=4)
     monkeypatch.setenv("RCMARL_LAT_BDIRECT", "1")
-    msg, wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=3, masked_agent=4)
+    msg, wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=2, masked_agent=4)
     np.testing.assert_array_equal(msg, ref_msg)
     np.testing.assert_array_equal(wp, ref_wp)
