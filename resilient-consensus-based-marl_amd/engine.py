@@ -484,7 +484,9 @@ class RPBCACEngine:
                 full[0, r * sh.n_loc:(r + 1) * sh.n_loc, c0:c1] = blk
 
     def sync_shards(self):
-        """all critic parameters on every rank (checkpoints, get_weights, the end of train()); no-op when not sharded"""
+        """Every rank gets the other ranks' rows of the sharded networks (checkpoints, get_weights, the end of train()).
+        A COLLECTIVE when the instance is sharded: every rank must call it (so also state_dict / save_checkpoint, which
+        call it); no-op otherwise."""
         if self.shard is not None:
             for net in self.shard.sc:
                 self._allgather_rows(self.theta[net], 0, self.ldp[net])

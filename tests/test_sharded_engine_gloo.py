@@ -1,7 +1,7 @@
 """C2 end to end (BASELINE configs[4] as ONE instance over several GPUs): RPBCACEngine.shard_agents
 shards the wide critic of a single-seed instance by AGENTS (TD targets, local fits, estimate consensus, values) and by
 parameter COLUMNS (hidden-layer consensus), with the exchanges of parallel.ShardedConsensus in between.  world_size 2
-under gloo, kernels from the hipemu build: after two update blocks every parameter of every network, the Adam slots,
+under gloo, kernels from the hipemu build: after two update blocks (and a trailing episode) every parameter of every network, the Adam slots,
 the replay rows and the three logged curves equal the UNSHARDED engine's bit for bit, on both ranks.  CPU-only."""
 import os
 import socket
@@ -36,7 +36,7 @@ def _run(case, lib, shard):
         nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
     else:
         nodes = [[i] + [int(x) for x in rng.permutation([j for j in range(n) if j != i])[:d - 1]] for i in range(n)]
-    args = EC.make_args(["Cooperative"] * n, H=H, n_episodes=5, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=17,
+    args = EC.make_args(["Cooperative"] * n, H=H, n_episodes=5, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=17,
                         in_nodes=nodes)
     W, goals = EC.make_inputs(args, 5, (17,), critic_hid=hid)
     calls = {"exchange": {}, "rows": []}
@@ -62,9 +62,9 @@ def _run(case, lib, shard):
     eng, logs = EC.run_engine(args, 5, 5, rng_mode, "cpu", lib, (17,), W, goals, lattice=lattice, critic_hid=hid,
                               tweak=tweak if shard else None)
     assert eng.wide and eng.lat_active == lattice and (eng.shard is not None) == shard and not eng._windowed
-    if shard:           # 2 update blocks x 2 epochs: one transpose each way per epoch, fits on half of the agents
-        assert calls["exchange"] == ({"critic": 4} if lattice else {"critic": 4, "tr": 4}), calls
-        assert calls["rows"] == [(n // 2, n // 2, n // 2)] * 4, calls
+    if shard:           # 2 update blocks x 1 epoch: one transpose each way per epoch, fits on half of the agents
+        assert calls["exchange"] == ({"critic": 2} if lattice else {"critic": 2, "tr": 2}), calls
+        assert calls["rows"] == [(n // 2, n // 2, n // 2)] * 2, calls
     out = {"theta_" + k: v.numpy().copy() for k, v in eng.theta.items()}
     out.update({"adam_m": eng.adam_m.numpy().copy(), "adam_v": eng.adam_v.numpy().copy(),
                 "loss_critic": eng.loss["critic"].numpy().copy(), "loss_tr": eng.loss["tr"].numpy().copy()})
