@@ -1113,7 +1113,9 @@ class RPBCACEngine:
                              self.ldb, self.stream)
         L.rcmarl_gather_agent_major(rptr, rstride, self.rcoop.data_ptr(), self.fit_mode.data_ptr(),
                                     self.ybuf["r_fit"].data_ptr(), S, N, B, self.ldb, self.stream)
-        for _ in range(c.n_epochs):
+        # opt-in (RCMARL_ADV_CHAIN=1, measured slower): adversaries that fit run all their epochs ahead on a side stream
+        chain = self.adv.chain_async(B, c.n_epochs) if hasattr(self, "adv") else None
+        for epoch in range(c.n_epochs):
             # I) local fits of TR and critic on a copy (= the transmitted message); live nets untouched
             if self._overlap_ok():
                 # the two local fits are independent until the consensus step: TR on a side stream, critic on the
@@ -1143,10 +1145,12 @@ class RPBCACEngine:
                 # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
                 # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
                 self._td_target(B)
-                join = self._adversary_messages_async(B)
+                join = self._adversary_messages_async(B) if chain is None else None
                 self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
                 self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
-                if join is not None:
+                if chain is not None:
+                    self.adv.consume(chain[epoch])
+                elif join is not None:
                     torch.cuda.current_stream(self.dev).wait_event(join)
             t0 = self._timed("phase1", t0)
             # II) resilient consensus (cooperative agents)
