@@ -472,9 +472,10 @@ ROOFLINE_KIND = {
                                 "small d (d=4: ~54% of 8 TB/s); at d=18 the 128-op min/max selection network makes it "
                                 "VALU-issue-bound (~83% of the v_min/v_max issue rate, DESIGN.md section 3)"),
     "rcmarl_consensus_params_circulant": ("hbm", "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d); circulant "
-                                          "graph: one selection network per G consecutive agents (96/4 + 13 min/max ops per "
-                                          "agent at (18,8) instead of 128) + 18 clamps + 18 adds + the IEEE division: still "
-                                          "VALU-issue-bound at d=18, HBM-bound at d=4"),
+                                          "graph: one selection network per G consecutive agents (96/4 + 16 min/max ops per "
+                                          "agent at (18,8) instead of 128) + 18 clamps + 9 packed adds + a 3-instruction "
+                                          "division: VALU-bound at d=18 (343 instructions per 4 agents, VALU busy 77 % of the "
+                                          "kernel: profiles/r02h_sq_counters_k1_circ_d18.json), toward HBM at d=4"),
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
                                "dz1 pieces written = 200 B; k_mid_fit_v5: layer 2 and the row reductions on the f32 matrix core "
                                "(72 MFMAs = 4.6k cycles + 630 VALU + 157 LDS instructions per 64 rows); bound by instruction "
@@ -524,9 +525,14 @@ def rooflines(tlib, ksum, workload=None):
         src = pmc.get("__source__") if traffic is not None else None
         if kind == "hbm":
             ach = byts / (tot_ms * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
-                    "algorithmic_bytes_per_launch": byts / n, "note": note}
+            out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
+                   "algorithmic_bytes_per_launch": byts / n, "note": note}
+            if name == "rcmarl_mid_fit_lattice":
+                # the 200 B per row count this build's own dz1 representation (3 bf16 pieces = 120 B); with a plain fp32
+                # dz1 (80 B) the same launch moves 160 B per row
+                out["frac_fp32_io"] = out["frac"] * 160.0 / 200.0
+            return out
         ach = flops / (tot_ms * 1e-3) / 1e12
         if kind == "mfma_bf16x3":
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
