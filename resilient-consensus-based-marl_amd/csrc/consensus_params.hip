@@ -582,6 +582,10 @@ RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* the
   nwg = 3;
 #endif
   if (nwg > tot) nwg = tot;
+  {   // the kernel keeps one "agent exists and is cooperative" bit per (pass, agent of the group) in a 64-bit mask per lane
+    const int per_pass = (wg_threads / 64) * (64 / TC), n_groups = rc_ceil_div(N, G);
+    if (rc_ceil_div(n_groups, per_pass) * G > 64) return RCMARL_ERR_UNSUPPORTED;      // (N > ~2000: beyond the LDS tile anyway)
+  }
   int rc = RCMARL_ERR_UNSUPPORTED;
 #define RC_CIRC_LAUNCH(DD, HH, GG, TT, THR)                                                                          \
   do {                                                                                                               \
