@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 CASES = [(8, 4, 1, "circ", 64, True),          # packed bf16x3 layer 1: 4 agents x 64 units = two 128-row tiles per rank
          (8, 3, 1, "rand", 128, False),        # dense f32-MFMA path, general K1 kernel
          (16, 6, 2, "circ", 512, True),        # the cfg-5 critic width
-         (64, 6, 2, "circ", 64, True)]         # 32 agents per rank: the 20-unit team-reward net is sharded too (packed operands)
+         (64, 6, 2, "circ", 64, True),         # 32 agents per rank: the 20-unit team-reward net is sharded too (packed operands)
+         (128, 66, 32, "circ", 512, True)]     # BASELINE configs[4] at an eighth of the agents: d = 66, H = 32, 512-unit critic
 
 
 def _setup(case):
