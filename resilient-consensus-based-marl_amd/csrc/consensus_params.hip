@@ -206,9 +206,7 @@ __global__ __launch_bounds__(1024) void k_consensus_params_v2(const float* __res
     // by itself when the LDS-DMA was issued in the previous trip of the loop (it did only for the first tile):
     // without the explicit wait short tiles (small N, small d) were aggregated from stale LDS -- wrong and
     // run-to-run different results at e.g. N=5, d=4, S>=256.
-#ifndef RCMARL_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    RC_WAIT_VMEM();
     __syncthreads();                                     // everybody's part of tile t landed; buffer cur^1 is free
     const int tn = t + gridDim.x;
     if (tn < total_tiles) stage(tn, lds + (cur ^ 1) * (tile_floats + 256));
@@ -307,9 +305,7 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
     }
   }
   for (; t < total_tiles; t += gridDim.x) {
-#ifndef RCMARL_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA of tile t (see k_consensus_params_v2)
-#endif
+    RC_WAIT_VMEM();                                      // the LDS-DMA of tile t (see k_consensus_params_v2)
     __syncthreads();
     const int tn = t + gridDim.x;
     if (tn < total_tiles) stage(tn, lds + (cur ^ 1) * buf_floats);
@@ -459,11 +455,7 @@ __global__ __launch_bounds__(256) void k_consensus_params_generic(const float* _
 
 template <class K>
 bool k1_want_lds(K kernel, size_t smem) {
-#ifndef RCMARL_EMU
-  if (smem > 64 * 1024)
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
-#endif
-  return true;
+  return rc_want_lds(kernel, smem, 64 * 1024);
 }
 
 // v2 is instantiated only where the d values + the neighbour table fit 128 VGPRs (16 waves per CU)
@@ -502,9 +494,7 @@ RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const 
   if (wg_per_cu > 4) wg_per_cu = 4;
   if (wg_per_cu < 1) wg_per_cu = 1;
   int nwg = 256 * wg_per_cu;
-#ifdef RCMARL_EMU
-  nwg = 3;                                 // make the CPU emulation exercise the strided tile walk
-#endif
+  nwg = rc_persistent_grid(nwg);
   if (nwg > total_tiles) nwg = total_tiles;
   const dim3 grid_p(nwg), grid(tiles_per_seed, S), block(256);
   bool done = false;
@@ -518,9 +508,7 @@ RCMARL_EXPORT int rcmarl_consensus_params(const float* msg, float* theta, const 
     if (wg_cu > 4) wg_cu = 4;
     const int threads = wg_cu >= 4 ? 256 : (wg_cu >= 2 ? 512 : 1024);
     int nwg2 = 256 * wg_cu;
-#ifdef RCMARL_EMU
-    nwg2 = 3;
-#endif
+    nwg2 = rc_persistent_grid(nwg2);
     if (nwg2 > tot) nwg2 = tot;
     if (N <= 64 * (threads / 64)) {
 #define RC_CASE2(DD, HH)                                                                                             \
@@ -578,9 +566,7 @@ RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* the
   static const int wgcu_env = getenv("RCMARL_K1_WGCU") ? atoi(getenv("RCMARL_K1_WGCU")) : 0;     // (tuning aid)
   if (wgcu_env > 0) wg_cu = wgcu_env;
   int nwg = 256 * wg_cu;
-#ifdef RCMARL_EMU
-  nwg = 3;
-#endif
+  nwg = rc_persistent_grid(nwg);
   if (nwg > tot) nwg = tot;
   {   // the kernel keeps one "agent exists and is cooperative" bit per (pass, agent of the group) in a 64-bit mask per lane
     const int per_pass = (wg_threads / 64) * (64 / TC), n_groups = rc_ceil_div(N, G);

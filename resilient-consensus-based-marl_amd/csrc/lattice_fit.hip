@@ -452,13 +452,8 @@ __global__ __launch_bounds__(256) void k_w1_split_fit(const float* __restrict__ 
 }
 
 bool fit_want_lds() {
-#ifndef RCMARL_EMU
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lat_fit), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             LDS_TOTAL) == hipSuccess;
+  static const bool ok = rc_want_lds(k_lat_fit, (size_t)LDS_TOTAL);
   return ok;
-#else
-  return true;
-#endif
 }
 
 }  // namespace

@@ -517,10 +517,7 @@ __device__ __forceinline__ void lat_decode(int g, int per_seed, int S, int& seed
 // whose bit `bit` of (id/8) is set sleep `n` x ~4 us once, so the pair drifts half a tile apart and one's
 // epilogue overlaps the other's k-loop.  Pure scheduling: no effect on results.
 __device__ __forceinline__ void lat_stagger(int bit, int n) {
-#ifndef RCMARL_EMU
-  if (bit >= 0 && blockIdx.x < 512u && (((blockIdx.x >> 3) >> bit) & 1u))
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
+  if (bit >= 0 && blockIdx.x < 512u && (((blockIdx.x >> 3) >> bit) & 1u)) rc_sleep(n);
 }
 
 // Static priority for every other workgroup (bit `bit` of id/8): the two workgroups that share a SIMD otherwise
@@ -528,9 +525,7 @@ __device__ __forceinline__ void lat_stagger(int bit, int n) {
 // phase with the matrix pipe idle.  With one of them at s_setprio 1 its burst runs first and the other's fills the
 // gap: the pair ping-pongs instead of marching in step.  Pure scheduling hint: no effect on results.
 __device__ __forceinline__ void lat_prio(int bit) {
-#ifndef RCMARL_EMU
-  if (bit >= 0 && (((blockIdx.x >> 3) >> bit) & 1u)) __builtin_amdgcn_s_setprio(1);
-#endif
+  if (bit >= 0 && (((blockIdx.x >> 3) >> bit) & 1u)) rc_setprio1();
 }
 
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
@@ -749,11 +744,7 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
 
 template <class K>
 bool lat_want_lds(K kernel, size_t smem) {
-#ifndef RCMARL_EMU
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return false;
-#endif
-  return true;
+  return rc_want_lds(kernel, smem);
 }
 
 int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -767,12 +758,8 @@ int lat_stagger_bit() {
 // (k x 256 CUs x workgroups per CU) and let each walk several tiles
 int lat_grid(int tiles, int ns) {
   static const int k = lat_env_int("RCMARL_LAT_PERSIST", 0);
-#ifdef RCMARL_EMU
-  return k > 0 ? (tiles < 3 ? tiles : 3) : tiles;
-#else
-  const int resident = 256 * (ns == 3 ? 1 : 2) * k;
+  const int resident = rc_persistent_grid(256 * (ns == 3 ? 1 : 2) * k);
   return (k > 0 && resident < tiles) ? resident : tiles;
-#endif
 }
 int lat_stagger_n() { static int v = lat_env_int("RCMARL_LAT_STAGGER_N", 3); return v; }
 // Eight wavefronts of 64 x 64 per workgroup instead of four of 64 x 128 / 128 x 64 (four instead of two wavefronts per

@@ -301,11 +301,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 template <class K>
 bool want_lds(K kernel, size_t smem) {
-#ifndef RCMARL_EMU
-  if (smem > 64 * 1024)
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
-#endif
-  return true;
+  return rc_want_lds(kernel, smem, 64 * 1024);
 }
 
 bool bad_common(const void* a, const void* b, const void* c, int S, int N, int B, int in_dim, int hid, int ldp,

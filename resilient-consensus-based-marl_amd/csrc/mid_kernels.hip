@@ -582,12 +582,9 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
   }
   const float* yrow = y + ((long)s * N + i) * ldb;
   __syncthreads();
-#ifndef RCMARL_EMU
   // de-phasing aid (pure scheduling): the workgroups resident on a CU start together and run identical instruction
   // streams; every second one of the first round waits `stagger` x ~3.4 us so that matrix-core and VALU phases interleave
-  if (stagger > 0 && blockIdx.y < 64u && (blockIdx.y & 1u))
-    for (int q = 0; q < stagger; ++q) __builtin_amdgcn_s_sleep(127);
-#endif
+  if (stagger > 0 && blockIdx.y < 64u && (blockIdx.y & 1u)) rc_sleep(stagger);
   // (requesting the activations of chunk c+1 while chunk c is processed, as v3 does, costs 20 registers = one wavefront
   // per SIMD of occupancy here and measured slower: 919 vs 857 us)
   for (int chunk = c_begin; chunk < c_end; ++chunk) {

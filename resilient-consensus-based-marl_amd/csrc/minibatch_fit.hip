@@ -513,11 +513,7 @@ size_t mb_smem_bytes(int in_dim, int hid, int out) {
 template <class K>
 int mb_launch(K kernel, const MbArgs& a, int S, size_t smem, void* stream) {
   if (smem > 160 * 1024) return RCMARL_ERR_UNSUPPORTED;
-#ifndef RCMARL_EMU
-  if (smem > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return RCMARL_ERR_LAUNCH;
-#endif
+  if (!rc_want_lds(kernel, smem, 48 * 1024)) return RCMARL_ERR_LAUNCH;
   const dim3 grid(a.n_adv, S), block(256);
   RCMARL_LAUNCH(kernel, grid, block, smem, stream, a);
   return rcmarl_check_launch();
@@ -542,14 +538,8 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
   if (wave_ok && in_dim <= 20) {
     const int n_nets = n_adv * S;
     const size_t smem = (size_t)4 * WP_FLOATS * sizeof(float);
-#ifndef RCMARL_EMU
-    static const bool attr_ok =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_minibatch_wave<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) == hipSuccess &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_minibatch_wave<20>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) == hipSuccess;
+    static const bool attr_ok = rc_want_lds(k_minibatch_wave<16>, smem) && rc_want_lds(k_minibatch_wave<20>, smem);
     if (!attr_ok) return RCMARL_ERR_LAUNCH;
-#endif
     if (in_dim <= 16) {
       RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
     } else {

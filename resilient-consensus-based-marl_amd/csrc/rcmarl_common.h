@@ -198,6 +198,40 @@ __device__ __forceinline__ void rc_half_sum3_lane31(float& a, float& b, float& c
 #endif
 }
 
+// ---- the few places where the host emulation of the test suite (RCMARL_EMU, tests/hipemu) and the gfx950 build differ in
+// kernel-independent plumbing live HERE, so that kernel sources carry no build switches for them -------------------------
+#ifdef RCMARL_EMU
+#define RC_WAIT_VMEM() ((void)0)                      // (the emulated LDS-DMA is a synchronous copy)
+#define RC_WAIT_VMEM_N(n) ((void)0)
+__device__ __forceinline__ void rc_sleep(int) {}
+__device__ __forceinline__ void rc_setprio1() {}
+#else
+// outstanding vector-memory operations of this wavefront (incl. LDS-DMA issued through inline asm, which hipcc does not see)
+#define RC_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define RC_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+__device__ __forceinline__ void rc_sleep(int n) {     // n x ~3.4 us (scheduling aid only)
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+__device__ __forceinline__ void rc_setprio1() { __builtin_amdgcn_s_setprio(1); }
+#endif
+
+// host side: opt a kernel into more dynamic LDS than the default limit; number of workgroups of a persistent launch
+template <class K>
+static inline bool rc_want_lds(K kernel, size_t smem, size_t above = 0) {
+#ifndef RCMARL_EMU
+  if (smem > above)
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+#endif
+  return true;
+}
+static inline int rc_persistent_grid(int resident) {
+#ifdef RCMARL_EMU
+  return 3;                                           // makes the CPU emulation exercise the strided tile walk
+#else
+  return resident;
+#endif
+}
+
 // True if `v` holds for any active lane of the wavefront (one v_cmp + one scalar test).  Used to put a rare slow path
 // on a wavefront-uniform branch; both sides of such a branch must give the same result for a lane whose own `v` is false
 // (the host emulation decides per lane).

@@ -93,8 +93,6 @@ __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c)
 #define RC_GLDS16S(sbase, voff, lds_base) __hipemu_glds16((sbase) + (voff), (lds_base))
 typedef unsigned char* rc_lds_t;                               // an LDS location handed to RC_GLDS16S
 __device__ __forceinline__ rc_lds_t rc_lds_addr(unsigned char* p) { return p; }
-#define RC_WAIT_VMEM() ((void)0)
-#define RC_WAIT_VMEM_N(n) ((void)0)
 #else
 typedef __bf16 rc_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c) {
@@ -124,6 +122,4 @@ __device__ __forceinline__ void rc_glds16s(const unsigned char* sbase, unsigned 
                : "memory", "m0");
 }
 #define RC_GLDS16S(sbase, voff, lds_base) rc_glds16s((sbase), (voff), (lds_base))
-#define RC_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define RC_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif
