@@ -324,8 +324,9 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
 #pragma unroll
       for (int q = 0; q < M; ++q) cm[q] = v[G - 1 + q];
       SelMid<M, H - G + 1, G + 1>::run(cm, mid);
-      // bounds of the G agents, then clip + mean for two agents at a time: the D dependent additions of a mean are the
-      // reference's summation order, and two agents' chains ride in one v_pk_add_f32
+      // bounds of the G agents, then clip + mean for two agents at a time: the D additions of a mean are taken in
+      // neighbour order, as aggregate_regs does (the general kernels' results, bit for bit; the reference's tf.reduce_mean
+      // fixes no order and parity with it is to fp32 tolerance), and two agents' chains ride in one v_pk_add_f32
       float lower[G], upper[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {

@@ -155,6 +155,59 @@ def check_consensus_params_circulant(bk, N, d, H, P, P_hid, S=2):
     np.testing.assert_array_equal(theta[:, :, P_hid:], theta0[:, :, P_hid:])
 
 
+def check_consensus_params_exact(bk, N, d, H, P_hid, S, seed, graph="circ"):
+    """K1 against the reference's arithmetic BIT FOR BIT on awkward data: clip bounds = the two order statistics
+    (agents/resilient_CAC_agents.py:48-53), mean = the d clipped values added IN NEIGHBOUR ORDER in fp32 and divided by d
+    (np.mean over axis 0 of a [d, P] fp32 array is that sequential sum).  Columns of zeros, of subnormal-range values (the
+    guarded slow path of the 3-instruction division), of 1e30-scale values, exact ties and an adversarial row; random
+    cooperation mask; N not a multiple of the kernel's agent group.  Circulant graphs run both kernels (equal bits)."""
+    rng = np.random.default_rng(seed)
+    ldp = pad64(P_hid + 21)
+    nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
+    coop = (rng.random(N) < 0.8).astype(np.int32)
+    coop[int(rng.integers(N))] = 1
+    msg = rng.normal(size=(S, N, ldp)).astype(np.float32)
+    kinds = rng.integers(0, 6, size=ldp)
+    msg[:, :, kinds == 1] = 0.0
+    msg[:, :, kinds == 2] *= np.float32(1e-38)                 # sums with subnormal quotients
+    msg[:, :, kinds == 3] *= np.float32(1e30)
+    msg[:, :, kinds == 4] = np.round(msg[:, :, kinds == 4])     # many exact ties
+    msg[:, int(rng.integers(N))] = np.float32(1e3)              # an adversarial row
+    theta0 = rng.normal(size=(S, N, ldp)).astype(np.float32)
+    d_msg, d_nbr, d_coop = bk.dev(msg), bk.dev(nbr), bk.dev(coop)
+    results = []
+    kernels = ["general"] + (["circ"] if graph == "circ" and bk.lib.rcmarl_consensus_params_circulant_supported(N, d, H) == 1 else [])
+    for kern in kernels:
+        d_theta = bk.dev(theta0)
+        d_lo, d_hi = bk.dev(np.zeros_like(theta0)), bk.dev(np.zeros_like(theta0))
+        if kern == "circ":
+            bk.lib.rcmarl_consensus_params_circulant(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_coop), S, N, ldp, P_hid, d, H,
+                                                     bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+        else:
+            bk.lib.rcmarl_consensus_params(bk.ptr(d_msg), bk.ptr(d_theta), bk.ptr(d_nbr), bk.ptr(d_coop), S, N, ldp, P_hid, d,
+                                           H, bk.ptr(d_lo), bk.ptr(d_hi), bk.stream)
+        results.append((kern, bk.host(d_theta), bk.host(d_lo), bk.host(d_hi)))
+    want = theta0.copy()
+    with np.errstate(over="ignore", under="ignore"):
+        for s in range(S):
+            for i in range(N):
+                if not coop[i]:
+                    continue
+                vals = msg[s, nbr[i], :P_hid]
+                srt = np.sort(vals, axis=0)
+                lo = np.minimum(srt[H], vals[0])
+                hi = np.maximum(srt[d - H - 1], vals[0])
+                acc = np.zeros(P_hid, np.float32)
+                for k in range(d):
+                    acc = (acc + np.clip(vals[k], lo, hi)).astype(np.float32)
+                want[s, i, :P_hid] = acc / np.float32(d)
+                for kern, _, klo, khi in results:
+                    np.testing.assert_array_equal(klo[s, i, :P_hid], lo, err_msg=kern)
+                    np.testing.assert_array_equal(khi[s, i, :P_hid], hi, err_msg=kern)
+    for kern, theta, _, _ in results:
+        np.testing.assert_array_equal(theta.view(np.uint32), want.view(np.uint32), err_msg=kern)      # bits, incl. signed zeros
+
+
 # ------------------------------------------------------------------------------------------
 def _layer1(bk, d_x, x_stride, d_theta, d_a1t, S, N, B, in_dim, ldp, ldb):
     bk.lib.rcmarl_layer1_forward(bk.ptr(d_x), x_stride, bk.ptr(d_theta), bk.ptr(d_a1t), S, N, B, in_dim, HID, ldp, ldb,

@@ -181,3 +181,16 @@ def test_lattice_backward_dz_fragments_from_global_bit_identical(bk, S, N, B, wi
     msg, wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=2, masked_agent=4)
     np.testing.assert_array_equal(msg, ref_msg)
     np.testing.assert_array_equal(wp, ref_wp)
+
+
+@pytest.mark.parametrize("d,H", [(4, 1), (6, 2), (10, 4), (18, 8), (5, 1), (9, 3)])
+def test_consensus_params_bits_on_awkward_data(bk, d, H):
+    """K1 (both kernels on circulant graphs) against a plain NumPy statement of its arithmetic, BIT FOR BIT, on columns of
+    zeros, subnormal-range sums (the guarded path of the constant division), 1e30-scale values, exact ties, a random
+    cooperation mask and agent counts that are not a multiple of the kernel's agent group; seeds and sizes drawn here."""
+    rng = np.random.default_rng(1000 * d + H)
+    for _ in range(3):
+        N = int(rng.integers(d, 40))
+        P_hid = int(rng.integers(1, 150))
+        graph = "circ" if rng.random() < 0.7 else "rand"
+        KC.check_consensus_params_exact(bk, N, d, H, P_hid, int(rng.integers(1, 3)), int(rng.integers(1 << 30)), graph)
