@@ -180,7 +180,10 @@ struct LatOperands {
 
 // DBG (measurement aid, RCMARL_LAT_DBG; results are WRONG for DBG != 0): bit 0 = no LDS-DMA after the prologue,
 // bit 1 = no vmcnt wait / barrier, bit 2 = fragments read from LDS once (k-loop = matrix core only)
-template <int PA, int PB, int MT, int NT, int NSTAGE, int DBG = 0, int WM = 2, int WN = 2>
+// SPREAD: the LDS-DMA bursts of the next k-tile are issued one at a time BETWEEN the matrix-core instructions of the first two
+// thirds of this k-tile instead of back to back right after the barrier (an LDS-DMA instruction blocks the wavefront's
+// issue for 60-180 cycles; in a burst those add up while no MFMA of this wavefront is in flight).
+template <int PA, int PB, int MT, int NT, int NSTAGE, int DBG = 0, int WM = 2, int WN = 2, bool SPREAD = false>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
                                              rc_f32x16 (&acc)[MT][NT]) {
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
@@ -220,6 +223,12 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
 #pragma unroll
     for (int i = 0; i < C::GLDS; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, dst + i * (C::NWV * 1024));
   };
+  auto stage_one = [&](int buf, int t, int i) {
+    RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, lds0 + buf * C::STAGE_BYTES + i * (C::NWV * 1024));
+  };
+  constexpr int N_MFMA = 2 * PA * PB * MT * NT;                 // matrix-core instructions of a wavefront per k-tile
+  constexpr int EVERY = (2 * N_MFMA / 3) / C::GLDS > 0 ? (2 * N_MFMA / 3) / C::GLDS : 1;
+  static_assert(!SPREAD || (NSTAGE == 2 && EVERY * C::GLDS <= N_MFMA), "spread issue: two stages, every burst has a slot");
 
   // fragment addresses: row = lane&31 (+ tile offsets), chunk = 2*kstep + lane>>5, XOR (row>>2)&3
   const int sw = (l31 >> 2) & 3;
@@ -261,10 +270,9 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
       else RC_WAIT_VMEM();
       __syncthreads();              // ... and everybody's; all reads of the buffer refilled next are done
     }
-    if (t + NSTAGE - 1 < n_ktiles && !(DBG & 1)) {
-      const int nb = cur == 0 ? NSTAGE - 1 : cur - 1;           // (t + NSTAGE - 1) % NSTAGE
-      stage(nb, t + NSTAGE - 1);
-    }
+    const bool more = t + NSTAGE - 1 < n_ktiles && !(DBG & 1);
+    const int nb = cur == 0 ? NSTAGE - 1 : cur - 1;             // (t + NSTAGE - 1) % NSTAGE
+    if (more && !SPREAD) stage(nb, t + NSTAGE - 1);
     pf_flying = pfd > 0 && t + pfd < n_ktiles;
 #ifndef RCMARL_EMU
     if (pf_flying && pf_wave)
@@ -292,7 +300,17 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
+              if constexpr (SPREAD) {
+                const int o = ks * (PA * PB * MT * NT) + (((PA - 1 - pa) * PB + (PB - 1 - pb)) * MT + mt) * NT + nt;
+                if (o % EVERY == EVERY - 1 && o / EVERY < C::GLDS) {
+                  RC_SCHED_FENCE();
+                  if (more) stage_one(nb, t + NSTAGE - 1, o / EVERY);
+                  RC_SCHED_FENCE();
+                }
+              }
+            }
     }
   }
 #ifndef RCMARL_EMU
@@ -570,6 +588,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, NSTAGE == 3 ? 1 : 2) void k_lat_for
   }
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (in_dim + 31) >> 5, lds, acc);
+  else if constexpr (NSTAGE == 6) lat_mainloop<PA, PB, MT, NT, 2, DBG, WM, WN, true>(op, (in_dim + 31) >> 5, lds, acc);
   else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG, WM, WN>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * hid;
@@ -664,6 +683,7 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   rc_f32x16 acc[MT][NT];
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
   else if constexpr (NSTAGE == 5) lat_mainloop_bdirect<MT, NT, WM, WN>(op, (B + 31) >> 5, lds, acc);
+  else if constexpr (NSTAGE == 6) lat_mainloop<PA, PB, MT, NT, 2, DBG, WM, WN, true>(op, (B + 31) >> 5, lds, acc);
   else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG, WM, WN>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
@@ -783,6 +803,8 @@ int lat_stages() {
 }
 // backward only: RCMARL_LAT_BDIRECT=1 loads the three-piece dz fragments global -> registers (lat_mainloop_bdirect)
 bool lat_bdirect() { return lat_env_int("RCMARL_LAT_BDIRECT", 0) != 0; }      // (read per call: tests switch it)
+// RCMARL_LAT_SPREAD: bit 0 = forward, bit 1 = backward: LDS-DMA bursts issued between the matrix-core instructions (lat_mainloop)
+int lat_spread() { return lat_env_int("RCMARL_LAT_SPREAD", 0); }
 
 }  // namespace
 
@@ -853,7 +875,17 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
 #undef RC_DBG_CASE
     return rcmarl_check_launch();
   }
-  if (ns == 2 && lat_w8(true)) {
+  if (ns == 2 && (lat_spread() & 1)) {
+    static const bool ok = lat_want_lds(k_lat_forward<6, 0, true>, smem) && lat_want_lds(k_lat_forward<6>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    if (lat_w8(true)) {
+      RCMARL_LAUNCH((k_lat_forward<6, 0, true>), grid, dim3(512), smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
+                    (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n(), hid);
+    } else {
+      RCMARL_LAUNCH((k_lat_forward<6>), grid, block, smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
+                    (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, dbg, lat_stagger_bit(), lat_stagger_n(), hid);
+    }
+  } else if (ns == 2 && lat_w8(true)) {
     static const bool ok = lat_want_lds(k_lat_forward<2, 0, true>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_forward<2, 0, true>), grid, dim3(512), smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
@@ -914,6 +946,12 @@ static int backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const v
     RCMARL_LAUNCH((k_lat_backward_sgd<5>), dim3((unsigned)(S * mtiles * ntiles)), block, smem5, stream, (const unsigned char*)ktp,
                   ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles,
                   ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
+  } else if (ns == 2 && (lat_spread() & 2)) {
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<6>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<6>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
   } else if (ns == 2 && lat_w8(false)) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<2, 0, true>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;

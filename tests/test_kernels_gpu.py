@@ -264,3 +264,14 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
         P_hid = int(rng.integers(1, 700))
         graph = "circ" if rng.random() < 0.7 else "rand"
         KC.check_consensus_params_exact(bk, N, d, H, P_hid, int(rng.integers(1, 3)), int(rng.integers(1 << 30)), graph)
+
+
+def test_lattice_gemms_spread_dma_issue_bit_identical(bk, monkeypatch):
+    """RCMARL_LAT_SPREAD=3: both lattice GEMMs issue the LDS-DMA bursts of the next k-tile between their matrix-core
+    instructions instead of back to back after the barrier.  Pure scheduling: same bits."""
+    args = (2, 20, 777, 3, 7, 9)
+    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
+    monkeypatch.setenv("RCMARL_LAT_SPREAD", "3")
+    msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
+    np.testing.assert_array_equal(msg, ref_msg)
+    np.testing.assert_array_equal(wp, ref_wp)
