@@ -250,8 +250,8 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
   // t + pf (24 KiB, contiguous in the packed format) with a plain load whose result is never used; the DMA of that
   // tile then finds its lines in L2.  The touch is the YOUNGEST memory instruction of its wavefront when the next
   // k-tile starts, so the wait before the barrier is vmcnt(1) there: it never waits for the prefetch itself.
-  static_assert(PA == 3 ? C::ART == 1 : (PB != 3 || C::BRT == 1), "the 3-piece side is one 128-row tile wide");
-  const int pfd = (NSTAGE == 2 && (PA == 3 || PB == 3)) ? op.pf : 0;
+  constexpr bool pf_ok = PA == 3 ? C::ART == 1 : (PB == 3 && C::BRT == 1);     // the 3-piece side is one 128-row tile wide
+  const int pfd = (NSTAGE == 2 && pf_ok) ? op.pf : 0;
   const bool pf_wave = wave < 3;
   const unsigned char* pf_src = (PA == 3 ? op.a + (long)op.art0 * op.a_kt * (3 * RC_PK_BLOCK)
                                          : op.b + (long)op.brt0 * op.b_kt * (3 * RC_PK_BLOCK)) + threadIdx.x * 128;
@@ -655,8 +655,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, NSTAGE == 3 ? 1 : 2) void k_lat_for
 #else
 #define RC_LAT_OCC(threads, waves) __attribute__((amdgpu_flat_work_group_size(threads, threads), amdgpu_waves_per_eu(waves)))
 #endif
+// NSTAGE 7 = two stages, EIGHT wavefronts of 128 x 64 on a 256 x 256 tile (one workgroup per CU): the one-piece operand's
+// stage is shared by twice the dz columns, 64 instead of 80 KiB of LDS-DMA per 256 x 256 x 32 of work
 template <int NSTAGE, int DBG = 0, bool W8 = false>
-__global__ RC_LAT_OCC(W8 ? 512 : 256, NSTAGE == 3 ? 1 : (W8 ? 4 : 2))
+__global__ RC_LAT_OCC((W8 || NSTAGE == 7 || NSTAGE == 8) ? 512 : 256, NSTAGE == 3 ? 1 : (W8 ? 4 : 2))
 void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
                                                              const unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
                                                              const float* __restrict__ alpha, float* __restrict__ theta,
@@ -664,7 +666,9 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
                                                              int in_dim, int ldp, float lr, int mtiles, int ntiles,
                                                              unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt,
                                                              int stg_bit, int stg_n, int hid, int wp_fit) {
-  constexpr int PA = 1, PB = 3, MT = W8 ? 2 : 4, NT = 2, WM = W8 ? 4 : 2, WN = 2;
+  // NSTAGE 8 = two stages, eight wavefronts of 128 x 64 on a 512 x 128 tile: the whole input width of the critic in one workgroup
+  // (the three-piece dz panel is read once instead of once per 256 input rows)
+  constexpr int PA = 1, PB = 3, MT = W8 ? 2 : 4, NT = 2, WM = (W8 || NSTAGE == 8) ? 4 : 2, WN = NSTAGE == 7 ? 4 : 2;
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   lat_stagger((stg_bit & 0xff) - 1, stg_n);
@@ -684,6 +688,7 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   if constexpr (NSTAGE == 4) lat_mainloop_half<PA, PB, MT, NT>(op, (B + 31) >> 5, lds, acc);
   else if constexpr (NSTAGE == 5) lat_mainloop_bdirect<MT, NT, WM, WN>(op, (B + 31) >> 5, lds, acc);
   else if constexpr (NSTAGE == 6) lat_mainloop<PA, PB, MT, NT, 2, DBG, WM, WN, true>(op, (B + 31) >> 5, lds, acc);
+  else if constexpr (NSTAGE == 7 || NSTAGE == 8) lat_mainloop<PA, PB, MT, NT, 2, DBG, WM, WN>(op, (B + 31) >> 5, lds, acc);
   else lat_mainloop<PA, PB, MT, NT, NSTAGE, DBG, WM, WN>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
@@ -946,6 +951,24 @@ static int backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const v
     RCMARL_LAUNCH((k_lat_backward_sgd<5>), dim3((unsigned)(S * mtiles * ntiles)), block, smem5, stream, (const unsigned char*)ktp,
                   ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles,
                   ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
+  } else if (ns == 2 && lat_env_int("RCMARL_LAT_WIDE", 0) != 0 && dzp_rt >= 2 * rc_ceil_div(N * hid, 256)) {
+    const int ntiles2 = rc_ceil_div(N * hid, 256);
+    const size_t smem7 = 2 * LatCfg<1, 3, 4, 2, 2, 4>::STAGE_BYTES;
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<7>, smem7);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<7>), dim3((unsigned)(S * mtiles * ntiles2)), dim3(512), smem7, stream,
+                  (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B,
+                  in_dim, ldp, lr, mtiles, ntiles2, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid,
+                  wp_fit);
+  } else if (ns == 2 && lat_env_int("RCMARL_LAT_TALL", 0) != 0 && ktp_rt >= 4 * rc_ceil_div(in_dim, 512)) {
+    const int mtiles4 = rc_ceil_div(in_dim, 512);
+    const size_t smem8 = 2 * LatCfg<1, 3, 4, 2, 4, 2>::STAGE_BYTES;
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<8>, smem8);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<8>), dim3((unsigned)(S * mtiles4 * ntiles)), dim3(512), smem8, stream,
+                  (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B,
+                  in_dim, ldp, lr, mtiles4, ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid,
+                  wp_fit);
   } else if (ns == 2 && (lat_spread() & 2)) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<6>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;

@@ -275,3 +275,16 @@ def test_lattice_gemms_spread_dma_issue_bit_identical(bk, monkeypatch):
     msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
     np.testing.assert_array_equal(msg, ref_msg)
     np.testing.assert_array_equal(wp, ref_wp)
+
+
+@pytest.mark.parametrize("knob", ["RCMARL_LAT_WIDE", "RCMARL_LAT_TALL"])
+def test_lattice_backward_wide_tile_bit_identical(bk, knob, monkeypatch):
+    """The backward GEMM on 256 x 256 tiles (RCMARL_LAT_WIDE: the one-piece operand's LDS stage shared by twice the dz
+    columns) or 512 x 128 tiles (RCMARL_LAT_TALL: the dz panel read once for up to 512 inputs), eight wavefronts each.
+    Same products in the same order per accumulator: same bits."""
+    args = (2, 26, 777, 3, 7, 9)
+    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
+    monkeypatch.setenv(knob, "1")
+    msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
+    np.testing.assert_array_equal(msg, ref_msg)
+    np.testing.assert_array_equal(wp, ref_wp)
