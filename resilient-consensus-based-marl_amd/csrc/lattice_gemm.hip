@@ -808,8 +808,9 @@ int lat_stages() {
 }
 // backward only: RCMARL_LAT_BDIRECT=1 loads the three-piece dz fragments global -> registers (lat_mainloop_bdirect)
 bool lat_bdirect() { return lat_env_int("RCMARL_LAT_BDIRECT", 0) != 0; }      // (read per call: tests switch it)
-// RCMARL_LAT_SPREAD: bit 0 = forward, bit 1 = backward: LDS-DMA bursts issued between the matrix-core instructions (lat_mainloop)
-int lat_spread() { return lat_env_int("RCMARL_LAT_SPREAD", 0); }
+// RCMARL_LAT_SPREAD: bit 0 = forward, bit 1 = backward: LDS-DMA bursts issued between the matrix-core instructions (lat_mainloop).
+// Default 2: measured -2 % on the backward at both cfg-4 shapes, +1..8 % on the forward; bit-identical either way.
+int lat_spread() { return lat_env_int("RCMARL_LAT_SPREAD", 2); }
 
 }  // namespace
 
@@ -969,16 +970,16 @@ static int backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const v
                   (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B,
                   in_dim, ldp, lr, mtiles4, ntiles, (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid,
                   wp_fit);
-  } else if (ns == 2 && (lat_spread() & 2)) {
-    static const bool ok = lat_want_lds(k_lat_backward_sgd<6>, smem);
-    if (!ok) return RCMARL_ERR_LAUNCH;
-    RCMARL_LAUNCH((k_lat_backward_sgd<6>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
-                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
   } else if (ns == 2 && lat_w8(false)) {
     static const bool ok = lat_want_lds(k_lat_backward_sgd<2, 0, true>, smem);
     if (!ok) return RCMARL_ERR_LAUNCH;
     RCMARL_LAUNCH((k_lat_backward_sgd<2, 0, true>), grid, dim3(512), smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
+                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
+                  (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
+  } else if (ns == 2 && (lat_spread() & 2)) {
+    static const bool ok = lat_want_lds(k_lat_backward_sgd<6>, smem);
+    if (!ok) return RCMARL_ERR_LAUNCH;
+    RCMARL_LAUNCH((k_lat_backward_sgd<6>), grid, block, smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
                   (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
                   (unsigned char*)wp_out, wp_rt, wp_kt, lat_stagger_bit(), lat_stagger_n(), hid, wp_fit);
   } else if (ns == 2) {

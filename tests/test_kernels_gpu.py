@@ -270,6 +270,7 @@ def test_lattice_gemms_spread_dma_issue_bit_identical(bk, monkeypatch):
     """RCMARL_LAT_SPREAD=3: both lattice GEMMs issue the LDS-DMA bursts of the next k-tile between their matrix-core
     instructions instead of back to back after the barrier.  Pure scheduling: same bits."""
     args = (2, 20, 777, 3, 7, 9)
+    monkeypatch.setenv("RCMARL_LAT_SPREAD", "0")
     ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
     monkeypatch.setenv("RCMARL_LAT_SPREAD", "3")
     msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
