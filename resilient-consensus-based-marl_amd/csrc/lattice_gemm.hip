@@ -180,8 +180,8 @@ struct LatOperands {
 
 // DBG (measurement aid, RCMARL_LAT_DBG; results are WRONG for DBG != 0): bit 0 = no LDS-DMA after the prologue,
 // bit 1 = no vmcnt wait / barrier, bit 2 = fragments read from LDS once (k-loop = matrix core only)
-// SPREAD: the LDS-DMA bursts of the next k-tile are issued one at a time BETWEEN the matrix-core instructions of the first two
-// thirds of this k-tile instead of back to back right after the barrier (an LDS-DMA instruction blocks the wavefront's
+// SPREAD: the LDS-DMA bursts of the next k-tile are issued one at a time BETWEEN the matrix-core instructions of the first
+// half of this k-tile (measured: every 2nd MFMA 717-733 us, every 3rd 729-736, every 4th 746 on the backward) instead of back to back right after the barrier (an LDS-DMA instruction blocks the wavefront's
 // issue for 60-180 cycles; in a burst those add up while no MFMA of this wavefront is in flight).
 template <int PA, int PB, int MT, int NT, int NSTAGE, int DBG = 0, int WM = 2, int WN = 2, bool SPREAD = false>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
@@ -227,7 +227,11 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
     RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, lds0 + buf * C::STAGE_BYTES + i * (C::NWV * 1024));
   };
   constexpr int N_MFMA = 2 * PA * PB * MT * NT;                 // matrix-core instructions of a wavefront per k-tile
-  constexpr int EVERY = (2 * N_MFMA / 3) / C::GLDS > 0 ? (2 * N_MFMA / 3) / C::GLDS : 1;
+#ifdef RC_LAT_SPREAD_EVERY
+  constexpr int EVERY = RC_LAT_SPREAD_EVERY;                    // (tuning builds)
+#else
+  constexpr int EVERY = (N_MFMA / 2) / C::GLDS > 0 ? (N_MFMA / 2) / C::GLDS : 1;     // all bursts within the first half
+#endif
   static_assert(!SPREAD || (NSTAGE == 2 && EVERY * C::GLDS <= N_MFMA), "spread issue: two stages, every burst has a slot");
 
   // fragment addresses: row = lane&31 (+ tile offsets), chunk = 2*kstep + lane>>5, XOR (row>>2)&3

@@ -264,7 +264,7 @@ def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
 
 
 if __name__ == "__main__":
-    L = capi.load()
+    L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
     {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "mid_ab": mid_ab, "minibatch": minibatch, "wide": wide}[what](L)
