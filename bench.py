@@ -477,8 +477,8 @@ ROOFLINE_KIND = {
                                           "division: VALU-bound at d=18 (343 instructions per 4 agents, VALU busy 77 % of the "
                                           "kernel: profiles/r02h_sq_counters_k1_circ_d18.json), toward HBM at d=4"),
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
-                               "dz1 pieces written = 200 B; k_mid_fit_v5: layer 2 and the row reductions on the f32 matrix core "
-                               "(72 MFMAs = 4.6k cycles + 630 VALU + 157 LDS instructions per 64 rows); bound by instruction "
+                               "dz1 pieces written = 200 B; k_mid_fit_v5: layer 2 (4x4x1 sixteen-block MFMAs, results born row-per-lane) and the "
+                               "row reductions (32x32x2) on the f32 matrix core; bound by instruction "
                                "issue on a SIMD whose matrix-core and VALU time add up (tools/micro/pipe_overlap.hip), "
                                "DESIGN.md section 5"),
     "rcmarl_minibatch_fit": ("mfma_f32", "the adversaries' fit(batch_size=32, epochs=10): 940 sequentially DEPENDENT SGD steps per "

@@ -534,7 +534,13 @@ __global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, 
 //     (G[i<20][j<20] = gW2, G[20][j<20] = gb2, G[21+i][20] = gW3[i], G[20][21] = gb3, G[20][22] = loss,
 //     G[20][23+i] = gW3[11+i]); gb1 = sum dz1 by six fused-DPP adds per value.
 // Same arithmetic as v3 (dz1 bit-identical, records to summation order).  EMIT as in v3.
-template <int HID, bool EMIT>
+// X4: the two 20x20 layer products as v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 outer products per instruction,
+// block b = lanes 4b..4b+3: D_b[i][j] += A(lane 4b+i) * B(lane 4b+j), lane 4b+j holding column j in its four registers.  With
+// B = the lane's OWN value (its replay row's a1[m] / dz2[k]) and A = W2[m][4g+i] (four units of group g, the same for every
+// block), register i of lane l accumulates unit 4g+i of ROW l: the result is born row-per-lane (no permlane swaps), 20 units
+// are five groups exactly (the 32x32 tiles spend 12 of 32 rows on padding), and the accumulator is 20 registers instead of 32.
+// Same fmaf chain per (unit, row), m ascending: bit-identical.  100 instructions of 8-12 cycles instead of 20 of 64-81.
+template <int HID, bool EMIT, bool X4 = false>
 __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restrict__ a1t, const float* __restrict__ theta,
                                                        const float* __restrict__ y, float* __restrict__ partials, int N,
                                                        int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
@@ -548,8 +554,8 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
 #endif
   constexpr int WLD = 32, PLD = RC_V5_PLD, GA = 11;    // padded weight rows; panel row stride (rows per pass + 1); gW3 values in the A panel
   constexpr int PANEL = (2 * 32 * PLD > 528 ? 2 * 32 * PLD : 528);   // floats per wavefront: A panel | B panel (later: its record)
-  __shared__ float sW2[HID * WLD];                     // W2[m][i]   (i >= HID: zeros)
-  __shared__ float sW2T[HID * WLD];                    // W2[j][k] stored as [k][j]
+  __shared__ __attribute__((aligned(16))) float sW2[HID * WLD];        // W2[m][i]   (i >= HID: zeros)
+  __shared__ __attribute__((aligned(16))) float sW2T[HID * WLD];       // W2[j][k] stored as [k][j]
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];         // b2 | W3 | b3
   __shared__ __attribute__((aligned(16))) float sPn[4 * PANEL];
   static_assert(!EMIT || (PANEL * 4 >= HID * 3 * 64 * 2 && PANEL % 4 == 0), "the dz transpose (HID x 3 pieces x 64 rows of bf16) fits the panel area");
@@ -595,7 +601,26 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
     const float ycur = valid ? yrow[b] : 0.f;
     // ---- layer 2 forward
     float z2[HID];
-    {
+    if constexpr (X4) {
+      static_assert(!X4 || HID % 4 == 0, "units in groups of four");
+      rc_f32x4 zq[HID / 4];
+#pragma unroll
+      for (int g4 = 0; g4 < HID / 4; ++g4) zq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mg = 0; mg < HID / 4; ++mg)
+#pragma unroll
+        for (int g4 = 0; g4 < HID / 4; ++g4) {       // sW2T[unit][m] = W2[m][unit]: four consecutive m in one read
+          const float4 w = *reinterpret_cast<const float4*>(&sW2T[(4 * g4 + (lane & 3)) * WLD + 4 * mg]);
+          zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, a1[4 * mg + 0], zq[g4], 0, 0, 0);
+          zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, a1[4 * mg + 1], zq[g4], 0, 0, 0);
+          zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, a1[4 * mg + 2], zq[g4], 0, 0, 0);
+          zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, a1[4 * mg + 3], zq[g4], 0, 0, 0);
+        }
+#pragma unroll
+      for (int g4 = 0; g4 < HID / 4; ++g4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z2[4 * g4 + e] = zq[g4][e];
+    } else {
       rc_f32x32 zz;
 #pragma unroll
       for (int q = 0; q < 32; ++q) zz[q] = 0.f;
@@ -657,7 +682,25 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
     }
     // ---- layer 2 backward
     float dz1[HID];
-    {
+    if constexpr (X4) {
+      rc_f32x4 dq[HID / 4];
+#pragma unroll
+      for (int g4 = 0; g4 < HID / 4; ++g4) dq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < HID / 4; ++kg)
+#pragma unroll
+        for (int g4 = 0; g4 < HID / 4; ++g4) {       // sW2[j][k] = W2[j][k]: da1[j] = sum_k dz2[k] W2[j][k], k ascending
+          const float4 w = *reinterpret_cast<const float4*>(&sW2[(4 * g4 + (lane & 3)) * WLD + 4 * kg]);
+          dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, dz2[4 * kg + 0], dq[g4], 0, 0, 0);
+          dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, dz2[4 * kg + 1], dq[g4], 0, 0, 0);
+          dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, dz2[4 * kg + 2], dq[g4], 0, 0, 0);
+          dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, dz2[4 * kg + 3], dq[g4], 0, 0, 0);
+        }
+#pragma unroll
+      for (int g4 = 0; g4 < HID / 4; ++g4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz1[4 * g4 + e] = dq[g4][e] * rc_lrelu_grad_from_act(a1[4 * g4 + e]);
+    } else {
       rc_f32x32 dd;
 #pragma unroll
       for (int q = 0; q < 32; ++q) dd[q] = 0.f;
@@ -1148,8 +1191,8 @@ int midfit_stagger() { const char* e = getenv("RCMARL_MIDFIT_STAGGER"); return e
 int midfit_variant(bool lattice = false) {
   const char* e = getenv("RCMARL_MIDFIT");
   (void)lattice;
-  int v = e ? atoi(e) : 5;
-  if (v != 5 && (v < 0 || v > 2)) v = 5;
+  int v = e ? atoi(e) : 6;               // 6 = v5 with the layer products as 4x4x1 sixteen-block MFMAs (measured -3..-5 %)
+  if (v != 5 && v != 6 && (v < 0 || v > 2)) v = 6;
   return v;
 }
 
@@ -1187,7 +1230,12 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(nchunk, N, S), block(ROWS);
   const int variant = midfit_variant();
-  if (variant == 5) {
+  if (variant == 6) {
+    const int cpw = midfit_cpw(nchunk);
+    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false, true>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
+                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, midfit_stagger()));
+  } else if (variant == 5) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
@@ -1214,7 +1262,12 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   const int nchunk = rc_ceil_div(B, ROWS);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(nchunk, N, S), block(ROWS);
-  if (midfit_variant(true) == 5) {
+  if (midfit_variant(true) == 6) {
+    const int cpw = midfit_cpw(nchunk);
+    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, midfit_stagger()));
+  } else if (midfit_variant(true) == 5) {
     const int cpw = midfit_cpw(nchunk);
     const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,

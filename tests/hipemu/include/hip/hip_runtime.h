@@ -179,6 +179,20 @@ inline __hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src,
   return r;
 }
 
+inline floatx4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, floatx4 c, int, int, int) {
+  // sixteen independent 4x4x1 products: block = l>>2; lane 4*blk+i supplies A[blk][i], lane 4*blk+j supplies B[blk][j];
+  // lane l = 4*blk+j holds D[blk][i = register][j]     (checked on gfx950: tools/micro/mfma4x4.hip)
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  s.xch_f[((size_t)w * 64 + l) * 2 + 0] = a;
+  hipemu::wave_barrier();
+  floatx4 d = c;
+  const int blk = l >> 2;
+  for (int i = 0; i < 4; ++i) d[i] = fmaf(s.xch_f[((size_t)w * 64 + 4 * blk + i) * 2 + 0], b, d[i]);
+  hipemu::wave_barrier();
+  return d;
+}
+
 inline floatx4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, floatx4 c, int, int, int) {
   // lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=(l>>4)*4+r][col=l&15]
   auto& s = hipemu::st();

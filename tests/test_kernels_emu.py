@@ -219,3 +219,34 @@ def test_lattice_backward_wide_tile_bit_identical(bk, knob, monkeypatch):
     msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
     np.testing.assert_array_equal(msg, ref_msg)
     np.testing.assert_array_equal(wp, ref_wp)
+
+
+def test_mid_fit_4x4_block_products_bit_identical(bk, monkeypatch):
+    """RCMARL_MIDFIT=6: the two 20x20 layer products of the mid kernel as 4x4x1 sixteen-block MFMAs (result born row-per-lane,
+    no padding rows, no permlane swaps).  Same fmaf chains: dz pieces AND gradient records equal v5's bit for bit, on both
+    entry points; and the usual oracle fit."""
+    from rcmarl_amd import lattice as LT
+    rng = np.random.default_rng(4)
+    S, N, B, in_dim = (1, 3, 300, 6)
+    P, _ = KC.geom(in_dim, 1)
+    ldp, ldb = KC.pad64(P), KC.pad64(B)
+    theta = KC.pack_rows(KC.random_params(rng, S, N, in_dim, 1), ldp)
+    a1 = np.maximum(rng.normal(size=(S, N * 20, ldb)), 0.1 * rng.normal(size=(S, N * 20, ldb))).astype(np.float32)
+    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    g = LT.Geometry(N, in_dim, B)
+    nchunk, psz = (B + 255) // 256, bk.lib.rcmarl_fit_partial_size(20)
+    out = {}
+    for var in ("5", "6"):
+        monkeypatch.setenv("RCMARL_MIDFIT", var)
+        d_a, d_th, d_y = bk.dev(a1), bk.dev(theta), bk.dev(y)
+        d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+        d_dzp = bk.dev(np.zeros(S * LT.Geometry.nbytes(g.dzp, 3) // 2, np.uint16))
+        bk.lib.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(d_dzp), g.dzp[0], g.dzp[1], S, N, B,
+                                      in_dim, 20, ldp, ldb, bk.stream)
+        d_a2 = bk.dev(a1)
+        d_part2 = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
+        bk.lib.rcmarl_mid_fit(bk.ptr(d_a2), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part2), S, N, B, in_dim, 20, ldp, ldb, bk.stream)
+        out[var] = (bk.host(d_dzp).copy(), bk.host(d_part).copy(), bk.host(d_a2).copy(), bk.host(d_part2).copy())
+    for a, b in zip(out["5"], out["6"]):
+        np.testing.assert_array_equal(a, b)
+    KC.check_sgd_fit(bk, 1, 5, 130, 10, steps=2, masked_agent=1)
