@@ -60,6 +60,7 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
     s.blk_arrived = 0; s.blk_gen = 0;
     s.wave_arrived.assign(nw, 0); s.wave_gen.assign(nw, 0);
     s.xch_f.assign((size_t)nw * 64 * 2, 0.f); s.xch_u.assign((size_t)nw * 64, 0ull);
+    s.xch_q.assign((size_t)nw * 64 * 2, 0.f); s.par_q.assign((size_t)nw * 64, 0);
     s.xch_m.assign((size_t)nw * 64 * 8, 0u);
     for (int t = 0; t < s.nthreads; ++t) {
       Fiber& f = s.fibers[t];

@@ -61,6 +61,8 @@ struct State {
   // wave exchange scratch: [wave][lane][slot]
   std::vector<float> xch_f; std::vector<unsigned long long> xch_u;
   std::vector<unsigned> xch_m;        // [wave][lane][8 dwords]: operands of the bf16 MFMA emulation
+  std::vector<float> xch_q;           // [wave][lane][2]: A operands of the 4x4x1 MFMA, two alternating slots
+  std::vector<unsigned char> par_q;   // [wave][lane]: slot the lane's next 4x4x1 MFMA uses
   std::vector<char> dyn_smem;
 };
 State& st();
@@ -182,14 +184,19 @@ inline __hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src,
 inline floatx4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, floatx4 c, int, int, int) {
   // sixteen independent 4x4x1 products: block = l>>2; lane 4*blk+i supplies A[blk][i], lane 4*blk+j supplies B[blk][j];
   // lane l = 4*blk+j holds D[blk][i = register][j]     (checked on gfx950: tools/micro/mfma4x4.hip)
+  // ONE barrier per call (kernels issue hundreds of these): the A operands go through two alternating slots of their own --
+  // a lane can only rewrite slot p two calls later, i.e. after the barrier of the call in between, which every lane
+  // reaches only when it has finished reading slot p.
   auto& s = hipemu::st();
-  int w = hipemu::wave(), l = hipemu::lane();
-  s.xch_f[((size_t)w * 64 + l) * 2 + 0] = a;
+  const int w = hipemu::wave(), l = hipemu::lane();
+  const size_t me = (size_t)w * 64 + l;
+  const int p = s.par_q[me];
+  s.par_q[me] = (unsigned char)(p ^ 1);
+  s.xch_q[me * 2 + p] = a;
   hipemu::wave_barrier();
   floatx4 d = c;
-  const int blk = l >> 2;
-  for (int i = 0; i < 4; ++i) d[i] = fmaf(s.xch_f[((size_t)w * 64 + 4 * blk + i) * 2 + 0], b, d[i]);
-  hipemu::wave_barrier();
+  const size_t blk0 = (size_t)w * 64 + 4 * (l >> 2);
+  for (int i = 0; i < 4; ++i) d[i] = fmaf(s.xch_q[(blk0 + i) * 2 + p], b, d[i]);
   return d;
 }
 
