@@ -64,7 +64,7 @@ def test_engine_wide_critic_with_faulty_agent_matches_oracle():
 
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])
 def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
-    EC.check_checkpoint_resume(labels, rng_mode, "cpu", emu_lib(), str(tmp_path / "ck.pt"))
+    EC.check_checkpoint_resume(labels, rng_mode, "cpu", emu_lib(), str(tmp_path / "ck.pt"), blocks=(1, 1))     # (1, 2) on the GPU
 
 
 def test_engine_buffer_not_a_multiple_of_the_episode_length():
