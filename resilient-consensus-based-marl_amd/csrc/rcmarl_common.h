@@ -278,6 +278,14 @@ __device__ __forceinline__ bool rc_all(bool v) {
 #define RC_OPAQUE_TRUE() ([]() __attribute__((always_inline)) { int c_ = 1; asm volatile("" : "+s"(c_)); return c_ != 0; }())
 #endif
 
+// Makes a register value opaque to the optimiser at this point (an empty asm that "modifies" it): what is computed from it
+// below cannot be hoisted above, e.g. out of a loop where it would occupy registers for the whole loop.
+#ifdef RCMARL_EMU
+#define RC_OPAQUE_REG(x) ((void)0)
+#else
+#define RC_OPAQUE_REG(x) asm volatile("" : "+v"(x))
+#endif
+
 // Ties a pointer to a value computed earlier (an empty asm that "modifies" both): loads through the pointer cannot be
 // started before that value exists.  Keeps hipcc from hoisting ALL weight reads of a fully unrolled chain of FMAs
 // above the chain (it then spills them: 100 ds_read_b128 = 400 registers).

@@ -580,6 +580,7 @@ def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shu
             for q in range(6):
                 rel_close(got[q], pw[q], 2e-5, "minibatch fit param %d" % q)
             assert abs(loss[s, n] - hist[0]) <= 2e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+    return th_new, loss
 
 
 def check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=200, lr=0.002, t0=0, shuffle=True):
