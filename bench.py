@@ -61,6 +61,19 @@ WORKLOADS = {
                               "512 independent seeds per GPU"),
     "cfg1_batched": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=512, graph="circulant",
                          desc="5 cooperative agents, 5x5 grid, H=1, 512 seeds per GPU"),
+    # BASELINE configs[0]: the reference's own CPU-runnable case (main.py defaults with --H 0): plain-mean consensus
+    "cfg0_H0_batched": dict(N=5, nrow=5, ncol=5, H=0, d=4, S=512, graph="circulant",
+                            desc="BASELINE configs[0]: 5 cooperative agents, 5x5 grid, H=0 (plain mean over the in-neighbourhood, "
+                                 "agents/resilient_CAC_agents.py:50-56 with H=0), circulant d=4, 512 seeds per GPU"),
+    # single-instance (S = 1) forms: what `python -m rcmarl_amd.main` / train_RPBCAC run (reference main.py:117 trains ONE seed);
+    # SURVEY.md section 8's size table has S per GPU = 1 for configs 1-3.  Latency-bound: ~600 launches per block.
+    "cfg0_H0_single": dict(N=5, nrow=5, ncol=5, H=0, d=4, S=1, graph="circulant",
+                           desc="BASELINE configs[0] as ONE instance (the drop-in train_RPBCAC path): 5 cooperative agents, H=0"),
+    "cfg2_single": dict(N=5, nrow=5, ncol=5, H=1, d=4, S=1, graph="circulant", labels=["Cooperative"] * 4 + ["Malicious"],
+                        desc="BASELINE configs[1] as ONE instance (the drop-in train_RPBCAC path): 4 cooperative + 1 Malicious "
+                             "agent, 5x5 grid, H=1"),
+    "cfg3_single": dict(N=64, nrow=16, ncol=16, H=4, d=10, S=1, graph="regular", fast_lr=0.005,
+                        desc="BASELINE configs[2] as ONE instance: 64 agents, 16x16 grid, random 9-regular in-graph + self, H=4"),
     # BASELINE configs[4] as ONE instance on ONE GPU (the 8-GPU agent/column sharding of SURVEY.md 8e is not built):
     # only the critic is widened to 512 units (BASELINE: "wide (512-unit) critic"), team-reward net and actor keep 20
     "cfg5_1gpu": dict(N=1024, nrow=32, ncol=32, H=32, d=66, S=1, graph="circulant", fast_lr=0.0005, critic_hid=512,
@@ -299,7 +312,8 @@ def extra_workloads(main_name, tlib, barrier, dev):
     bench line also carries BASELINE configs[1], [2], [4] and the north-star target shape; K1's roofline on the target
     shape is measured here with HIP events (`roofline_consensus_target`)."""
     out, k1_target = {}, None
-    for name in ("target_N256_H1", "cfg3", "cfg2_batched", "cfg1_batched", "cfg5_1gpu"):
+    for name in ("target_N256_H1", "cfg3", "cfg2_batched", "cfg1_batched", "cfg0_H0_batched", "cfg0_H0_single", "cfg2_single",
+                 "cfg3_single", "cfg5_1gpu"):
         if name == main_name:
             continue
         w = WORKLOADS[name]
@@ -381,8 +395,9 @@ def main(argv=None):
         from rcmarl_amd.timing import TimedLib
         tlib = TimedLib(capi.load())
         eng = make_engine(w, S, seeds, tlib)
-        if one_instance and world > 1:
-            eng.shard_agents()                                     # over the default process group
+        if one_instance and use_pg:
+            eng.shard_agents(force=True)                           # over the default process group (also ONE rank: the
+            #                                                        RCCL path of the sharded instance on a 1-GPU box)
     c = eng.cfg
     jobs = 1 if one_instance else world                            # independent instances of the workload in the job
 
@@ -406,7 +421,15 @@ def main(argv=None):
     ph = phase_split(eng)
 
     finite = all(bool(torch.isfinite(eng.theta[k]).all().item()) for k in ("actor", "critic", "tr"))
+    if use_pg:
+        # every rank must reach the same verdict BEFORE anyone leaves: a rank that exits alone leaves the others in the
+        # barrier below (and in a sharded instance a remote shard's divergence is invisible in the local rows)
+        fl = torch.tensor([1.0 if finite else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(fl, op=dist.ReduceOp.MIN)
+        finite = bool(fl.item() > 0.5)
     if not finite:
+        if use_pg:
+            dist.destroy_process_group()
         raise SystemExit("bench invalid: non-finite network weights after the timed region (diverged training)")
     if rank == 0:
         env_steps = c.n_ep_fixed * c.max_ep_len
@@ -448,11 +471,22 @@ def main(argv=None):
             out["extra"], k1t = extra_workloads(args.workload, tlib, barrier, dev)
             if k1t is not None:
                 out["roofline_consensus_target"] = k1t
+        cache = os.path.join(ROOT, ".bench_cpu_baseline_%s.json" % args.workload.replace("cfg5_shard", "cfg5_1gpu"))
         if not args.no_cpu_baseline and world == 1 and not stub:
             try:
                 out["cpu_baseline"] = cpu_baseline(w)
                 out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+                with open(cache, "w") as f:                            # the N > 1 lines of the same box sit beside it
+                    json.dump(out["cpu_baseline"], f)
             except Exception as e:                                     # the baseline must never kill the bench line
+                out["cpu_baseline"] = {"error": repr(e)}
+        elif not args.no_cpu_baseline and not stub and os.path.exists(cache):
+            # timed on rank 0 at N = 1 only (a few tens of CPU-seconds); the N > 1 lines of the same box carry that record
+            try:
+                with open(cache) as f:
+                    out["cpu_baseline"] = dict(json.load(f), carried_from="the N=1 run of this workload on this box")
+                out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()

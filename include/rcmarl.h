@@ -312,6 +312,14 @@ int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float
 int rcmarl_wide_head_apply(const float* grads, float* theta, const int* coop, int S, int N, int B, int in_dim, int hid,
                            int ldp, void* stream);
 
+/* C2 (one instance over several GPUs): the pack / unpack pass of the two all-to-all transposes of the message
+ * matrix, which replace the reference's in-process gather `[critic_weights[i] for i in in_nodes[node]]`
+ * (training/train_agents.py:129-130).  dst[b][r][c] = src[b][r][c] for b < batches, r < rows, c < cols; strides in
+ * floats; rows with row_mask[r] == 0 are left untouched (row_mask may be NULL).  One pass, 16-byte accesses when the
+ * strides allow. */
+int rcmarl_copy3d(const float* src, long src_batch, long ld_src, float* dst, long dst_batch, long ld_dst, int batches,
+                  int rows, int cols, const int* row_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -169,6 +169,9 @@ SIGNATURES = {
                                    c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # grads, theta, coop, S, N, B, in_dim, hid, ldp, stream
     "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # ---- sharded instance (csrc/shard_pack.hip) ----------------------------------------------------------
+    # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
+    "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_rows", "rcmarl_fit_fused_chunks", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
              "rcmarl_fit_small_partial_size", "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",

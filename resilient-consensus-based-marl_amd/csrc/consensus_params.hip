@@ -39,15 +39,30 @@ __device__ __forceinline__ float rc_div_fast(float x) {
   return fmaf(fmaf(-q0, (float)D, x), rcp, q0);
 }
 
+// want_window: the caller stores lower/upper (debug outputs of the bit-exactness tests).  H == 0 (BASELINE configs[0],
+// agents/resilient_CAC_agents.py:50-56 with H = 0): the window is [min, max] of the d values, clipping is the identity and
+// the aggregate is the plain mean -- no selection network and no clamps unless the window itself is asked for.
 template <int D, int H>
-__device__ __forceinline__ float aggregate_regs(const float (&v)[D], float& lower, float& upper) {
-  float lo, hi;
-  SelNet<D, H>::run(v, lo, hi);
-  lower = fminf(lo, v[0]);
-  upper = fmaxf(hi, v[0]);
+__device__ __forceinline__ float aggregate_regs(const float (&v)[D], float& lower, float& upper, bool want_window = true) {
   float sum = 0.f;
+  if (H == 0) {
+    lower = upper = v[0];
+    if (want_window) {
+      float lo, hi;
+      SelNet<D, H>::run(v, lo, hi);
+      lower = fminf(lo, v[0]);
+      upper = fmaxf(hi, v[0]);
+    }
 #pragma unroll
-  for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[k], lower, upper);  // clamp
+    for (int k = 0; k < D; ++k) sum += v[k];
+  } else {
+    float lo, hi;
+    SelNet<D, H>::run(v, lo, hi);
+    lower = fminf(lo, v[0]);
+    upper = fmaxf(hi, v[0]);
+#pragma unroll
+    for (int k = 0; k < D; ++k) sum += __builtin_amdgcn_fmed3f(v[k], lower, upper);  // clamp
+  }
   float q = rc_div_fast<D>(sum);
   if (__builtin_expect(rc_any(fabsf(sum) < 1e-30f), 0)) {
     RC_NO_SPECULATE();
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void k_consensus_params(const float* __restric
     };
     auto finish = [&](const int i, const float (&v)[D]) {
       float lower, upper;
-      const float out = aggregate_regs<D, H>(v, lower, upper);
+      const float out = aggregate_regs<D, H>(v, lower, upper, lo_dbg != nullptr);
       if (col_ok) {
         const size_t o = ((size_t)s * N + i) * ldp + c0 + c;
         theta[o] = out;
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(1024) void k_consensus_params_v2(const float* __res
 #pragma unroll
       for (int k = 0; k < D; ++k) v[k] = *reinterpret_cast<const float*>(tb + rc_readlane(tab[k], j));
       float lower, upper;
-      const float out = aggregate_regs<D, H>(v, lower, upper);
+      const float out = aggregate_regs<D, H>(v, lower, upper, lo_dbg != nullptr);
       if (col_ok) {
         const size_t o = ((size_t)s * N + (wave + nw * j)) * ldp + c0 + lane;
         theta[o] = out;

@@ -352,7 +352,7 @@ class RPBCACEngine:
                                         self.ldb, self.stream)
 
     # ---- ONE instance over several GPUs (C2, SURVEY.md 8e / BASELINE configs[4]) ---------------------------------
-    def shard_agents(self, rank=None, world=None, group=None, comm=None):
+    def shard_agents(self, rank=None, world=None, group=None, comm=None, force=False):
         """Shard the wide critic of this (single-seed) instance over the ranks of `group`: rank r owns a contiguous block of
         agents for everything that is independent per agent (TD targets, local fits, estimate consensus + projection,
         values) and a block of parameter COLUMNS for the hidden-layer consensus K1; two all-to-all transposes of the
@@ -362,13 +362,15 @@ class RPBCACEngine:
         nets (team reward, actors), the environment and the replay buffer stay replicated: they are a few per cent of a
         wide-critic block and every rank computes them bit-identically.  Results equal the unsharded engine bit for bit
         (tests/test_sharded_engine_gloo.py).  Call after torch.distributed.init_process_group; world 1 = no-op.
-        comm: the collectives (parallel.TorchComm over `group` by default; parallel.ThreadComm in the one-GPU test)."""
+        comm: the collectives (parallel.TorchComm over `group` by default; parallel.ThreadComm in the one-GPU test).
+        force: shard even at world size 1, so that EVERY collective of the sharded instance runs through the communicator
+        (the one-rank RCCL run on a single-GPU box: tests/test_rccl_one_rank_gpu.py, `bench.py --workload cfg5_shard`)."""
         from .parallel import ShardedConsensus, TorchComm, agent_range
         if comm is None and world is None:
             comm = TorchComm(group)
         if comm is not None:
             rank, world = comm.rank, comm.world
-        if world == 1:
+        if world == 1 and not force:
             self.shard = None
             return self
         if self.S != 1 or not self.wide:
@@ -395,7 +397,8 @@ class RPBCACEngine:
         sh.sc = {}
         for net in ("critic", "tr") if sh.shard_tr else ("critic",):
             sh.sc[net] = ShardedConsensus(self.lib, 1, self.N, self.P[net] - (self.hid[net] + 1), self.cfg.d, self.cfg.H,
-                                          self.cfg.in_nodes, self.coop_np, self.dev, comm=sh.comm)
+                                          self.cfg.in_nodes, self.coop_np, self.dev, comm=sh.comm, circulant=self.k1_circulant,
+                                          force_collectives=force)
         self.shard = sh
         return self
 

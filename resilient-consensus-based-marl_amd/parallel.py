@@ -27,7 +27,7 @@ def allreduce_curves(local_sums, n_local_seeds, device=None, sq_sums=None):
     buf = torch.from_numpy(np.concatenate(parts))
     if device is not None:
         buf = buf.to(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():            # also with ONE rank: the same RCCL call path
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     out = buf.cpu().numpy()
     n = out[-1]
@@ -129,76 +129,130 @@ class ShardedConsensus:
         sc.consensus(msg_cols)                     # K1 on this rank's columns -> sc.theta_cols
         sc.gather(theta_local)                     # [S][N][ldc] -> columns < P_hid of [S][N_loc][ldp]   (all-to-all #2)
 
-    Rows of non-cooperative agents are never aggregated (agents/resilient_CAC_agents.py is the cooperative agent's
-    class); gather() leaves them as they are."""
+    Data movement: ONE pack pass (rcmarl_copy3d, csrc/shard_pack.hip) per direction and nothing else.  The sender of
+    all-to-all #1 packs its (agents x peer's columns) boxes with the RECEIVER's row stride, so with one seed (the
+    sharded instance) the blocks land in place in msg_cols; all-to-all #2 sends row ranges of theta_cols as they lie
+    (contiguous with one seed) and the receiver scatters them into its parameter rows in one masked pass.  (Round 2 did
+    .contiguous() + torch.cat + slice-assign / torch.where: three passes over a 5.4 GB matrix per net and epoch at
+    BASELINE configs[4].)  Several seeds take one extra staging pass on the strided side.
 
-    def __init__(self, lib, S, N, P_hid, d, H, in_nodes, coop, device, stream=None, group=None, comm=None):
+    Rows of non-cooperative agents are never aggregated (agents/resilient_CAC_agents.py is the cooperative agent's
+    class); gather() leaves them as they are.  circulant: None = decide from the graph (RCMARL_K1_CIRC=0 forces the
+    general kernel), True/False = the caller's decision (the engine passes its own, so that a sharded run takes the same
+    K1 kernel as the unsharded one it is compared with).  force_collectives: run the all-to-all even at world size 1
+    (the one-rank RCCL test on a single-GPU box)."""
+
+    def __init__(self, lib, S, N, P_hid, d, H, in_nodes, coop, device, stream=None, group=None, comm=None, circulant=None,
+                 force_collectives=False):
+        import os
         self.lib, self.S, self.N, self.P_hid, self.d, self.H = lib, int(S), int(N), int(P_hid), int(d), int(H)
         self.dev, self.stream, self.group = torch.device(device), stream, group
         self.comm = TorchComm(group) if comm is None else comm
         self.world, self.rank = self.comm.world, self.comm.rank
+        self.force = bool(force_collectives)
         self.a_lo, self.a_hi = agent_range(N, self.rank, self.world)
         self.agents = [agent_range(N, r, self.world) for r in range(self.world)]
         self.cols = column_ranges(P_hid, self.world)
         self.c_lo, self.c_hi = self.cols[self.rank]
         self.width = self.c_hi - self.c_lo
-        self.ldc = max(64, (self.width + 63) // 64 * 64)
+        self.ldcs = [max(64, (c1 - c0 + 63) // 64 * 64) for (c0, c1) in self.cols]       # every rank's row stride
+        self.ldc = self.ldcs[self.rank]
         nodes = np.asarray(in_nodes, dtype=np.int32)
-        self.circulant = bool(all(list(nodes[i]) == [(i + k) % N for k in range(d)] for i in range(N)) and
-                              lib.rcmarl_consensus_params_circulant_supported(N, d, H) == 1)
+        is_circ = bool(all(list(nodes[i]) == [(i + k) % N for k in range(d)] for i in range(N)) and
+                       lib.rcmarl_consensus_params_circulant_supported(N, d, H) == 1)
+        if circulant is None:
+            circulant = os.environ.get("RCMARL_K1_CIRC", "1") not in ("0", "false")
+        self.circulant = bool(circulant) and is_circ
         self.nbr = torch.tensor(nodes, dtype=torch.int32, device=self.dev)
         self.coop = torch.tensor(np.asarray(coop, dtype=np.int32), dtype=torch.int32, device=self.dev)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.msg_cols = torch.zeros(self.S, self.N, self.ldc, **f32)
         self.theta_cols = torch.zeros(self.S, self.N, self.ldc, **f32)
+        n_loc = self.a_hi - self.a_lo
+        # boxes this rank sends in #1 / receives in #2: [S][n_loc][ldc_r] per peer r (pad columns stay zero)
+        self._box_sizes = [self.S * n_loc * l for l in self.ldcs]
+        self._boxes = torch.zeros(sum(self._box_sizes), **f32)
+        # row blocks this rank receives in #1 / sends in #2: [S][n_r][ldc] per peer r; with one seed they ARE msg_cols /
+        # theta_cols (peer r's agents are rows a0_r..a1_r), otherwise a staging buffer
+        self._blk_sizes = [self.S * (a1 - a0) * self.ldc for (a0, a1) in self.agents]
+        self._stage = None if self.S == 1 else torch.zeros(sum(self._blk_sizes), **f32)
+        self.passes = 0                           # pack / unpack launches so far (tests count them)
 
-    def _a2a(self, send_blocks, recv_shapes):
-        """all-to-all of one block per peer (flattened, unequal sizes); returns the received blocks."""
-        if self.world == 1:
-            return [send_blocks[0]]
-        send = torch.cat([b.reshape(-1) for b in send_blocks])
-        sizes_in = [int(b.numel()) for b in send_blocks]
-        sizes_out = [int(np.prod(sh)) for sh in recv_shapes]
-        recv = torch.empty(sum(sizes_out), dtype=send.dtype, device=send.device)
-        self.comm.all_to_all_single(recv, send, sizes_out, sizes_in)
-        out, o = [], 0
-        for sh, n in zip(recv_shapes, sizes_out):
-            out.append(recv[o:o + n].view(*sh))
-            o += n
+    # -- the two copy shapes ------------------------------------------------------------------------------------
+    def _copy(self, src, src_batch, ld_src, dst, dst_batch, ld_dst, rows, cols, mask=None):
+        if rows > 0 and cols > 0:
+            self.lib.rcmarl_copy3d(src, src_batch, ld_src, dst, dst_batch, ld_dst, self.S, rows, cols,
+                                   None if mask is None else mask.data_ptr(), self.stream)
+            self.passes += 1
+
+    def _box_ptrs(self):
+        off, out = 0, []
+        for n in self._box_sizes:
+            out.append(self._boxes.data_ptr() + 4 * off)
+            off += n
         return out
+
+    def _a2a(self, recv, send, out_sizes, in_sizes):
+        if self.world == 1 and not self.force:
+            recv.copy_(send)                      # one rank, no process group: the self-exchange is a copy
+        else:
+            self.comm.all_to_all_single(recv, send, out_sizes, in_sizes)
 
     def exchange(self, msg_local):
         """msg_local [S][N_loc][ldp] (this rank's agents, all columns) -> self.msg_cols [S][N][ldc] (all agents, this
         rank's columns)."""
         n_loc = self.a_hi - self.a_lo
-        assert msg_local.shape[0] == self.S and msg_local.shape[1] == n_loc
-        send = [msg_local[:, :, c0:c1].contiguous() for (c0, c1) in self.cols]
-        shapes = [(self.S, a1 - a0, self.width) for (a0, a1) in self.agents]
-        for (a0, a1), blk in zip(self.agents, self._a2a(send, shapes)):
-            self.msg_cols[:, a0:a1, :self.width] = blk
+        assert msg_local.shape[0] == self.S and msg_local.shape[1] == n_loc and msg_local.is_contiguous()
+        ldp = msg_local.shape[2]
+        for r, ((c0, c1), dst) in enumerate(zip(self.cols, self._box_ptrs())):       # pack: strided column box -> contiguous
+            self._copy(msg_local.data_ptr() + 4 * c0, n_loc * ldp, ldp, dst, n_loc * self.ldcs[r], self.ldcs[r], n_loc, c1 - c0)
+        recv = self.msg_cols.view(-1) if self.S == 1 else self._stage
+        self._a2a(recv, self._boxes, self._blk_sizes, self._box_sizes)
+        if self.S > 1:                                                                # [S][n_r][ldc] blocks -> [S][N][ldc]
+            off = 0
+            for (a0, a1), n in zip(self.agents, self._blk_sizes):
+                self._copy(self._stage.data_ptr() + 4 * off, (a1 - a0) * self.ldc, self.ldc,
+                           self.msg_cols.data_ptr() + 4 * a0 * self.ldc, self.N * self.ldc, self.ldc, a1 - a0, self.ldc)
+                off += n
         return self.msg_cols
 
     def consensus(self, msg_cols=None):
         """K1 (agents/resilient_CAC_agents.py:142-166) on this rank's columns; same launch as the unsharded step."""
+        from .capi import RcmarlError
         msg = self.msg_cols if msg_cols is None else msg_cols
         if self.width == 0:
             return self.theta_cols
         if self.circulant:
-            self.lib.rcmarl_consensus_params_circulant(msg.data_ptr(), self.theta_cols.data_ptr(), self.coop.data_ptr(), self.S,
-                                                       self.N, self.ldc, self.width, self.d, self.H, None, None, self.stream)
-        else:
-            self.lib.rcmarl_consensus_params(msg.data_ptr(), self.theta_cols.data_ptr(), self.nbr.data_ptr(),
-                                             self.coop.data_ptr(), self.S, self.N, self.ldc, self.width, self.d, self.H, None,
-                                             None, self.stream)
+            try:
+                self.lib.rcmarl_consensus_params_circulant(msg.data_ptr(), self.theta_cols.data_ptr(), self.coop.data_ptr(),
+                                                           self.S, self.N, self.ldc, self.width, self.d, self.H, None, None,
+                                                           self.stream)
+                return self.theta_cols
+            except RcmarlError as e:              # e.g. the 64-bit cooperation-mask guard: the general kernel serves any shape
+                if "UNSUPPORTED" not in str(e):
+                    raise
+                self.circulant = False
+        self.lib.rcmarl_consensus_params(msg.data_ptr(), self.theta_cols.data_ptr(), self.nbr.data_ptr(), self.coop.data_ptr(),
+                                         self.S, self.N, self.ldc, self.width, self.d, self.H, None, None, self.stream)
         return self.theta_cols
 
     def gather(self, theta_local):
         """self.theta_cols [S][N][ldc] -> columns < P_hid of theta_local [S][N_loc][ldp], cooperative agents only."""
-        send = [self.theta_cols[:, a0:a1, :self.width].contiguous() for (a0, a1) in self.agents]
         n_loc = self.a_hi - self.a_lo
-        shapes = [(self.S, n_loc, c1 - c0) for (c0, c1) in self.cols]
-        mine = self.coop[self.a_lo:self.a_hi].bool()
-        for (c0, c1), blk in zip(self.cols, self._a2a(send, shapes)):
-            if c1 > c0:
-                theta_local[:, :, c0:c1] = torch.where(mine[None, :, None], blk, theta_local[:, :, c0:c1])
+        assert theta_local.shape[0] == self.S and theta_local.shape[1] == n_loc and theta_local.is_contiguous()
+        ldp = theta_local.shape[2]
+        if self.S == 1:
+            send = self.theta_cols.view(-1)
+        else:                                                                         # [S][N][ldc] -> [S][n_r][ldc] blocks
+            off = 0
+            for (a0, a1), n in zip(self.agents, self._blk_sizes):
+                self._copy(self.theta_cols.data_ptr() + 4 * a0 * self.ldc, self.N * self.ldc, self.ldc,
+                           self._stage.data_ptr() + 4 * off, (a1 - a0) * self.ldc, self.ldc, a1 - a0, self.ldc)
+                off += n
+            send = self._stage
+        self._a2a(self._boxes, send, self._box_sizes, self._blk_sizes)
+        mine = self.coop[self.a_lo:self.a_hi]
+        for r, ((c0, c1), src) in enumerate(zip(self.cols, self._box_ptrs())):       # unpack: scatter into the parameter rows
+            self._copy(src, n_loc * self.ldcs[r], self.ldcs[r], theta_local.data_ptr() + 4 * c0, n_loc * ldp, ldp, n_loc,
+                       c1 - c0, mask=mine)
         return theta_local

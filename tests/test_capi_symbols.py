@@ -68,6 +68,7 @@ def test_argument_validation_needs_no_gpu():
         ("rcmarl_wide_consensus_head", (None, None, None, None, None, None, None, None, None, None, None, None, 1, 5, 100, 10, 32,
                                         1472, 128, 4, 1, None)),
         ("rcmarl_wide_head_apply", (None, None, None, 1, 5, 100, 10, 32, 1472, None)),
+        ("rcmarl_copy3d", (None, 0, 64, None, 0, 64, 1, 5, 40, None, None)),
     ]
     for name, args in bad:
         with pytest.raises(capi.RcmarlError, match="RCMARL_ERR_ARG|RCMARL_ERR_UNSUPPORTED"):
