@@ -504,236 +504,6 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
   for (int e = lane; e < g.P; e += 64) th[e] = W[e];
 }
 
-// The same kernel with the three 20-unit layer products (layer 1, layer 2, dz1) on the matrix core as 4x4x1 sixteen-block
-// MFMAs (see k_mid_fit_v5 X4 in mid_kernels.hip): B = the lane's own value, A = four units of the weight matrix read from the
-// LDS copy, register i of lane l = unit 4g+i of the lane's row.  Every lane then holds ALL 20 units of its row (both halves of
-// the wavefront compute the same 32 rows), so the ten-units-per-half split, its 30 cross-half exchanges and -- the point -- the
-// LDS weight broadcasts that hipcc hoisted into ~200 registers are gone: the kernel fits two wavefronts per SIMD (it held
-// 448 registers, i.e. a whole SIMD, per network).  Same fmaf chains per (unit, row): results bit-identical to k_minibatch_wave.
-// OPT-IN (RCMARL_MB_WAVE=2), measured SLOWER: 13.6 instead of 6.7 ms per launch of 940 steps at 512 seeds -- with one latency-bound
-// wavefront per network every A-operand read (80 + 25 + 25 per step) exposes its LDS latency in front of the MFMAs that need it;
-// the VALU kernel hides it with the very register-hungry hoisting this form avoids.  A software-pipelined operand fetch would be
-// the next step; the block time with this kernel is 225 instead of 208 ms.
-template <int INMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_minibatch_x4(MbArgs a, int n_nets) {
-  constexpr int HID = 20, U = 10, XR = 11;                    // XR: first x row of the P2 panel
-  RCMARL_DYN_SMEM(float, smem);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int net = blockIdx.x * 4 + wave;
-  if (net >= n_nets) return;                               // (wave-uniform; the kernel has no workgroup barrier)
-  const int s = net / a.n_adv, adv = net - s * a.n_adv;
-  float* W = smem + wave * WP_FLOATS;
-  float* W2T = W + WP_W;
-  float* pA = W2T + WP_W2T;                                  // P1 A panel
-  float* pA2 = pA + WP_A;                                    // P2 A panel
-  float* pB = pA2 + WP_A;
-  const int in = a.in_dim;
-  const NetGeom g = make_geom(in, HID, 1);
-  const int agent = a.agents[adv];
-  const long row = (long)s * a.N + agent;
-  float* th = a.theta + row * a.ldp;
-  const float* xg = a.x + (long)s * a.x_seed_stride;
-  const float* yv = a.y + row * a.ldb;
-  const int* perm = a.perm ? a.perm + ((long)s * a.n_adv + adv) * a.epochs * a.B : nullptr;
-  const int r = lane & 31, h = lane >> 5, u0 = U * h, l31 = r;
-  for (int e = lane; e < g.P; e += 64) W[e] = th[e];
-  RC_WAVE_SYNC();
-  for (int e = lane; e < HID * HID; e += 64) { const int j = e / HID, k = e - j * HID; W2T[k * HID + j] = W[g.o_W2 + e]; }
-  for (int e = lane; e < WP_B; e += 64) pB[e] = 0.f;       // incl. the zero row 21
-  for (int e = lane; e < WP_A; e += 64) {                  // constant rows: P1 ones (20) / zeros (21), P2 ones (0) / zero tail
-    pA[e] = (e / WP_LD) == 20 ? 1.f : 0.f;
-    pA2[e] = (e / WP_LD) == 0 ? 1.f : 0.f;
-  }
-  RC_WAVE_SYNC();
-  rc_f32x16 acc1, acc2;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) { acc1[q] = 0.f; acc2[q] = 0.f; }
-  // parameter owned by accumulator slot q of this lane in P1 / P2 (D[row = (q&3) + 8(q>>2) + 4h][col = lane&31]);
-  // WP_W - 1 / WP_W2T - 1 are dummy words nobody reads
-  // (16-bit indices, packed: i1 | iT << 16 per slot, two i2 per register -- 24 registers instead of 48)
-  unsigned pk1[16], pk2[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) pk2[q] = 0u;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int rw = (q & 3) + 8 * (q >> 2) + 4 * h, col = l31;
-    int i1 = WP_W - 1, iT = WP_W2T - 1, i2 = WP_W - 1;
-    if (col < HID) {
-      if (rw < HID) { i1 = g.o_W2 + rw * HID + col; iT = col * HID + rw; }
-      else if (rw == HID) i1 = g.o_b2 + col;
-      if (rw == 0) i2 = g.o_b1 + col;
-      else if (rw >= XR && rw < XR + in) i2 = (rw - XR) * HID + col;
-    } else if (col == HID) {
-      if (rw >= 22) i1 = g.o_W3 + (rw - 22);
-      else if (rw == HID) i1 = g.o_b3;
-      if (rw >= 1 && rw <= U) i2 = g.o_W3 + U + (rw - 1);
-    }
-    pk1[q] = (unsigned)i1 | ((unsigned)iT << 16);
-    pk2[q >> 1] |= (unsigned)i2 << (16 * (q & 1));
-  }
-  const int ibp = (l31 < 21 ? l31 : 21) * WP_LD + h;       // B-panel row of this lane (cols >= 21 read zeros)
-  const int iap = l31 * WP_LD + h;
-  float loss_part = 0.f;
-  // The walk over (epoch, mini-batch, 32-row tile) is flattened so that the rows of tile t+1 (shuffle index, then the
-  // input row and the target: two dependent trips to L2) are requested while tile t is processed -- a single
-  // wavefront has nothing else to hide that latency with.
-  const int tpb = (a.bs + 31) / 32, nbatch = (a.B + a.bs - 1) / a.bs, tpe = tpb * nbatch, T = tpe * a.epochs;
-  auto fetch = [&](int t, float (&xo)[INMAX], float& yo, bool& vo) {
-    const int ep = t / tpe, w = t - ep * tpe, bi = w / tpb, lo = bi * a.bs;
-    const int nb = min(a.bs, a.B - lo), nrt = nb - (w - bi * tpb) * 32;
-    vo = r < nrt;
-    const int p = lo + (w - bi * tpb) * 32 + (vo ? r : 0);
-    const int b = vo ? (perm ? perm[(long)ep * a.B + p] : p) : 0;
-#pragma unroll
-    for (int k = 0; k < INMAX; ++k) xo[k] = (vo && k < in) ? xg[(long)b * in + k] : 0.f;
-    yo = vo ? yv[b] : 0.f;
-  };
-  float xn[INMAX], ybn;
-  bool validn;
-  fetch(0, xn, ybn, validn);
-  for (int t = 0; t < T; ++t) {
-    {
-      {
-        const int ep = t / tpe, w = t - ep * tpe, bi = w / tpb;
-        const int nb = min(a.bs, a.B - bi * a.bs);
-        const bool last_tile = (w - bi * tpb) == tpb - 1, last_of_epoch = w == tpe - 1;
-        float x[INMAX];
-#pragma unroll
-        for (int k = 0; k < INMAX; ++k) x[k] = xn[k];
-        const float yb = ybn;
-        const bool valid = validn;
-        if (t + 1 < T) fetch(t + 1, xn, ybn, validn);
-        // ---- layer 1: z1[unit][row] = sum_k W1[k][unit] x[row][k], k ascending (rows >= in_dim multiply x = 0)
-        float a1[HID];
-        {
-          rc_f32x4 zq[HID / 4];
-#pragma unroll
-          for (int g4 = 0; g4 < HID / 4; ++g4) zq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < INMAX; ++kk)
-#pragma unroll
-            for (int g4 = 0; g4 < HID / 4; ++g4)
-              zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(W[kk * HID + 4 * g4 + (lane & 3)], x[kk], zq[g4], 0, 0, 0);
-#pragma unroll
-          for (int g4 = 0; g4 < HID / 4; ++g4) {
-            const float4 b4 = *reinterpret_cast<const float4*>(&W[g.o_b1 + 4 * g4]);
-            a1[4 * g4 + 0] = rc_lrelu(zq[g4][0] + b4.x); a1[4 * g4 + 1] = rc_lrelu(zq[g4][1] + b4.y);
-            a1[4 * g4 + 2] = rc_lrelu(zq[g4][2] + b4.z); a1[4 * g4 + 3] = rc_lrelu(zq[g4][3] + b4.w);
-          }
-        }
-        // ---- layer 2: z2[u] = sum_j a1[j] W2[j][u], j ascending; W2T[u][j] gives four consecutive j in one read
-        float a2[HID];
-        {
-          rc_f32x4 zq[HID / 4];
-#pragma unroll
-          for (int g4 = 0; g4 < HID / 4; ++g4) zq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int jg = 0; jg < HID / 4; ++jg)
-#pragma unroll
-            for (int g4 = 0; g4 < HID / 4; ++g4) {
-              const float4 w = *reinterpret_cast<const float4*>(&W2T[(4 * g4 + (lane & 3)) * HID + 4 * jg]);
-              zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, a1[4 * jg + 0], zq[g4], 0, 0, 0);
-              zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, a1[4 * jg + 1], zq[g4], 0, 0, 0);
-              zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, a1[4 * jg + 2], zq[g4], 0, 0, 0);
-              zq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, a1[4 * jg + 3], zq[g4], 0, 0, 0);
-            }
-#pragma unroll
-          for (int g4 = 0; g4 < HID / 4; ++g4) {
-            const float4 b4 = *reinterpret_cast<const float4*>(&W[g.o_b2 + 4 * g4]);
-            a2[4 * g4 + 0] = rc_lrelu(zq[g4][0] + b4.x); a2[4 * g4 + 1] = rc_lrelu(zq[g4][1] + b4.y);
-            a2[4 * g4 + 2] = rc_lrelu(zq[g4][2] + b4.z); a2[4 * g4 + 3] = rc_lrelu(zq[g4][3] + b4.w);
-          }
-        }
-        // ---- head and loss gradient
-        float v = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < HID; ++kk) v = fmaf(a2[kk], W[g.o_W3 + kk], v);
-        v += W[g.o_b3];
-        const float diff = valid ? v - yb : 0.f;
-        const float dv = (2.0f * diff) / (float)nb;
-        if (ep == 0 && h == 0) loss_part += diff * diff;
-        float dz2[HID];
-#pragma unroll
-        for (int kk = 0; kk < HID; ++kk) dz2[kk] = dv * W[g.o_W3 + kk] * rc_lrelu_grad_from_act(a2[kk]);
-        // ---- dz1: da1[u] = sum_k dz2[k] W2[u][k], k ascending (W2 rows are contiguous in k)
-        float dz1[HID];
-        {
-          rc_f32x4 dq[HID / 4];
-#pragma unroll
-          for (int g4 = 0; g4 < HID / 4; ++g4) dq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kg = 0; kg < HID / 4; ++kg)
-#pragma unroll
-            for (int g4 = 0; g4 < HID / 4; ++g4) {
-              const float4 w = *reinterpret_cast<const float4*>(&W[g.o_W2 + (4 * g4 + (lane & 3)) * HID + 4 * kg]);
-              dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, dz2[4 * kg + 0], dq[g4], 0, 0, 0);
-              dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, dz2[4 * kg + 1], dq[g4], 0, 0, 0);
-              dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, dz2[4 * kg + 2], dq[g4], 0, 0, 0);
-              dq[g4] = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, dz2[4 * kg + 3], dq[g4], 0, 0, 0);
-            }
-#pragma unroll
-          for (int g4 = 0; g4 < HID / 4; ++g4)
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) dz1[4 * g4 + e4] = dq[g4][e4] * rc_lrelu_grad_from_act(a1[4 * g4 + e4]);
-        }
-        // ---- P1 = [a1 | 1 | 0 | a2[0:10]]^T [dz2 | dv | 0]
-        RC_WAVE_SYNC();                                      // previous product's fragments consumed
-#pragma unroll
-        for (int u = 0; u < U; ++u) { pA[(u0 + u) * WP_LD + r] = h ? a1[U + u] : a1[u]; pB[(u0 + u) * WP_LD + r] = h ? dz2[U + u] : dz2[u]; }
-        if (h == 0) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) pA[(22 + u) * WP_LD + r] = a2[u];            // a2[0:10]
-          pB[20 * WP_LD + r] = dv;
-        }
-        RC_WAVE_SYNC();
-#pragma unroll 4
-        for (int m = 0; m < 16; ++m) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA[iap + 2 * m], pB[ibp + 2 * m], acc1, 0, 0, 0);
-        // ---- P2 = [1 | a2[10:20] | x | 0]^T [dz1 | dv | 0]   (own A panel: its constant rows are written once)
-        RC_WAVE_SYNC();
-#pragma unroll
-        for (int k = 0; k < INMAX / 2; ++k) pA2[(XR + 2 * k + h) * WP_LD + r] = h ? x[2 * k + 1] : x[2 * k];
-#pragma unroll
-        for (int u = 0; u < U; ++u) pB[(u0 + u) * WP_LD + r] = h ? dz1[U + u] : dz1[u];
-        if (h == 1) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) pA2[(1 + u) * WP_LD + r] = a2[U + u];       // a2[10:20]
-        }
-        RC_WAVE_SYNC();
-#pragma unroll 4
-        for (int m = 0; m < 16; ++m) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pA2[iap + 2 * m], pB[ibp + 2 * m], acc2, 0, 0, 0);
-        if (last_tile) {
-          // ---- SGD step in the D layout: every accumulator slot owns one parameter (or a dummy word) of the LDS copy and
-          // updates it in place (k_minibatch_wave keeps a register master copy instead: 32 registers this kernel spends on
-          // sharing its SIMD with a second wavefront)
-          RC_WAVE_SYNC();
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            unsigned p1 = pk1[q], p2 = pk2[q >> 1];
-            RC_OPAQUE_REG(p1);                         // (keeps the unpacked indices from being hoisted out of the loop)
-            RC_OPAQUE_REG(p2);
-            const int i1 = p1 & 0xffffu, iT = p1 >> 16, i2 = (q & 1) ? (p2 >> 16) : (p2 & 0xffffu);
-            const float w1 = W[i1] - a.lr * acc1[q];
-            const float w2 = W[i2] - a.lr * acc2[q];
-            W[i1] = w1;
-            W2T[iT] = w1;
-            W[i2] = w2;
-            acc1[q] = 0.f; acc2[q] = 0.f;
-          }
-          RC_WAVE_SYNC();
-        }
-        if (ep == 0 && last_of_epoch && a.loss_out) {          // Keras History: first-epoch loss
-          float tl = loss_part;
-#pragma unroll
-          for (int mk = 16; mk >= 1; mk >>= 1) tl += __shfl_xor(tl, mk, 64);
-          if (lane == 0) a.loss_out[row] = tl / (float)a.B;
-        }
-      }
-    }
-  }
-  RC_WAVE_SYNC();
-  for (int e = lane; e < g.P; e += 64) th[e] = W[e];
-}
-
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
   const NetGeom g = make_geom(in_dim, hid, out);
   const int Ppad = (g.P + 3) & ~3;
@@ -763,22 +533,13 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
   a.x = x; a.x_seed_stride = x_seed_stride; a.theta = theta; a.agents = agents; a.y = y; a.perm = perm;
   a.loss_out = loss_out; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb;
   a.bs = batch_size < B ? batch_size : B; a.epochs = epochs; a.n_adv = n_adv; a.lr = lr;
-  // RCMARL_MB_WAVE: 0 = one workgroup per network, 1 = one wavefront per network with VALU layers, 2 = with 4x4x1 MFMA layers
-  const char* mbw = getenv("RCMARL_MB_WAVE");
-  const int wave_ok = mbw ? atoi(mbw) : 1;
-  if (wave_ok && in_dim <= 20) {
+  // <= 20 inputs (the reference's own 5-agent scenarios): one wavefront per network; wider inputs: one workgroup per network
+  if (in_dim <= 20) {
     const int n_nets = n_adv * S;
     const size_t smem = (size_t)4 * WP_FLOATS * sizeof(float);
-    static const bool attr_ok = rc_want_lds(k_minibatch_wave<16>, smem) && rc_want_lds(k_minibatch_wave<20>, smem) &&
-                                rc_want_lds(k_minibatch_x4<16>, smem) && rc_want_lds(k_minibatch_x4<20>, smem);
+    static const bool attr_ok = rc_want_lds(k_minibatch_wave<16>, smem) && rc_want_lds(k_minibatch_wave<20>, smem);
     if (!attr_ok) return RCMARL_ERR_LAUNCH;
-    if (wave_ok == 2) {
-      if (in_dim <= 16) {
-        RCMARL_LAUNCH((k_minibatch_x4<16>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
-      } else {
-        RCMARL_LAUNCH((k_minibatch_x4<20>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
-      }
-    } else if (in_dim <= 16) {
+    if (in_dim <= 16) {
       RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
     } else {
       RCMARL_LAUNCH((k_minibatch_wave<20>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);

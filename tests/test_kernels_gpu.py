@@ -321,16 +321,3 @@ def test_mid_fit_4x4_block_products_bit_identical(bk, monkeypatch):
         np.testing.assert_array_equal(a, b)
     KC.check_sgd_fit(bk, 2, 5, 1000, 10, steps=2, masked_agent=1)
 
-
-@pytest.mark.parametrize("S,N,B,in_dim,advs,bs", [(2, 5, 100, 10, [4], 32), (1, 5, 70, 15, [1, 3], 32), (1, 6, 90, 18, [2, 5], 40), (3, 5, 50, 20, [0], 7), (64, 5, 3000, 10, [4], 32)])
-def test_minibatch_fit_4x4_block_layers_bit_identical(bk, S, N, B, in_dim, advs, bs, monkeypatch):
-    """RCMARL_MB_WAVE=2: the adversaries' one-wavefront mini-batch fit with its three layer products as 4x4x1 sixteen-block MFMAs
-    (k_minibatch_x4: every lane holds all 20 units of its row; no ten-units-per-half split, no register master copy of the
-    weights; fits two wavefronts per SIMD).  Same fmaf chains: same oracle fit and parameters / first-epoch loss bit-identical to
-    the VALU-layer kernel."""
-    monkeypatch.setenv("RCMARL_MB_WAVE", "1")
-    ref = KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=True)
-    monkeypatch.setenv("RCMARL_MB_WAVE", "2")
-    got = KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=True)
-    np.testing.assert_array_equal(got[0], ref[0])
-    np.testing.assert_array_equal(got[1], ref[1])

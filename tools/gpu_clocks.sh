@@ -10,16 +10,19 @@ CMD="python $R/bench.py --steps 1 --warmup 1 --workload $W --no-cpu-baseline --n
 timeout 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/clk -o ${W}_pmc -- $CMD > $R/gpurun_out/clk/${W}_pmc.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/clk -o ${W}_trace -- $CMD > $R/gpurun_out/clk/${W}_trace.log 2>&1
 python - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, re
+def key(n):
+    m = re.search(r'(k_\w+|at::native::\w+|__amd_\w+)', n)
+    return m.group(1) if m else n[:40]
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
 for f in glob.glob('$R/gpurun_out/clk/${W}_pmc*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0][:60]
+        k = key(r['Kernel_Name'])
         tot[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[k][r['Counter_Name']] += 1
 dur = {}
 for f in glob.glob('$R/gpurun_out/clk/${W}_trace*kernel_stats.csv'):
     for r in csv.DictReader(open(f)):
-        dur[r['Name'].split('(')[0][:60]] = (float(r['AverageNs']), int(r['Calls']), float(r['Percentage']))
+        dur[key(r['Name'])] = (float(r['AverageNs']), int(r['Calls']), float(r['Percentage']))
 out = {}
 for k, (ns, calls, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2])[:14]:
     if k not in tot: continue
