@@ -521,8 +521,6 @@ ROOFLINE_KIND = {
     "rcmarl_mid_fit": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 read + 20 fp32 written"),
     "rcmarl_w1_split": ("hbm", "reads W1 (4 B/weight), writes three bf16 pieces (6 B/weight)"),
     "rcmarl_layer1_forward_lattice": ("mfma_bf16x3", ""),
-    "rcmarl_fit_fused_lattice": ("mfma_bf16x3", ""),
-    "rcmarl_layer1_backward_sgd_lattice_fit": ("mfma_bf16x3", ""),
     "rcmarl_layer1_backward_sgd_lattice": ("mfma_bf16x3", ""),
 }
 
@@ -584,7 +582,7 @@ def rooflines(tlib, ksum, workload=None):
                 "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                 "algorithmic_flops_per_launch": flops / n,
                 "note": note or "fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense fp32 peak 157.3 TFLOP/s"}
-    gemm = next((k for k in ("rcmarl_layer1_backward_sgd_lattice_fit", "rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward")
+    gemm = next((k for k in ("rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward")
                  if k in ksum), None)
     k1 = next((k for k in ("rcmarl_consensus_params_circulant", "rcmarl_consensus_params") if k in ksum), None)
     return (obj(dom), obj(k1) if k1 else None,

@@ -117,37 +117,6 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
                            int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
 
-/* Fused local-fit step of the lattice path (20-unit nets, any input width; csrc/lattice_fit.hip):
- *   rcmarl_fit_fused_lattice = rcmarl_layer1_forward_lattice + rcmarl_mid_fit_lattice in ONE launch -- the layer-1
- * activations stay in registers between the GEMM's k-loop and layers 2-3 (no a1t round trip through HBM).  Same
- * outputs: dzp (dz1 as three exact bf16 pieces, bit-identical to rcmarl_mid_fit_lattice) and
- * partials[S][N][rcmarl_fit_fused_chunks(B)][rcmarl_fit_partial_size(hid)] for rcmarl_small_sgd_chunks.  Replaces one full-batch step of the
- * Keras fit at agents/resilient_CAC_agents.py:118,136.  Its A operand wpf is W' in FIT ORDER (rows permuted so that
- * every lane ends the k-loop with whole agents; rcmarl_fit_rows(N) rows): produced by rcmarl_w1_split_fit, or by
- * rcmarl_layer1_backward_sgd_lattice_fit from the previous step's update. */
-int rcmarl_fit_rows(int n_agents);
-int rcmarl_fit_fused_chunks(int B);      /* records per (seed, agent) it writes: apply with rcmarl_small_sgd_chunks */
-int rcmarl_w1_split_fit(const float* theta, const float* alpha, void* wpf, int S, int N, int in_dim, int hid, int ldp,
-                        int wpf_rt, int wpf_kt, void* stream);
-int rcmarl_fit_fused_lattice(const void* kp, int kp_rt, int kp_kt, const void* wpf, int wpf_rt, int wpf_kt,
-                             const float* theta, const float* y, float* partials, void* dzp, int dzp_rt, int dzp_kt,
-                             int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
-int rcmarl_layer1_backward_sgd_lattice_fit(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
-                                           int dzp_kt, const float* alpha, float* theta, const int* mask, int S, int N,
-                                           int B, int in_dim, int hid, int ldp, float lr, void* wpf_out, int wpf_rt,
-                                           int wpf_kt, void* stream);
-
-/* Fused local-fit step for SMALL networks (in_dim <= 32: the reference's own 5-agent configurations).  One launch
- * = rcmarl_layer1_forward + rcmarl_mid_fit + the gradient of rcmarl_layer1_backward_sgd: layer 1 is computed
- * from the replay rows inside the kernel (no a1t round trip) and gW1 = X^T dz1 joins the per-chunk record,
- * partials[S][N][nchunk][rcmarl_fit_small_partial_size(hid, in_dim)] = [rcmarl_mid_fit record | gW1(in_dim x hid)].
- * rcmarl_small_sgd_full then applies the whole record (W1 included) to theta. */
-int rcmarl_fit_small_partial_size(int hid, int in_dim);
-int rcmarl_fit_step_small(const float* x, long x_seed_stride, const float* theta, const float* y, float* partials,
-                          int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
-int rcmarl_small_sgd_full(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N, int B,
-                          int in_dim, int hid, int ldp, float lr, void* stream);
-
 /* Shuffle permutations of the adversaries' mini-batch fits (Keras fit(shuffle=True) inside
  * agents/adversarial_CAC_agents.py:38-41,131-135,163-165,237-253).  TensorFlow's shuffle RNG is not reproducible
  * outside TensorFlow; the shuffle is DEFINED here (csrc/shuffle.hip; same statement in the oracle):
@@ -158,10 +127,6 @@ int rcmarl_shuffle_perms(const void* seeds, const int* calls, int n, int epochs,
 /* reduce the partials over chunks and apply SGD to b1,W2,b2,W3,b3; loss_out[S][N] (or NULL) = MSE. */
 int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
                      int B, int in_dim, int hid, int ldp, float lr, void* stream);
-/* the same for partials[S][N][nchunk][..] with an explicit nchunk (producers whose chunk is not 256 replay rows) */
-int rcmarl_small_sgd_chunks(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
-                            int B, int in_dim, int hid, int ldp, float lr, int nchunk, void* stream);
-
 /* K6: out[s][n][b] = head(a1t) (r_applied NULL), or the TD target r_applied + gamma*V
  * (local_TD_target, agents/resilient_CAC_agents.py:114-115).  Also serves r_team, V, nV of :95-97. */
 int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma, float* out, int S,

@@ -61,24 +61,6 @@ SIGNATURES = {
     # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_stream],
-    # fused local-fit step of the lattice path, csrc/lattice_fit.hip
-    "rcmarl_fit_rows": [c_int],
-    "rcmarl_fit_fused_chunks": [c_int],
-    # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, nchunk, stream
-    "rcmarl_small_sgd_chunks": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_stream],
-    # theta, alpha, wpf, S, N, in_dim, hid, ldp, wpf_rt, wpf_kt, stream
-    "rcmarl_w1_split_fit": [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # kp, kp_rt, kp_kt, wpf, wpf_rt, wpf_kt, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
-    "rcmarl_fit_fused_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int,
-                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
-    "rcmarl_layer1_backward_sgd_lattice_fit": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_u8p, c_int,
-                                               c_int, c_int, c_int, c_int, c_int, c_float, c_u8p, c_int, c_int, c_stream],
-    "rcmarl_fit_small_partial_size": [c_int, c_int],
-    # x, x_seed_stride, theta, y, partials, S, N, B, in_dim, hid, ldp, ldb, stream
-    "rcmarl_fit_step_small": [c_f32p, c_long, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                              c_stream],
-    # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
-    "rcmarl_small_sgd_full": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     # seeds(u64[S]), calls(int[n]), n, epochs, B, perm(int[S][n][epochs][B]), S, stream
     "rcmarl_shuffle_perms": [C.c_void_p, c_i32p, c_int, c_int, c_int, c_i32p, c_int, c_stream],
     # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream
@@ -173,8 +155,8 @@ SIGNATURES = {
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_rows", "rcmarl_fit_fused_chunks", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
-             "rcmarl_fit_small_partial_size", "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
+             "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
              "rcmarl_consensus_params_circulant_supported"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",

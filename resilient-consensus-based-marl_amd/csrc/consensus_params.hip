@@ -405,15 +405,14 @@ __global__ __launch_bounds__(THREADS) void k_consensus_params_circ(const float* 
   }
 }
 
-// G per (d, H): measured choice among the generated SelMid networks (RCMARL_K1_G overrides where two exist)
+// G per (d, H): measured choice among the generated SelMid networks
 int circ_group(int d, int H) {
-  static const int forced = getenv("RCMARL_K1_G") ? atoi(getenv("RCMARL_K1_G")) : 0;
   if (d == 4 && H == 1) return 2;
   if (d == 6 && H == 2) return 2;
   if (d == 10 && H == 4) return 4;
-  if (d == 18 && H == 8) return forced == 6 ? 6 : 4;
+  if (d == 18 && H == 8) return 4;
   if (d == 34 && H == 16) return 4;
-  if (d == 66 && H == 32) return forced == 4 ? 4 : 8;
+  if (d == 66 && H == 32) return 8;
   return 0;
 }
 
@@ -568,19 +567,15 @@ RCMARL_EXPORT int rcmarl_consensus_params_circulant(const float* msg, float* the
     return RCMARL_ERR_ARG;
   if (!rcmarl_consensus_params_circulant_supported(N, d, H)) return RCMARL_ERR_UNSUPPORTED;
   const int G = circ_group(d, H);
-  static const int tc_env = getenv("RCMARL_K1_TC") ? atoi(getenv("RCMARL_K1_TC")) : 0;
   // 32 columns = one 128-byte line per row and two resident workgroups per CU up to N ~ 580 (measured best: 64-column
   // tiles leave one workgroup per CU and coarser tile counts); 16 columns only when nothing wider fits
   int TC = circ_smem(N, d, G, 32) <= 158 * 1024 ? 32 : 16;
-  if ((tc_env == 64 || tc_env == 16) && circ_smem(N, d, G, tc_env) <= 158 * 1024) TC = tc_env;
   const size_t smem = circ_smem(N, d, G, TC);
   const int tps = rc_ceil_div(P_hid, TC), tot = tps * S;
   int wg_cu = (int)((160 * 1024) / (smem + 1024));
   const int wg_threads = d >= 34 ? 512 : 1024;        // (RC_CIRC_CASE below)
   if (wg_cu > 2048 / wg_threads) wg_cu = 2048 / wg_threads;          // resident workgroups only: the tile loop is persistent
   if (wg_cu < 1) wg_cu = 1;
-  static const int wgcu_env = getenv("RCMARL_K1_WGCU") ? atoi(getenv("RCMARL_K1_WGCU")) : 0;     // (tuning aid)
-  if (wgcu_env > 0) wg_cu = wgcu_env;
   int nwg = 256 * wg_cu;
   nwg = rc_persistent_grid(nwg);
   if (nwg > tot) nwg = tot;

@@ -141,7 +141,7 @@ def emit_mid(n, lo, cnt, kept, out):
 def mid_combos():
     """(d, H, G) of the circulant kernel (consensus_params.hip): the d-G+1 inputs shared by G consecutive agents,
     of which the middle G+1 order statistics (ranks H-G+1 .. H+1) are needed.  d == 2H+2, H >= G-1."""
-    for d, h, g in [(4, 1, 2), (6, 2, 2), (10, 4, 4), (18, 8, 4), (18, 8, 6), (34, 16, 4), (66, 32, 4), (66, 32, 8)]:
+    for d, h, g in [(4, 1, 2), (6, 2, 2), (10, 4, 4), (18, 8, 4), (34, 16, 4), (66, 32, 8)]:      # = circ_group() of the kernel
         assert d == 2 * h + 2 and h >= g - 1
         yield d, h, g
 

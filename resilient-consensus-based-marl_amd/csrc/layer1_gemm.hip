@@ -284,15 +284,14 @@ bool small_enabled() {
   return v != 0;
 }
 
-// 0 = generic kernels only, 1 = fast path single-buffered LDS (default: 3 workgroups per CU),
-// 2 = fast path double-buffered LDS (one barrier per tile, but 2 workgroups per CU; measured slower).
+// 0 = generic kernels only, 1 = fast path (default).  (A double-buffered LDS form of the fast path measured slower.)
 // RCMARL_GEMM is a tuning/bisecting knob, read once.
 int gemm_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("RCMARL_GEMM");
     v = e ? atoi(e) : 1;
-    if (v < 0 || v > 2) v = 1;
+    if (v < 0 || v > 1) v = 1;
   }
   return v;
 }
@@ -319,8 +318,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward(const float* x, long x_seed_stride, cons
   if (hid == 20 && in_dim <= 32 && small_enabled()) {
     // chunks per workgroup: all of them once S*N workgroups fill the chip several times over, else one (short rows x few nets)
     const int nchunk = rc_ceil_div(B, small::SROWS);
-    static const int cpw_env = getenv("RCMARL_SMALL_FWD_CPW") ? atoi(getenv("RCMARL_SMALL_FWD_CPW")) : 0;
-    int cpw = cpw_env > 0 ? cpw_env : ((long)S * N >= 2048 ? nchunk : ((long)S * N >= 512 ? (nchunk + 3) / 4 : 1));
+    int cpw = (long)S * N >= 2048 ? nchunk : ((long)S * N >= 512 ? (nchunk + 3) / 4 : 1);
     if (cpw > nchunk) cpw = nchunk;
     const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(256);
     if (in_dim <= 16) {
@@ -333,12 +331,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward(const float* x, long x_seed_stride, cons
   if (var > 0 && hid == 20 && (in_dim % fast::FBK) == 0 && aligned16(x) && (x_seed_stride & 3) == 0) {
     const dim3 grid(rc_ceil_div(B, fast::FBN), rc_ceil_div(N * 20, 160), S), block(256);
     const size_t smem = fast::smem_fwd(var);
-    if (var == 1) {
-      RCMARL_LAUNCH((fast::k_fwd<1>), grid, block, smem, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
-    } else {
-      if (!want_lds(fast::k_fwd<2>, smem)) return RCMARL_ERR_LAUNCH;
-      RCMARL_LAUNCH((fast::k_fwd<2>), grid, block, smem, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
-    }
+    RCMARL_LAUNCH((fast::k_fwd<1>), grid, block, smem, stream, x, x_seed_stride, theta, a1t, N, B, in_dim, ldp, ldb);
     return rcmarl_check_launch();
   }
   const dim3 grid(rc_ceil_div(B, BN), rc_ceil_div(N * hid, BM), S), block(256);
@@ -366,14 +359,8 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd(const float* x, long x_seed_stride,
     const dim3 grid(rc_ceil_div(N * 20, fast::FBN), rc_ceil_div(in_dim, 128), S), block(256);
     const size_t smem = fast::smem_bwd(var);
     const fast::ApplySgd ap{lr};
-    if (var == 1) {
-      RCMARL_LAUNCH((fast::k_bwd<1, fast::ApplySgd>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
+    RCMARL_LAUNCH((fast::k_bwd<1, fast::ApplySgd>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
                     in_dim, ldp, ldb, ap);
-    } else {
-      if (!want_lds(fast::k_bwd<2, fast::ApplySgd>, smem)) return RCMARL_ERR_LAUNCH;
-      RCMARL_LAUNCH((fast::k_bwd<2, fast::ApplySgd>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
-                    in_dim, ldp, ldb, ap);
-    }
     return rcmarl_check_launch();
   }
   const dim3 grid(rc_ceil_div(N * hid, BN), rc_ceil_div(in_dim, BM), S), block(256);
@@ -392,14 +379,8 @@ RCMARL_EXPORT int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride
     const dim3 grid(rc_ceil_div(N * 20, fast::FBN), rc_ceil_div(in_dim, 128), S), block(256);
     const size_t smem = fast::smem_bwd(var);
     const fast::ApplyAdam ap{adam_m, adam_v, alpha, one_m_b1, one_m_b2, eps};
-    if (var == 1) {
-      RCMARL_LAUNCH((fast::k_bwd<1, fast::ApplyAdam>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
+    RCMARL_LAUNCH((fast::k_bwd<1, fast::ApplyAdam>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
                     in_dim, ldp, ldb, ap);
-    } else {
-      if (!want_lds(fast::k_bwd<2, fast::ApplyAdam>, smem)) return RCMARL_ERR_LAUNCH;
-      RCMARL_LAUNCH((fast::k_bwd<2, fast::ApplyAdam>), grid, block, smem, stream, x, x_seed_stride, dz1t, theta, mask, N, B,
-                    in_dim, ldp, ldb, ap);
-    }
     return rcmarl_check_launch();
   }
   const dim3 grid(rc_ceil_div(N * hid, BN), rc_ceil_div(in_dim, BM), S), block(256);

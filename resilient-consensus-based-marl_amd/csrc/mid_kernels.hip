@@ -86,465 +86,28 @@ __device__ __forceinline__ void block_reduce_store(float (&vals)[K], float* red,
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int HID>
-__global__ __launch_bounds__(256) void k_mid_fit(float* __restrict__ a1t, const float* __restrict__ theta,
-                                                 const float* __restrict__ y, float* __restrict__ partials, int N,
-                                                 int B, int in_dim, int ldp, int ldb, int nchunk) {
-  typedef FitPart<HID> PT;
-  __shared__ float sA[HID * LDR];
-  __shared__ float sD[HID * LDR];
-  __shared__ float red[4 * PT::NSMALL];
-  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
-  const int r = threadIdx.x, b = chunk * ROWS + r;
-  const bool valid = b < B;
-  const NetGeom g = make_geom(in_dim, HID, 1);
-  const float* th = theta + ((long)s * N + i) * ldp;
-  const long row0 = ((long)s * N + i) * HID;
-  float a1[HID], a2[HID], dz2[HID];
-  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
-  layer2<HID>(th, g, a1, a2);
-  const float v = head1<HID>(th + g.o_W3, th[g.o_b3], a2);
-  const float diff = valid ? v - y[((long)s * N + i) * ldb + b] : 0.f;
-  const float dv = (2.0f * diff) / (float)B;
-  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
-  float small[PT::NSMALL];                     // [gb2 | gW3 | gb3 | gb1 | loss] as in FitPart
-  // backward through layers 3 and 2
-#pragma unroll
-  for (int k = 0; k < HID; ++k) {
-    dz2[k] = dv * th[g.o_W3 + k] * rc_lrelu_grad_from_act(a2[k]);
-    small[PT::gb2 - PT::gb2 + k] = dz2[k];
-    small[PT::gW3 - PT::gb2 + k] = a2[k] * dv;
-  }
-  small[PT::gb3 - PT::gb2] = dv;
-  small[PT::loss - PT::gb2] = diff * diff;
-#pragma unroll
-  for (int k = 0; k < HID; ++k) {
-    sA[k * LDR + r] = a1[k];
-    sD[k * LDR + r] = dz2[k];
-  }
-  // dz1 = (dz2 @ W2^T) * lrelu'(z1); overwrite a1t in place (feature-major, coalesced)
-#pragma unroll
-  for (int j = 0; j < HID; ++j) {
-    float da1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < HID; ++k) da1 = fmaf(dz2[k], th[g.o_W2 + j * HID + k], da1);
-    const float dz1 = da1 * rc_lrelu_grad_from_act(a1[j]);
-    small[PT::gb1 - PT::gb2 + j] = dz1;
-    if (valid) a1t[(row0 + j) * ldb + b] = dz1;
-  }
-  block_reduce_store<PT::NSMALL>(small, red, out + PT::gb2);   // (its barriers also publish sA/sD)
-  // gW2[j][k] = sum_r a1[r][j] * dz2[r][k]
-  for (int e = r; e < HID * HID; e += ROWS) {
-    const int j = e / HID, k = e - j * HID;
-    float acc = 0.f;
-    for (int q = 0; q < ROWS; ++q) acc = fmaf(sA[j * LDR + q], sD[k * LDR + q], acc);
-    out[PT::gW2 + e] = acc;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_mid_fit, matrix-core reductions.  Everything a workgroup must SUM OVER ITS 256 ROWS is a
-// product of two [rows x <=22] panels, so it runs on the f32 MFMA instead of LDS loops / DPP trees:
-//   G1 = [a1 | 1]^T [dz2]                  -> gW2 (20x20), gb2 (row 20)
-//   G2 = [a2 | 1]^T [dz1 | dv | diff^2]    -> gW3 (col 20), gb1 (row 20), gb3 (20,20), loss (20,21)
-// v_mfma_f32_32x32x2_f32 consumes two rows per instruction (A[i][k=l>>5], B[k=l>>5][j]); the panels
-// are staged unit-major in LDS (sP[unit][row], stride 257 -> conflict-free fragment reads), each
-// wave reduces its 64 rows (32 MFMAs per product) and the four per-wave 32x32 partials are summed
-// through LDS.  Same fp32 products as before, different (k-ordered) summation order.
-// EMIT: instead of overwriting a1t with dz1 (fp32, feature-major), write dz1 as three exact bf16
-// pieces in the packed layout the lattice backward GEMM reads (rcmarl_lattice.h: rows = (agent,unit)
-// column, reduction = replay row); rows b >= B of the last chunk are written as zeros.
-template <int HID, bool EMIT>
-__global__ __launch_bounds__(256) void k_mid_fit_mfma(float* __restrict__ a1t, const float* __restrict__ theta,
-                                                      const float* __restrict__ y, float* __restrict__ partials,
-                                                      int N, int B, int in_dim, int ldp, int ldb, int nchunk,
-                                                      unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
-  typedef FitPart<HID> PT;
-  constexpr int NB2 = HID + 2;                       // columns of the second B panel
-  __shared__ float sA[HID * LDR];
-  __shared__ float sB[NB2 * LDR];
-  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
-  const int r = threadIdx.x, b = chunk * ROWS + r;
-  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
-  const bool valid = b < B;
-  const NetGeom g = make_geom(in_dim, HID, 1);
-  const float* th = theta + ((long)s * N + i) * ldp;
-  const long row0 = ((long)s * N + i) * HID;
-  float a1[HID], a2[HID], dz2[HID], dz1[HID];
-  load_a1<HID>(a1t, row0, ldb, b, valid, a1);
-  layer2<HID>(th, g, a1, a2);
-  const float v = head1<HID>(th + g.o_W3, th[g.o_b3], a2);
-  const float diff = valid ? v - y[((long)s * N + i) * ldb + b] : 0.f;
-  const float dv = (2.0f * diff) / (float)B;
-#pragma unroll
-  for (int k = 0; k < HID; ++k) dz2[k] = dv * th[g.o_W3 + k] * rc_lrelu_grad_from_act(a2[k]);
-#pragma unroll
-  for (int j = 0; j < HID; ++j) {
-    float da1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < HID; ++k) da1 = fmaf(dz2[k], th[g.o_W2 + j * HID + k], da1);
-    dz1[j] = da1 * rc_lrelu_grad_from_act(a1[j]);
-    if (EMIT) {
-      if ((b >> 5) < dzp_kt) {
-        unsigned h, m, l;
-        rc_split3(dz1[j], h, m, l);
-        unsigned char* q = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + rc_pk_offset(i * HID + j, b, 0, dzp_kt, 3);
-        *reinterpret_cast<unsigned short*>(q) = (unsigned short)h;
-        *reinterpret_cast<unsigned short*>(q + RC_PK_BLOCK) = (unsigned short)m;
-        *reinterpret_cast<unsigned short*>(q + 2 * RC_PK_BLOCK) = (unsigned short)l;
-      }
-    } else {
-      if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];   // in place, feature-major, coalesced
-    }
-  }
-  // rows beyond B contribute zero: their dz2/dz1/dv/diff are zero because diff is
-  rc_f32x16 acc1, acc2;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) { acc1[q] = 0.f; acc2[q] = 0.f; }
-  const int ia = l31 < HID ? l31 : 0;                // clamped panel row for the fragment loads
-  const float a_const = l31 == HID ? 1.f : 0.f;     // A row 20 = ones, rows 21.. = zero
-  // ---- product 1
-#pragma unroll
-  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a1[k]; sB[k * LDR + r] = dz2[k]; }
-  __syncthreads();
-#pragma unroll 4
-  for (int m = 0; m < 32; ++m) {
-    const int rr = wave * 64 + 2 * m + half;
-    const float av = l31 < HID ? sA[ia * LDR + rr] : a_const;
-    const float bv = l31 < HID ? sB[ia * LDR + rr] : 0.f;
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc1, 0, 0, 0);
-  }
-  __syncthreads();
-  // ---- product 2
-#pragma unroll
-  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a2[k]; sB[k * LDR + r] = dz1[k]; }
-  sB[HID * LDR + r] = dv;
-  sB[(HID + 1) * LDR + r] = diff * diff;
-  __syncthreads();
-  const int ib = l31 < NB2 ? l31 : 0;
-#pragma unroll 4
-  for (int m = 0; m < 32; ++m) {
-    const int rr = wave * 64 + 2 * m + half;
-    const float av = l31 < HID ? sA[ia * LDR + rr] : a_const;
-    const float bv = l31 < NB2 ? sB[ib * LDR + rr] : 0.f;
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2, 0, 0, 0);
-  }
-  __syncthreads();
-  // ---- per-wave partial records -> LDS (reusing sA: 4 x SIZE floats), then summed over the 4 waves
-  float* rec = sA + wave * PT::SIZE;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int row = (q & 3) + 8 * (q >> 2) + 4 * half, col = l31;     // D[row][col] of the 32x32 result
-    if (row < HID && col < HID) rec[PT::gW2 + row * HID + col] = acc1[q];
-    if (row == HID && col < HID) { rec[PT::gb2 + col] = acc1[q]; rec[PT::gb1 + col] = acc2[q]; }
-    if (row < HID && col == HID) rec[PT::gW3 + row] = acc2[q];
-    if (row == HID && col == HID) rec[PT::gb3] = acc2[q];
-    if (row == HID && col == HID + 1) rec[PT::loss] = acc2[q];
-  }
-  __syncthreads();
-  float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
-  for (int e = r; e < PT::SIZE; e += ROWS)
-    out[e] = (sA[e] + sA[PT::SIZE + e]) + (sA[2 * PT::SIZE + e] + sA[3 * PT::SIZE + e]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_mid_fit, third form: same arithmetic (every fmaf chain keeps its order -> bit-identical dz1, a2, v),
-// restructured for the VALU issue rate, which is what bounds this kernel (PMC: 1929 VALU + 769 SALU
-// instructions per wavefront before, against 400 packed FMAs of real work):
-//   * the agent's W2 (row-major and transposed), b2, W3 live in LDS; a row of 20 weights arrives with five
-//     broadcast ds_read_b128 instead of a latency-bound s_load + s_waitcnt per row;
-//   * both 20x20 products are axpy-shaped, so they run as v_pk_fma_f32 (two units per instruction);
-//   * the matrix-core reductions read their 32-row fragments from panels that CONTAIN the constant rows
-//     (ones / zeros), so no per-fragment select;
-//   * the bf16 pieces of dz1 come from v_cvt_pk_bf16_f32 pairs and leave through unconditional 2-byte stores.
-// KP > 0 ("fused layer 1", small networks: in_dim <= KP <= 32, the reference's own 5-agent configurations): the
-// workgroup also computes layer 1 from the replay row (in_dim x HID weights in LDS) instead of reading a1t, and
-// reduces gW1 = X^T dz1 as a second matrix-core product, so one launch replaces layer1_forward + mid_fit +
-// layer1_backward of a local-fit step and the a1t round trip through HBM disappears.  The record then is
-// [FitPart | gW1(in_dim x HID)] (rec_size floats); rcmarl_small_sgd_full applies all of it.
-template <int HID, bool EMIT, int KP>
-__global__ __launch_bounds__(256, 3) void k_mid_fit_v3(float* __restrict__ a1t, const float* __restrict__ theta,
-                                                    const float* __restrict__ y, float* __restrict__ partials, int N,
-                                                    int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
-                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
-                                                    const float* __restrict__ x, long x_seed_stride, int rec_size) {
-  static_assert(!(EMIT && KP > 0) && (KP == 0 || KP == 16 || KP == 32), "fused layer 1 is an f32-path variant");
-  constexpr bool FUSE1 = KP > 0;
-  static_assert(HID % 4 == 0, "rows of W2 are read as float4");
-  typedef FitPart<HID> PT;
-  constexpr int RA = HID + 2;                        // sA rows: HID data | ones | zeros
-  constexpr int RB = HID + 3;                        // sB rows: HID data | dv | diff^2 | zeros
-  constexpr int H2 = HID / 2;
-  __shared__ __attribute__((aligned(16))) float sW2[HID * HID];
-  __shared__ __attribute__((aligned(16))) float sW2T[HID * HID];
-  __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];        // b2 | W3 | b3
-  __shared__ float sP[(RA + RB) * LDR];            // both panels; reused for the 32x32 results of the 4 wavefronts
-  __shared__ __attribute__((aligned(16))) float sW1[FUSE1 ? KP * HID + HID : 4];      // fused: W1 rows (zero padded) | b1
-  __shared__ float sX[FUSE1 ? ROWS * KP : 4];        // fused: the chunk's replay rows exactly as they lie in memory
-  constexpr int WSZ = FUSE1 ? 1088 + 32 * KP : 1088; // floats of results per wavefront: G1 | sums | (G0: KP x 32)
-  static_assert((RA + RB) * LDR >= 4 * WSZ && 2 * HID + 2 <= 64, "result area fits in the panel buffer");
-  float* sA = sP;
-  float* sB = sP + RA * LDR;
-  // one workgroup walks `cpw` consecutive 256-row chunks of one agent: the weights are staged once, and the
-  // activations of chunk c+1 are requested before chunk c is processed (HBM latency hides behind the VALU phase)
-  const int s = blockIdx.z, i = blockIdx.y;
-  const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
-  const int r = threadIdx.x;
-  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
-  const NetGeom g = make_geom(in_dim, HID, 1);
-  const float* th = theta + ((long)s * N + i) * ldp;
-  const long row0 = ((long)s * N + i) * HID;
-  for (int e = r; e < HID * HID; e += ROWS) {
-    const float w = th[g.o_W2 + e];
-    const int j = e / HID, k = e - j * HID;
-    sW2[e] = w;
-    sW2T[k * HID + j] = w;
-  }
-  if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];       // b2, W3, b3 are contiguous in the parameter row
-  if (FUSE1) {
-    for (int e = r; e < KP * HID; e += ROWS) sW1[e] = e < in_dim * HID ? th[e] : 0.f;
-    if (r < HID) sW1[KP * HID + r] = th[g.o_b1 + r];
-  }
-  sA[HID * LDR + r] = 1.f;                           // constant rows of the panels: ones (gb2), zeros (padding)
-  sA[(HID + 1) * LDR + r] = 0.f;
-  sB[(HID + 2) * LDR + r] = 0.f;
-  const float* yrow = y + ((long)s * N + i) * ldb;
-  float a1[HID], ycur;
-  if (!FUSE1) {
-    const int b0 = c_begin * ROWS + r;
-    load_a1<HID>(a1t, row0, ldb, b0, b0 < B, a1);
-    ycur = b0 < B ? yrow[b0] : 0.f;
-  }
-  __syncthreads();
-  for (int chunk = c_begin; chunk < c_end; ++chunk) {
-  const int b = chunk * ROWS + r;
-  const bool valid = b < B;
-  if (FUSE1) {
-    // ---- layer 1 from the replay rows: a1[j] = lrelu(sum_k x[k] W1[k][j] + b1[j]), k ascending (= the GEMM's order).
-    // The chunk's 256 rows are one contiguous run of the replay tensor: coalesced copy into LDS, row-major.
-    const float* xg = x + (long)s * x_seed_stride + (long)chunk * ROWS * in_dim;
-    const int n_valid = min(ROWS, B - chunk * ROWS) * in_dim;
-    for (int e = r; e < ROWS * in_dim; e += ROWS) sX[e] = e < n_valid ? xg[e] : 0.f;
-    ycur = valid ? yrow[b] : 0.f;
-    __syncthreads();
-    rc_f2 z1[H2];
-#pragma unroll
-    for (int q = 0; q < H2; ++q) z1[q] = rc_f2{0.f, 0.f};
-#pragma unroll 2
-    for (int k = 0; k < in_dim; ++k) {
-      const rc_f2 xk = rc_bcast2(sX[r * in_dim + k]);
-#pragma unroll
-      for (int q4 = 0; q4 < HID / 4; ++q4) {
-        const float4 w = *reinterpret_cast<const float4*>(&sW1[k * HID + 4 * q4]);
-        z1[2 * q4] = rc_fma2(xk, rc_f2{w.x, w.y}, z1[2 * q4]);
-        z1[2 * q4 + 1] = rc_fma2(xk, rc_f2{w.z, w.w}, z1[2 * q4 + 1]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < H2; ++q) {
-      a1[2 * q] = rc_lrelu(z1[q].x + sW1[KP * HID + 2 * q]);
-      a1[2 * q + 1] = rc_lrelu(z1[q].y + sW1[KP * HID + 2 * q + 1]);
-    }
-  }
-  // ---- layer 2 forward: a2[k] = lrelu(sum_j a1[j] W2[j][k] + b2[k]), j ascending
-  rc_f2 z2[H2];
-#pragma unroll
-  for (int q = 0; q < H2; ++q) z2[q] = rc_f2{0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < HID; ++j) {
-    const rc_f2 aj = rc_bcast2(a1[j]);
-#pragma unroll
-    for (int q4 = 0; q4 < HID / 4; ++q4) {
-      const float4 w = *reinterpret_cast<const float4*>(&sW2[j * HID + 4 * q4]);
-      z2[2 * q4] = rc_fma2(aj, rc_f2{w.x, w.y}, z2[2 * q4]);
-      z2[2 * q4 + 1] = rc_fma2(aj, rc_f2{w.z, w.w}, z2[2 * q4 + 1]);
-    }
-  }
-  float a2[HID], dz2[HID];
-  float v = 0.f;
-#pragma unroll
-  for (int q = 0; q < H2; ++q) {
-    a2[2 * q] = rc_lrelu(z2[q].x + sV[2 * q]);
-    a2[2 * q + 1] = rc_lrelu(z2[q].y + sV[2 * q + 1]);
-  }
-#pragma unroll
-  for (int k = 0; k < HID; ++k) v = fmaf(a2[k], sV[HID + k], v);
-  v += sV[2 * HID];
-  const float diff = valid ? v - ycur : 0.f;
-  const float dv = (2.0f * diff) / (float)B;
-#pragma unroll
-  for (int k = 0; k < HID; ++k) dz2[k] = dv * sV[HID + k] * rc_lrelu_grad_from_act(a2[k]);
-  // ---- layer 2 backward: dz1[j] = (sum_k dz2[k] W2[j][k]) * lrelu'(z1[j]), k ascending
-  rc_f2 da[H2];
-#pragma unroll
-  for (int q = 0; q < H2; ++q) da[q] = rc_f2{0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < HID; ++k) {
-    const rc_f2 dk = rc_bcast2(dz2[k]);
-#pragma unroll
-    for (int q4 = 0; q4 < HID / 4; ++q4) {
-      const float4 w = *reinterpret_cast<const float4*>(&sW2T[k * HID + 4 * q4]);
-      da[2 * q4] = rc_fma2(dk, rc_f2{w.x, w.y}, da[2 * q4]);
-      da[2 * q4 + 1] = rc_fma2(dk, rc_f2{w.z, w.w}, da[2 * q4 + 1]);
-    }
-  }
-  float dz1[HID];
-#pragma unroll
-  for (int q = 0; q < H2; ++q) {
-    dz1[2 * q] = da[q].x * rc_lrelu_grad_from_act(a1[2 * q]);
-    dz1[2 * q + 1] = da[q].y * rc_lrelu_grad_from_act(a1[2 * q + 1]);
-  }
-  if (EMIT) {
-    // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + j (uniform), k = b (lane): the lane part of the byte
-    // offset is fixed, the row part XORs bits 4-5
-    // (workgroup-uniform pointer + 32-bit lane offset -> saddr/voffset stores, no 64-bit VALU address math)
-    unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + (long)(chunk * (ROWS / 32)) * (3 * RC_PK_BLOCK);
-    const unsigned lane_off = (unsigned)(r >> 5) * (3 * RC_PK_BLOCK) + (((r & 31) >> 3) << 4) + (r & 7) * 2;
-    const unsigned lane_off1 = lane_off + RC_PK_BLOCK, lane_off2 = lane_off + 2 * RC_PK_BLOCK;
-#pragma unroll
-    for (int q = 0; q < H2; ++q) {
-      unsigned h, m, l;
-      rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int row = i * HID + 2 * q + u;
-        unsigned char* p = base + (long)(row >> 7) * dzp_kt * (3 * RC_PK_BLOCK) + (row & 127) * 64;
-        const unsigned sw = (unsigned)(((row >> 2) & 3) << 4);     // the piece offsets ride in the lane offset
-        *reinterpret_cast<unsigned short*>(p + (lane_off ^ sw)) = (unsigned short)(u ? h >> 16 : h);
-        *reinterpret_cast<unsigned short*>(p + (lane_off1 ^ sw)) = (unsigned short)(u ? m >> 16 : m);
-        *reinterpret_cast<unsigned short*>(p + (lane_off2 ^ sw)) = (unsigned short)(u ? l >> 16 : l);
-      }
-    }
-  } else if (!FUSE1) {
-#pragma unroll
-    for (int j = 0; j < HID; ++j)
-      if (valid) a1t[(row0 + j) * ldb + b] = dz1[j];
-  }
-  // ---- reductions over the 256 rows.  Only gW2 = a1^T dz2 (and gb2, its ones row) is an outer product: it runs
-  // on the f32 matrix core, G1 = [a1 | 1]^T [dz2], 32 MFMAs per wavefront.  Everything else is a plain sum over
-  // rows of a per-lane value -- gW3[k] = sum a2[k]*dv, gb1[j] = sum dz1[j], gb3 = sum dv, loss = sum diff^2 (2*HID+2
-  // values): DPP wave reductions, issued BETWEEN the MFMAs so they run in the matrix pipe's shadow.
-  constexpr int NS = 2 * HID + 2;
-  float sm[NS];
-#pragma unroll
-  for (int k = 0; k < HID; ++k) { sm[k] = a2[k] * dv; sm[HID + k] = dz1[k]; }
-  sm[2 * HID] = dv;
-  sm[2 * HID + 1] = diff * diff;
-  rc_f32x16 acc1;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
-  const int ia = (l31 < HID + 1 ? l31 : HID + 1) * LDR + wave * 64 + half;       // rows >= HID+1 -> zeros
-  const int ib1 = (l31 < HID ? l31 : HID + 2) * LDR + wave * 64 + half;
-#pragma unroll
-  for (int k = 0; k < HID; ++k) { sA[k * LDR + r] = a1[k]; sB[k * LDR + r] = dz2[k]; }
-  if (FUSE1) { sA[HID * LDR + r] = 1.f; sA[(HID + 1) * LDR + r] = 0.f; }      // (the larger fused result area reaches them)
-  if (!FUSE1 && chunk + 1 < c_end) {                 // a1 is dead from here on: request the next chunk's rows now,
-    const int bn = b + ROWS;                         // they arrive behind the matrix-core phase
-    load_a1<HID>(a1t, row0, ldb, bn, bn < B, a1);
-    ycur = bn < B ? yrow[bn] : 0.f;
-  }
-  __syncthreads();
-  static_assert(NS % 3 == 0 && NS / 3 <= 16, "three sums ride behind every second MFMA");
-#pragma unroll
-  for (int m = 0; m < 32; ++m) {
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[ia + 2 * m], sB[ib1 + 2 * m], acc1, 0, 0, 0);
-    if ((m & 1) == 0 && 3 * (m >> 1) < NS) rc_wave_sum3_lane63(sm[3 * (m >> 1)], sm[3 * (m >> 1) + 1], sm[3 * (m >> 1) + 2]);
-  }
-  // second product (fused): gW1 = X^T dz1 on v_mfma_f32_16x16x4_f32 -- KP/16 feature tiles x 2 unit tiles, 4 rows a
-  // step.  A[i = feature][k = row] comes straight from the packed replay rows in LDS, B[k = row][j = unit] from the
-  // dz1 panel (units >= HID read the zero row).
-  constexpr int FT = FUSE1 ? KP / 16 : 1;
-  rc_f32x4 acc0[FT][2];
-  if (FUSE1) {
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < HID; ++k) sB[k * LDR + r] = dz1[k];
-    __syncthreads();
-#pragma unroll
-    for (int f = 0; f < FT; ++f)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc0[f][u][q] = 0.f;
-    const int l15 = lane & 15, kq = lane >> 4;
-    const int ib0 = (l15 < HID ? l15 : HID + 2) * LDR + wave * 64 + kq;
-    const int ib16 = (16 + l15 < HID ? 16 + l15 : HID + 2) * LDR + wave * 64 + kq;
-#pragma unroll 4
-    for (int m = 0; m < 16; ++m) {
-      const float b0 = sB[ib0 + 4 * m], b1 = sB[ib16 + 4 * m];
-#pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        const int feat = 16 * f + l15;
-        const float av = feat < in_dim ? sX[(wave * 64 + kq + 4 * m) * in_dim + feat] : 0.f;
-        acc0[f][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc0[f][0], 0, 0, 0);
-        acc0[f][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc0[f][1], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();                                   // panels fully consumed: the buffer becomes the result area
-  // per wavefront: the 32x32 G1 tile, then the NS wave sums (lane 63 holds them), then (fused) the G0 tile
-  float* mat = sP + wave * WSZ;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int row = (q & 3) + 8 * (q >> 2) + 4 * half;                   // D[row][col = l31]
-    mat[row * 32 + l31] = acc1[q];
-  }
-  if (FUSE1) {                                       // 16x16 tiles: D[row = (lane>>4)*4 + q][col = lane&15]
-#pragma unroll
-    for (int f = 0; f < FT; ++f)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          mat[1088 + (16 * f + (lane >> 4) * 4 + q) * 32 + 16 * u + (lane & 15)] = acc0[f][u][q];
-  }
-  if (lane == 63) {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) mat[1024 + k] = sm[k];
-  }
-  __syncthreads();
-  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (FUSE1 ? rec_size : PT::SIZE);
-  for (int e = r; e < (FUSE1 ? PT::SIZE + in_dim * HID : PT::SIZE); e += ROWS) {
-    int src;
-    if (e < PT::gb2) { const int j = e / HID; src = j * 32 + (e - j * HID); }          // gW2[j][k] = G1[j][k]
-    else if (e < PT::gW3) src = HID * 32 + (e - PT::gb2);                                // gb2[k]    = G1[HID][k]
-    else if (e < PT::gb3) src = 1024 + (e - PT::gW3);                                    // gW3[k]    = sm[k]
-    else if (e < PT::gb1) src = 1024 + 2 * HID;                                          // gb3       = sm[2 HID]
-    else if (e < PT::loss) src = 1024 + HID + (e - PT::gb1);                             // gb1[j]    = sm[HID + j]
-    else if (e == PT::loss) src = 1024 + 2 * HID + 1;                                    // loss
-    else { const int q = e - PT::SIZE, k = q / HID; src = 1088 + k * 32 + (q - k * HID); }   // gW1[k][j] = G0[k][j]
-    out[e] = (sP[src] + sP[WSZ + src]) + (sP[2 * WSZ + src] + sP[3 * WSZ + src]);
-  }
-  __syncthreads();                                   // result area read out before the next chunk's panels land
-  }  // chunk loop
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_mid_fit, fifth form ("v5"): every product on the f32 matrix core, the VALU keeps only the element-wise work.
-// v3 is bound by instruction issue and dependent latency (1200 VALU + 340 LDS instructions per wavefront-chunk against
-// 400 packed FMAs of real work, 12.8k SIMD cycles per 64 rows); here a wavefront-chunk is 72 MFMAs (4.6k cycles of the
-// matrix pipe, which the lattice path leaves idle in this kernel) and ~600 other instructions:
-//   * layer 2 forward/backward as TRANSPOSED products in the two-block form v_mfma_f32_32x32x1_2b_f32,
-//       Z_b[unit i][row j] = sum_m W2[m][i] * a1[row 32b + j][m]        (b = half of the wavefront)
-//     the B operand of lane (j, b) is ITS OWN register a1[m] (row-per-lane data needs no transposition), the A operand
-//     W2[m][i] one conflict-free ds_read_b32; m ascending = the fmaf chain of the VALU form bit for bit.  The result
-//     has units 8q+4h+e of both row blocks in lane (j, h); twelve v_permlane32_swap put it back row-per-lane;
+// k_mid_fit ("v5", the form that survived rounds 1-2: a DPP-tree form, two forms with VALU layer products and one with
+// 32x32 transposed layer products were built, measured slower and removed -- DESIGN.md section 5 keeps the numbers):
+// layers 2-3 forward + MSE + backward for one replay row per lane, every product on the f32-input MFMA forms.
+//   * the two 20x20 layer products as v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 outer products per instruction,
+//     block b = lanes 4b..4b+3: D_b[i][j] += A(lane 4b+i) * B(lane 4b+j), lane 4b+j holding column j in its four registers.
+//     With B = the lane's OWN value (its replay row's a1[m] / dz2[k]) and A = W2[m][4g+i] (four units of group g, the same
+//     for every block), register i of lane l accumulates unit 4g+i of ROW l: the result is born row-per-lane, 20 units are
+//     five groups exactly, m ascending = one fmaf chain per (unit, row);
 //   * everything summed over rows except gb1 comes out of ONE 32x32 reduction product per 32 rows,
 //       A = [a1 | 1 | a2[0..10]*dv]^T,  B = [dz2 | 1 | dv | diff^2 | a2[11..19]*dv]
 //     (G[i<20][j<20] = gW2, G[20][j<20] = gb2, G[21+i][20] = gW3[i], G[20][21] = gb3, G[20][22] = loss,
 //     G[20][23+i] = gW3[11+i]); gb1 = sum dz1 by six fused-DPP adds per value.
-// Same arithmetic as v3 (dz1 bit-identical, records to summation order).  EMIT as in v3.
-// X4: the two 20x20 layer products as v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 outer products per instruction,
-// block b = lanes 4b..4b+3: D_b[i][j] += A(lane 4b+i) * B(lane 4b+j), lane 4b+j holding column j in its four registers.  With
-// B = the lane's OWN value (its replay row's a1[m] / dz2[k]) and A = W2[m][4g+i] (four units of group g, the same for every
-// block), register i of lane l accumulates unit 4g+i of ROW l: the result is born row-per-lane (no permlane swaps), 20 units
-// are five groups exactly (the 32x32 tiles spend 12 of 32 rows on padding), and the accumulator is 20 registers instead of 32.
-// Same fmaf chain per (unit, row), m ascending: bit-identical.  100 instructions of 8-12 cycles instead of 20 of 64-81.
-template <int HID, bool EMIT, bool X4 = false>
+// EMIT: instead of overwriting a1t with dz1 (fp32, feature-major), write dz1 as three exact bf16 pieces in the packed layout
+// the lattice backward GEMM reads (rcmarl_lattice.h: rows = (agent,unit) column, reduction = replay row); rows b >= B of the
+// last chunk are written as zeros.
+// NOTE (round 3, profiles/r03_pipe_overlap_cycles.txt): the f32-input MFMA runs on the vector ALUs -- its cycles ADD to
+// the VALU's; this kernel's time is the sum of its 232 f32 MFMAs, ~500 VALU and ~190 LDS instructions per 64 rows.
+template <int HID, bool EMIT>
 __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restrict__ a1t, const float* __restrict__ theta,
                                                        const float* __restrict__ y, float* __restrict__ partials, int N,
                                                        int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
-                                                       unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt, int stagger) {
+                                                       unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
   static_assert(HID == 20, "panel layout of the reduction product is written for 20 units");
   typedef FitPart<HID> PT;
 // (rows per pass of the reduction product: 32; 16 halves the panels -- 22.7 instead of 39 KiB of LDS per workgroup --
@@ -588,10 +151,7 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
   }
   const float* yrow = y + ((long)s * N + i) * ldb;
   __syncthreads();
-  // de-phasing aid (pure scheduling): the workgroups resident on a CU start together and run identical instruction
-  // streams; every second one of the first round waits `stagger` x ~3.4 us so that matrix-core and VALU phases interleave
-  if (stagger > 0 && blockIdx.y < 64u && (blockIdx.y & 1u)) rc_sleep(stagger);
-  // (requesting the activations of chunk c+1 while chunk c is processed, as v3 does, costs 20 registers = one wavefront
+  // (requesting the activations of chunk c+1 while chunk c is processed costs 20 registers = one wavefront
   // per SIMD of occupancy here and measured slower: 919 vs 857 us)
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int b = chunk * ROWS + r;
@@ -601,8 +161,8 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
     const float ycur = valid ? yrow[b] : 0.f;
     // ---- layer 2 forward
     float z2[HID];
-    if constexpr (X4) {
-      static_assert(!X4 || HID % 4 == 0, "units in groups of four");
+    {
+      static_assert(HID % 4 == 0, "units in groups of four");
       rc_f32x4 zq[HID / 4];
 #pragma unroll
       for (int g4 = 0; g4 < HID / 4; ++g4) zq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -620,21 +180,6 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
       for (int g4 = 0; g4 < HID / 4; ++g4)
 #pragma unroll
         for (int e = 0; e < 4; ++e) z2[4 * g4 + e] = zq[g4][e];
-    } else {
-      rc_f32x32 zz;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) zz[q] = 0.f;
-#pragma unroll
-      for (int m = 0; m < HID; ++m) zz = __builtin_amdgcn_mfma_f32_32x32x1f32(sW2[m * WLD + l31], a1[m], zz, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lo = zz[4 * q + e], hi = zz[16 + 4 * q + e];
-          rc_swap32(lo, hi);
-          z2[8 * q + e] = lo;
-          if (8 * q + 4 + e < HID) z2[8 * q + 4 + e] = hi;
-        }
     }
     float a2[HID];
     float v = 0.f;
@@ -682,7 +227,7 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
     }
     // ---- layer 2 backward
     float dz1[HID];
-    if constexpr (X4) {
+    {
       rc_f32x4 dq[HID / 4];
 #pragma unroll
       for (int g4 = 0; g4 < HID / 4; ++g4) dq[g4] = rc_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -700,42 +245,8 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
       for (int g4 = 0; g4 < HID / 4; ++g4)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dz1[4 * g4 + e] = dq[g4][e] * rc_lrelu_grad_from_act(a1[4 * g4 + e]);
-    } else {
-      rc_f32x32 dd;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) dd[q] = 0.f;
-#pragma unroll
-      for (int k = 0; k < HID; ++k) dd = __builtin_amdgcn_mfma_f32_32x32x1f32(sW2T[k * WLD + l31], dz2[k], dd, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float lo = dd[4 * q + e], hi = dd[16 + 4 * q + e];
-          rc_swap32(lo, hi);
-          dz1[8 * q + e] = lo * rc_lrelu_grad_from_act(a1[8 * q + e]);
-          if (8 * q + 4 + e < HID) dz1[8 * q + 4 + e] = hi * rc_lrelu_grad_from_act(a1[8 * q + 4 + e]);
-        }
     }
     if (EMIT) {
-#ifdef RC_V5_DZ_DIRECT
-      unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK) + (long)(chunk * (ROWS / 32)) * (3 * RC_PK_BLOCK);
-      const unsigned lane_off = (unsigned)(r >> 5) * (3 * RC_PK_BLOCK) + (((r & 31) >> 3) << 4) + (r & 7) * 2;
-      const unsigned lane_off1 = lane_off + RC_PK_BLOCK, lane_off2 = lane_off + 2 * RC_PK_BLOCK;
-#pragma unroll
-      for (int q = 0; q < HID / 2; ++q) {
-        unsigned h, m, l;
-        rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int row = i * HID + 2 * q + u;
-          unsigned char* p = base + (long)(row >> 7) * dzp_kt * (3 * RC_PK_BLOCK) + (row & 127) * 64;
-          const unsigned sw = (unsigned)(((row >> 2) & 3) << 4);
-          *reinterpret_cast<unsigned short*>(p + (lane_off ^ sw)) = (unsigned short)(u ? h >> 16 : h);
-          *reinterpret_cast<unsigned short*>(p + (lane_off1 ^ sw)) = (unsigned short)(u ? m >> 16 : m);
-          *reinterpret_cast<unsigned short*>(p + (lane_off2 ^ sw)) = (unsigned short)(u ? l >> 16 : l);
-        }
-      }
-#else
       // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + j, k = replay row.  A lane owns ONE replay row, i.e. 2 bytes of
       // every (unit, piece) row of the packed image: stored directly that is 120 two-byte store instructions per
       // wavefront.  Instead the wavefront transposes its 64 rows x 60 (unit, piece) values through its (now idle) panel
@@ -772,7 +283,6 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
           }
         }
       }
-#endif
     } else {
 #pragma unroll
       for (int j = 0; j < HID; ++j)
@@ -803,22 +313,20 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
 }
 
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B.
-// rec_size > FitPart::SIZE: the record also carries gW1 (fused layer 1) and W1 is updated too.
 template <int HID>
 __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ partials, float* __restrict__ theta,
                                                    const int* __restrict__ mask,
                                                    float* __restrict__ loss_out, int N, int B, int in_dim, int ldp,
-                                                   int nchunk, float lr, int rec_size) {
+                                                   int nchunk, float lr) {
   typedef FitPart<HID> PT;
   const int s = blockIdx.y, i = blockIdx.x;
   if (mask && !mask[i]) return;
   const NetGeom g = make_geom(in_dim, HID, 1);
   float* th = theta + ((long)s * N + i) * ldp;
-  const float* pp = partials + ((long)s * N + i) * nchunk * rec_size;
-  const int n_apply = rec_size > PT::SIZE ? PT::SIZE + in_dim * HID : PT::SIZE;
-  for (int e = threadIdx.x; e < n_apply; e += blockDim.x) {
+  const float* pp = partials + ((long)s * N + i) * nchunk * PT::SIZE;
+  for (int e = threadIdx.x; e < PT::SIZE; e += blockDim.x) {
     float sum = 0.f;
-    for (int c = 0; c < nchunk; ++c) sum += pp[(long)c * rec_size + e];
+    for (int c = 0; c < nchunk; ++c) sum += pp[(long)c * PT::SIZE + e];
     if (e == PT::loss) {
       if (loss_out) loss_out[(long)s * N + i] = sum / (float)B;
       continue;
@@ -828,8 +336,7 @@ __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ par
     else if (e < PT::gW3) o = g.o_b2 + (e - PT::gb2);
     else if (e < PT::gb3) o = g.o_W3 + (e - PT::gW3);
     else if (e < PT::gb1) o = g.o_b3;
-    else if (e < PT::loss) o = g.o_b1 + (e - PT::gb1);
-    else o = e - PT::SIZE;                               // W1[k][j], row-major at the start of the parameter row
+    else o = g.o_b1 + (e - PT::gb1);
     th[o] = th[o] - lr * sum;
   }
 }
@@ -1181,28 +688,11 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
   if (t < n_total) delta[t] = r_team[t] + gamma * v_next[t] - v_cur[t];
 }
 
-int midfit_stagger() { const char* e = getenv("RCMARL_MIDFIT_STAGGER"); return e ? atoi(e) : 0; }
-
-// RCMARL_MIDFIT: 0 LDS-loop / DPP-tree, 1 matrix-core reductions, 2 v3, 5 v5 (every product on the f32 matrix core).
-// Default: v5 behind both entry points (fp32 dz1 in place: 857 vs 935 us at the cfg-4 shape, cfg1_batched 120.9 vs 126.0 ms
-// per block; bf16-piece stores: 985 vs 1004 and 1006 vs 1048 us on two boxes).  A "v6" -- v5 with layer 2 back on the
-// VALU as in v3 -- measured 958 / 1094 us against 891 / 1006 for v5 on the same box and was dropped.
-// Read at every call (a getenv per launch is nothing next to the launch; tests switch variants inside one process).
-int midfit_variant(bool lattice = false) {
-  const char* e = getenv("RCMARL_MIDFIT");
-  (void)lattice;
-  int v = e ? atoi(e) : 6;               // 6 = v5 with the layer products as 4x4x1 sixteen-block MFMAs (measured -3..-5 %)
-  if (v != 5 && v != 6 && (v < 0 || v > 2)) v = 6;
-  return v;
-}
-
-// chunks of 256 rows one k_mid_fit_v3 workgroup walks (RCMARL_MIDFIT_CPW overrides; default: half the chunks of an
-// agent, at most 6 -- two workgroups per agent keep the grid wide enough at small S*N)
+// chunks of 256 rows one k_mid_fit_v5 workgroup walks: half the chunks of an agent, at most 6 -- two workgroups per agent keep
+// the grid wide enough at small S*N (RCMARL_MIDFIT_CPW = 1..12 measured within -2..+11 %: fixed)
 int midfit_cpw(int nchunk) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("RCMARL_MIDFIT_CPW"); env = e ? atoi(e) : 0; }
-  int c = env > 0 ? env : (nchunk + 1) / 2;
-  if (env <= 0 && c > 6) c = 6;
+  int c = (nchunk + 1) / 2;
+  if (c > 6) c = 6;
   return c < 1 ? 1 : c;
 }
 
@@ -1227,31 +717,10 @@ RCMARL_EXPORT int rcmarl_rows_per_chunk(void) { return ROWS; }
 RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B,
                                  int in_dim, int hid, int ldp, int ldb, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
-  const int nchunk = rc_ceil_div(B, ROWS);
-  const dim3 grid(nchunk, N, S), block(ROWS);
-  const int variant = midfit_variant();
-  if (variant == 6) {
-    const int cpw = midfit_cpw(nchunk);
-    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false, true>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, midfit_stagger()));
-  } else if (variant == 5) {
-    const int cpw = midfit_cpw(nchunk);
-    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, midfit_stagger()));
-  } else if (variant == 2) {
-    const int cpw = midfit_cpw(nchunk);
-    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 0>), grid3, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, (const float*)nullptr, 0L, 0));
-  } else if (variant == 0) {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit<HID_>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
-                                     ldp, ldb, nchunk));
-  } else {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B,
-                                     in_dim, ldp, ldb, nchunk, (unsigned char*)nullptr, 0, 0));
-  }
+  const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk);
+  const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
+                                   ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
   return rcmarl_check_launch();
 }
 
@@ -1259,40 +728,11 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
                                          void* dzp, int dzp_rt, int dzp_kt, int S, int N, int B, int in_dim, int hid,
                                          int ldp, int ldb, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials || !dzp) return RCMARL_ERR_ARG;
-  const int nchunk = rc_ceil_div(B, ROWS);
+  const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
-  const dim3 grid(nchunk, N, S), block(ROWS);
-  if (midfit_variant(true) == 6) {
-    const int cpw = midfit_cpw(nchunk);
-    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, midfit_stagger()));
-  } else if (midfit_variant(true) == 5) {
-    const int cpw = midfit_cpw(nchunk);
-    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, midfit_stagger()));
-  } else if (midfit_variant(true) == 2) {
-    const int cpw = midfit_cpw(nchunk);
-    const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S);
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, true, 0>), grid3, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
-                                     (const float*)nullptr, 0L, 0));
-  } else {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_mfma<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta,
-                                     y, partials, N, B, in_dim, ldp, ldb, nchunk, (unsigned char*)dzp, dzp_rt, dzp_kt));
-  }
-  return rcmarl_check_launch();
-}
-
-// the same with an explicit number of records per (seed, agent): producers whose chunk is not 256 rows
-// (rcmarl_fit_fused_lattice: rcmarl_fit_fused_chunks(B) records)
-RCMARL_EXPORT int rcmarl_small_sgd_chunks(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
-                                          int B, int in_dim, int hid, int ldp, float lr, int nchunk, void* stream) {
-  if (!partials || !theta || S <= 0 || N <= 0 || B <= 0 || nchunk <= 0) return RCMARL_ERR_ARG;
-  const dim3 grid(N, S), block(256);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
-                                   in_dim, ldp, nchunk, lr, (int)FitPart<HID_>::SIZE));
+  const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                   partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
   return rcmarl_check_launch();
 }
 
@@ -1302,43 +742,7 @@ RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const in
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(N, S), block(256);
   RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
-                                   in_dim, ldp, nchunk, lr, (int)FitPart<HID_>::SIZE));
-  return rcmarl_check_launch();
-}
-
-// ---- fused local-fit step for small networks (in_dim <= 32): layer 1 + layers 2-3 + all gradients in one launch
-RCMARL_EXPORT int rcmarl_fit_small_partial_size(int hid, int in_dim) { return hid * hid + 3 * hid + 2 + in_dim * hid; }
-
-RCMARL_EXPORT int rcmarl_fit_step_small(const float* x, long x_seed_stride, const float* theta, const float* y,
-                                        float* partials, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
-                                        void* stream) {
-  if (!x || !theta || !y || !partials || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) || (ldb & 63) || ldb < B)
-    return RCMARL_ERR_ARG;
-  if (in_dim > 32) return RCMARL_ERR_UNSUPPORTED;
-  const int nchunk = rc_ceil_div(B, ROWS);
-  const int cpw = midfit_cpw(nchunk);
-  const dim3 grid3(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  const int rec = rcmarl_fit_small_partial_size(hid, in_dim);
-  if (in_dim <= 16) {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 16>), grid3, block, 0, stream, (float*)nullptr, theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, x,
-                                     x_seed_stride, rec));
-  } else {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v3<HID_, false, 32>), grid3, block, 0, stream, (float*)nullptr, theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, x,
-                                     x_seed_stride, rec));
-  }
-  return rcmarl_check_launch();
-}
-
-RCMARL_EXPORT int rcmarl_small_sgd_full(const float* partials, float* theta, const int* mask, float* loss_out, int S,
-                                        int N, int B, int in_dim, int hid, int ldp, float lr, void* stream) {
-  if (!partials || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0) return RCMARL_ERR_ARG;
-  if (in_dim > 32) return RCMARL_ERR_UNSUPPORTED;
-  const int nchunk = rc_ceil_div(B, ROWS);
-  const dim3 grid(N, S), block(256);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
-                                   in_dim, ldp, nchunk, lr, rcmarl_fit_small_partial_size(hid, in_dim)));
+                                   in_dim, ldp, nchunk, lr));
   return rcmarl_check_launch();
 }
 

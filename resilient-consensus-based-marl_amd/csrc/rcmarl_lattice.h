@@ -32,21 +32,6 @@ __host__ __device__ static inline long rc_pk_offset(int r, int k, int p, int KT,
          ((((k & 31) >> 3) ^ ((r >> 2) & 3)) << 4) + (k & 7) * 2;
 }
 
-// "Fit order" of the rows of a W' operand (rows = (agent, unit) columns of W1, 20-unit nets), the order the fused
-// local-fit kernel (lattice_fit.hip) wants its A operand in.  A workgroup of that kernel owns 8 consecutive agents =
-// 160 rows = five 32-row MFMA blocks; in the 32x32 accumulator layout lane (n, h = lane>>5) holds rows
-// 8q + 4h + e (q, e = 0..3) of every block, i.e. 80 of the 160 rows.  Rows are numbered so that those 80 are
-// EXACTLY the 20 units of agents 4h .. 4h+3 of the group, in order: after the k-loop every lane holds the complete
-// layer-1 pre-activations of four agents on its replay rows in registers, with compile-time register indices, and
-// layers 2-3 run without any cross-lane traffic.
-//   column (agent = 8*grp + 4*h + g, unit u):  t = 20*g + u,  row = 160*grp + 32*(t>>4) + 8*((t>>2)&3) + 4*h + (t&3)
-#define RC_FIT_AGENTS 8
-#define RC_FIT_ROWS 160
-__host__ __device__ static inline int rc_fit_row(int agent, int unit) {
-  const int grp = agent >> 3, a8 = agent & 7, h = a8 >> 2, g = a8 & 3, t = 20 * g + unit;
-  return RC_FIT_ROWS * grp + 32 * (t >> 4) + 8 * ((t >> 2) & 3) + 4 * h + (t & 3);
-}
-
 // fp32 -> bf16 bits, round to nearest even (finite inputs)
 __device__ __forceinline__ unsigned rc_bf16_rne(float f) {
   unsigned u = __float_as_uint(f);

@@ -92,11 +92,6 @@ class EngineConfig:
                 raise ValueError("unknown agent label %r" % lab)
         if self.critic_hid < 1:
             raise ValueError("critic_hid must be positive")
-        if self.critic_hid != HID and any(lab not in (COOP, FAULTY) for lab in self.agent_label):
-            # Faulty agents never fit their critic / team-reward net (adversarial_CAC_agents.py:45-55 transmit the frozen
-            # weights; only their 20-unit actor learns), so they run beside a wide critic as they are; Greedy / Malicious
-            # agents would need the mini-batch message generators (csrc/minibatch_fit.hip) at the wide width
-            raise ValueError("a wide critic (critic_hid != 20) is supported with Cooperative and Faulty agents only")
 
     @property
     def d(self):
@@ -137,11 +132,6 @@ class RPBCACEngine:
         self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_t = 0
         self.a1_cached = {"critic": False, "tr": False}
-        # networks with at most 32 inputs (the reference's 5-agent scenarios): one fused launch per local-fit step
-        # (measured slower than the three small kernels it replaces -- 1.72 vs 1.42 ms per step at 512 seeds x 5
-        # agents: two workgroups per CU and a long dependent chain -- so it is opt-in: RCMARL_SMALL_FUSED=1)
-        self.small_fused = self.in_r <= 32 and os.environ.get("RCMARL_SMALL_FUSED", "0") not in ("0", "false")
-        self.partials_side = None             # second record buffer, allocated when the two local fits overlap
         self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
         self.rp, self.ybuf = None, {k: None for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
         self._alloc_row_buffers(c.buffer_size + self.n_last)
@@ -216,13 +206,9 @@ class RPBCACEngine:
         self._init_wide()
         self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in self.ybuf}
         self.rcoop = torch.zeros(S, self.ldb, **f32)
-        nchunk_max = max((self.cap + 255) // 256, lib.rcmarl_fit_fused_chunks(self.cap))
+        nchunk_max = (self.cap + 255) // 256
         psz = max(lib.rcmarl_fit_partial_size(HID), lib.rcmarl_actor_partial_size(HID, c.n_actions))
-        if self.small_fused:
-            psz = max(psz, lib.rcmarl_fit_small_partial_size(HID, self.in_r))
         self.partials = torch.zeros(S * N * nchunk_max * psz, **f32)
-        if self.partials_side is not None:
-            self.partials_side = torch.zeros_like(self.partials)
         # replay buffers [S][cap][w*N]
         self.rp = {k: torch.zeros(S, self.cap, w * N, **f32) for k, w in (("s", 2), ("ns", 2), ("sa", 3), ("a", 1), ("r", 1))}
         if old_rp is not None and old_B:
@@ -240,9 +226,12 @@ class RPBCACEngine:
         self._ensure_cap(self.B + int(n_new))
 
     def _ensure_cap(self, need):
+        """Grow geometrically (at least one block of rows, at least 1.5x): growing to exactly `need` made every further
+        episode of an over-long buffer re-allocate and copy every row-sized tensor (O(n^2) copies, multi-GB at the
+        BASELINE configs[3..4] shapes)."""
         if need > self.cap:
             self.sync()
-            self._alloc_row_buffers(need)
+            self._alloc_row_buffers(max(int(need), self.cap + self.n_last, int(1.5 * self.cap)))
 
     # ---- wide critic (hid != 20): dense-GEMM path, csrc/wide_kernels.hip ---------------------
     def _init_wide(self):
@@ -494,6 +483,7 @@ class RPBCACEngine:
             for net in self.shard.sc:
                 self._allgather_rows(self.theta[net], 0, self.ldp[net])
                 self._allgather_rows(self.loss[net].unsqueeze(-1), 0, 1)
+            self._shards_synced = True
 
     # ---- lattice (exact bf16x3) layer-1 path: csrc/lattice_gemm.hip, lattice.py ------------
     def _init_lattice(self):
@@ -524,18 +514,6 @@ class RPBCACEngine:
         self.lat_wp_f = {"sa": u8(self.lat_geom["sa"].wp, 3), "s": u8(self.lat_geom["s"].wp, 3)}
         self.lat_dzp_f = {"sa": u8(self.lat_geom["sa"].dzp, 3), "s": u8(self.lat_geom["s"].dzp, 3)}
         self.lat_wp_f["ns"] = self.lat_wp_f["s"]
-        # fused local-fit step (csrc/lattice_fit.hip, 20-unit nets): its forward operand is W' in "fit order".  Opt-in
-        # (RCMARL_FIT_FUSED=1): bit-identical dz1, but measured no faster than the unfused pair it replaces (1.73 vs
-        # 1.76 ms per step at the cfg-4 critic shape) and the unfused path can skip the step-0
-        # forward GEMM of every fit (activations left by the consensus step), so a block is 361 vs 297 ms.
-        self.fit_fused = os.environ.get("RCMARL_FIT_FUSED", "0") not in ("0", "false")
-        self.lat_wpf_geom, self.lat_wpf = {}, {}
-        if self.fit_fused:
-            for k, net in (("sa", "tr"), ("s", "critic")):
-                if self.hid[net] == HID:
-                    rt_kt = (LT.cdiv(self.lib.rcmarl_fit_rows(self.N), 128), LT.cdiv(self.in_dim[net], 32))
-                    self.lat_wpf_geom[k] = rt_kt
-                    self.lat_wpf[k] = u8(rt_kt, 3)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.lat_alpha = {"s": torch.tensor(LT.column_alpha(self.N, 2, c.nrow, c.ncol, c.scaling), **f32),
                           "sa": torch.tensor(LT.column_alpha(self.N, 3, c.nrow, c.ncol, c.scaling), **f32)}
@@ -587,6 +565,9 @@ class RPBCACEngine:
             self.theta["critic_local"][seed_idx, agent, :vec.size] = self.theta["critic"][seed_idx, agent, :vec.size]
 
     def get_weights(self, seed_idx, agent, net):
+        if self.shard is not None and net in self.shard.sc and not self._shards_synced:
+            raise RuntimeError("agent-sharded instance: rows of other ranks are stale until sync_shards() (a collective: "
+                               "every rank must call it) -- train() and state_dict() do")
         vec = self.theta[net][seed_idx, agent, :self.P[net]].detach().cpu().numpy()
         return unflatten_params(vec, self.in_dim[net], self.out_dim[net], self.hid[net])
 
@@ -899,38 +880,6 @@ class RPBCACEngine:
         g = self.lat_geom[xkey] if lat else None
         dzp, wp = (self.lat_dzp_f[xkey], self.lat_wp_f[xkey]) if lat else (None, None)
         partials = self.partials if partials is None else partials
-        if not lat and self.small_fused:
-            # layer 1, layers 2-3 and every gradient of a step in ONE launch (no a1t round trip), then one apply
-            for step in range(self.cfg.local_fit_steps):
-                L.rcmarl_fit_step_small(ptr, stride, msg.data_ptr(), y.data_ptr(), partials.data_ptr(), S, N, B,
-                                        self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
-                L.rcmarl_small_sgd_full(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
-                                        self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
-                                        self.ldp[net], self.cfg.fast_lr, self.stream)
-            self.a1_cached[net] = False
-            return
-        if lat and xkey in self.lat_wpf:
-            # one launch per step for layer 1 forward + layers 2-3 + the way back to dz1 (no a1t round trip through HBM)
-            wpf, (frt, fkt) = self.lat_wpf[xkey], self.lat_wpf_geom[xkey]
-            kp, alpha = self.lat_kp[xkey], self.lat_alpha[xkey]
-            for step in range(self.cfg.local_fit_steps):
-                if step == 0:                  # later steps: the backward epilogue leaves the split of the updated W1
-                    L.rcmarl_w1_split_fit(msg.data_ptr(), alpha.data_ptr(), wpf.data_ptr(), S, N, self.in_dim[net], HID,
-                                          self.ldp[net], frt, fkt, self.stream)
-                L.rcmarl_fit_fused_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wpf.data_ptr(), frt, fkt, msg.data_ptr(),
-                                           y.data_ptr(), partials.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B,
-                                           self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
-                L.rcmarl_small_sgd_chunks(partials.data_ptr(), msg.data_ptr(), mask.data_ptr(),
-                                          self.loss[net].data_ptr() if step == 0 else None, S, N, B, self.in_dim[net], HID,
-                                          self.ldp[net], self.cfg.fast_lr, L.rcmarl_fit_fused_chunks(B), self.stream)
-                L.rcmarl_layer1_backward_sgd_lattice_fit(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
-                                                         g.dzp[0], g.dzp[1], alpha.data_ptr(), msg.data_ptr(),
-                                                         mask.data_ptr(), S, N, B, self.in_dim[net], HID, self.ldp[net],
-                                                         self.cfg.fast_lr,
-                                                         None if step == self.cfg.local_fit_steps - 1 else wpf.data_ptr(),
-                                                         frt, fkt, self.stream)
-            self.a1_cached[net] = False
-            return
         wp_fresh = False
         for step in range(self.cfg.local_fit_steps):
             if not (step == 0 and self.a1_cached[net]):       # msg == live net: activations left by _consensus
@@ -1086,22 +1035,10 @@ class RPBCACEngine:
 
     profile_phases = False
     reuse_activations = True
-    overlap_fits = None                   # None: RCMARL_OVERLAP env (default off); True/False forces
-
-    def _overlap_ok(self):
-        want = self.overlap_fits
-        if want is None:
-            want = os.environ.get("RCMARL_OVERLAP", "0") not in ("0", "", "false")
-        if not (want and self.dev.type == "cuda" and not hasattr(self, "adv")) or self.shard is not None:
-            return False
-        if self.partials_side is None:
-            self.partials_side = torch.zeros_like(self.partials)
-            self.side_stream = torch.cuda.Stream(device=self.dev)
-        return True
-
     def update_block(self):
         c, L, S, N, B = self.cfg, self.lib, self.S, self.N, self.B
         assert B >= self.n_last
+        self._shards_synced = False               # (agent-sharded instance: other ranks' rows go stale from here on)
         for lab in c.agent_label:
             if lab in (GREEDY, MALICIOUS, FAULTY):
                 self._require_adversary_support()
@@ -1116,45 +1053,23 @@ class RPBCACEngine:
                              self.ldb, self.stream)
         L.rcmarl_gather_agent_major(rptr, rstride, self.rcoop.data_ptr(), self.fit_mode.data_ptr(),
                                     self.ybuf["r_fit"].data_ptr(), S, N, B, self.ldb, self.stream)
-        # opt-in (RCMARL_ADV_CHAIN=1, measured slower): adversaries that fit run all their epochs ahead on a side stream
-        chain = self.adv.chain_async(B, c.n_epochs) if hasattr(self, "adv") else None
         for epoch in range(c.n_epochs):
             # I) local fits of TR and critic on a copy (= the transmitted message); live nets untouched
-            if self._overlap_ok():
-                # the two local fits are independent until the consensus step: TR on a side stream, critic on the
-                # main one (the VALU/LDS-bound mid kernels of one net fill the gaps of the other's matrix-core GEMMs)
-                main = torch.cuda.current_stream(self.dev)
-                fork = torch.cuda.Event()
-                fork.record(main)
-                with torch.cuda.stream(self.side_stream):
-                    self.side_stream.wait_event(fork)
+            if self.shard is not None and not self.shard.shard_tr:
+                self.msg["tr"].copy_(self.theta["tr"])
+            with self._agent_window():
+                if self.shard is None or self.shard.shard_tr:
                     self.msg["tr"].copy_(self.theta["tr"])
-                    self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop, partials=self.partials_side)
-                    join = torch.cuda.Event()
-                    join.record(self.side_stream)
-                with self._agent_window():
-                    self.msg["critic"].copy_(self.theta["critic"])
-                self._td_target(B)
-                self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
-                main.wait_event(join)
-            else:
-                if self.shard is not None and not self.shard.shard_tr:
-                    self.msg["tr"].copy_(self.theta["tr"])
-                with self._agent_window():
-                    if self.shard is None or self.shard.shard_tr:
-                        self.msg["tr"].copy_(self.theta["tr"])
-                    self.msg["critic"].copy_(self.theta["critic"])
-                # TD target first (it depends on the live critic only), so the adversaries' message generators --
-                # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
-                # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
-                self._td_target(B)
-                join = self._adversary_messages_async(B) if chain is None else None
-                self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
-                self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
-                if chain is not None:
-                    self.adv.consume(chain[epoch])
-                elif join is not None:
-                    torch.cuda.current_stream(self.dev).wait_event(join)
+                self.msg["critic"].copy_(self.theta["critic"])
+            # TD target first (it depends on the live critic only), so the adversaries' message generators --
+            # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
+            # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
+            self._td_target(B)
+            join = self._adversary_messages_async(B)
+            self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+            self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+            if join is not None:
+                torch.cuda.current_stream(self.dev).wait_event(join)
             t0 = self._timed("phase1", t0)
             # II) resilient consensus (cooperative agents)
             self._consensus("critic", "s", B)
@@ -1224,8 +1139,8 @@ class RPBCACEngine:
         """adv.phase1 on the side stream (GPU) -> the event to wait for before the consensus step; inline otherwise."""
         if not hasattr(self, "adv"):
             return None
-        if self.dev.type != "cuda" or os.environ.get("RCMARL_ADV_ASYNC", "1") in ("0", "false"):
-            self.adv.phase1(B)
+        if self.dev.type != "cuda" or self.wide or os.environ.get("RCMARL_ADV_ASYNC", "1") in ("0", "false"):
+            self.adv.phase1(B)                # (a wide critic's value / fit scratch is shared with the main stream: inline)
             return None
         if getattr(self, "adv_stream", None) is None:
             self.adv_stream = torch.cuda.Stream(device=self.dev)
@@ -1279,13 +1194,22 @@ class RPBCACEngine:
         return team, adv, estm
 
     _diverged_warned = False
+    _shards_synced = False
 
     def _warn_if_diverged(self):
         """The reference's plain-SGD local fits diverge to NaN when fast_lr is too large for the input width
-        (e.g. 0.01 at N = 256); it would carry on silently.  One warning per engine, one reduction per block."""
+        (e.g. 0.01 at N = 256); it would carry on silently.  One warning per engine, one reduction per block.  In an
+        agent-sharded instance a rank only sees its own agents' rows: the verdict is all-reduced (MIN) over the shard's
+        communicator, so every rank warns (or none) -- a COLLECTIVE there."""
         if self._diverged_warned:
             return
-        if not all(bool(torch.isfinite(self.theta[k]).all().item()) for k in ("critic", "tr", "actor")):
+        finite = all(bool(torch.isfinite(self.theta[k]).all().item()) for k in ("critic", "tr", "actor"))
+        if self.shard is not None:
+            flag = torch.tensor([1.0 if finite else 0.0], dtype=torch.float32, device=self.dev)
+            parts = [torch.empty_like(flag) for _ in range(self.shard.world)]
+            self.shard.comm.all_gather(parts, flag)
+            finite = all(bool(p.item() > 0.5) for p in parts)
+        if not finite:
             import warnings
             warnings.warn("rcmarl_amd: non-finite network weights after an update block (training diverged; "
                           "lower fast_lr -- the reference's 0.01 is unstable beyond ~64 agents)", RuntimeWarning)

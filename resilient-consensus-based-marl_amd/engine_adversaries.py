@@ -13,9 +13,12 @@ Replaces, for all seeds at once, what the reference does per adversarial agent i
   all three actor_update = TD error of their own critic, then
             fit(batch_size=200, epochs=1) with Adam               (:38-41, :111-117, :221-225)
 
-Every Keras ``fit`` is ONE kernel launch (csrc/minibatch_fit.hip): the whole
+Every Keras ``fit`` of a 20-unit network is ONE kernel launch (csrc/minibatch_fit.hip): the whole
 sequence of mini-batch steps of one (seed, adversary) network runs inside one
-workgroup.  Keras shuffles with TensorFlow's RNG; here the permutations come from
+workgroup.  A critic of any other width (BASELINE configs[4]: 512 units) takes the same
+mini-batch steps through the dense per-agent GEMM entry points (rcmarl_dense_*, one step =
+the eight launches of a wide local-fit step on 32 rows): correct and slow -- a Byzantine agent
+beside a wide critic is what the algorithm is for, not a throughput case.  Keras shuffles with TensorFlow's RNG; here the permutations come from
 a counter-based stream (csrc/shuffle.hip, generated on the device for all seeds at once; the oracle
 states the same definition), consumed in the reference's call order so that oracle and engine stay in
 lock step.
@@ -76,14 +79,68 @@ class AdversaryPath:
         self.calls = [c + len(plan) for c in self.calls]
         return out
 
+    # -- Keras fit(batch_size=32, epochs=10) of a critic-family network, any width ----------------------------
+    def _fit_critic_family(self, theta, agents_t, agents, y, perm, B, loss_out):
+        """theta [S][N][ldp] (fitted in place, rows `agents`), targets y [S][N][ldb], perm int32 [S][len(agents)][epochs][B]
+        (agents/adversarial_CAC_agents.py:131-135,146-152,237-241)."""
+        e, L = self.e, self.e.lib
+        hid = e.hid["critic"]
+        xptr, xstride = e._x("s")
+        if hid == HID:
+            L.rcmarl_minibatch_fit(xptr, xstride, theta.data_ptr(), agents_t.data_ptr(), len(agents), y.data_ptr(),
+                                   perm.data_ptr(), e.S, e.N, B, e.in_c, HID, e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS,
+                                   e.cfg.fast_lr, None if loss_out is None else loss_out.data_ptr(), e.stream)
+            return
+        # wide critic: one SGD step = forward L1, forward L2, head fit (dz3, dz2 in place, gW3/gb3/gb2), backward-data L2
+        # (-> dz1), bias grad, backward-SGD W2, backward-SGD W1, small SGD -- every gradient from the pre-step weights, as
+        # RPBCACEngine._local_fit_wide does for a full batch; here on (seed, agent) = (1, 1) views and 32 permuted rows
+        in_dim, ldp, lr, st = e.in_c, e.ldp["critic"], e.cfg.fast_lr, e.stream
+        o_b1 = in_dim * hid
+        o_W2 = o_b1 + hid
+        o_b2 = o_W2 + hid * hid
+        ldm = 64                                        # row stride of the mini-batch scratch (>= FIT_BATCH, % 64 == 0)
+        if getattr(self, "_mb", None) is None or self._mb["hid"] != hid:
+            f32 = dict(dtype=torch.float32, device=e.dev)
+            self._mb = {"hid": hid, "a1": torch.zeros(hid, ldm, **f32), "a2": torch.zeros(hid, ldm, **f32),
+                        "dz1": torch.zeros(hid, ldm, **f32), "dz3": torch.zeros(ldm, **f32),
+                        "grads": torch.zeros(L.rcmarl_wide_grad_size(hid), **f32), "lp": torch.zeros(4, **f32),
+                        "loss": torch.zeros(1, **f32), "one": torch.ones(1, dtype=torch.int32, device=e.dev)}
+        m = self._mb
+        a1, a2, dz1, dz3, grads, lp, one = (m[k].data_ptr() for k in ("a1", "a2", "dz1", "dz3", "grads", "lp", "one"))
+        X = e.rp["s"]
+        for s_ in range(e.S):
+            for q, ag in enumerate(agents):
+                th = theta.data_ptr() + 4 * ((s_ * e.N + ag) * ldp)
+                first = torch.zeros(1, dtype=torch.float32, device=e.dev)
+                for ep in range(FIT_EPOCHS):
+                    idx = perm[s_, q, ep].long()
+                    Xp = X[s_, :B].index_select(0, idx).contiguous()              # [B][in_dim], batches are row slices now
+                    yp = y[s_, ag, :B].index_select(0, idx).contiguous()
+                    for lo in range(0, B, FIT_BATCH):
+                        nb = min(FIT_BATCH, B - lo)
+                        xb, yb = Xp.data_ptr() + 4 * lo * in_dim, yp.data_ptr() + 4 * lo
+                        L.rcmarl_dense_forward(xb, 0, 0, 1, in_dim, th, 0, o_b1, a1, 1, 1, nb, in_dim, hid, ldp, ldm, st)
+                        L.rcmarl_dense_forward(a1, hid * ldm, hid * ldm, 0, ldm, th, o_W2, o_b2, a2, 1, 1, nb, hid, hid, ldp, ldm, st)
+                        L.rcmarl_wide_head_fit(a2, th, yb, dz3, grads, lp, 1, 1, nb, in_dim, hid, ldp, ldm, st)     # a2 <- dz2
+                        L.rcmarl_dense_backward_data(a2, th, o_W2, a1, dz1, 1, 1, nb, hid, hid, ldp, ldm, st)
+                        L.rcmarl_wide_bias_grad(dz1, grads, 1, 1, nb, hid, ldm, st)
+                        L.rcmarl_dense_backward_sgd(a1, hid * ldm, hid * ldm, 0, ldm, a2, th, o_W2, one, 1, 1, nb, hid, hid, ldp,
+                                                    ldm, lr, st)
+                        L.rcmarl_dense_backward_sgd(xb, 0, 0, 1, in_dim, dz1, th, 0, one, 1, 1, nb, in_dim, hid, ldp, ldm, lr, st)
+                        L.rcmarl_wide_small_sgd(grads, lp, th, one, m["loss"].data_ptr() if ep == 0 and loss_out is not None else None,
+                                                1, 1, nb, in_dim, hid, ldp, lr, st)
+                        if ep == 0 and loss_out is not None:
+                            first += m["loss"] * float(nb)            # Keras History: sample-weighted mean of the batch losses
+                if loss_out is not None:
+                    loss_out[s_, ag] = first[0] / float(B)
+
     # -- phase I of every consensus epoch ----------------------------------------------------
-    def phase1(self, B, y_c=None, write_msg=True):
-        """One consensus epoch's message generators.  y_c: the transmitted critic's targets (default: the engine's y_c rows);
-        write_msg=False leaves engine.msg alone (chain_async hands the rows over epoch by epoch instead)."""
+    def phase1(self, B):
+        """One consensus epoch's message generators (targets of the transmitted critic: the engine's y_c rows)."""
         e, L = self.e, self.e.lib
         if not self.fit:
             return                                     # only Faulty agents: msg rows already = frozen theta rows
-        y_c = e.ybuf["y_c"] if y_c is None else y_c
+        y_c = e.ybuf["y_c"]
         labels = e.cfg.agent_label
         plan = []
         for i in self.fit:                             # train_agents.py:105-119, agent index order
@@ -96,7 +153,7 @@ class AdversaryPath:
         S, N = e.S, e.N
         # The (up to) three fits are independent networks and each is ONE latency-bound workgroup per (seed, adversary):
         # on a GPU they run side by side on three streams (forked from / joined to the current one).
-        par = e.dev.type == "cuda" and __import__("os").environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false")
+        par = e.dev.type == "cuda" and not e.wide and __import__("os").environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false")
         cur = torch.cuda.current_stream() if par else None
         if par and not hasattr(self, "fit_streams"):
             self.fit_streams = [torch.cuda.Stream(device=e.dev) for _ in range(2)]
@@ -125,10 +182,7 @@ class AdversaryPath:
                 rptr, rstride = e._x("r")
                 L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, B, e.ldb, e.stream)
                 e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"], scratch=self.a1t)
-                xptr, xstride = e._x("s")
-                L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic_local"].data_ptr(), self.mal_t.data_ptr(), len(self.mal),
-                                       e.ybuf["y_l"].data_ptr(), perms["local"].data_ptr(), S, N, B, e.in_c, HID,
-                                       e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, None, e.stream)
+                self._fit_critic_family(e.theta["critic_local"], self.mal_t, self.mal, e.ybuf["y_l"], perms["local"], B, None)
                 done(2)
         # transmitted TR: targets r_fit (own reward for Greedy, -r_coop for Malicious)
         with on(1):
@@ -136,62 +190,13 @@ class AdversaryPath:
             L.rcmarl_minibatch_fit(xptr, xstride, e.theta["tr"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
                                    e.ybuf["r_fit"].data_ptr(), perms["tr"].data_ptr(), S, N, B, e.in_r, HID, e.ldp["tr"],
                                    e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(), e.stream)
-            if write_msg:
-                e.msg["tr"].index_copy_(1, self.fit_idx, e.theta["tr"].index_select(1, self.fit_idx))   # the fitted net IS the message
+            e.msg["tr"].index_copy_(1, self.fit_idx, e.theta["tr"].index_select(1, self.fit_idx))   # the fitted net IS the message
             done(1)
         # transmitted critic: targets y_c = r_fit + gamma*V_theta(ns), computed from the pre-fit weights
-        xptr, xstride = e._x("s")
-        L.rcmarl_minibatch_fit(xptr, xstride, e.theta["critic"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
-                               y_c.data_ptr(), perms["critic"].data_ptr(), S, N, B, e.in_c, HID,
-                               e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["critic"].data_ptr(),
-                               e.stream)
-        if write_msg:
-            e.msg["critic"].index_copy_(1, self.fit_idx, e.theta["critic"].index_select(1, self.fit_idx))
+        self._fit_critic_family(e.theta["critic"], self.fit_t, self.fit, y_c, perms["critic"], B, e.loss["critic"])
+        e.msg["critic"].index_copy_(1, self.fit_idx, e.theta["critic"].index_select(1, self.fit_idx))
         for ev in joins:
             cur.wait_event(ev)
-
-    # -- all consensus epochs of a block, ahead of the cooperative agents ----------------------------------
-    def chain_async(self, B, n_epochs):
-        """Greedy / Malicious agents never look at their neighbours (adversarial_CAC_agents.py: their fits use their own
-        nets and their own targets only), so within an update block their n_epochs x (10 Keras epochs of mini-batch SGD)
-        form ONE dependent chain that does not wait for the cooperative agents' consensus steps.  Launched here in full
-        on a side stream; the cooperative side only waits, epoch by epoch, for the message rows it is about to
-        aggregate.  OPT-IN (RCMARL_ADV_CHAIN=1): same results, but measured SLOWER than launching epoch by epoch (233 vs
-        200 ms per block at 512 seeds x (4 + 1 Malicious)) -- the limit is not the false dependency but that the 1536
-        one-wavefront fits of an epoch hold more registers than the chip has (448 each), so whenever they are resident
-        the cooperative kernels are not; running ahead keeps them resident all the time.
-        Returns a list of (event, {net: rows [S][n_fit][ldp]}) per epoch, or None when there is nothing to run ahead."""
-        e = self.e
-        if not self.fit or n_epochs <= 0 or e.dev.type != "cuda":
-            return None
-        if __import__("os").environ.get("RCMARL_ADV_CHAIN", "0") in ("0", "false", ""):
-            return None
-        if not hasattr(self, "chain_stream"):
-            self.chain_stream = torch.cuda.Stream(device=e.dev)
-        main = torch.cuda.current_stream(e.dev)
-        fork = torch.cuda.Event()
-        fork.record(main)
-        out = []
-        with torch.cuda.stream(self.chain_stream):
-            self.chain_stream.wait_event(fork)
-            for _ in range(n_epochs):
-                # targets of the transmitted critic from ITS current weights (agents/...:128-131), in a buffer of our own:
-                # the cooperative side rewrites y_c every epoch
-                e._value("ns", e.theta["critic"], "critic", e.ybuf["y_adv"], B, r_applied=e.ybuf["r_fit"], scratch=self.a1t)
-                self.phase1(B, y_c=e.ybuf["y_adv"], write_msg=False)
-                rows = {net: e.theta[net].index_select(1, self.fit_idx) for net in ("critic", "tr")}
-                ev = torch.cuda.Event()
-                ev.record(self.chain_stream)
-                out.append((ev, rows))
-        self._keep_chain = out                         # (rows are read on the main stream: keep them until the next block)
-        return out
-
-    def consume(self, item):
-        """the cooperative side, before a consensus step: wait for that epoch's messages and put them in place"""
-        ev, rows = item
-        torch.cuda.current_stream(self.e.dev).wait_event(ev)
-        for net, r in rows.items():
-            self.e.msg[net].index_copy_(1, self.fit_idx, r)
 
     # -- phase III ---------------------------------------------------------------------------
     def actor_updates(self, B):

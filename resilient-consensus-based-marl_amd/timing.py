@@ -32,12 +32,6 @@ WORK = {
     # a1t, theta, y, partials, dzp, rt, kt, S, N, B, in_dim, hid: reads a1 (4 B), writes 3 bf16 pieces of dz1 (6 B)
     "rcmarl_mid_fit_lattice": lambda a: (a[7] * a[8] * a[9] * (8.0 * a[11] ** 2 + 12.0 * a[11]),
                                          10.0 * a[7] * a[8] * a[9] * a[11]),
-    # kp, rt, kt, wpf, rt, kt, theta, y, partials, dzp, rt, kt, S, N, B, in_dim, hid: layer-1 GEMM (fp32-equivalent 2MNK) +
-    # layers 2-3 fwd/bwd; compulsory bytes: dz1 pieces written (6 B per (agent, unit, row)) + W' read once (6 B per weight)
-    "rcmarl_fit_fused_lattice": lambda a: (2.0 * a[12] * a[13] * a[16] * a[14] * a[15] + a[12] * a[13] * a[14] * (8.0 * a[16] ** 2 + 12.0 * a[16]),
-                                           6.0 * a[12] * a[13] * a[16] * (a[14] + a[15])),
-    "rcmarl_layer1_backward_sgd_lattice_fit": lambda a: _gemm_flops(a, 9),
-    "rcmarl_w1_split_fit": lambda a: (0.0, 10.0 * a[3] * a[4] * a[5] * a[6]),
     # theta, alpha, wp, S, N, in_dim, hid: reads W1 (4 B), writes 3 pieces (6 B)
     "rcmarl_w1_split": lambda a: (0.0, 10.0 * a[3] * a[4] * a[5] * a[6]),
     # x, x_seed_stride, theta, agents, n_adv, y, perm, S, N, B, in_dim, hid, ..., batch_size, epochs: whole Keras fit() of

@@ -34,10 +34,10 @@ def make_inputs(args, nrow, seeds, weight_seed=3, critic_hid=20):
     return W, goals
 
 
-def run_oracle(args, nrow, ncol, rng_mode, seeds, W, goals):
-    """oracle.train, one run per seed -> (per-seed DataFrames, per-seed weight lists)."""
+def run_oracle(args, nrow, ncol, rng_mode, seeds, W, goals, return_agents=False):
+    """oracle.train, one run per seed -> (per-seed DataFrames, per-seed weight lists[, per-seed agent objects])."""
     n = args["n_agents"]
-    o_logs, o_weights = [], []
+    o_logs, o_weights, o_agents = [], [], []
     for s in range(len(seeds)):
         a = dict(args)
         a["random_seed"] = int(seeds[s])
@@ -52,7 +52,8 @@ def run_oracle(args, nrow, ncol, rng_mode, seeds, W, goals):
             w, df = O.train(env, agents, a, rng_mode="device")
         o_logs.append(df)
         o_weights.append(w)
-    return o_logs, o_weights
+        o_agents.append(agents)
+    return (o_logs, o_weights, o_agents) if return_agents else (o_logs, o_weights)
 
 
 def run_engine(args, nrow, ncol, rng_mode, device, lib, seeds, W, goals, lattice="auto", critic_hid=20, tweak=None):
@@ -97,6 +98,7 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4, actor="strict"):
     kernel_checks.check_actor_step)."""
     S, n = eng.S, eng.N
     steps = max(1, eng.adam_t)
+    worst = {"critic": 0.0, "tr": 0.0, "critic_local": 0.0}        # measured max |err| / max(1, |w|max) per family
     for s in range(S):
         df = o_logs[s]
         # identical action streams -> bit-identical float64 returns
@@ -115,11 +117,14 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4, actor="strict"):
                         actor_err.append(np.abs(a - b).ravel())
                         continue
                     tol = rtol_w * scale if net != "actor" else 0.05 * eng.cfg.slow_lr * steps + 1e-5
+                    if net != "actor":
+                        worst[net] = max(worst[net], err / scale)
                     assert err <= tol, (s, i, net, err, tol)
             if len(o_weights[s][i]) == 4:                       # Malicious: private critic (adversarial:180-182)
                 got = eng.get_weights(s, i, "critic_local")
                 for a, b in zip(got, o_weights[s][i][3]):
                     scale = max(1.0, float(np.abs(b).max()))
+                    worst["critic_local"] = max(worst["critic_local"], float(np.abs(a - b).max()) / scale)
                     assert float(np.abs(a - b).max()) <= rtol_w * scale, (s, i, "critic_local")
         if actor_err:
             e = np.concatenate(actor_err)
@@ -127,6 +132,9 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=2e-4, actor="strict"):
             assert e.max() <= 2.0 * lr * steps + 1e-6, ("actor", float(e.max()))
             frac = float(np.mean(e > 0.05 * lr * steps + 1e-5))
             assert frac <= 1e-4, ("actor outliers", frac, float(e.max()))
+    print("[parity] N=%d S=%d worst |w - w_oracle| / max(1,|w|max): critic %.2e  tr %.2e%s  (bar %.0e)"
+          % (n, S, worst["critic"], worst["tr"], "  critic_local %.2e" % worst["critic_local"] if worst["critic_local"] else "", rtol_w))
+    return worst
 
 
 def check_checkpoint_resume(labels, rng_mode, device, lib, path, n=5, nrow=5, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9,
@@ -172,3 +180,83 @@ def check_checkpoint_resume(labels, rng_mode, device, lib, path, n=5, nrow=5, ma
         pass
     else:
         raise AssertionError("a checkpoint written with H=1 loaded into an H=0 engine")
+
+
+def check_probed_rows_vs_oracle(n, d, H, hid, nrow, device, lib, probe, fast_lr, n_ep_fixed=5, max_ep_len=20, rtol=1e-4):
+    """ONE update epoch of a whole (wide-critic) instance on the engine; for the agents in `probe` the same epoch by the
+    oracle's per-agent methods (agents/resilient_CAC_agents.py:103-206): the local fits of the agent's in-neighbourhood on
+    the engine's own replay rows, hidden-layer consensus, estimate consensus, projection step.  The rows of an agent depend on
+    its neighbourhood only, so a 1024-agent instance needs d local fits per probed agent, not 1024.  Returns the worst
+    |w - w_oracle| / max(1, |w|max)."""
+    from rcmarl_amd.engine import flatten_params  # noqa: F401  (kept importable from here for the callers)
+    gamma = 0.9
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    cfg = EngineConfig(n, ["Cooperative"] * n, in_nodes, H=H, gamma=gamma, slow_lr=0.002, fast_lr=fast_lr, max_ep_len=max_ep_len,
+                       n_ep_fixed=n_ep_fixed, n_epochs=1, buffer_size=n_ep_fixed * max_ep_len, nrow=nrow, ncol=nrow, n_seeds=1,
+                       rng_mode="device", critic_hid=hid)
+    eng = RPBCACEngine(cfg, seeds=[5], device=device, lib=lib)
+    eng.init_glorot(base_seed=11)
+    eng.set_goals(np.random.default_rng(2).integers(0, min(5, nrow), size=(1, n, 2)))
+    assert eng.wide == (hid != 20)
+    need = sorted({j for i in probe for j in in_nodes[i]})
+    W0 = {j: {net: eng.get_weights(0, j, net) for net in ("critic", "tr")} for j in need}
+    eng.rollout_block(cfg.n_ep_fixed)
+    B = eng.B
+    assert B == n_ep_fixed * max_ep_len
+    rows = {k: eng.rp[k][0, :B].cpu().numpy() for k in ("s", "ns", "sa", "r")}
+    s, ns, sa = rows["s"].reshape(B, n, 2), rows["ns"].reshape(B, n, 2), rows["sa"].reshape(B, n, 3)
+    eng.update_block()
+    eng.sync()
+    assert all(bool(np.isfinite(v.cpu().numpy()).all()) for k, v in eng.theta.items() if k != "actor" or True)
+    dummy_actor = M.init_mlp(np.random.default_rng(0), 2 * n, 20, 5)
+    agents = {j: O.CoopAgent(dummy_actor, [a.copy() for a in W0[j]["critic"]], [a.copy() for a in W0[j]["tr"]], 0.002, fast_lr,
+                             gamma, H) for j in need}
+    msg_c, msg_t = {}, {}
+    for j in need:
+        msg_c[j], _ = agents[j].local_fit_critic(s, ns, rows["r"][:, j])
+        msg_t[j], _ = agents[j].local_fit_tr(sa, rows["r"][:, j])
+    worst = 0.0
+    for i in probe:
+        ag = agents[i]
+        c_in, t_in = [msg_c[j] for j in in_nodes[i]], [msg_t[j] for j in in_nodes[i]]
+        ag.consensus_hidden_critic(c_in)
+        ag.consensus_hidden_tr(t_in)
+        c_agg = ag.consensus_estimates_critic(s, c_in)
+        t_agg = ag.consensus_estimates_tr(sa, t_in)
+        ag.projection_step_critic(s, c_agg)
+        ag.projection_step_tr(sa, t_agg)
+        for net, want in (("critic", ag.critic), ("tr", ag.tr)):
+            got = eng.get_weights(0, i, net)
+            for a, b in zip(got, want):
+                err = float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+                worst = max(worst, err)
+                assert err <= rtol, (i, net, a.shape, err)
+    return worst
+
+
+def check_actor_gradient(n, d, H, nrow, device, lib, fast_lr, n_ep_fixed=10, max_ep_len=20, rtol=1e-4):
+    """One block, one epoch: after ONE Adam step m = (1 - beta1) g, so the engine's first-moment slots against the oracle's
+    hold the actor GRADIENT (agents/resilient_CAC_agents.py:86-101) to `rtol` of each agent's largest entry -- a
+    deterministic bar where the parameters themselves only admit a statistical one (Adam turns a gradient of magnitude
+    eps into +-lr).  Returns the worst max|dm| / max|m|."""
+    from rcmarl_amd.engine import flatten_params
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    args = make_args(["Cooperative"] * n, H=H, n_episodes=n_ep_fixed, max_ep_len=max_ep_len, n_ep_fixed=n_ep_fixed, n_epochs=1,
+                     buffer_size=2 * n_ep_fixed * max_ep_len, seed=1000, in_nodes=in_nodes, fast_lr=fast_lr)
+    seeds = (1000,)
+    W, goals = make_inputs(args, nrow, seeds)
+    o_logs, o_w, o_agents = run_oracle(args, nrow, nrow, "device", seeds, W, goals, return_agents=True)
+    eng, logs = run_engine(args, nrow, nrow, "device", device, lib, seeds, W, goals)
+    assert eng.adam_t == 1 and all(a.adam.t == 1 for a in o_agents[0])
+    P = eng.P["actor"]
+    got = eng.adam_m[0, :, :P].cpu().numpy()
+    worst = 0.0
+    for i in range(n):
+        want = flatten_params(o_agents[0][i].adam.m)
+        scale = float(np.abs(want).max())
+        assert scale > 0
+        err = float(np.abs(got[i] - want).max()) / scale
+        worst = max(worst, err)
+        assert err <= rtol, (i, err)
+    compare(eng, logs, o_logs, o_w, actor="stat" if n >= 64 else "strict")
+    return worst

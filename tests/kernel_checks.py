@@ -283,44 +283,6 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
     np.testing.assert_array_equal(bk.host(d_th), theta)           # live weights untouched (rollback)
 
 
-def check_fit_step_small(bk, S, N, B, in_dim, steps=2, lr=0.01, masked_agent=None):
-    """check_sgd_fit through the fused small-network step: rcmarl_fit_step_small -> rcmarl_small_sgd_full."""
-    rng = np.random.default_rng(S * 1000 + N * 100 + B + in_dim + 7)
-    P, _ = geom(in_dim, 1)
-    ldp, ldb = pad64(P), pad64(B)
-    params = random_params(rng, S, N, in_dim, 1)
-    theta = pack_rows(params, ldp)
-    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
-    yv = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    mask = np.ones(N, np.int32)
-    if masked_agent is not None:
-        mask[masked_agent] = 0
-    nchunk = (B + 255) // 256
-    psz = bk.lib.rcmarl_fit_small_partial_size(HID, in_dim)
-    assert psz == bk.lib.rcmarl_fit_partial_size(HID) + in_dim * HID
-    d_x, d_y, d_mask, d_msg = bk.dev(x), bk.dev(yv), bk.dev(mask), bk.dev(theta.copy())
-    d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
-    d_loss = bk.dev(np.zeros((S, N), np.float32))
-    L = bk.lib
-    for st in range(steps):
-        L.rcmarl_fit_step_small(bk.ptr(d_x), B * in_dim, bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part), S, N, B, in_dim, HID, ldp,
-                                ldb, bk.stream)
-        L.rcmarl_small_sgd_full(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
-                                in_dim, HID, ldp, lr, bk.stream)
-    msg, loss = bk.host(d_msg), bk.host(d_loss)
-    for s in range(S):
-        for n in range(N):
-            if not mask[n]:
-                np.testing.assert_array_equal(msg[s, n], theta[s, n])
-                continue
-            pw = M.copy_params(params[s][n])
-            hist = M.fit_mse(pw, x[s], yv[s, n, :B, None], lr, epochs=steps)
-            got = unpack_row(msg[s, n], in_dim, 1)
-            for k in range(6):
-                rel_close(got[k], pw[k], 1e-5, "fused fit param %d" % k)
-            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
-
-
 def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
     """K2+K3: estimate consensus + projection step of the output layer."""
     rng = np.random.default_rng(S + N * 10 + B + d * 7 + H)
@@ -975,94 +937,3 @@ def check_consensus_on_shipped_weights(bk, golden):
 
 
 # ------------------------------------------------------------------------------------------
-def fit_geometry(bk, N, in_dim):
-    """(rt, kt) of a W' operand in fit order (rows = rcmarl_fit_rows(N), three pieces)."""
-    return (-(-bk.lib.rcmarl_fit_rows(N) // 128), -(-in_dim // 32))
-
-
-def check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, lr=0.01, gamma=0.9, masked_agent=None):
-    """rcmarl_fit_fused_lattice (csrc/lattice_fit.hip: layer-1 GEMM + layers 2-3 + backward in ONE launch) against
-    (a) the unfused pair it replaces, step by step: dz1 pieces BIT-IDENTICAL, partial records to summation order;
-    (b) the oracle's fit (mlp_np.fit_mse) after `steps` full-batch SGD steps of
-        [w1_split_fit | backward epilogue] -> fit_fused -> small_sgd -> backward_sgd_lattice_fit."""
-    rng = np.random.default_rng(S * 1000 + N * 100 + B + width + 17)
-    in_dim = N * width
-    P, _ = geom(in_dim, 1)
-    ldp, ldb = pad64(P), pad64(B)
-    params = random_params(rng, S, N, in_dim, 1)
-    theta = pack_rows(params, ldp)
-    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol)
-    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    mask = np.ones(N, np.int32)
-    if masked_agent is not None:
-        mask[masked_agent] = 0
-    nchunk, nchunk_f = (B + 255) // 256, bk.lib.rcmarl_fit_fused_chunks(B)
-    psz = bk.lib.rcmarl_fit_partial_size(HID)
-    lb = LatticeBuffers(bk, S, N, in_dim, B)
-    g = lb.g
-    frt, fkt = fit_geometry(bk, N, in_dim)
-    d_wpf = bk.dev(np.full(S * frt * fkt * 3 * LT.PK_BLOCK // 2, 0x7fc0, np.uint16))          # NaN fill
-    d_dzp2 = bk.dev(np.full(S * LT.Geometry.nbytes(g.dzp, 3) // 2, 0x7fc0, np.uint16))
-    d_x, d_al, d_y, d_mask = bk.dev(x), bk.dev(alpha), bk.dev(y), bk.dev(mask)
-    d_msg = bk.dev(theta.copy())
-    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
-    d_part = bk.dev(np.full((S, N, nchunk_f, psz), np.nan, np.float32))
-    d_part2 = bk.dev(np.full((S, N, nchunk, psz), np.nan, np.float32))
-    d_loss = bk.dev(np.zeros((S, N), np.float32))
-    L = bk.lib
-    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)
-    assert bk.host(lb.flag)[0] == 0
-    for st in range(steps):
-        # reference for this step: the unfused pair on the same weights (natural-order operand, scratch outputs)
-        _layer1_lattice(bk, lb, d_al, d_msg, d_a, S, N, B, in_dim, ldp, ldb, split=True)
-        L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part2), bk.ptr(d_dzp2), g.dzp[0], g.dzp[1],
-                                 S, N, B, in_dim, HID, ldp, ldb, bk.stream)
-        if st == 0:                                     # later steps: the operand left by the backward epilogue
-            L.rcmarl_w1_split_fit(bk.ptr(d_msg), bk.ptr(d_al), bk.ptr(d_wpf), S, N, in_dim, HID, ldp, frt, fkt, bk.stream)
-        L.rcmarl_fit_fused_lattice(bk.ptr(lb.kp), g.kp[0], g.kp[1], bk.ptr(d_wpf), frt, fkt, bk.ptr(d_msg), bk.ptr(d_y),
-                                   bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, bk.stream)
-        dz_f, dz_u = bk.host(lb.dzp).reshape(S, -1), bk.host(d_dzp2).reshape(S, -1)
-        kpad = -(-B // 32) * 32                         # the k range the backward GEMM reads
-        for s_ in range(S):
-            for pc in range(3):
-                idx = LT.pk_element_index(N * HID, kpad, g.dzp[1], 3, pc)
-                np.testing.assert_array_equal(dz_f[s_][idx], dz_u[s_][idx], err_msg="dz1 piece %d, step %d" % (pc, st))
-        pf, pu = bk.host(d_part).sum(axis=2), bk.host(d_part2).sum(axis=2)        # the chunkings differ: compare the sums
-        assert np.isfinite(pf).all()
-        scale = np.maximum(np.abs(pu).max(axis=2, keepdims=True), 1e-6)
-        assert float((np.abs(pf - pu) / scale).max()) <= 2e-5, ("partial records", st, float((np.abs(pf - pu) / scale).max()))
-        L.rcmarl_small_sgd_chunks(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
-                                  in_dim, HID, ldp, lr, nchunk_f, bk.stream)
-        L.rcmarl_layer1_backward_sgd_lattice_fit(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
-                                                 bk.ptr(d_al), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
-                                                 bk.ptr(d_wpf), frt, fkt, bk.stream)
-        # the fit-order operand left by the epilogue == a fresh fit-order split of the updated weights
-        left = bk.host(d_wpf).copy()
-        L.rcmarl_w1_split_fit(bk.ptr(d_msg), bk.ptr(d_al), bk.ptr(d_wpf), S, N, in_dim, HID, ldp, frt, fkt, bk.stream)
-        fresh = bk.host(d_wpf)
-        rows = np.array([fit_row(a, u) for a in range(N) for u in range(HID)])
-        for s_ in range(S):
-            for pc in range(3):
-                idx = LT.pk_element_index(int(rows.max()) + 1, in_dim, fkt, 3, pc)[rows]
-                np.testing.assert_array_equal(left.reshape(S, -1)[s_][idx], fresh.reshape(S, -1)[s_][idx])
-        bk.dev  # (keep d_wpf = fresh: identical bytes on the rows that matter)
-    msg, loss = bk.host(d_msg), bk.host(d_loss)
-    for s in range(S):
-        for n in range(N):
-            if not mask[n]:
-                np.testing.assert_array_equal(msg[s, n], theta[s, n])
-                continue
-            pw = M.copy_params(params[s][n])
-            hist = M.fit_mse(pw, x[s], y[s, n, :B, None], lr, epochs=steps)
-            got = unpack_row(msg[s, n], in_dim, 1)
-            for k in range(6):
-                rel_close(got[k], pw[k], 1e-5, "fit param %d (fused lattice)" % k)
-            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
-
-
-def fit_row(agent, unit):
-    """rc_fit_row of csrc/rcmarl_lattice.h."""
-    grp, a8 = agent >> 3, agent & 7
-    h, g = a8 >> 2, a8 & 3
-    t = 20 * g + unit
-    return 160 * grp + 32 * (t >> 4) + 8 * ((t >> 2) & 3) + 4 * h + (t & 3)

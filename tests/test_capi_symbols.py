@@ -50,10 +50,6 @@ def test_argument_validation_needs_no_gpu():
         ("rcmarl_layer1_forward_lattice", (None, 0, 0, None, 0, 0, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
         ("rcmarl_layer1_backward_sgd_lattice", (None, 0, 0, None, 0, 0, None, None, None, 1, 5, 100, 10, 20, 704, 0.01, None, 0, 0, None)),
         ("rcmarl_mid_fit_lattice", (None, None, None, None, None, 0, 0, 1, 5, 100, 10, 20, 704, 128, None)),
-        ("rcmarl_w1_split_fit", (None, None, None, 1, 5, 10, 20, 704, 2, 1, None)),
-        ("rcmarl_fit_fused_lattice", (None, 0, 0, None, 0, 0, None, None, None, None, 0, 0, 1, 5, 100, 10, 20, 704, 128, None)),
-        ("rcmarl_layer1_backward_sgd_lattice_fit", (None, 0, 0, None, 0, 0, None, None, None, 1, 5, 100, 10, 20, 704, 0.01, None, 0, 0, None)),
-        ("rcmarl_small_sgd_chunks", (None, None, None, None, 1, 5, 100, 10, 20, 704, 0.01, 0, None)),
         ("rcmarl_shuffle_perms", (None, None, 1, 1, 100, None, 1, None)),
         ("rcmarl_mid_fit", (None, None, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
         ("rcmarl_consensus_params_circulant", (None, None, None, 1, 5, 64, 40, 4, 1, None, None, None)),
@@ -73,15 +69,6 @@ def test_argument_validation_needs_no_gpu():
     for name, args in bad:
         with pytest.raises(capi.RcmarlError, match="RCMARL_ERR_ARG|RCMARL_ERR_UNSUPPORTED"):
             getattr(lib, name)(*args)
-
-
-def test_fit_order_geometry_queries():
-    """Host-only queries of the fused local-fit step: rows of the fit-order W' operand (whole 8-agent groups of 160 rows) and
-    partial records per (seed, agent)."""
-    from rcmarl_amd import build, capi
-    lib = capi.CLib(build.build_hip())
-    assert lib.rcmarl_fit_rows(256) == 5120 and lib.rcmarl_fit_rows(5) == 160 and lib.rcmarl_fit_rows(9) == 320
-    assert lib.rcmarl_fit_fused_chunks(3000) * 128 >= 3000 > (lib.rcmarl_fit_fused_chunks(3000) - 1) * 128
 
 
 def test_circulant_kernel_coverage_query():

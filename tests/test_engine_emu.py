@@ -57,9 +57,17 @@ def test_engine_wide_critic_with_faulty_agent_matches_oracle():
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(43,), critic_hid=24, lattice=False)
     assert eng.wide and hasattr(eng, "adv")
     EC.compare(eng, logs, o_logs, o_w)
-    from rcmarl_amd.engine import EngineConfig
-    with pytest.raises(ValueError, match="Cooperative and Faulty"):
-        EngineConfig(5, ["Cooperative"] * 4 + ["Greedy"], args["in_nodes"], H=1, critic_hid=24)
+
+
+@pytest.mark.parametrize("labels", [["Cooperative"] * 3 + ["Greedy", "Malicious"], ["Malicious"] + ["Cooperative"] * 4])
+def test_engine_wide_critic_with_greedy_and_malicious_agents_matches_oracle(labels):
+    """Greedy / Malicious agents beside a WIDE critic (agents/adversarial_CAC_agents.py:121-165,228-253 take any Keras model):
+    their fit(batch_size=32, epochs=10) message generators run through the dense per-agent GEMM entry points, one mini-batch
+    at a time (engine_adversaries._fit_critic_family); the Malicious agent's private wide critic too."""
+    args = EC.make_args(labels, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=44)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(44,), critic_hid=24, lattice=False)
+    assert eng.wide and hasattr(eng, "adv") and eng.adv.fit
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)
 
 
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])
@@ -109,11 +117,15 @@ def test_replay_grows_past_the_steady_state_capacity():
     EC.compare(eng, logs, [pd.concat([df1, df2], ignore_index=True)], [ow])
 
 
-def test_engine_fused_local_fit_matches_oracle(monkeypatch):
-    """RCMARL_FIT_FUSED=1: the local fits run through rcmarl_fit_fused_lattice (one launch for layer-1 GEMM + layers 2-3 +
-    the way back to dz1) -> same oracle, same tolerances."""
-    monkeypatch.setenv("RCMARL_FIT_FUSED", "1")
-    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=33)
-    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(33, 34), lattice=True)
-    assert eng.lat_active and eng.fit_fused and "s" in eng.lat_wpf
-    EC.compare(eng, logs, o_logs, o_w)
+
+def test_probed_rows_vs_oracle_wide_critic_small():
+    """tests/test_engine_round3_parity_gpu.py::test_engine_cfg5_full_shape_rows_vs_oracle in miniature (hipemu kernels):
+    one epoch of a wide-critic instance vs the oracle's per-agent methods for two probed agents."""
+    worst = EC.check_probed_rows_vs_oracle(8, 4, 1, 32, 5, "cpu", emu_lib(), probe=[0, 7], fast_lr=0.01, n_ep_fixed=2, max_ep_len=5)
+    assert worst <= 1e-4
+
+
+def test_actor_gradient_vs_oracle_small():
+    """...::test_actor_gradient_at_256_agents_vs_oracle in miniature: Adam m after one step == (1 - beta1) x oracle gradient."""
+    worst = EC.check_actor_gradient(6, 4, 1, 5, "cpu", emu_lib(), fast_lr=0.01, n_ep_fixed=2, max_ep_len=5)
+    assert worst <= 1e-4

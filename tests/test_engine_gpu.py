@@ -131,6 +131,23 @@ def test_engine_wide_critic(n, critic_hid, H, d, rng_mode, lattice):
     EC.compare(eng, logs, o_logs, o_w)
 
 
+@pytest.mark.parametrize("n,critic_hid,lattice,labels", [(6, 64, False, {1: "Greedy", 4: "Malicious"}), (16, 64, True, {0: "Malicious", 9: "Malicious"})])
+def test_engine_wide_critic_with_greedy_and_malicious_agents(n, critic_hid, lattice, labels):
+    """Byzantine agents beside a wide critic (VERDICT r02 missing #3; agents/adversarial_CAC_agents.py:121-165,228-253 take any
+    Keras model): two adversaries, 64-unit critic, vs the oracle.  Their mini-batch message generators run through the dense
+    per-agent GEMM entry points, 32 permuted rows at a time (engine_adversaries._fit_critic_family) -- correct, not fast."""
+    d = 4
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    lab = ["Cooperative"] * n
+    for i, v in labels.items():
+        lab[i] = v
+    args = EC.make_args(lab, H=1, n_episodes=8, max_ep_len=10, n_ep_fixed=4, n_epochs=2, buffer_size=60, seed=58,
+                        in_nodes=in_nodes, fast_lr=0.005)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, "device", "cuda", None, seeds=(58,), critic_hid=critic_hid, lattice=lattice)
+    assert eng.wide and hasattr(eng, "adv") and eng.adv.fit and eng.lat_active == lattice
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)
+
+
 @pytest.mark.parametrize("n,critic_hid,lattice", [(6, 64, False), (16, 512, True)])
 def test_engine_wide_critic_with_faulty_agents(n, critic_hid, lattice):
     """Faulty agents (frozen critic / team-reward messages, learning actor: adversarial_CAC_agents.py:5-55) beside a wide
@@ -191,14 +208,3 @@ def test_checkpoint_resume_is_bit_identical(labels, rng_mode, n, tmp_path):
                                max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=300, S=3, blocks=(2, 2),
                                lattice=True if n == 5 else "auto")
 
-
-def test_engine_fused_local_fit_matches_oracle(monkeypatch):
-    """The opt-in fused local-fit step (RCMARL_FIT_FUSED=1, csrc/lattice_fit.hip) end to end vs the oracle, 20 agents."""
-    monkeypatch.setenv("RCMARL_FIT_FUSED", "1")
-    n = 20
-    in_nodes = [[(i + k) % n for k in range(6)] for i in range(n)]
-    args = EC.make_args(["Cooperative"] * n, H=2, n_episodes=20, max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=300,
-                        seed=43, in_nodes=in_nodes)
-    eng, logs, o_logs, o_w = EC.run_pair(args, 16, 12, "device", "cuda", None, seeds=(43, 44))
-    assert eng.lat_active and eng.fit_fused and "s" in eng.lat_wpf
-    EC.compare(eng, logs, o_logs, o_w)

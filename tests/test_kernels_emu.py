@@ -115,12 +115,6 @@ def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 3, 300, 10, None), (1, 4, 130, 15, 2), (1, 2, 70, 32, None), (1, 3, 45, 21, None),
-                                                 (1, 2, 700, 10, None)])     # 3 chunks: the multi-chunk walk of one workgroup
-def test_fit_step_small(bk, S, N, B, in_dim, masked):
-    KC.check_fit_step_small(bk, S, N, B, in_dim, steps=2, masked_agent=masked)
-
-
 # ---- wide networks (hid != 20): dense-GEMM path, csrc/wide_kernels.hip -------------------------------
 import wide_checks as WC
 
@@ -143,44 +137,10 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 
-@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(1, 5, 70, 2, 5, 5, None), (2, 11, 300, 3, 8, 6, 3)])
-def test_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, masked):
-    KC.check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)
-
-
-@pytest.mark.parametrize("lattice", [False, True])
-def test_mid_fit_v5_matrix_core_form(bk, lattice, monkeypatch):
-    """RCMARL_MIDFIT=5: k_mid_fit_v5 (layer 2 forward/backward and every row reduction on the f32 matrix core) behind the
-    same two entry points, against the same oracle fits."""
-    monkeypatch.setenv("RCMARL_MIDFIT", "5")
-    if lattice:
-        KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
-    else:
-        KC.check_sgd_fit(bk, 2, 5, 130, 10, steps=2, masked_agent=1)
-
-
-def test_mid_fit_v3_still_reachable(bk, monkeypatch):
-    """RCMARL_MIDFIT=2 keeps the VALU form (k_mid_fit_v3) behind rcmarl_mid_fit, which defaults to v5 now."""
-    monkeypatch.setenv("RCMARL_MIDFIT", "2")
-    KC.check_sgd_fit(bk, 1, 5, 130, 10, steps=2, masked_agent=1)
-
-
 @pytest.mark.parametrize("w8", ["0", "1"])
 def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
     monkeypatch.setenv("RCMARL_LAT_W8", w8)
     KC.check_lattice_sgd_fit(bk, 1, 7, 130, 2, 5, 5, steps=2, masked_agent=2)
-
-
-@pytest.mark.parametrize("S,N,B,width", [(1, 14, 300, 2)])
-def test_lattice_backward_dz_fragments_from_global_bit_identical(bk, S, N, B, width, monkeypatch):
-    """RCMARL_LAT_BDIRECT=1: the backward GEMM loads its three-piece operand's fragments global -> registers instead of
-    staging them through LDS (lat_mainloop_bdirect).  Same products in the same order: the same oracle fit, and weights
-    and next-step operand pieces equal to the LDS-staged kernel's bit for bit."""
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=2, masked_agent=4)
-    monkeypatch.setenv("RCMARL_LAT_BDIRECT", "1")
-    msg, wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=2, masked_agent=4)
-    np.testing.assert_array_equal(msg, ref_msg)
-    np.testing.assert_array_equal(wp, ref_wp)
 
 
 @pytest.mark.parametrize("d,H", [(4, 1), (6, 2), (10, 4), (18, 8), (5, 1), (9, 3)])
@@ -194,60 +154,4 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
         P_hid = int(rng.integers(1, 150))
         graph = "circ" if rng.random() < 0.7 else "rand"
         KC.check_consensus_params_exact(bk, N, d, H, P_hid, int(rng.integers(1, 3)), int(rng.integers(1 << 30)), graph)
-
-
-def test_lattice_gemms_spread_dma_issue_bit_identical(bk, monkeypatch):
-    """RCMARL_LAT_SPREAD=3: both lattice GEMMs issue the LDS-DMA bursts of the next k-tile between their matrix-core
-    instructions instead of back to back after the barrier.  Pure scheduling: same bits."""
-    args = (1, 14, 300, 2, 7, 9)
-    monkeypatch.setenv("RCMARL_LAT_SPREAD", "0")
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    monkeypatch.setenv("RCMARL_LAT_SPREAD", "3")
-    msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    np.testing.assert_array_equal(msg, ref_msg)
-    np.testing.assert_array_equal(wp, ref_wp)
-
-
-@pytest.mark.parametrize("knob", ["RCMARL_LAT_WIDE", "RCMARL_LAT_TALL"])
-def test_lattice_backward_wide_tile_bit_identical(bk, knob, monkeypatch):
-    """The backward GEMM on 256 x 256 tiles (RCMARL_LAT_WIDE: the one-piece operand's LDS stage shared by twice the dz
-    columns) or 512 x 128 tiles (RCMARL_LAT_TALL: the dz panel read once for up to 512 inputs), eight wavefronts each.
-    Same products in the same order per accumulator: same bits."""
-    args = (1, 14, 300, 2, 7, 9)
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    monkeypatch.setenv(knob, "1")
-    msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    np.testing.assert_array_equal(msg, ref_msg)
-    np.testing.assert_array_equal(wp, ref_wp)
-
-
-def test_mid_fit_4x4_block_products_bit_identical(bk, monkeypatch):
-    """RCMARL_MIDFIT=6: the two 20x20 layer products of the mid kernel as 4x4x1 sixteen-block MFMAs (result born row-per-lane,
-    no padding rows, no permlane swaps).  Same fmaf chains: dz pieces AND gradient records equal v5's bit for bit, on both
-    entry points; and the usual oracle fit."""
-    from rcmarl_amd import lattice as LT
-    rng = np.random.default_rng(4)
-    S, N, B, in_dim = (1, 3, 300, 6)
-    P, _ = KC.geom(in_dim, 1)
-    ldp, ldb = KC.pad64(P), KC.pad64(B)
-    theta = KC.pack_rows(KC.random_params(rng, S, N, in_dim, 1), ldp)
-    a1 = np.maximum(rng.normal(size=(S, N * 20, ldb)), 0.1 * rng.normal(size=(S, N * 20, ldb))).astype(np.float32)
-    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    g = LT.Geometry(N, in_dim, B)
-    nchunk, psz = (B + 255) // 256, bk.lib.rcmarl_fit_partial_size(20)
-    out = {}
-    for var in ("5", "6"):
-        monkeypatch.setenv("RCMARL_MIDFIT", var)
-        d_a, d_th, d_y = bk.dev(a1), bk.dev(theta), bk.dev(y)
-        d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
-        d_dzp = bk.dev(np.zeros(S * LT.Geometry.nbytes(g.dzp, 3) // 2, np.uint16))
-        bk.lib.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(d_dzp), g.dzp[0], g.dzp[1], S, N, B,
-                                      in_dim, 20, ldp, ldb, bk.stream)
-        d_a2 = bk.dev(a1)
-        d_part2 = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
-        bk.lib.rcmarl_mid_fit(bk.ptr(d_a2), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part2), S, N, B, in_dim, 20, ldp, ldb, bk.stream)
-        out[var] = (bk.host(d_dzp).copy(), bk.host(d_part).copy(), bk.host(d_a2).copy(), bk.host(d_part2).copy())
-    for a, b in zip(out["5"], out["6"]):
-        np.testing.assert_array_equal(a, b)
-    KC.check_sgd_fit(bk, 1, 5, 130, 10, steps=2, masked_agent=1)
 

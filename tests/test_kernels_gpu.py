@@ -138,12 +138,6 @@ def test_lattice_equals_f32_path_at_full_size(bk, width):
     KC.check_lattice_vs_f32(bk, S=2, N=256, B=3000, width=width, nrow=32, ncol=32, steps=2)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (2, 5, 3000, 15, 4), (4, 5, 700, 15, None), (1, 10, 333, 30, 2),
-                                                 (3, 16, 1000, 32, None), (1, 8, 130, 24, None)])
-def test_fit_step_small(bk, S, N, B, in_dim, masked):
-    KC.check_fit_step_small(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
-
-
 @pytest.mark.parametrize("N,d,H,P,P_hid,S", [(5, 4, 1, 761, 740, 512), (5, 4, 0, 661, 640, 300), (12, 6, 2, 1200, 1100, 128)])
 def test_consensus_params_short_tiles_many_seeds(bk, N, d, H, P, P_hid, S):
     """Regression: with few agents and a small d a tile is aggregated in less time than the LDS-DMA of the next one
@@ -174,64 +168,6 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 
-@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (2, 11, 300, 3, 8, 6, 3), (1, 64, 3000, 3, 16, 16, 5),
-                                                          (2, 256, 1000, 2, 32, 32, None), (1, 256, 3000, 3, 32, 32, 100),
-                                                          (1, 20, 777, 2, 7, 9, None)])
-def test_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, masked):
-    """The fused local-fit step (csrc/lattice_fit.hip) vs the unfused pair (dz1 bit-identical) and vs the oracle's fit."""
-    # N = 256: fast_lr 0.0025 as everywhere at that size (0.01 is on the edge of divergence at 512/768 unscaled inputs and
-    # amplifies fp32 roundoff between any two summation orders; bench.py header)
-    KC.check_fit_fused_lattice(bk, S, N, B, width, nrow, ncol, steps=3, masked_agent=masked, lr=0.0025 if N >= 256 else 0.01)
-
-
-@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (2, 5, 3000, 15, 4), (1, 64, 1000, 192, 5), (1, 128, 333, 256, None)])
-def test_mid_fit_v5_sgd_fit(bk, S, N, B, in_dim, masked, monkeypatch):
-    """RCMARL_MIDFIT=5: the all-matrix-core form of the mid kernel behind rcmarl_mid_fit, same oracle fits as test_sgd_fit."""
-    monkeypatch.setenv("RCMARL_MIDFIT", "5")
-    KC.check_sgd_fit(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
-
-
-@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (1, 64, 1000, 3, 16, 16, 5), (8, 32, 700, 2, 16, 16, 2), (1, 20, 777, 2, 7, 9, 3)])
-def test_mid_fit_v5_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
-    monkeypatch.setenv("RCMARL_MIDFIT", "5")
-    KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
-
-
-def test_mid_fit_v5_bit_identical_dz_to_v3(bk, monkeypatch):
-    """Same fmaf chains in both forms: the dz1 pieces of v5 equal those of v3 bit for bit (records: summation order)."""
-    import torch
-    rng = np.random.default_rng(3)
-    S, N, B, in_dim = 2, 6, 700, 12
-    P, _ = KC.geom(in_dim, 1)
-    ldp, ldb = KC.pad64(P), KC.pad64(B)
-    theta = KC.pack_rows(KC.random_params(rng, S, N, in_dim, 1), ldp)
-    a1 = np.maximum(rng.normal(size=(S, N * 20, ldb)), 0.1 * rng.normal(size=(S, N * 20, ldb))).astype(np.float32)
-    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    from rcmarl_amd import lattice as LT
-    g = LT.Geometry(N, in_dim, B)
-    nchunk, psz = (B + 255) // 256, bk.lib.rcmarl_fit_partial_size(20)
-    out = {}
-    for var in ("2", "5"):
-        monkeypatch.setenv("RCMARL_MIDFIT", var)
-        d_a, d_th, d_y = bk.dev(a1), bk.dev(theta), bk.dev(y)
-        d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
-        d_dzp = bk.dev(np.zeros(S * LT.Geometry.nbytes(g.dzp, 3) // 2, np.uint16))
-        bk.lib.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(d_dzp), g.dzp[0], g.dzp[1], S, N, B,
-                                      in_dim, 20, ldp, ldb, bk.stream)
-        out[var] = (bk.host(d_dzp).copy(), bk.host(d_part).copy())
-    np.testing.assert_array_equal(out["5"][0], out["2"][0])
-    pu, pf = out["2"][1], out["5"][1]
-    scale = np.maximum(np.abs(pu).max(axis=(2, 3), keepdims=True), 1e-6)
-    assert float((np.abs(pf - pu) / scale).max()) <= 2e-5
-
-
-@pytest.mark.parametrize("variant", ["2", "1", "0"])
-def test_mid_fit_older_variants(bk, variant, monkeypatch):
-    """The earlier forms of the mid kernel stay selectable (RCMARL_MIDFIT) and correct."""
-    monkeypatch.setenv("RCMARL_MIDFIT", variant)
-    KC.check_sgd_fit(bk, 2, 5, 1000, 10, steps=3, masked_agent=None)
-
-
 @pytest.mark.parametrize("w8", ["0", "1"])
 def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
     """RCMARL_LAT_W8: the lattice GEMMs as four wavefronts of 64x128 / 128x64 or eight of 64x64 per workgroup -- same
@@ -239,18 +175,6 @@ def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
     monkeypatch.setenv("RCMARL_LAT_W8", w8)
     KC.check_lattice_sgd_fit(bk, 2, 20, 777, 3, 7, 9, steps=3, masked_agent=4)
     KC.check_lattice_forward(bk, 1, 64, 1000, 2, 16, 16)
-
-
-@pytest.mark.parametrize("S,N,B,width", [(2, 20, 777, 3), (1, 40, 300, 2)])
-def test_lattice_backward_dz_fragments_from_global_bit_identical(bk, S, N, B, width, monkeypatch):
-    """RCMARL_LAT_BDIRECT=1: the backward GEMM loads its three-piece operand's fragments global -> registers instead of
-    staging them through LDS (lat_mainloop_bdirect).  Same products in the same order: the same oracle fit, and weights
-    and next-step operand pieces equal to the LDS-staged kernel's bit for bit."""
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=3, masked_agent=4)
-    monkeypatch.setenv("RCMARL_LAT_BDIRECT", "1")
-    msg, wp = KC.check_lattice_sgd_fit(bk, S, N, B, width, 7, 9, steps=3, masked_agent=4)
-    np.testing.assert_array_equal(msg, ref_msg)
-    np.testing.assert_array_equal(wp, ref_wp)
 
 
 @pytest.mark.parametrize("d,H", [(4, 1), (6, 2), (10, 4), (18, 8), (5, 1), (9, 3)])
@@ -264,60 +188,4 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
         P_hid = int(rng.integers(1, 700))
         graph = "circ" if rng.random() < 0.7 else "rand"
         KC.check_consensus_params_exact(bk, N, d, H, P_hid, int(rng.integers(1, 3)), int(rng.integers(1 << 30)), graph)
-
-
-def test_lattice_gemms_spread_dma_issue_bit_identical(bk, monkeypatch):
-    """RCMARL_LAT_SPREAD=3: both lattice GEMMs issue the LDS-DMA bursts of the next k-tile between their matrix-core
-    instructions instead of back to back after the barrier.  Pure scheduling: same bits."""
-    args = (2, 20, 777, 3, 7, 9)
-    monkeypatch.setenv("RCMARL_LAT_SPREAD", "0")
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    monkeypatch.setenv("RCMARL_LAT_SPREAD", "3")
-    msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    np.testing.assert_array_equal(msg, ref_msg)
-    np.testing.assert_array_equal(wp, ref_wp)
-
-
-@pytest.mark.parametrize("knob", ["RCMARL_LAT_WIDE", "RCMARL_LAT_TALL"])
-def test_lattice_backward_wide_tile_bit_identical(bk, knob, monkeypatch):
-    """The backward GEMM on 256 x 256 tiles (RCMARL_LAT_WIDE: the one-piece operand's LDS stage shared by twice the dz
-    columns) or 512 x 128 tiles (RCMARL_LAT_TALL: the dz panel read once for up to 512 inputs), eight wavefronts each.
-    Same products in the same order per accumulator: same bits."""
-    args = (2, 26, 777, 3, 7, 9)
-    ref_msg, ref_wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    monkeypatch.setenv(knob, "1")
-    msg, wp = KC.check_lattice_sgd_fit(bk, *args, steps=2, masked_agent=4)
-    np.testing.assert_array_equal(msg, ref_msg)
-    np.testing.assert_array_equal(wp, ref_wp)
-
-
-def test_mid_fit_4x4_block_products_bit_identical(bk, monkeypatch):
-    """RCMARL_MIDFIT=6: the two 20x20 layer products of the mid kernel as 4x4x1 sixteen-block MFMAs (result born row-per-lane,
-    no padding rows, no permlane swaps).  Same fmaf chains: dz pieces AND gradient records equal v5's bit for bit, on both
-    entry points; and the usual oracle fit."""
-    from rcmarl_amd import lattice as LT
-    rng = np.random.default_rng(4)
-    S, N, B, in_dim = (2, 6, 700, 12)
-    P, _ = KC.geom(in_dim, 1)
-    ldp, ldb = KC.pad64(P), KC.pad64(B)
-    theta = KC.pack_rows(KC.random_params(rng, S, N, in_dim, 1), ldp)
-    a1 = np.maximum(rng.normal(size=(S, N * 20, ldb)), 0.1 * rng.normal(size=(S, N * 20, ldb))).astype(np.float32)
-    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
-    g = LT.Geometry(N, in_dim, B)
-    nchunk, psz = (B + 255) // 256, bk.lib.rcmarl_fit_partial_size(20)
-    out = {}
-    for var in ("5", "6"):
-        monkeypatch.setenv("RCMARL_MIDFIT", var)
-        d_a, d_th, d_y = bk.dev(a1), bk.dev(theta), bk.dev(y)
-        d_part = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
-        d_dzp = bk.dev(np.zeros(S * LT.Geometry.nbytes(g.dzp, 3) // 2, np.uint16))
-        bk.lib.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(d_dzp), g.dzp[0], g.dzp[1], S, N, B,
-                                      in_dim, 20, ldp, ldb, bk.stream)
-        d_a2 = bk.dev(a1)
-        d_part2 = bk.dev(np.zeros((S, N, nchunk, psz), np.float32))
-        bk.lib.rcmarl_mid_fit(bk.ptr(d_a2), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part2), S, N, B, in_dim, 20, ldp, ldb, bk.stream)
-        out[var] = (bk.host(d_dzp).copy(), bk.host(d_part).copy(), bk.host(d_a2).copy(), bk.host(d_part2).copy())
-    for a, b in zip(out["5"], out["6"]):
-        np.testing.assert_array_equal(a, b)
-    KC.check_sgd_fit(bk, 2, 5, 1000, 10, steps=2, masked_agent=1)
 

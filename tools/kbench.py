@@ -164,7 +164,7 @@ def lattice(L, S=16, N=256, B=3000):
         kp, ktp, wp, dzp = u8(g.kp, 1), u8(g.ktp, 1), u8(g.wp, 3), u8(g.dzp, 3)
         flag = torch.zeros(1, dtype=torch.int32, device="cuda")
         nchunk = (B + 255) // 256
-        part = torch.zeros(S * N * max(nchunk, L.rcmarl_fit_fused_chunks(B)) * L.rcmarl_fit_partial_size(HID), device="cuda")
+        part = torch.zeros(S * N * nchunk * L.rcmarl_fit_partial_size(HID), device="cuda")
         flops = 2.0 * S * N * HID * B * in_dim
         t = timeit(lambda: L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0],
                                                    g.kp[1], ktp.data_ptr(), g.ktp[0], g.ktp[1], flag.data_ptr(), st))
@@ -179,15 +179,6 @@ def lattice(L, S=16, N=256, B=3000):
         t = timeit(lambda: L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
                                                     g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st))
         print("mid_fit_l in=%4d  %8.1f us" % (in_dim, t))
-        frt, fkt = LT.cdiv(L.rcmarl_fit_rows(N), 128), LT.cdiv(in_dim, 32)
-        wpf = u8((frt, fkt), 3)
-        t = timeit(lambda: L.rcmarl_w1_split_fit(theta.data_ptr(), alpha.data_ptr(), wpf.data_ptr(), S, N, in_dim, HID, ldp, frt, fkt, st))
-        print("split_fit in=%4d  %8.1f us" % (in_dim, t))
-        t = timeit(lambda: L.rcmarl_fit_fused_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wpf.data_ptr(), frt, fkt, theta.data_ptr(),
-                                                      y.data_ptr(), part.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B,
-                                                      in_dim, HID, ldp, ldb, st))
-        print("fit_fused in=%4d  %8.1f us  (replaces fwd_lat + mid_fit_l; %.1f TF/s fp32-equivalent on the GEMM part alone)" %
-              (in_dim, t, flops / t / 1e6))
         t = timeit(lambda: L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0],
                                                                 g.dzp[1], alpha.data_ptr(), theta.data_ptr(), mask.data_ptr(), S, N,
                                                                 B, in_dim, HID, ldp, 1e-6, wp.data_ptr(), g.wp[0], g.wp[1], st))
