@@ -312,6 +312,336 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_mid_fit, bf16 matrix-core form ("v7", round 3).  Why: v_mfma_f32_* (every product of v5) executes on the vector ALUs --
+// measured in shader cycles, its time ADDS to the VALU's (profiles/r03_pipe_overlap_cycles.txt) -- while the bf16 matrix
+// core is a separate pipe that VALU work hides behind and is 16x faster per flop.  Here all three products of the step run
+// as v_mfma_f32_32x32x16_bf16 on bf16 PIECES of their fp32 operands: x = h + m + l exactly (rcmarl_lattice.h), and a
+// product x*y is taken as hh + hm + mh + hl + lh + mm (six exact bf16 x bf16 products, fp32 accumulate, smallest first):
+// the dropped terms ml, lm, ll are <= 2^-23 of the product, the class of one fp32 rounding.  Results therefore differ
+// from v5's fmaf chains in the last bits (same bars vs the oracle: tests), NOT bit-identical to v5.
+//
+// Layout.  A wavefront owns 64 replay rows as two blocks of 32.  In a block, lane (j = lane&31, h = lane>>5) works for row
+// j and holds TEN of its 20 units: U_0 = {0..7, 16, 17}, U_1 = {8..15, 18, 19} (local index u = 0..9).  That is exactly the
+// B-operand shape of the 32x32x16 instruction for a contraction over units -- lane (row j, k-group h) supplies 8 contraction
+// slots per k-step: slots 8h..8h+7 of step 0 are local units 0..7, of step 1 local units 8, 9 and six zeros -- and, with
+// the rows of the weight operand (A) permuted the same way, also its OUTPUT shape: accumulator register r of lane (j, h) is
+// local unit r of row j (r < 10).  So a1 -> z2 -> a2 -> dz2 -> da1 -> dz1 never leave their lanes: no swaps, no LDS.
+//   z2[row][unit]  = sum_m a1[row][m] W2[m][unit]      A = W2^T (permuted rows/slots), B = a1 pieces
+//   da1[row][m]    = sum_j dz2[row][j] W2[m][j]        A = W2   (permuted),            B = dz2 pieces
+// The row REDUCTION gW2 = a1^T dz2 (+ gb2 as its ones row) contracts over ROWS, i.e. over the lane axis: the bf16 pieces the
+// layer products already made are written row-major into per-wavefront LDS planes ([piece][row][unit], one 16-byte + one
+// 4-byte store per piece) and read back TRANSPOSED with ds_read_b64_tr_b16 (a lane = one unit, eight consecutive rows =
+// one MFMA operand): no second split.  The plain row sums (gb1, gW3, gb3, loss: 22 values) are fused-DPP half-wave sums.
+// First form of this kernel (fp32 panels, re-split after the transposed read, g3 inside the product): 1300 VALU per 64 rows,
+// 900 us against v5's 790 (profiles/r03c_*): a 3-piece split costs 9 VALU per value pair and there were 31 pairs per block.
+// This form: 1040 VALU + 200 LDS instructions per 64 rows, matrix pipe 23 % busy, 827 us at two wavefronts per SIMD (975 at
+// three: the wavefronts WAIT 68 % of their cycles -- dependent MFMA chains, LDS round trips, DPP sums --, profiles/r03d_*)
+// against 797 us for v5: the bf16 matrix core removes the 5 k cycles of f32 MFMA from the vector ALUs, and the splits,
+// plane traffic and waits put them back.  Kept as the alternative (RCMARL_MIDFIT=7), not the default.
+__device__ __forceinline__ int v7_unit(int h, int u) { return u < 8 ? u + 8 * h : 16 + 2 * h + (u - 8); }
+// unit of accumulator / A-operand row i (0..31), or -1 (padding row)
+__device__ __forceinline__ int v7_row_unit(int i) {
+  const int h = (i >> 2) & 1, q = i >> 3, e = i & 3;
+  if (q < 2) return v7_unit(h, 4 * q + e);
+  return (q == 2 && e < 2) ? v7_unit(h, 8 + e) : -1;
+}
+// unit of contraction slot k (0..31), or -1
+__device__ __forceinline__ int v7_slot_unit(int k) {
+  if (k < 16) return v7_unit(k >> 3, k & 7);
+  const int h = (k - 16) >> 3, u = 8 + ((k - 16) & 7);
+  return u < 10 ? v7_unit(h, u) : -1;
+}
+
+struct V7Pieces { uint4 h, m, l; };
+// the same for two independent accumulator chains, interleaved: back-to-back MFMAs on ONE accumulator wait for each other
+// (48 instead of 32 cycles per instruction, tools/micro/pipe_overlap_cycles.hip)
+__device__ __forceinline__ void v7_mfma6x2(const V7Pieces& a0, const V7Pieces& b0, rc_f32x16& c0, const V7Pieces& a1,
+                                           const V7Pieces& b1, rc_f32x16& c1) {
+  c0 = rc_mfma_bf16(a0.m, b0.m, c0); c1 = rc_mfma_bf16(a1.m, b1.m, c1);
+  c0 = rc_mfma_bf16(a0.l, b0.h, c0); c1 = rc_mfma_bf16(a1.l, b1.h, c1);
+  c0 = rc_mfma_bf16(a0.h, b0.l, c0); c1 = rc_mfma_bf16(a1.h, b1.l, c1);
+  c0 = rc_mfma_bf16(a0.m, b0.h, c0); c1 = rc_mfma_bf16(a1.m, b1.h, c1);
+  c0 = rc_mfma_bf16(a0.h, b0.m, c0); c1 = rc_mfma_bf16(a1.h, b1.m, c1);
+  c0 = rc_mfma_bf16(a0.h, b0.h, c0); c1 = rc_mfma_bf16(a1.h, b1.h, c1);
+}
+// six exact bf16 products, smallest first
+__device__ __forceinline__ rc_f32x16 v7_mfma6(const V7Pieces& a, const V7Pieces& b, rc_f32x16 c) {
+  c = rc_mfma_bf16(a.m, b.m, c);
+  c = rc_mfma_bf16(a.l, b.h, c);
+  c = rc_mfma_bf16(a.h, b.l, c);
+  c = rc_mfma_bf16(a.m, b.h, c);
+  c = rc_mfma_bf16(a.h, b.m, c);
+  c = rc_mfma_bf16(a.h, b.h, c);
+  return c;
+}
+__device__ __forceinline__ V7Pieces v7_split8(const float (&x)[8]) {
+  V7Pieces p;
+  rc_split3_pair(x[0], x[1], p.h.x, p.m.x, p.l.x);
+  rc_split3_pair(x[2], x[3], p.h.y, p.m.y, p.l.y);
+  rc_split3_pair(x[4], x[5], p.h.z, p.m.z, p.l.z);
+  rc_split3_pair(x[6], x[7], p.h.w, p.m.w, p.l.w);
+  return p;
+}
+
+#ifndef RC_V7_WAVES
+#define RC_V7_WAVES 2                    // wavefronts per SIMD the register allocation aims at (3: 168 registers, measured 975 us vs 827)
+#endif
+template <int HID, bool EMIT>
+__global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restrict__ a1t, const float* __restrict__ theta,
+                                                    const float* __restrict__ y, float* __restrict__ partials, int N,
+                                                    int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
+                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
+  static_assert(HID == 20, "unit sets and panel layout are written for 20 units");
+  typedef FitPart<HID> PT;
+  constexpr int LU = 10;                               // units per lane
+  constexpr int PC = 24;                               // columns of a plane row (48 bytes): 20 units | 1.0 | 3 spare; a transpose read of
+  //                                                      columns 16..31 runs 8 columns into the next row: those only feed elements of G nobody reads
+  constexpr int PLANE = 32 * PC;                       // bf16 elements of one piece plane: [32 rows][PC columns]
+  constexpr int PANEL_B = 2 * 3 * PLANE * 2;           // bytes per wavefront: A planes (a1 | 1) then B planes (dz2; later dz transpose, record)
+  __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 3 * 2 * 32];   // [product][k-step][piece][k-group][row i]: 16-byte A fragments
+  __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];           // b2 | W3 | b3
+  __shared__ __attribute__((aligned(16))) unsigned char sPn[4 * PANEL_B];
+  static_assert(3 * PLANE * 2 >= HID * 3 * 32 * 2, "the dz transpose (HID x 3 pieces x 32 rows of bf16) fits the B planes");
+  static_assert(3 * PLANE * 2 >= (PT::SIZE + 64) * 4, "a staged record (+ one dump word per lane) fits the B planes");
+  const int s = blockIdx.z, i = blockIdx.y;
+  const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
+  const int r = threadIdx.x;
+  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  // ---- the agent's W2 as bf16 pieces in A-fragment order, both orientations (once per workgroup)
+  {
+    unsigned short* wf16 = reinterpret_cast<unsigned short*>(sWf);
+    for (int e = r; e < 2 * 32 * 32; e += ROWS) {
+      const int prod = e >> 10, ri = (e >> 5) & 31, k = e & 31;
+      const int ui = v7_row_unit(ri), uk = v7_slot_unit(k);
+      float w = 0.f;
+      if (ui >= 0 && uk >= 0) w = prod == 0 ? th[g.o_W2 + uk * HID + ui] : th[g.o_W2 + ui * HID + uk];
+      unsigned ph, pm, pl;
+      rc_split3(w, ph, pm, pl);
+      const int ks = k >> 4, kg = (k >> 3) & 1;
+      const int base = ((((prod * 2 + ks) * 3 + 0) * 2 + kg) * 32 + ri) * 8 + (k & 7);     // in bf16 elements; piece stride 2*32*8
+      wf16[base] = (unsigned short)ph;
+      wf16[base + 2 * 32 * 8] = (unsigned short)pm;
+      wf16[base + 2 * 2 * 32 * 8] = (unsigned short)pl;
+    }
+  }
+  if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];
+  unsigned short* pA = reinterpret_cast<unsigned short*>(sPn + wave * PANEL_B);     // [piece][row][column]: a1 units 0..19 | 1.0 | unused
+  unsigned short* pB = pA + 3 * PLANE;                                              // [piece][row][column]: dz2 units 0..19 | unused
+  float* sRec = reinterpret_cast<float*>(pB);                                       // the wavefront's record, staged over the B planes
+  // column 20 of the A planes is the constant 1 (-> gb2 = sum dz2): pieces (1.0, 0, 0); written once, nothing else touches it.
+  // The spare columns of the A planes are zeroed once; columns 20.. of the B planes (and what a transpose read picks up
+  // beyond column 23) only feed elements of G nobody reads.
+  for (int e = lane; e < 3 * 32 * (PC - 20); e += 64) {
+    const int pc = e / (32 * (PC - 20)), rw = (e / (PC - 20)) & 31, cl = 20 + e % (PC - 20);
+    pA[pc * PLANE + rw * PC + cl] = (pc == 0 && cl == 20) ? (unsigned short)0x3F80 : (unsigned short)0;
+  }
+  const float* yrow = y + ((long)s * N + i) * ldb;
+  __syncthreads();
+  const float b3 = sV[2 * HID];
+  const uint4* wfA = sWf + half * 32 + l31;             // + ((prod*2 + ks)*3 + piece) * 64
+  auto loadA = [&](int prod, int ks) {
+    V7Pieces a;
+    a.h = wfA[((prod * 2 + ks) * 3 + 0) * 64];
+    a.m = wfA[((prod * 2 + ks) * 3 + 1) * 64];
+    a.l = wfA[((prod * 2 + ks) * 3 + 2) * 64];
+    return a;
+  };
+  // transpose-read address of this lane inside a plane (rcmarl_lattice.h: rc_lds_read_tr16): as MFMA operand lane (i = l31,
+  // k-group = half) it wants rows 8*half .. 8*half+7 of column l31 -> two reads of four rows; its 16-lane group fetches the
+  // [4 rows][16 columns] block of columns 16*((lane>>4)&1).., this lane row (lane&15)>>2 of it, columns 4*(lane&3)..
+  const int tr_off = (8 * half + ((lane & 15) >> 2)) * PC + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  // this lane's own slots in a plane: row l31, columns 8*half..8*half+7 (local units 0..7) and 16+2*half, 17+2*half (8, 9)
+  const int wr8 = l31 * PC + 8 * half, wr2 = l31 * PC + 16 + 2 * half;
+  uint4 z4;
+  z4.x = z4.y = z4.z = z4.w = 0u;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    rc_f32x16 g1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g1[q] = 0.f;
+    float gb1l[LU], gw3l[LU], gb3a = 0.f, lossa = 0.f;  // per-lane partial sums over this wavefront's two blocks
+#pragma unroll
+    for (int u = 0; u < LU; ++u) gb1l[u] = gw3l[u] = 0.f;
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+      const int b = chunk * ROWS + wave * 64 + 32 * blk + l31;
+      const bool valid = b < B;
+      // ---- the lane's ten layer-1 activations of its row
+      float a1l[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) a1l[u] = valid ? a1t[(row0 + v7_unit(half, u)) * ldb + b] : 0.f;
+      const float ycur = valid ? yrow[b] : 0.f;
+      // ---- layer 2 forward on the bf16 matrix core; the a1 pieces also go to the A planes (operand of the row reduction)
+      V7Pieces pa0, pa1;
+      {
+        const float x0[8] = {a1l[0], a1l[1], a1l[2], a1l[3], a1l[4], a1l[5], a1l[6], a1l[7]};
+        pa0 = v7_split8(x0);
+        pa1.h = z4; pa1.m = z4; pa1.l = z4;
+        rc_split3_pair(a1l[8], a1l[9], pa1.h.x, pa1.m.x, pa1.l.x);
+      }
+      RC_SCHED_FENCE();
+      RC_WAVE_SYNC();                                    // the previous block's transpose reads of the planes are done
+      *reinterpret_cast<uint4*>(pA + 0 * PLANE + wr8) = pa0.h;
+      *reinterpret_cast<uint4*>(pA + 1 * PLANE + wr8) = pa0.m;
+      *reinterpret_cast<uint4*>(pA + 2 * PLANE + wr8) = pa0.l;
+      *reinterpret_cast<unsigned*>(pA + 0 * PLANE + wr2) = pa1.h.x;
+      *reinterpret_cast<unsigned*>(pA + 1 * PLANE + wr2) = pa1.m.x;
+      *reinterpret_cast<unsigned*>(pA + 2 * PLANE + wr2) = pa1.l.x;
+      rc_f32x16 zz;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+      zz = v7_mfma6(loadA(0, 1), pa1, zz);
+      zz = v7_mfma6(loadA(0, 0), pa0, zz);
+      RC_SCHED_FENCE();
+      float a2l[LU], vp = 0.f;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) a2l[u] = rc_lrelu(zz[u] + sV[v7_unit(half, u)]);
+#pragma unroll
+      for (int u = 0; u < LU; ++u) vp = fmaf(a2l[u], sV[HID + v7_unit(half, u)], vp);
+      float va = vp, vb = vp;
+      rc_swap32(va, vb);                                 // va: lanes 32-63 now hold the low half's partial; vb: lanes 0-31 the high half's
+      const float v = (vp + (half ? va : vb)) + b3;
+      const float diff = valid ? v - ycur : 0.f;
+      const float dv = (2.0f * diff) / (float)B;
+      if (half == 0) { gb3a += dv; lossa = fmaf(diff, diff, lossa); }   // (both lanes of a row hold the same v: count it once)
+      float dz2l[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        gw3l[u] = fmaf(a2l[u], dv, gw3l[u]);
+        dz2l[u] = dv * sV[HID + v7_unit(half, u)] * rc_lrelu_grad_from_act(a2l[u]);
+      }
+      // ---- layer 2 backward; the dz2 pieces also go to the B planes
+      V7Pieces pd0, pd1;
+      {
+        const float x0[8] = {dz2l[0], dz2l[1], dz2l[2], dz2l[3], dz2l[4], dz2l[5], dz2l[6], dz2l[7]};
+        pd0 = v7_split8(x0);
+        pd1.h = z4; pd1.m = z4; pd1.l = z4;
+        rc_split3_pair(dz2l[8], dz2l[9], pd1.h.x, pd1.m.x, pd1.l.x);
+      }
+      *reinterpret_cast<uint4*>(pB + 0 * PLANE + wr8) = pd0.h;
+      *reinterpret_cast<uint4*>(pB + 1 * PLANE + wr8) = pd0.m;
+      *reinterpret_cast<uint4*>(pB + 2 * PLANE + wr8) = pd0.l;
+      *reinterpret_cast<unsigned*>(pB + 0 * PLANE + wr2) = pd1.h.x;
+      *reinterpret_cast<unsigned*>(pB + 1 * PLANE + wr2) = pd1.m.x;
+      *reinterpret_cast<unsigned*>(pB + 2 * PLANE + wr2) = pd1.l.x;
+      rc_f32x16 dd;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dd[q] = 0.f;
+      dd = v7_mfma6(loadA(1, 1), pd1, dd);
+      dd = v7_mfma6(loadA(1, 0), pd0, dd);
+      RC_SCHED_FENCE();
+      float dz1l[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        dz1l[u] = dd[u] * rc_lrelu_grad_from_act(a1l[u]);
+        gb1l[u] += dz1l[u];
+      }
+      if (!EMIT) {
+#pragma unroll
+        for (int u = 0; u < LU; ++u)
+          if (valid) a1t[(row0 + v7_unit(half, u)) * ldb + b] = dz1l[u];
+      }
+      // ---- the row reduction G = [a1 | 1]^T [dz2] over this block's 32 rows: operands read back TRANSPOSED from the planes
+      // (a lane = one column, eight consecutive rows), straight into the MFMA: no second split, no fp32 panels
+      RC_WAVE_SYNC();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        V7Pieces ra, rb;
+        const int o = tr_off + 16 * PC * ks;
+        uint2 t0, t1;
+        t0 = rc_lds_read_tr16(pA + 0 * PLANE + o); t1 = rc_lds_read_tr16(pA + 0 * PLANE + o + 4 * PC);
+        ra.h.x = t0.x; ra.h.y = t0.y; ra.h.z = t1.x; ra.h.w = t1.y;
+        t0 = rc_lds_read_tr16(pA + 1 * PLANE + o); t1 = rc_lds_read_tr16(pA + 1 * PLANE + o + 4 * PC);
+        ra.m.x = t0.x; ra.m.y = t0.y; ra.m.z = t1.x; ra.m.w = t1.y;
+        t0 = rc_lds_read_tr16(pA + 2 * PLANE + o); t1 = rc_lds_read_tr16(pA + 2 * PLANE + o + 4 * PC);
+        ra.l.x = t0.x; ra.l.y = t0.y; ra.l.z = t1.x; ra.l.w = t1.y;
+        t0 = rc_lds_read_tr16(pB + 0 * PLANE + o); t1 = rc_lds_read_tr16(pB + 0 * PLANE + o + 4 * PC);
+        rb.h.x = t0.x; rb.h.y = t0.y; rb.h.z = t1.x; rb.h.w = t1.y;
+        t0 = rc_lds_read_tr16(pB + 1 * PLANE + o); t1 = rc_lds_read_tr16(pB + 1 * PLANE + o + 4 * PC);
+        rb.m.x = t0.x; rb.m.y = t0.y; rb.m.z = t1.x; rb.m.w = t1.y;
+        t0 = rc_lds_read_tr16(pB + 2 * PLANE + o); t1 = rc_lds_read_tr16(pB + 2 * PLANE + o + 4 * PC);
+        rb.l.x = t0.x; rb.l.y = t0.y; rb.l.z = t1.x; rb.l.w = t1.y;
+        g1 = v7_mfma6(ra, rb, g1);
+        RC_SCHED_FENCE();                              // (keeps the second k-step's twelve reads from being hoisted: registers)
+      }
+      if (EMIT) {
+        // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + unit, k = replay row.  The block's 32 rows x 60 (unit, piece)
+        // values are transposed through the (now idle) B planes so that the stores are 16-byte chunks = 8 consecutive
+        // replay rows of one (unit, piece); a block is exactly one k-tile of the packed image.
+        unsigned short* stg = pB;                      // [60 (unit, piece)][32 rows] bf16 = 3840 B
+        RC_WAVE_SYNC();                                // the reduction's transpose reads are done
+#pragma unroll
+        for (int q = 0; q < LU / 2; ++q) {
+          unsigned ph, pm, pl;
+          rc_split3_pair(dz1l[2 * q], dz1l[2 * q + 1], ph, pm, pl);          // bits 0-15: local unit 2q, bits 16-31: 2q+1
+          const int u0 = v7_unit(half, 2 * q), u1 = v7_unit(half, 2 * q + 1);
+          stg[(u0 * 3 + 0) * 32 + l31] = (unsigned short)ph;
+          stg[(u0 * 3 + 1) * 32 + l31] = (unsigned short)pm;
+          stg[(u0 * 3 + 2) * 32 + l31] = (unsigned short)pl;
+          stg[(u1 * 3 + 0) * 32 + l31] = (unsigned short)(ph >> 16);
+          stg[(u1 * 3 + 1) * 32 + l31] = (unsigned short)(pm >> 16);
+          stg[(u1 * 3 + 2) * 32 + l31] = (unsigned short)(pl >> 16);
+        }
+        RC_WAVE_SYNC();
+        unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK);
+        const int kt = (chunk * ROWS + wave * 64 + 32 * blk) >> 5;             // this block's k-tile
+#pragma unroll
+        for (int it = 0; it < (HID * 3 * 4 + 63) / 64; ++it) {
+          const int c = it * 64 + lane;                // chunk index: (unit, piece) = c >> 2, rows 8*(c&3) .. +7
+          if (c < HID * 3 * 4 && kt < dzp_kt) {
+            const int up = c >> 2, c4 = c & 3;
+            const int unit = up / 3, piece = up - 3 * unit;
+            const int R = i * HID + unit;
+            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 32 + 8 * c4);
+            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 3 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
+                                 (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
+            *reinterpret_cast<uint4*>(base + off) = v4;
+          }
+        }
+      }
+    }
+    // ---- what is summed over rows outside the matrix core: gb1, gW3 (per unit), gb3, loss -- both blocks were added above per
+    // lane; now over the 32 lanes of each half (results in lanes 31 and 63)
+    {
+      float sm[2 * LU + 4];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) { sm[u] = gb1l[u]; sm[LU + u] = gw3l[u]; }
+      sm[2 * LU] = gb3a; sm[2 * LU + 1] = lossa; sm[2 * LU + 2] = sm[2 * LU + 3] = 0.f;
+#pragma unroll
+      for (int q = 0; q < (2 * LU + 4) / 3; ++q) rc_half_sum3_lane31(sm[3 * q], sm[3 * q + 1], sm[3 * q + 2]);
+      RC_WAVE_SYNC();                                  // this wavefront's plane / transpose reads are done: the B planes take its record
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {               // element q of the lane's tile G[(q&3) + 8*(q>>2) + 4*half][l31] -> its record slot
+        const int ii = (q & 3) + 8 * (q >> 2) + 4 * half, jj = l31;
+        int idx = -1;
+        if (jj < HID) idx = ii < HID ? ii * HID + jj : (ii == HID ? PT::gb2 + jj : -1);
+        sRec[idx >= 0 ? idx : PT::SIZE + lane] = g1[q];                        // (else: a dump word of the lane's own)
+      }
+      if (l31 == 31) {
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+          sRec[PT::gb1 + v7_unit(half, u)] = sm[u];
+          sRec[PT::gW3 + v7_unit(half, u)] = sm[LU + u];
+        }
+        if (half == 0) { sRec[PT::gb3] = sm[2 * LU]; sRec[PT::loss] = sm[2 * LU + 1]; }
+      }
+    }
+    __syncthreads();
+    float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
+    {
+      const float* r0 = reinterpret_cast<const float*>(sPn + 0 * PANEL_B + 3 * PLANE * 2);
+      const float* r1 = reinterpret_cast<const float*>(sPn + 1 * PANEL_B + 3 * PLANE * 2);
+      const float* r2 = reinterpret_cast<const float*>(sPn + 2 * PANEL_B + 3 * PLANE * 2);
+      const float* r3 = reinterpret_cast<const float*>(sPn + 3 * PANEL_B + 3 * PLANE * 2);
+      for (int e = r; e < PT::SIZE; e += ROWS) out[e] = (r0[e] + r1[e]) + (r2[e] + r3[e]);
+    }
+    __syncthreads();                                   // records read out before the next chunk's planes land
+  }
+}
+
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B.
 template <int HID>
 __global__ __launch_bounds__(256) void k_small_sgd(const float* __restrict__ partials, float* __restrict__ theta,
@@ -688,13 +1018,20 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
   if (t < n_total) delta[t] = r_team[t] + gamma * v_next[t] - v_cur[t];
 }
 
-// chunks of 256 rows one k_mid_fit_v5 workgroup walks: half the chunks of an agent, at most 6 -- two workgroups per agent keep
-// the grid wide enough at small S*N (RCMARL_MIDFIT_CPW = 1..12 measured within -2..+11 %: fixed)
-int midfit_cpw(int nchunk) {
+// chunks of 256 rows one mid-fit workgroup walks (the agent's weights are staged once per workgroup): half the chunks of an
+// agent, at most 6, when S*N workgroup columns fill the chip anyway; fewer -- down to one -- when they do not (a single
+// instance of the reference's 5-agent scenario is 5 columns: 10 workgroups of 6 chunks each were 37 us of latency)
+int midfit_cpw(int nchunk, long columns) {
   int c = (nchunk + 1) / 2;
   if (c > 6) c = 6;
+  while (c > 1 && columns * ((nchunk + c - 1) / c) < 512) --c;
   return c < 1 ? 1 : c;
 }
+
+// Default: k_mid_fit_v5 (f32-input MFMA forms, fmaf-chain arithmetic).  RCMARL_MIDFIT=7 selects the bf16 matrix-core form
+// (k_mid_fit_v7): measured 825-830 us against 795-800 at the BASELINE configs[3] shape (profiles/r03d_*), so it is the
+// alternative, not the default.  Read at every call (tests switch it inside one process).
+bool midfit_v5() { const char* e = getenv("RCMARL_MIDFIT"); return !(e && atoi(e) == 7); }
 
 bool bad_mid(const void* a, const void* b, int S, int N, int B, int in_dim, int hid, int ldp, int ldb) {
   return !a || !b || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) || ldb < B;
@@ -717,10 +1054,15 @@ RCMARL_EXPORT int rcmarl_rows_per_chunk(void) { return ROWS; }
 RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B,
                                  int in_dim, int hid, int ldp, int ldb, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
-  const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk);
+  const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
-                                   ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
+  if (midfit_v5()) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
+                                     ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
+  } else {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v7<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
+                                     ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
+  }
   return rcmarl_check_launch();
 }
 
@@ -728,11 +1070,16 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
                                          void* dzp, int dzp_rt, int dzp_kt, int S, int N, int B, int in_dim, int hid,
                                          int ldp, int ldb, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials || !dzp) return RCMARL_ERR_ARG;
-  const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk);
+  const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                   partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  if (midfit_v5()) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  } else {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v7<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  }
   return rcmarl_check_launch();
 }
 

@@ -108,3 +108,22 @@ __device__ __forceinline__ void rc_glds16s(const unsigned char* sbase, unsigned 
 }
 #define RC_GLDS16S(sbase, voff, lds_base) rc_glds16s((sbase), (voff), (lds_base))
 #endif
+
+// ds_read_b64_tr_b16: LDS transpose read for 16-bit elements.  Every lane supplies the address of 8 bytes; within each group
+// of 16 lanes the fetched [16 lanes][4 elements] are transposed (lane ll gets element (ll&3) of lanes (ll>>2), 4+(ll>>2),
+// 8+(ll>>2), 12+(ll>>2)).  With lane ll fetching row (ll>>2), columns 4*(ll&3).. of a row-major [4][16] block, lane ll ends up
+// with COLUMN ll of the block (rows 0..3): two reads give a lane 8 consecutive rows of its column = one MFMA operand.
+// Returns the four 16-bit elements as two packed dwords (element 0 in the low half of .x).
+__device__ __forceinline__ uint2 rc_lds_read_tr16(const unsigned short* p) {
+#ifdef RCMARL_EMU
+  const __hipemu_s4 v = __hipemu_ds_read_tr16_b64(p);
+  uint2 r;
+  r.x = (unsigned)(unsigned short)v[0] | ((unsigned)(unsigned short)v[1] << 16);
+  r.y = (unsigned)(unsigned short)v[2] | ((unsigned)(unsigned short)v[3] << 16);
+  return r;
+#else
+  typedef short rc_s4 __attribute__((ext_vector_type(4)));
+  const rc_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rc_s4*)(p));
+  return __builtin_bit_cast(uint2, v);
+#endif
+}

@@ -9,8 +9,9 @@
    (b) configs[2] at STEADY STATE: 64 agents, random 9-regular + self, H = 4, B = 1000, 2000, 3000, 3000 over four blocks --
        the replay trim, the TD-target row-shift shortcut and the cached activations all live at B = 3000 -- vs oracle.train.
    (c) a deterministic actor bar at 256 agents: after ONE Adam step m = (1 - beta1) g, so the engine's first-moment slots
-       against the oracle's give the actor GRADIENT at rtol 1e-4 of the array's scale (the parameters themselves can only be
-       held to a statistical bar there: Adam turns a gradient of magnitude eps into +-lr).
+       against the oracle's give the actor GRADIENT (the parameters themselves can only be held to a statistical bar there:
+       Adam turns a gradient of magnitude eps into +-lr): 1e-4 of the largest entry with identical inputs (test_actor_step at
+       256 agents, tests/test_kernels_gpu.py), 2e-3 end to end (cancellation amplifies upstream 1e-5 differences).
 """
 import numpy as np
 import pytest
@@ -55,4 +56,5 @@ def test_engine_cfg3_steady_state_B3000_vs_oracle():
 
 def test_actor_gradient_at_256_agents_vs_oracle():
     worst = EC.check_actor_gradient(256, 18, 8, 32, "cuda", None, fast_lr=0.0025)
-    print("[parity] actor gradient (Adam m after one step) at 256 agents: worst max|dm| / max|m| = %.2e (bar 1e-4)" % worst)
+    print("[parity] actor gradient end to end (Adam m after one step) at 256 agents: worst max|dm| / max|m| = %.2e (bar 2e-3; "
+          "identical-input kernel bar 1e-4: test_actor_step)" % worst)

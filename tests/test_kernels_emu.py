@@ -155,3 +155,15 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
         graph = "circ" if rng.random() < 0.7 else "rand"
         KC.check_consensus_params_exact(bk, N, d, H, P_hid, int(rng.integers(1, 3)), int(rng.integers(1 << 30)), graph)
 
+
+
+@pytest.mark.parametrize("lattice", [False, True])
+def test_mid_fit_bf16_matrix_core_form(bk, lattice, monkeypatch):
+    """RCMARL_MIDFIT=7: k_mid_fit_v7 -- layers 2-3 and the row reduction as bf16 MFMAs on exact three-piece splits (six products
+    per fp32 product), operands of the reduction through ds_read_b64_tr_b16 -- behind the same two entry points, against the
+    same oracle fits as the default kernel."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "7")
+    if lattice:
+        KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
+    else:
+        KC.check_sgd_fit(bk, 2, 5, 130, 10, steps=2, masked_agent=1)

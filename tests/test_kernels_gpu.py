@@ -72,7 +72,7 @@ def test_consensus_head(bk, S, N, B, in_dim, d, H, graph):
     KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
 
 
-@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 16, 300, 32), (1, 64, 1000, 128)])
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 16, 300, 32), (1, 64, 1000, 128), (1, 256, 1000, 512)])     # last: BASELINE configs[3]
 def test_actor_step(bk, S, N, B, in_dim):
     KC.check_actor_step(bk, S, N, B, in_dim, steps=3)
 
@@ -189,3 +189,16 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
         graph = "circ" if rng.random() < 0.7 else "rand"
         KC.check_consensus_params_exact(bk, N, d, H, P_hid, int(rng.integers(1, 3)), int(rng.integers(1 << 30)), graph)
 
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (1, 64, 1000, 192, 5), (1, 128, 333, 256, None)])
+def test_mid_fit_bf16_matrix_core_form_sgd_fit(bk, S, N, B, in_dim, masked, monkeypatch):
+    """RCMARL_MIDFIT=7 (k_mid_fit_v7: bf16 MFMAs on exact three-piece splits, transposed LDS reads) vs the oracle's fits."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "7")
+    KC.check_sgd_fit(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (1, 64, 1000, 3, 16, 16, 5), (1, 20, 777, 2, 7, 9, 3)])
+def test_mid_fit_bf16_matrix_core_form_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
+    monkeypatch.setenv("RCMARL_MIDFIT", "7")
+    KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)

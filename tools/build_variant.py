@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Variant build of the product library for A/B kernel measurements (tools/kbench.py mid_ab):
+    python tools/build_variant.py NAME SOURCE.hip -DFOO=1 ...   ->  resilient-consensus-based-marl_amd/lib/variants/libNAME.so
+Only SOURCE is recompiled with the extra flags; the other objects are the product build's (lib/obj)."""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rcmarl_amd import build as B  # noqa: E402
+
+
+def main():
+    name, src, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+    B.build_hip()
+    objdir = os.path.join(B.LIBDIR, "obj")
+    outdir = os.path.join(B.LIBDIR, "variants")
+    os.makedirs(outdir, exist_ok=True)
+    obj = os.path.join(outdir, name + "_" + os.path.basename(src) + ".o")
+    subprocess.run([B.HIPCC] + B.FLAGS + extra + ["-I", B.CSRC, "-c", os.path.join(B.CSRC, src), "-o", obj], check=True,
+                   stderr=subprocess.DEVNULL)
+    others = [o for o in glob.glob(os.path.join(objdir, "*.o")) if os.path.basename(o) != os.path.basename(src) + ".o"]
+    out = os.path.join(outdir, "lib%s.so" % name)
+    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", out, obj] + others, check=True)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()

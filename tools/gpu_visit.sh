@@ -7,7 +7,7 @@ TAG=$1; shift
 for what in "$@"; do
 case $what in
 tests)
-  timeout 1200 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider --durations=10 > gpurun_out/${TAG}_test_gpu.log 2>&1
+  timeout 1200 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider --durations=10 -rP > gpurun_out/${TAG}_test_gpu.log 2>&1
   grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_test_gpu.log | tail -30
   grep -E "^E  " gpurun_out/${TAG}_test_gpu.log | head -40
   grep -A12 "slowest" gpurun_out/${TAG}_test_gpu.log | head -14 ;;

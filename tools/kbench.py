@@ -187,28 +187,39 @@ def lattice(L, S=16, N=256, B=3000):
 
 
 def mid_ab(L, S=16, N=256, B=3000):
-    """A/B of rcmarl_mid_fit_lattice between the product library and RCMARL_KBENCH_LIB_B (a variant build), interleaved."""
+    """A/B of rcmarl_mid_fit_lattice: the product library (default kernel, and RCMARL_MIDFIT=5 = the f32-MFMA form) against the
+    variant builds named in RCMARL_KBENCH_LIB_B (comma-separated paths; tools/build_variant.py), interleaved."""
     from rcmarl_amd import lattice as LT
-    LB = capi.CLib(os.environ["RCMARL_KBENCH_LIB_B"])
+    libs = [("product", L, None), ("product-v5", L, "5")]
+    for pth in [x for x in os.environ.get("RCMARL_KBENCH_LIB_B", "").split(",") if x]:
+        libs.append((os.path.basename(pth).replace("lib", "").replace(".so", ""), capi.CLib(pth), None))
     st = torch.cuda.current_stream().cuda_stream
-    in_dim = 2 * N
-    P = in_dim * HID + HID + HID * HID + HID + HID + 1
-    ldp, ldb = pad64(P), pad64(B)
-    g = LT.Geometry(N, in_dim, B)
-    theta = torch.randn(S, N, ldp, device="cuda") * 0.05
-    a1t = torch.randn(S, N * HID, ldb, device="cuda")
-    y = torch.randn(S, N, ldb, device="cuda")
-    dzp = torch.zeros(S * LT.Geometry.nbytes(g.dzp, 3), dtype=torch.uint8, device="cuda")
-    part = torch.zeros(S * N * ((B + 255) // 256) * L.rcmarl_fit_partial_size(HID), device="cuda")
-    outs = {}
-    for rnd in range(4):
-        for name, lib in (("product", L), ("variant", LB)):
-            dzp.zero_()
-            t = timeit(lambda: lib.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
-                                                          g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st), iters=20)
-            outs[name] = dzp.clone()
-            print("round %d  %-8s %8.1f us" % (rnd, name, t))
-    print("dz images identical:", bool(torch.equal(outs["product"], outs["variant"])))
+    for in_dim in (2 * N, 3 * N):
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        g = LT.Geometry(N, in_dim, B)
+        theta = torch.randn(S, N, ldp, device="cuda") * 0.05
+        a1t = torch.randn(S, N * HID, ldb, device="cuda")
+        y = torch.randn(S, N, ldb, device="cuda")
+        dzp = torch.zeros(S * LT.Geometry.nbytes(g.dzp, 3), dtype=torch.uint8, device="cuda")
+        part = torch.zeros(S * N * ((B + 255) // 256) * L.rcmarl_fit_partial_size(HID), device="cuda")
+        outs = {}
+        for rnd in range(3):
+            for name, lib, midfit in libs:
+                if midfit is None:
+                    os.environ.pop("RCMARL_MIDFIT", None)
+                else:
+                    os.environ["RCMARL_MIDFIT"] = midfit
+                dzp.zero_()
+                t = timeit(lambda: lib.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
+                                                              g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st), iters=20)
+                outs[name] = (dzp.clone(), part.clone())
+                print("in=%d round %d  %-16s %8.1f us  (%.0f GB/s of its 200 B per row and agent)" % (in_dim, rnd, name, t, 200.0 * S * N * B / t / 1e3))
+        os.environ.pop("RCMARL_MIDFIT", None)
+        ref = outs["product"]
+        for name, (dz, pt) in outs.items():
+            rel = float(((pt - ref[1]).abs().max() / ref[1].abs().max()).item())
+            print("   %-16s dz image identical to product: %s   records max rel diff %.2e" % (name, bool(torch.equal(dz, ref[0])), rel))
 
 
 def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
