@@ -253,6 +253,31 @@ inline floatx16 __hipemu_mfma_f32_32x32x16_bf16(uint4 a, uint4 b, floatx16 c) {
   hipemu::wave_barrier();
   return d;
 }
+// ---- int8 MFMA 32x32x32 (16 int8 per lane per operand, packed in a uint4), i32 accumulate: exact ----------
+// lane l supplies A[i=l&31][k=16*(l>>5)+e], B[k=16*(l>>5)+e][j=l&31] (e = 0..15, byte e&3 of dword e>>2); D layout as the f32 forms.
+struct intx16 { int v[16]; int& operator[](int i) { return v[i]; } const int& operator[](int i) const { return v[i]; } };
+inline intx16 __hipemu_mfma_i32_32x32x32_i8(uint4 a, uint4 b, intx16 c) {
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  unsigned* m = &s.xch_m[((size_t)w * 64 + l) * 8];
+  m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+  hipemu::wave_barrier();
+  intx16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    int acc = d[r];
+    for (int k = 0; k < 32; ++k) {
+      const unsigned* ma = &s.xch_m[((size_t)w * 64 + row + 32 * (k >> 4)) * 8];
+      const unsigned* mb = &s.xch_m[((size_t)w * 64 + col + 32 * (k >> 4)) * 8 + 4];
+      int e = k & 15;
+      acc += (int)(signed char)((ma[e >> 2] >> (8 * (e & 3))) & 0xff) * (int)(signed char)((mb[e >> 2] >> (8 * (e & 3))) & 0xff);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16 (the hardware takes the
 // base from M0, i.e. from the first lane), global source per lane.
 inline void __hipemu_glds16(const void* gsrc, void* lds_base) {

@@ -5,7 +5,7 @@
        cached-activation reuse ON and OFF (engine.py:_value_next_cached / _cached_rows_ok)
    (c) configs[4] in width/degree: a wide critic with circulant d = 66, H = 32 on 72 agents
 Same tolerances as the small-N engine tests (tests/engine_checks.py:compare): returns bit-identical, start-state
-values rtol 1e-4, end-of-block weights rtol 2e-4 * max(1, |w|max)."""
+values rtol 1e-4, end-of-block weights rtol 1e-4 * max(1, |w|max) (2e-4 for the 256-agent run: measured 9.3e-5)."""
 import numpy as np
 import pytest
 
@@ -53,7 +53,9 @@ def test_engine_cfg4_shape_vs_oracle(cfg4_oracle, shortcut):
     assert eng.lat_active and eng.k1_circulant
     for df in o_logs:
         assert np.isfinite(df["Estimated_team_returns"].to_numpy()).all()
-    EC.compare(eng, logs, o_logs, o_w, actor="stat")       # 2.8 M actor parameters: statistical bar, see EC.compare
+    # 2.8 M actor parameters: statistical bar, see EC.compare; weights: measured worst case 9.3e-5 (team-reward net) -- inside
+    # SURVEY 8c's 1e-4 but without margin for another summation order, so this one run is held to 2e-4
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=2e-4, actor="stat")
 
 
 def test_engine_wide_critic_d66_vs_oracle():

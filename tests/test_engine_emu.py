@@ -67,7 +67,7 @@ def test_engine_wide_critic_with_greedy_and_malicious_agents_matches_oracle(labe
     args = EC.make_args(labels, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=1, buffer_size=9, seed=44)
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(44,), critic_hid=24, lattice=False)
     assert eng.wide and hasattr(eng, "adv") and eng.adv.fit
-    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)
+    EC.compare(eng, logs, o_logs, o_w)
 
 
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])

@@ -36,7 +36,7 @@ def test_engine_with_adversaries(labels):
     mini-batch fits (32 x 10 epochs) and shuffled actor fits (200-row Adam mini-batches)."""
     args = EC.make_args(labels, H=1, n_episodes=30, max_ep_len=20, n_ep_fixed=15, n_epochs=2, buffer_size=450, seed=300)
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cuda", None, seeds=(300, 301))
-    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)
+    EC.compare(eng, logs, o_logs, o_w)
 
 
 @pytest.mark.parametrize("n,nrow,ncol,labels", [(5, 5, 5, None), (20, 16, 12, None), (5, 5, 5, ["Cooperative"] * 4 + ["Malicious"])])
@@ -50,7 +50,7 @@ def test_engine_lattice_path(n, nrow, ncol, labels):
                         seed=41, in_nodes=in_nodes)
     eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, "device", "cuda", None, seeds=(41, 42), lattice=True if n == 5 else "auto")
     assert eng.lat_enabled and eng.lat_active
-    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4 if "Malicious" in labels else 2e-4)
+    EC.compare(eng, logs, o_logs, o_w)
 
 
 def test_engine_full_size_lattice_equals_f32_path():
@@ -145,7 +145,7 @@ def test_engine_wide_critic_with_greedy_and_malicious_agents(n, critic_hid, latt
                         in_nodes=in_nodes, fast_lr=0.005)
     eng, logs, o_logs, o_w = EC.run_pair(args, 6, 6, "device", "cuda", None, seeds=(58,), critic_hid=critic_hid, lattice=lattice)
     assert eng.wide and hasattr(eng, "adv") and eng.adv.fit and eng.lat_active == lattice
-    EC.compare(eng, logs, o_logs, o_w, rtol_w=5e-4)
+    EC.compare(eng, logs, o_logs, o_w)
 
 
 @pytest.mark.parametrize("n,critic_hid,lattice", [(6, 64, False), (16, 512, True)])

@@ -202,3 +202,10 @@ def test_mid_fit_bf16_matrix_core_form_sgd_fit(bk, S, N, B, in_dim, masked, monk
 def test_mid_fit_bf16_matrix_core_form_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
     monkeypatch.setenv("RCMARL_MIDFIT", "7")
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol", [(2, 5, 1000, 2, 5, 5), (1, 64, 700, 3, 16, 16), (2, 256, 3000, 2, 32, 32)])
+def test_lattice_forward_int8_limbs_prototype(bk, S, N, B, width, nrow, ncol):
+    """csrc/lattice_i8.hip: the layer-1 forward on the int8 matrix core (four balanced base-256 limbs of alpha*W1 under one scale per
+    column, exact int32 dot products) holds the bf16x3 path's bar against float64."""
+    KC.check_lattice_forward_i8(bk, S, N, B, width, nrow, ncol)
