@@ -512,9 +512,10 @@ ROOFLINE_KIND = {
                                           "kernel: profiles/r02h_sq_counters_k1_circ_d18.json), toward HBM at d=4"),
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
                                "dz1 pieces written = 200 B; k_mid_fit_v5: layer 2 (4x4x1 sixteen-block MFMAs, results born row-per-lane) and the "
-                               "row reductions (32x32x2) on the f32 matrix core; bound by instruction "
-                               "issue on a SIMD whose matrix-core and VALU time add up (tools/micro/pipe_overlap.hip), "
-                               "DESIGN.md section 5"),
+                               "row reductions (32x32x2) as f32-input MFMAs.  Those execute ON the vector ALUs (measured in shader "
+                               "cycles: profiles/r03_pipe_overlap_cycles.txt), so the kernel's time is the SUM of its 232 f32 MFMAs, "
+                               "~500 VALU and ~190 LDS instructions per 64 rows, not its HBM traffic; the bf16 matrix-core form "
+                               "(k_mid_fit_v7, RCMARL_MIDFIT=7) measured 4 % slower (DESIGN.md section 5, Round 3)"),
     "rcmarl_minibatch_fit": ("mfma_f32", "the adversaries' fit(batch_size=32, epochs=10): 940 sequentially DEPENDENT SGD steps per "
                              "network, one wavefront per network (6 us per step): bound by the latency of one step, not by a pipe; "
                              "flops = 6 per weight per row"),
