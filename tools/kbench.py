@@ -230,10 +230,10 @@ def i8(L, S=16, N=256, B=3000):
 
 
 def mid_ab(L, S=16, N=256, B=3000):
-    """A/B of rcmarl_mid_fit_lattice: the product library (default kernel, and RCMARL_MIDFIT=5 = the f32-MFMA form) against the
-    variant builds named in RCMARL_KBENCH_LIB_B (comma-separated paths; tools/build_variant.py), interleaved."""
+    """A/B of rcmarl_mid_fit_lattice: the product library (default kernel = v5, and RCMARL_MIDFIT=7 = the bf16 matrix-core form)
+    against the variant builds named in RCMARL_KBENCH_LIB_B (comma-separated paths; tools/build_variant.py), interleaved."""
     from rcmarl_amd import lattice as LT
-    libs = [("product", L, None), ("product-v5", L, "5")]
+    libs = [("product", L, None), ("product-v7", L, "7")]
     for pth in [x for x in os.environ.get("RCMARL_KBENCH_LIB_B", "").split(",") if x]:
         libs.append((os.path.basename(pth).replace("lib", "").replace(".so", ""), capi.CLib(pth), None))
     st = torch.cuda.current_stream().cuda_stream
