@@ -163,7 +163,7 @@ def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 1000, 10, 64, 4, 1, "circ"), (1, 24, 700, 48, 128, 10, 4, "rand"),
-                                                        (1, 70, 300, 140, 512, 66, 32, "circ"), (1, 30, 300, 60, 64, 23, 5, "rand")])
+                                                        (1, 70, 130, 140, 512, 66, 32, "circ"), (1, 30, 300, 60, 64, 23, 5, "rand")])
 def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
