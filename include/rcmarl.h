@@ -75,8 +75,10 @@ int rcmarl_layer1_backward_adam(const float* x, long x_seed_stride, const float*
 
 /* K4/K5 layers 2-3 of one full-batch SGD step of critic.fit / TR.fit with MSE loss
  * (agents/resilient_CAC_agents.py:116-118,134-136): forward, loss vs y[s][n][b], backward.
- * a1t is overwritten IN PLACE by dz1 (feature-major); per-chunk partial gradients go to
- * partials[S][N][nchunk][rcmarl_fit_partial_size(hid)] = [gW2|gb2|gW3|gb3|gb1|sum (v-y)^2]. */
+ * a1t is overwritten IN PLACE by dz1 (feature-major); partial gradient records go to
+ * partials[S][N][nrec][rcmarl_fit_partial_size(hid)] = [gW2|gb2|gW3|gb3|gb1|sum (v-y)^2], one record per workgroup of the
+ * launch (nrec <= nchunk = ceil(B / rcmarl_rows_per_chunk()): size the buffer for nchunk records); rcmarl_small_sgd with the
+ * same (S, N, B) reads exactly the records this call wrote. */
 int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partials, int S, int N, int B, int in_dim,
                    int hid, int ldp, int ldb, void* stream);
 /* ---- lattice (exact bf16x3) form of the layer-1 GEMMs: csrc/lattice_gemm.hip, csrc/rcmarl_lattice.h ----

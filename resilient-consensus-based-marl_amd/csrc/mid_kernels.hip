@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
   }
   const float* yrow = y + ((long)s * N + i) * ldb;
   __syncthreads();
+  static_assert(PT::SIZE <= 2 * ROWS, "a thread carries at most two elements of the workgroup's record");
+  float racc0 = 0.f, racc1 = 0.f;
   // (requesting the activations of chunk c+1 while chunk c is processed costs 20 registers = one wavefront
   // per SIMD of occupancy here and measured slower: 919 vs 857 us)
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
@@ -306,10 +308,15 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
       }
     }
     __syncthreads();
-    float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
-    for (int e = r; e < PT::SIZE; e += ROWS) out[e] = (sPn[e] + sPn[PANEL + e]) + (sPn[2 * PANEL + e] + sPn[3 * PANEL + e]);
+    // the four wavefronts' records of this chunk, added to the workgroup's running record (ONE record per workgroup leaves the
+    // kernel: a twelfth to a half of the per-chunk records rcmarl_small_sgd used to re-read)
+    racc0 += (sPn[r] + sPn[PANEL + r]) + (sPn[2 * PANEL + r] + sPn[3 * PANEL + r]);
+    if (r + ROWS < PT::SIZE) racc1 += (sPn[r + ROWS] + sPn[PANEL + r + ROWS]) + (sPn[2 * PANEL + r + ROWS] + sPn[3 * PANEL + r + ROWS]);
     __syncthreads();                                   // records read out before the next chunk's panels land
   }
+  float* out = partials + (((long)s * N + i) * gridDim.x + blockIdx.x) * PT::SIZE;
+  out[r] = racc0;
+  if (r + ROWS < PT::SIZE) out[r + ROWS] = racc1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -458,6 +465,7 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
   const int wr8 = l31 * PC + 8 * half, wr2 = l31 * PC + 16 + 2 * half;
   uint4 z4;
   z4.x = z4.y = z4.z = z4.w = 0u;
+  float racc0 = 0.f, racc1 = 0.f;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     rc_f32x16 g1;
 #pragma unroll
@@ -630,16 +638,19 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
       }
     }
     __syncthreads();
-    float* out = partials + (((long)s * N + i) * nchunk + chunk) * PT::SIZE;
     {
       const float* r0 = reinterpret_cast<const float*>(sPn + 0 * PANEL_B + 3 * PLANE * 2);
       const float* r1 = reinterpret_cast<const float*>(sPn + 1 * PANEL_B + 3 * PLANE * 2);
       const float* r2 = reinterpret_cast<const float*>(sPn + 2 * PANEL_B + 3 * PLANE * 2);
       const float* r3 = reinterpret_cast<const float*>(sPn + 3 * PANEL_B + 3 * PLANE * 2);
-      for (int e = r; e < PT::SIZE; e += ROWS) out[e] = (r0[e] + r1[e]) + (r2[e] + r3[e]);
+      racc0 += (r0[r] + r1[r]) + (r2[r] + r3[r]);                            // the workgroup's running record (as k_mid_fit_v5)
+      if (r + ROWS < PT::SIZE) racc1 += (r0[r + ROWS] + r1[r + ROWS]) + (r2[r + ROWS] + r3[r + ROWS]);
     }
     __syncthreads();                                   // records read out before the next chunk's planes land
   }
+  float* out = partials + (((long)s * N + i) * gridDim.x + blockIdx.x) * PT::SIZE;
+  out[r] = racc0;
+  if (r + ROWS < PT::SIZE) out[r + ROWS] = racc1;
 }
 
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B.
@@ -1086,10 +1097,10 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
 RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float* loss_out,
                                    int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream) {
   if (!partials || !theta || S <= 0 || N <= 0 || B <= 0) return RCMARL_ERR_ARG;
-  const int nchunk = rc_ceil_div(B, ROWS);
+  const int nchunk = rc_ceil_div(B, ROWS), nrec = rc_ceil_div(nchunk, midfit_cpw(nchunk, (long)S * N));   // = rcmarl_mid_fit's grid
   const dim3 grid(N, S), block(256);
   RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
-                                   in_dim, ldp, nchunk, lr));
+                                   in_dim, ldp, nrec, lr));
   return rcmarl_check_launch();
 }
 
