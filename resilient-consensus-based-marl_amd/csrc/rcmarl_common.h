@@ -268,33 +268,6 @@ __device__ __forceinline__ bool rc_all(bool v) {
 #define RC_SCHED_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
-// A condition that is always true but opaque to the compiler: `if (RC_OPAQUE_TRUE()) { ... }` puts its body into a
-// basic block of its own (one s_cmp + s_cbranch at run time).  Instruction selection and scheduling work per basic
-// block, so this bounds how far hipcc can reorder a long fully unrolled computation (see lattice_fit.hip: left as one
-// block, all weight reads are scheduled first and the FMAs that consume them last -> 2000 spilled registers).
-#ifdef RCMARL_EMU
-#define RC_OPAQUE_TRUE() (true)
-#else
-#define RC_OPAQUE_TRUE() ([]() __attribute__((always_inline)) { int c_ = 1; asm volatile("" : "+s"(c_)); return c_ != 0; }())
-#endif
-
-// Makes a register value opaque to the optimiser at this point (an empty asm that "modifies" it): what is computed from it
-// below cannot be hoisted above, e.g. out of a loop where it would occupy registers for the whole loop.
-#ifdef RCMARL_EMU
-#define RC_OPAQUE_REG(x) ((void)0)
-#else
-#define RC_OPAQUE_REG(x) asm volatile("" : "+v"(x))
-#endif
-
-// Ties a pointer to a value computed earlier (an empty asm that "modifies" both): loads through the pointer cannot be
-// started before that value exists.  Keeps hipcc from hoisting ALL weight reads of a fully unrolled chain of FMAs
-// above the chain (it then spills them: 100 ds_read_b128 = 400 registers).
-#ifdef RCMARL_EMU
-#define RC_TIE(ptr, val) ((void)0)
-#else
-#define RC_TIE(ptr, val) asm volatile("" : "+v"(ptr), "+v"(val))
-#endif
-
 // v_permlane32_swap on two floats: lanes 32-63 of `a` swap with lanes 0-31 of `b`
 __device__ __forceinline__ void rc_swap32(float& a, float& b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
