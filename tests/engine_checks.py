@@ -116,6 +116,8 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict"):
                 for a, b in zip(got, o_weights[s][i][k]):
                     scale = max(1.0, float(np.abs(b).max()))
                     err = float(np.abs(a - b).max())
+                    if net == "actor" and actor == "none":
+                        continue
                     if net == "actor" and actor == "stat":
                         actor_err.append(np.abs(a - b).ravel())
                         continue
