@@ -93,7 +93,15 @@ int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partia
  * rcmarl_lattice_encode: K = x/alpha (verified integer, |K| <= 256, else *flag = 1) packed as
  *   kp  (rows = replay row, reduction = feature; forward operand)  and/or
  *   ktp (rows = feature,    reduction = replay row; backward operand); either may be NULL.
- *   Rows/features up to the next multiple of 256 replay rows / of the buffer extents are zero-filled. */
+ *   Rows/features up to the next multiple of 256 replay rows / of the buffer extents are zero-filled.
+ *
+ * Operand form (rcmarl_lattice_f16_mode(), env RCMARL_LAT_F16, default 3): bit 0 -- the forward operand (wp, and kp) --
+ *   and bit 1 -- the backward operand (dzp, and ktp) -- are carried as TWO f16 pieces of the value scaled by a fixed
+ *   power of two (2^10 alpha W1; 2^8 dz1) instead of three bf16 pieces: the value up to one unit in the last place of
+ *   its fp32 significand (exact for 3 in 4), two matrix passes and 4 bytes per value instead of three and 6.  The
+ *   epilogues multiply the scale out; finite while |alpha W1| < 64 and |dz1| < 256.  0 = three exact bf16 pieces
+ *   everywhere.  Buffers are sized for three pieces in either form; producer and consumer calls must see the same mode. */
+int rcmarl_lattice_f16_mode(void);
 int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, void* kp,
                           int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag, void* stream);
 /* wp (3 pieces, rows = (agent,unit) column, reduction = feature) <- bf16x3 split of alpha[k]*W1[s][n][k][j] */

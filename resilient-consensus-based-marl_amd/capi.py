@@ -25,6 +25,7 @@ SIGNATURES = {
     "rcmarl_fit_partial_size": [c_int],
     "rcmarl_actor_partial_size": [c_int, c_int],
     "rcmarl_rows_per_chunk": [],
+    "rcmarl_lattice_f16_mode": [],
     # msg, theta, nbr, coop, S, N, ldp, P_hid, d, H, lo_dbg, hi_dbg, stream
     "rcmarl_consensus_params": [c_f32p, c_f32p, c_i32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_f32p, c_f32p, c_stream],
@@ -163,7 +164,7 @@ SIGNATURES = {
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk",
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
              "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
              "rcmarl_consensus_params_circulant_supported"}
 

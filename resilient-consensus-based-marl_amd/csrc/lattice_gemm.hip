@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void k_lattice_encode(const float* __restrict_
                                                         const float* __restrict__ alpha, int B, int in_dim,
                                                         unsigned char* __restrict__ kp, int kp_rt, int kp_kt,
                                                         unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt,
-                                                        int* __restrict__ flag) {
-  __shared__ unsigned short tile[32][128 + 2];
+                                                        int* __restrict__ flag, int kp_f16, int ktp_f16) {
+  __shared__ unsigned short tileB[32][128 + 2], tileH[32][128 + 2];    // the integers as bf16 / as f16 bits (|K| <= 256: exact in both)
   const int s = blockIdx.z, b0 = blockIdx.y * 32, c0 = blockIdx.x * 128;
   const int t = threadIdx.x;
   {
@@ -53,13 +53,15 @@ __global__ __launch_bounds__(256) void k_lattice_encode(const float* __restrict_
         // lattice property: x == alpha*K up to fp32 roundoff, |K| <= 256 (exact in bf16)
         if (!(fabsf(kq) <= 256.f) || !(fabsf(fmaf(kq, al, -xv)) <= 4.76837158e-7f * fabsf(xv))) bad = true;
       }
-      tile[bl][cl] = (unsigned short)rc_bf16_rne(kq);
+      tileB[bl][cl] = (unsigned short)rc_bf16_rne(kq);
+      tileH[bl][cl] = (unsigned short)rc_f16_rne(kq);
     }
     if (bad) *flag = 1;
   }
   __syncthreads();
   // KTp block (row tile c0/128, k-tile b0/32): 128 rows x 4 chunks
   if (ktp != nullptr && (c0 >> 7) < ktp_rt && (b0 >> 5) < ktp_kt) {
+    const unsigned short(*tile)[128 + 2] = ktp_f16 ? tileH : tileB;
     unsigned char* blk = ktp + (long)s * ktp_rt * ktp_kt * RC_PK_BLOCK + ((long)(c0 >> 7) * ktp_kt + (b0 >> 5)) * RC_PK_BLOCK;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void k_lattice_encode(const float* __restrict_
   }
   // Kp: rows b0..b0+31 of row tile b0/128, k-tiles c0/32 .. +3
   if (kp != nullptr && (b0 >> 7) < kp_rt) {
+    const unsigned short(*tile)[128 + 2] = kp_f16 ? tileH : tileB;
     unsigned char* base = kp + (long)s * kp_rt * kp_kt * RC_PK_BLOCK + (long)(b0 >> 7) * kp_kt * RC_PK_BLOCK;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -90,8 +93,32 @@ __global__ __launch_bounds__(256) void k_lattice_encode(const float* __restrict_
   }
 }
 
+// the pieces of eight consecutive-k values as one 16-byte chunk per piece plane (8 KiB apart); F16: of scale * w
+template <bool F16>
+__device__ __forceinline__ void store_pieces(unsigned char* dst, const float (&w)[8], float scale) {
+  if constexpr (F16) {
+    uint4 vh, vl;
+    rc_split2h_pair(w[0] * scale, w[1] * scale, vh.x, vl.x);
+    rc_split2h_pair(w[2] * scale, w[3] * scale, vh.y, vl.y);
+    rc_split2h_pair(w[4] * scale, w[5] * scale, vh.z, vl.z);
+    rc_split2h_pair(w[6] * scale, w[7] * scale, vh.w, vl.w);
+    st_u4(dst, vh);
+    st_u4(dst + RC_PK_BLOCK, vl);
+  } else {
+    uint4 vh, vm, vl;
+    rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
+    rc_split3_pair(w[2], w[3], vh.y, vm.y, vl.y);
+    rc_split3_pair(w[4], w[5], vh.z, vm.z, vl.z);
+    rc_split3_pair(w[6], w[7], vh.w, vm.w, vl.w);
+    st_u4(dst, vh);
+    st_u4(dst + RC_PK_BLOCK, vm);
+    st_u4(dst + 2 * RC_PK_BLOCK, vl);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
-// W1 split: one workgroup = 128 (agent,unit) columns x 32 features -> three 8-KiB blocks.
+// W1 split: one workgroup = 128 (agent,unit) columns x 32 features -> three 8-KiB blocks (F16: two, of 2^10 alpha W1).
+template <bool F16>
 __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ theta, const float* __restrict__ alpha,
                                                   unsigned char* __restrict__ wp, int N, int in_dim, int ldp,
                                                   int wp_rt, int wp_kt, int hid) {
@@ -101,7 +128,9 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
   const bool col_ok = col < ncols;
   const int ag = col_ok ? col / hid : 0, j = col - ag * hid;
   const float* th = theta + ((long)s * N + ag) * ldp + j;
-  unsigned char* blk = wp + (long)s * wp_rt * wp_kt * 3 * RC_PK_BLOCK + ((long)rt * wp_kt + kt) * 3 * RC_PK_BLOCK;
+  constexpr int NP = F16 ? 2 : 3;
+  if (F16) rc_f16_saturate();
+  unsigned char* blk = wp + (long)s * wp_rt * wp_kt * NP * RC_PK_BLOCK + ((long)rt * wp_kt + kt) * NP * RC_PK_BLOCK;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int c4 = (t >> 7) + 2 * q;
@@ -112,15 +141,7 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
       const bool ok = col_ok && k < in_dim;
       w[e] = ok ? th[(long)k * hid] * alpha[k] : 0.f;
     }
-    uint4 vh, vm, vl;
-    rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
-    rc_split3_pair(w[2], w[3], vh.y, vm.y, vl.y);
-    rc_split3_pair(w[4], w[5], vh.z, vm.z, vl.z);
-    rc_split3_pair(w[6], w[7], vh.w, vm.w, vl.w);
-    const int o = r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4);
-    st_u4(blk + o, vh);
-    st_u4(blk + RC_PK_BLOCK + o, vm);
-    st_u4(blk + 2 * RC_PK_BLOCK + o, vl);
+    store_pieces<F16>(blk + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), w, RC_F16_W_SCALE);
   }
 }
 
@@ -128,11 +149,14 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
 // dz pack: fp32 feature-major dz[S][rows][ldb] (rows = (agent,unit)) -> three exact bf16 pieces in PK form
 // (reduction = replay row), zero beyond B / beyond the last row: the backward operand of a wide net, whose dz1 comes
 // out of a dense GEMM (wide_kernels.hip) instead of mid_fit's fused epilogue.  One workgroup = 128 rows x 32 rows b.
+template <bool F16>
 __global__ __launch_bounds__(256) void k_dz_pack(const float* __restrict__ dz, unsigned char* __restrict__ dzp, int nrows,
                                                  int B, int ldb, int dzp_rt, int dzp_kt) {
   const int s = blockIdx.z, rt = blockIdx.y, kt = blockIdx.x;
   const int t = threadIdx.x, c4 = t & 3;             // four adjacent lanes = the 128 B (32 k) of one row: coalesced both ways
-  unsigned char* blk = dzp + (long)s * dzp_rt * dzp_kt * 3 * RC_PK_BLOCK + ((long)rt * dzp_kt + kt) * 3 * RC_PK_BLOCK;
+  constexpr int NP = F16 ? 2 : 3;
+  if (F16) rc_f16_saturate();
+  unsigned char* blk = dzp + (long)s * dzp_rt * dzp_kt * NP * RC_PK_BLOCK + ((long)rt * dzp_kt + kt) * NP * RC_PK_BLOCK;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int r = (t >> 2) + 64 * q;
@@ -147,15 +171,7 @@ __global__ __launch_bounds__(256) void k_dz_pack(const float* __restrict__ dz, u
 #pragma unroll
       for (int e = 0; e < 8; ++e) w[e] = (row_ok && kt * 32 + 8 * c4 + e < B) ? src[e] : 0.f;
     }
-    uint4 vh, vm, vl;
-    rc_split3_pair(w[0], w[1], vh.x, vm.x, vl.x);
-    rc_split3_pair(w[2], w[3], vh.y, vm.y, vl.y);
-    rc_split3_pair(w[4], w[5], vh.z, vm.z, vl.z);
-    rc_split3_pair(w[6], w[7], vh.w, vm.w, vl.w);
-    const int o = r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4);
-    st_u4(blk + o, vh);
-    st_u4(blk + RC_PK_BLOCK + o, vm);
-    st_u4(blk + 2 * RC_PK_BLOCK + o, vl);
+    store_pieces<F16>(blk + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), w, RC_F16_DZ_SCALE);
   }
 }
 
@@ -186,7 +202,7 @@ struct LatOperands {
 // three-piece operand's fragments loaded global -> registers, 256 x 256 and 512 x 128 tiles with eight wavefronts,
 // persistent workgroups, start staggers, static priorities, L2 prefetch touches -- all within -15..+0 % of this form;
 // DESIGN.md section 5 keeps the numbers.)
-template <int PA, int PB, int MT, int NT, int WM, int WN, bool SPREAD>
+template <int PA, int PB, int MT, int NT, int WM, int WN, bool SPREAD, bool F16>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
                                              rc_f32x16 (&acc)[MT][NT]) {
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
@@ -276,7 +292,7 @@ __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              acc[mt][nt] = rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
+              acc[mt][nt] = F16 ? rc_mfma_f16(af[mt][pa], bf[nt][pb], acc[mt][nt]) : rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
               if constexpr (SPREAD) {
                 const int o = ks * (PA * PB * MT * NT) + (((PA - 1 - pa) * PB + (PB - 1 - pb)) * MT + mt) * NT + nt;
                 if (o % EVERY == EVERY - 1 && o / EVERY < C::GLDS) {
@@ -313,12 +329,12 @@ __device__ __forceinline__ void lat_decode(int g, int per_seed, int S, int& seed
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
 // 128 x 256 block tile, two 40-KiB stages, two workgroups per CU.  W8: eight wavefronts of 64 x 64 (four per SIMD) instead
 // of four of 64 x 128: measured 749 / 988 us against 776 / 1037 at the two cfg-4 shapes -> the forward's default.
-template <bool W8>
+template <bool W8, bool F16>
 __global__ RC_LAT_OCC(W8 ? 512 : 256, W8 ? 4 : 2)
 void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, const unsigned char* __restrict__ kp, int kp_rt,
                    int kp_kt, const float* __restrict__ theta, float* __restrict__ a1t, int S, int N, int B, int in_dim, int ldp,
                    int ldb, int mtiles, int ntiles, int hid) {
-  constexpr int PA = 3, PB = 1, MT = 2, NT = W8 ? 2 : 4, WM = 2, WN = W8 ? 4 : 2;
+  constexpr int PA = F16 ? 2 : 3, PB = 1, MT = 2, NT = W8 ? 2 : 4, WM = 2, WN = W8 ? 4 : 2;
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
@@ -328,7 +344,7 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
   op.b = kp + (long)s * kp_rt * kp_kt * (PB * RC_PK_BLOCK); op.b_kt = kp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
-  lat_mainloop<PA, PB, MT, NT, WM, WN, false>(op, (in_dim + 31) >> 5, lds, acc);
+  lat_mainloop<PA, PB, MT, NT, WM, WN, false, F16>(op, (in_dim + 31) >> 5, lds, acc);
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * hid;
   const float* theta_s = theta + (long)s * N * ldp;
@@ -371,7 +387,7 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            const float z = acc[mt][nt][r] + bv[mt][r];
+            const float z = F16 ? fmaf(acc[mt][nt][r], RC_F16_W_UNSCALE, bv[mt][r]) : acc[mt][nt][r] + bv[mt][r];
             const float o = fmaxf(z, RC_LEAK * z);                 // == rc_lrelu(z) bit for bit (0 < leak < 1), 2 ops not 3
             float* __restrict__ dst = reinterpret_cast<float*>(rowbase + (long)dr * ldb * 4 + lane_byte);
             if (FULL || m0 + dr + 4 * half < ncols) RC_NT_STORE(dst, o);
@@ -386,13 +402,14 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
 // 256 x 128 block tile.  Default: four wavefronts of 128 x 64 with the spread LDS-DMA issue (875 -> 824 us in a block);
 // W8 (eight wavefronts of 64 x 64): 780 / 1103 against 756 / 1103 us -- the alternative.
-template <bool W8>
+template <bool W8, bool DZ16, bool WP16>
 __global__ RC_LAT_OCC(W8 ? 512 : 256, W8 ? 4 : 2)
 void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt, const unsigned char* __restrict__ dzp,
                         int dzp_rt, int dzp_kt, const float* __restrict__ alpha, float* __restrict__ theta,
                         const int* __restrict__ mask, int S, int N, int B, int in_dim, int ldp, float lr, int mtiles, int ntiles,
                         unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt, int hid) {
-  constexpr int PA = 1, PB = 3, MT = W8 ? 2 : 4, NT = 2, WM = W8 ? 4 : 2, WN = 2;
+  constexpr int PA = 1, PB = DZ16 ? 2 : 3, MT = W8 ? 2 : 4, NT = 2, WM = W8 ? 4 : 2, WN = 2;
+  constexpr int WNP = WP16 ? 2 : 3;                                 // pieces of the forward operand written by the epilogue
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
@@ -402,11 +419,12 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
-  lat_mainloop<PA, PB, MT, NT, WM, WN, !W8>(op, (B + 31) >> 5, lds, acc);
+  lat_mainloop<PA, PB, MT, NT, WM, WN, !W8, DZ16>(op, (B + 31) >> 5, lds, acc);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
   const int ncols = N * hid;
+  if (WP16) rc_f16_saturate();
   __syncthreads();
   float* al = reinterpret_cast<float*>(lds);
   if (threadIdx.x < C::BM) {
@@ -432,7 +450,7 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
       const int k0 = bm * C::BM + wm * 32 * MT + 4 * half;
       float* th = theta + ((long)s * N + ag) * ldp + j + (long)k0 * hid;
       unsigned char* wrow = wp_out == nullptr ? nullptr
-          : wp_out + (long)s * wp_rt * wp_kt * (3 * RC_PK_BLOCK) + (long)(col >> 7) * wp_kt * (3 * RC_PK_BLOCK) + (col & 127) * 64 + half * 8;
+          : wp_out + (long)s * wp_rt * wp_kt * (WNP * RC_PK_BLOCK) + (long)(col >> 7) * wp_kt * (WNP * RC_PK_BLOCK) + (col & 127) * 64 + half * 8;
       const int sw = (col >> 2) & 3;
       float wold[MT][16];
 #pragma unroll
@@ -461,13 +479,21 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
             wn4[e] = w * av[e];
           }
           if (wrow != nullptr && kt < wp_kt) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            rc_split3_pair(wn4[0], wn4[1], h0, m0, l0);
-            rc_split3_pair(wn4[2], wn4[3], h1, m1, l1);
-            unsigned char* q = wrow + (long)kt * (3 * RC_PK_BLOCK) + ((gq ^ sw) << 4);
-            *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(q + RC_PK_BLOCK) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(q + 2 * RC_PK_BLOCK) = make_uint2(l0, l1);
+            unsigned char* q = wrow + (long)kt * (WNP * RC_PK_BLOCK) + ((gq ^ sw) << 4);
+            if constexpr (WP16) {
+              unsigned h0, l0, h1, l1;
+              rc_split2h_pair(wn4[0] * RC_F16_W_SCALE, wn4[1] * RC_F16_W_SCALE, h0, l0);
+              rc_split2h_pair(wn4[2] * RC_F16_W_SCALE, wn4[3] * RC_F16_W_SCALE, h1, l1);
+              *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+              *reinterpret_cast<uint2*>(q + RC_PK_BLOCK) = make_uint2(l0, l1);
+            } else {
+              unsigned h0, m0, l0, h1, m1, l1;
+              rc_split3_pair(wn4[0], wn4[1], h0, m0, l0);
+              rc_split3_pair(wn4[2], wn4[3], h1, m1, l1);
+              *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+              *reinterpret_cast<uint2*>(q + RC_PK_BLOCK) = make_uint2(m0, m1);
+              *reinterpret_cast<uint2*>(q + 2 * RC_PK_BLOCK) = make_uint2(l0, l1);
+            }
           }
         }
       }
@@ -479,7 +505,36 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
 // default: forward eight, backward four (see the kernels' comments).
 bool lat_w8(bool forward) { const char* e = getenv("RCMARL_LAT_W8"); return e ? atoi(e) != 0 : forward; }
 
+template <bool W8, bool F16>
+int launch_forward(unsigned nblocks, void* stream, const unsigned char* wp, int wp_rt, int wp_kt, const unsigned char* kp, int kp_rt,
+                   int kp_kt, const float* theta, float* a1t, int S, int N, int B, int in_dim, int ldp, int ldb, int mtiles,
+                   int ntiles, int hid) {
+  const size_t smem = (size_t)2 * LatCfg<F16 ? 2 : 3, 1, 2, 4>::STAGE_BYTES;
+  static const bool ok = rc_want_lds(k_lat_forward<W8, F16>, smem);
+  if (!ok) return RCMARL_ERR_LAUNCH;
+  RCMARL_LAUNCH((k_lat_forward<W8, F16>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, wp, wp_rt, wp_kt, kp, kp_rt, kp_kt,
+                theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid);
+  return rcmarl_check_launch();
+}
+
+template <bool W8, bool DZ16, bool WP16>
+int launch_backward(unsigned nblocks, void* stream, const unsigned char* ktp, int ktp_rt, int ktp_kt, const unsigned char* dzp,
+                    int dzp_rt, int dzp_kt, const float* alpha, float* theta, const int* mask, int S, int N, int B, int in_dim,
+                    int ldp, float lr, int mtiles, int ntiles, unsigned char* wp_out, int wp_rt, int wp_kt, int hid) {
+  const size_t smem = (size_t)2 * LatCfg<1, DZ16 ? 2 : 3, 4, 2>::STAGE_BYTES;
+  static const bool ok = rc_want_lds(k_lat_backward_sgd<W8, DZ16, WP16>, smem);
+  if (!ok) return RCMARL_ERR_LAUNCH;
+  RCMARL_LAUNCH((k_lat_backward_sgd<W8, DZ16, WP16>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, ktp, ktp_rt, ktp_kt, dzp,
+                dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, DZ16 ? lr * RC_F16_DZ_UNSCALE : lr, mtiles, ntiles,
+                wp_out, wp_rt, wp_kt, hid);
+  return rcmarl_check_launch();
+}
+
 }  // namespace
+
+// 0: exact bf16x3 everywhere; bit 0: forward operand (W', and K of the forward image) as f16x2; bit 1: backward operand (dz1, and
+// K^T) as f16x2.  Callers that decode packed buffers (tests) ask here; the buffers are always sized for three pieces.
+RCMARL_EXPORT int rcmarl_lattice_f16_mode(void) { return rc_lat_f16_mode(); }
 
 RCMARL_EXPORT int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim,
                                         void* kp, int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag,
@@ -493,8 +548,9 @@ RCMARL_EXPORT int rcmarl_lattice_encode(const float* x, long x_seed_stride, cons
   if (kp) c_ext = kp_kt * 32 > c_ext ? kp_kt * 32 : c_ext;
   if (ktp) c_ext = ktp_rt * 128 > c_ext ? ktp_rt * 128 : c_ext;
   const dim3 grid(rc_ceil_div(c_ext, 128), b_pad / 32, S), block(256);
+  const int mode = rc_lat_f16_mode();
   RCMARL_LAUNCH(k_lattice_encode, grid, block, 0, stream, x, x_seed_stride, alpha, B, in_dim, (unsigned char*)kp, kp_rt,
-                kp_kt, (unsigned char*)ktp, ktp_rt, ktp_kt, flag);
+                kp_kt, (unsigned char*)ktp, ktp_rt, ktp_kt, flag, mode & 1, (mode >> 1) & 1);
   return rcmarl_check_launch();
 }
 
@@ -505,7 +561,11 @@ RCMARL_EXPORT int rcmarl_w1_split(const float* theta, const float* alpha, void* 
   if (hid <= 0) return RCMARL_ERR_ARG;
   if ((long)wp_rt * 128 < (long)N * hid || wp_kt * 32 < in_dim) return RCMARL_ERR_ARG;
   const dim3 grid(rc_ceil_div(in_dim, 32), rc_ceil_div(N * hid, 128), S), block(256);
-  RCMARL_LAUNCH(k_w1_split, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt, hid);
+  if (rc_lat_f16_mode() & 1) {
+    RCMARL_LAUNCH(k_w1_split<true>, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt, hid);
+  } else {
+    RCMARL_LAUNCH(k_w1_split<false>, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt, hid);
+  }
   return rcmarl_check_launch();
 }
 
@@ -516,7 +576,11 @@ RCMARL_EXPORT int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int 
     return RCMARL_ERR_ARG;
   const int rts = rc_ceil_div(N * hid, 128), kts = rc_ceil_div(B, 32);
   if (dzp_rt < rts || dzp_kt < kts) return RCMARL_ERR_ARG;
-  RCMARL_LAUNCH(k_dz_pack, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
+  if (rc_lat_f16_mode() & 2) {
+    RCMARL_LAUNCH(k_dz_pack<true>, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
+  } else {
+    RCMARL_LAUNCH(k_dz_pack<false>, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
+  }
   return rcmarl_check_launch();
 }
 
@@ -529,18 +593,13 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   if (hid <= 0) return RCMARL_ERR_ARG;
   const int mtiles = rc_ceil_div(N * hid, 128), ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
   if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
-  const size_t smem = (size_t)2 * LatCfg<3, 1, 2, 4>::STAGE_BYTES;
-  const dim3 grid((unsigned)(S * mtiles * ntiles));
-  static const bool ok = rc_want_lds(k_lat_forward<true>, smem) && rc_want_lds(k_lat_forward<false>, smem);
-  if (!ok) return RCMARL_ERR_LAUNCH;
-  if (lat_w8(true)) {
-    RCMARL_LAUNCH((k_lat_forward<true>), grid, dim3(512), smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
-                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid);
-  } else {
-    RCMARL_LAUNCH((k_lat_forward<false>), grid, dim3(256), smem, stream, (const unsigned char*)wp, wp_rt, wp_kt,
-                  (const unsigned char*)kp, kp_rt, kp_kt, theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid);
-  }
-  return rcmarl_check_launch();
+  const unsigned nb = (unsigned)(S * mtiles * ntiles);
+  const bool w8 = lat_w8(true), f16 = rc_lat_f16_mode() & 1;
+#define RC_FWD(W8, F16)                                                                                                       \
+  launch_forward<W8, F16>(nb, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp, kp_rt, kp_kt, theta, \
+                          a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid)
+  return f16 ? (w8 ? RC_FWD(true, true) : RC_FWD(false, true)) : (w8 ? RC_FWD(true, false) : RC_FWD(false, false));
+#undef RC_FWD
 }
 
 RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
@@ -554,18 +613,22 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
   const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * hid, 128), ktiles = rc_ceil_div(B, 32);
   if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
   if (wp_out && ((long)wp_rt * 128 < (long)ntiles * 128 || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
-  const size_t smem = (size_t)2 * LatCfg<1, 3, 4, 2>::STAGE_BYTES;
-  const dim3 grid((unsigned)(S * mtiles * ntiles));
-  static const bool ok = rc_want_lds(k_lat_backward_sgd<true>, smem) && rc_want_lds(k_lat_backward_sgd<false>, smem);
-  if (!ok) return RCMARL_ERR_LAUNCH;
-  if (lat_w8(false)) {
-    RCMARL_LAUNCH((k_lat_backward_sgd<true>), grid, dim3(512), smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
-                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, hid);
-  } else {
-    RCMARL_LAUNCH((k_lat_backward_sgd<false>), grid, dim3(256), smem, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt,
-                  (const unsigned char*)dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,
-                  (unsigned char*)wp_out, wp_rt, wp_kt, hid);
+  const unsigned nb = (unsigned)(S * mtiles * ntiles);
+  const int mode = rc_lat_f16_mode();
+  const bool w8 = lat_w8(false);
+#define RC_BWD(W8, DZ16, WP16)                                                                                              \
+  launch_backward<W8, DZ16, WP16>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, \
+                                  dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,                     \
+                                  (unsigned char*)wp_out, wp_rt, wp_kt, hid)
+  switch (mode * 2 + (w8 ? 1 : 0)) {
+    case 0: return RC_BWD(false, false, false);
+    case 1: return RC_BWD(true, false, false);
+    case 2: return RC_BWD(false, false, true);
+    case 3: return RC_BWD(true, false, true);
+    case 4: return RC_BWD(false, true, false);
+    case 5: return RC_BWD(true, true, false);
+    case 6: return RC_BWD(false, true, true);
+    default: return RC_BWD(true, true, true);
   }
-  return rcmarl_check_launch();
+#undef RC_BWD
 }

@@ -103,7 +103,7 @@ __device__ __forceinline__ void block_reduce_store(float (&vals)[K], float* red,
 // last chunk are written as zeros.
 // NOTE (round 3, profiles/r03_pipe_overlap_cycles.txt): the f32-input MFMA runs on the vector ALUs -- its cycles ADD to
 // the VALU's; this kernel's time is the sum of its 232 f32 MFMAs, ~500 VALU and ~190 LDS instructions per 64 rows.
-template <int HID, bool EMIT>
+template <int HID, bool EMIT, bool DZ16 = false>
 __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restrict__ a1t, const float* __restrict__ theta,
                                                        const float* __restrict__ y, float* __restrict__ partials, int N,
                                                        int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
   const NetGeom g = make_geom(in_dim, HID, 1);
   const float* th = theta + ((long)s * N + i) * ldp;
   const long row0 = ((long)s * N + i) * HID;
+  if (EMIT && DZ16) rc_f16_saturate();
   for (int e = r; e < HID * WLD; e += ROWS) {
     const int m = e / WLD, c = e - m * WLD;
     sW2[e] = c < HID ? th[g.o_W2 + m * HID + c] : 0.f;
@@ -253,33 +254,44 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
       // every (unit, piece) row of the packed image: stored directly that is 120 two-byte store instructions per
       // wavefront.  Instead the wavefront transposes its 64 rows x 60 (unit, piece) values through its (now idle) panel
       // area and writes 16-byte chunks = 8 consecutive replay rows of one (unit, piece): 8 store instructions.
-      unsigned short* stg = reinterpret_cast<unsigned short*>(sA);          // [60 (unit, piece)][64 rows] bf16 = 7680 B
+      // DZ16: two f16 pieces of 2^8 dz1 instead of three bf16 pieces of dz1 (rcmarl_lattice.h).
+      constexpr int NP = DZ16 ? 2 : 3;
+      unsigned short* stg = reinterpret_cast<unsigned short*>(sA);          // [HID * NP (unit, piece)][64 rows] 16-bit = 7680 / 5120 B
       RC_WAVE_SYNC();                                  // the reduction product's fragment reads are done
 #pragma unroll
       for (int q = 0; q < HID / 2; ++q) {
-        unsigned h, m, l;
-        rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);              // bits 0-15: unit 2q, bits 16-31: unit 2q+1
-        stg[((2 * q) * 3 + 0) * 64 + lane] = (unsigned short)h;
-        stg[((2 * q) * 3 + 1) * 64 + lane] = (unsigned short)m;
-        stg[((2 * q) * 3 + 2) * 64 + lane] = (unsigned short)l;
-        stg[((2 * q + 1) * 3 + 0) * 64 + lane] = (unsigned short)(h >> 16);
-        stg[((2 * q + 1) * 3 + 1) * 64 + lane] = (unsigned short)(m >> 16);
-        stg[((2 * q + 1) * 3 + 2) * 64 + lane] = (unsigned short)(l >> 16);
+        if constexpr (DZ16) {
+          unsigned h, l;
+          rc_split2h_pair(dz1[2 * q] * RC_F16_DZ_SCALE, dz1[2 * q + 1] * RC_F16_DZ_SCALE, h, l);
+          stg[((2 * q) * 2 + 0) * 64 + lane] = (unsigned short)h;
+          stg[((2 * q) * 2 + 1) * 64 + lane] = (unsigned short)l;
+          stg[((2 * q + 1) * 2 + 0) * 64 + lane] = (unsigned short)(h >> 16);
+          stg[((2 * q + 1) * 2 + 1) * 64 + lane] = (unsigned short)(l >> 16);
+        } else {
+          unsigned h, m, l;
+          rc_split3_pair(dz1[2 * q], dz1[2 * q + 1], h, m, l);              // bits 0-15: unit 2q, bits 16-31: unit 2q+1
+          stg[((2 * q) * 3 + 0) * 64 + lane] = (unsigned short)h;
+          stg[((2 * q) * 3 + 1) * 64 + lane] = (unsigned short)m;
+          stg[((2 * q) * 3 + 2) * 64 + lane] = (unsigned short)l;
+          stg[((2 * q + 1) * 3 + 0) * 64 + lane] = (unsigned short)(h >> 16);
+          stg[((2 * q + 1) * 3 + 1) * 64 + lane] = (unsigned short)(m >> 16);
+          stg[((2 * q + 1) * 3 + 2) * 64 + lane] = (unsigned short)(l >> 16);
+        }
       }
       RC_WAVE_SYNC();
-      unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK);
+      unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (NP * RC_PK_BLOCK);
       const int k0 = chunk * ROWS + wave * 64;         // first replay row of this wavefront (a multiple of 64: two k-tiles)
 #pragma unroll
-      for (int it = 0; it < (HID * 3 * 8 + 63) / 64; ++it) {
+      for (int it = 0; it < (HID * NP * 8 + 63) / 64; ++it) {
         const int c = it * 64 + lane;                  // chunk index: (unit, piece) = c >> 3, rows 8*(c&7) .. +7
-        if (c < HID * 3 * 8) {
+        if (c < HID * NP * 8) {
           const int up = c >> 3, c8 = c & 7;
-          const int unit = up / 3, piece = up - 3 * unit;
+          const int unit = up / NP, piece = up - NP * unit;
           const int R = i * HID + unit;
           const int kt = (k0 >> 5) + (c8 >> 2), c4 = c8 & 3;
           if (kt < dzp_kt) {
             const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 64 + 8 * c8);
-            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 3 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
+            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * NP + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
                                  (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
             *reinterpret_cast<uint4*>(base + off) = v4;
           }
@@ -1084,7 +1096,10 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  if (midfit_v5()) {
+  if (rc_lat_f16_mode() & 2) {                       // the backward operand as two f16 pieces: v5 only
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+  } else if (midfit_v5()) {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
                                      partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
   } else {

@@ -24,6 +24,7 @@
 // read  ds_read_b128(row = lane&31, chunk = 2*kstep + lane>>5)  is bank-conflict free.
 #pragma once
 #include "rcmarl_common.h"
+#include <stdlib.h>
 
 #define RC_PK_BLOCK 8192
 
@@ -70,9 +71,84 @@ __device__ __forceinline__ void rc_split3_pair(float w0, float w1, unsigned& h, 
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Two-piece f16 form ("f16x2", round 3).  A fp32 value v, scaled by a fixed power of two, is carried as h = rn_f16(v),
+// l = rn_f16(v - h): 11 + 11 significand bits and the sign of the residual, i.e. v up to ONE unit in the last place of its
+// fp32 significand (exact for 3 values in 4; the rest are off by exactly one fp32 ulp), or up to 2^-25 of the scaled unit
+// where the residual falls into f16's subnormals.  Products K * piece (|K| <= 256) have <= 20 significant bits: exact in
+// the fp32 accumulator of v_mfma_f32_32x32x16_f16.  Two matrix passes and 4 bytes per value instead of three and 6 -- the
+// GEMMs' matrix time AND their LDS traffic, which bound them.  f16 has 5 exponent bits, hence the
+// fixed scales:  forward  W'' = 2^10 * alpha_k * W1  (finite while |alpha_k W1| < 64, full precision above 2.4e-4,
+// absolute 3e-11 below), backward dz'' = 2^8 * dz1 (finite while |dz1| < 256; absolute 1.2e-10, far below what lr * dz
+// contributes to one ulp of a weight); the epilogues multiply the scale out (exact).  RCMARL_LAT_F16: bit 0 = forward
+// operand, bit 1 = backward operand in this form; 0 = the exact three-piece bf16 form everywhere.
+#define RC_F16_W_SCALE 1024.f
+#define RC_F16_W_UNSCALE 0.0009765625f
+#define RC_F16_DZ_SCALE 256.f
+#define RC_F16_DZ_UNSCALE 0.00390625f
+#ifndef RC_LAT_F16_DEFAULT
+#define RC_LAT_F16_DEFAULT 3
+#endif
+static inline int rc_lat_f16_mode() {               // read at every call: tests switch it
+  const char* e = getenv("RCMARL_LAT_F16");
+  return e ? (atoi(e) & 3) : RC_LAT_F16_DEFAULT;
+}
+
+// Saturation.  Kernels that form f16 pieces call rc_f16_saturate() first: MODE.FP16_OVFL (bit 23) makes a f32 -> f16 conversion
+// of a FINITE value beyond +-65504 return +-65504 instead of infinity (true infinities and NaNs pass).  A value beyond the form's
+// range is then carried as h + l = +-131008 / scale at most (|alpha W1| <= 127.9, |dz1| <= 511.8) -- a clipped but FINITE operand:
+// a fit that has blown up (the reference's fast_lr leaves a few of 4096 TR nets at 1e8 in the BASELINE configs[3] workload, finite
+// in fp32) keeps producing finite numbers that the trimmed mean of its neighbours discards, instead of NaNs that spread.
+__device__ __forceinline__ void rc_f16_saturate() {
+#ifndef RCMARL_EMU
+  __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1u);          // hwreg(HW_REG_MODE, offset 23, size 1) = 1
+#endif
+}
+
+// fp32 -> f16 bits, round to nearest even, subnormals kept, finite overflow saturates (the emulation's twin of FP16_OVFL = 1)
+__device__ __forceinline__ unsigned rc_f16_rne(float f) {
+  unsigned x = __float_as_uint(f);
+  const unsigned sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u);
+  if (x >= 0x38800000u) {                            // >= 2^-14: a normal f16 (or overflow)
+    x += 0x00000fffu + ((x >> 13) & 1u);
+    x -= 0x38000000u;
+    const unsigned h = x >> 13;
+    return sign | (h >= 0x7c00u ? 0x7bffu : h);
+  }
+  return sign | (unsigned)rintf(__uint_as_float(x) * 16777216.f);     // multiples of 2^-24 (0x400 = 2^-14 falls out right)
+}
+__device__ __forceinline__ float rc_f16_to_f32(unsigned h) {
+  const unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  if (e == 31u) return __uint_as_float(sign | 0x7f800000u | (m << 13));
+  if (e == 0u) { const float v = (float)m * 5.9604644775390625e-8f; return sign ? -v : v; }
+  return __uint_as_float(sign | ((e + 112u) << 23) | (m << 13));
+}
+// two values at once: h, l pieces of (w0, w1) -- already scaled by the caller -- packed low/high as rc_split3_pair does
+#ifdef RCMARL_EMU
+__device__ __forceinline__ void rc_split2h_pair(float w0, float w1, unsigned& h, unsigned& l) {
+  const unsigned h0 = rc_f16_rne(w0), h1 = rc_f16_rne(w1);
+  const unsigned l0 = rc_f16_rne(w0 - rc_f16_to_f32(h0)), l1 = rc_f16_rne(w1 - rc_f16_to_f32(h1));
+  h = h0 | (h1 << 16); l = l0 | (l1 << 16);
+}
+#else
+typedef _Float16 rc_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rc_split2h_pair(float w0, float w1, unsigned& h, unsigned& l) {
+  const rc_f2 v = {w0, w1};
+  const rc_h2 hh = __builtin_convertvector(v, rc_h2);
+  const rc_f2 r = v - __builtin_convertvector(hh, rc_f2);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rc_h2));
+}
+#endif
+
 #ifdef RCMARL_EMU
 __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c) {
   return __hipemu_mfma_f32_32x32x16_bf16(a, b, c);
+}
+__device__ __forceinline__ rc_f32x16 rc_mfma_f16(uint4 a, uint4 b, rc_f32x16 c) {
+  return __hipemu_mfma_f32_32x32x16_f16(a, b, c);
 }
 #define RC_GLDS16(gsrc, lds_base) __hipemu_glds16((gsrc), (lds_base))
 #define RC_GLDS16S(sbase, voff, lds_base) __hipemu_glds16((sbase) + (voff), (lds_base))
@@ -83,6 +159,10 @@ typedef __bf16 rc_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rc_bf16x8, a), __builtin_bit_cast(rc_bf16x8, b), c,
                                                  0, 0, 0);
+}
+typedef _Float16 rc_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ rc_f32x16 rc_mfma_f16(uint4 a, uint4 b, rc_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rc_f16x8, a), __builtin_bit_cast(rc_f16x8, b), c, 0, 0, 0);
 }
 // global_load_lds_dwordx4: LDS destination = wave-uniform base (M0) + lane*16, global source per lane.
 // Issued through inline asm ON PURPOSE: with the builtin, hipcc cannot tell the LDS-DMA destination

@@ -60,7 +60,15 @@ def bf16_bits_to_f32(u16):
     return (np.asarray(u16, np.uint32) << 16).view(np.float32)
 
 
-def pk_unpack(buf_u16, n_rows, n_k, kt_alloc, pieces):
-    """Decode one seed's packed buffer (1-D uint16 view) -> float32 [pieces][n_rows][n_k]."""
-    return np.stack([bf16_bits_to_f32(buf_u16[pk_element_index(n_rows, n_k, kt_alloc, pieces, p)])
-                     for p in range(pieces)])
+def f16_bits_to_f32(u16):
+    return np.asarray(u16, np.uint16).view(np.float16).astype(np.float32)
+
+
+def pk_unpack(buf_u16, n_rows, n_k, kt_alloc, pieces, f16=False):
+    """Decode one seed's packed buffer (1-D uint16 view) -> float32 [pieces][n_rows][n_k] (bf16 pieces, or f16 ones)."""
+    dec = f16_bits_to_f32 if f16 else bf16_bits_to_f32
+    return np.stack([dec(buf_u16[pk_element_index(n_rows, n_k, kt_alloc, pieces, p)]) for p in range(pieces)])
+
+
+# the two-piece f16 form (csrc/rcmarl_lattice.h): fixed scales of the forward / backward operand
+F16_W_SCALE, F16_DZ_SCALE = 1024.0, 256.0

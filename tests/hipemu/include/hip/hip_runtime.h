@@ -253,6 +253,37 @@ inline floatx16 __hipemu_mfma_f32_32x32x16_bf16(uint4 a, uint4 b, floatx16 c) {
   hipemu::wave_barrier();
   return d;
 }
+// ---- f16 MFMA 32x32x16: operand layout of the bf16 form; products of two f16 are exact in fp32 ----------
+inline float __hipemu_f16(unsigned dword, int hi) {
+  unsigned h = hi ? (dword >> 16) : (dword & 0xffffu);
+  unsigned sign = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu, bits;
+  if (e == 31u) bits = sign | 0x7f800000u | (m << 13);
+  else if (e == 0u) { float v = (float)m * 5.9604644775390625e-8f; return sign ? -v : v; }
+  else bits = sign | ((e + 112u) << 23) | (m << 13);
+  float f; memcpy(&f, &bits, 4); return f;
+}
+inline floatx16 __hipemu_mfma_f32_32x32x16_f16(uint4 a, uint4 b, floatx16 c) {
+  auto& s = hipemu::st();
+  int w = hipemu::wave(), l = hipemu::lane();
+  unsigned* m = &s.xch_m[((size_t)w * 64 + l) * 8];
+  m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+  hipemu::wave_barrier();
+  floatx16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 16; ++k) {
+      const unsigned* ma = &s.xch_m[((size_t)w * 64 + row + 32 * (k >> 3)) * 8];
+      const unsigned* mb = &s.xch_m[((size_t)w * 64 + col + 32 * (k >> 3)) * 8 + 4];
+      int e = k & 7;
+      acc += __hipemu_f16(ma[e >> 1], e & 1) * __hipemu_f16(mb[e >> 1], e & 1);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_barrier();
+  return d;
+}
 // ---- int8 MFMA 32x32x32 (16 int8 per lane per operand, packed in a uint4), i32 accumulate: exact ----------
 // lane l supplies A[i=l&31][k=16*(l>>5)+e], B[k=16*(l>>5)+e][j=l&31] (e = 0..15, byte e&3 of dword e>>2); D layout as the f32 forms.
 struct intx16 { int v[16]; int& operator[](int i) { return v[i]; } const int& operator[](int i) const { return v[i]; } };

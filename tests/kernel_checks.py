@@ -670,6 +670,14 @@ class LatticeBuffers:
         self.flag = bk.dev(np.zeros(1, np.int32))
 
 
+def seed_views(buf_u16, S, rt_kt, pieces):
+    """Per-seed 1-D views of a packed buffer: the kernels' seed stride is rt*kt*pieces blocks (the buffers are sized for three
+    pieces; the two-piece form uses the first two thirds)."""
+    n = LT.Geometry.nbytes(rt_kt, pieces) // 2
+    flat = np.asarray(buf_u16).reshape(-1)
+    return [flat[s * n:(s + 1) * n] for s in range(S)]
+
+
 def _encode(bk, lb, d_x, x_stride, d_alpha, S, B, in_dim, with_t=True):
     g = lb.g
     bk.lib.rcmarl_lattice_encode(bk.ptr(d_x), x_stride, bk.ptr(d_alpha), S, B, in_dim, bk.ptr(lb.kp), g.kp[0], g.kp[1],
@@ -697,12 +705,13 @@ def check_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling=True):
     assert np.abs(K).max() <= 256 and np.abs(K).max() > 0
     g = lb.g
     b_pad = (B + 255) // 256 * 256
+    mode = bk.lib.rcmarl_lattice_f16_mode()           # bit 0: forward image as f16, bit 1: backward image as f16
     for s in range(S):
-        got = LT.pk_unpack(kp[s], b_pad, g.kp[1] * 32, g.kp[1], 1)[0]
+        got = LT.pk_unpack(kp[s], b_pad, g.kp[1] * 32, g.kp[1], 1, f16=bool(mode & 1))[0]
         want = np.zeros_like(got)
         want[:B, :in_dim] = K[s]
         np.testing.assert_array_equal(got, want)
-        got = LT.pk_unpack(ktp[s], g.ktp[0] * 128, b_pad, g.ktp[1], 1)[0]
+        got = LT.pk_unpack(ktp[s], g.ktp[0] * 128, b_pad, g.ktp[1], 1, f16=bool(mode & 2))[0]
         want = np.zeros_like(got)
         want[:in_dim, :B] = K[s].T
         np.testing.assert_array_equal(got, want)
@@ -713,12 +722,19 @@ def check_lattice_encode(bk, S, n_agents, B, width, nrow, ncol, scaling=True):
     assert bk.host(lb.flag)[0] == 1
 
 
-def check_lattice_forward(bk, S, N, B, width, nrow, ncol, scaling=True):
+def check_lattice_forward(bk, S, N, B, width, nrow, ncol, scaling=True, w_scale=None, tol=2e-6):
+    """w_scale: layer-1 weights multiplied by it and b1 zeroed (a probe of the f16 form's subnormal range: with 1e-6 every piece
+    of 2^10 alpha W1 is a f16 subnormal; a matrix core that flushed them would return zeros)."""
     rng = np.random.default_rng(B + N * 3 + width)
     in_dim = N * width
     P, _ = geom(in_dim, 1)
     ldp, ldb = pad64(P), pad64(B)
     params = random_params(rng, S, N, in_dim, 1)
+    if w_scale is not None:
+        for s_ in range(S):
+            for n_ in range(N):
+                params[s_][n_][0] *= np.float32(w_scale)
+                params[s_][n_][1] *= np.float32(0)
     theta = pack_rows(params, ldp)
     x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol, scaling)
     lb = LatticeBuffers(bk, S, N, in_dim, B)
@@ -728,20 +744,93 @@ def check_lattice_forward(bk, S, N, B, width, nrow, ncol, scaling=True):
     _layer1_lattice(bk, lb, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb)
     a1t = bk.host(d_a)
     assert bk.host(lb.flag)[0] == 0
-    # the three pieces reproduce alpha*W1 exactly
-    wp = bk.host(lb.wp).reshape(S, -1)
+    # the three bf16 pieces reproduce alpha*W1 exactly; the two f16 pieces reproduce 2^10 alpha*W1 to one fp32 ulp (exact for
+    # most), or to 2^-25 where the residual is a f16 subnormal
+    f16 = bool(bk.lib.rcmarl_lattice_f16_mode() & 1)
+    wp = seed_views(bk.host(lb.wp), S, lb.g.wp, 2 if f16 else 3)
     for s in range(S):
-        pieces = LT.pk_unpack(wp[s], N * HID, in_dim, lb.g.wp[1], 3).astype(np.float64)
         w1 = np.stack([params[s][n][0] for n in range(N)], axis=0)                     # [N][in][HID]
         want = (w1 * alpha[None, :, None]).astype(np.float32).transpose(0, 2, 1).reshape(N * HID, in_dim)
-        np.testing.assert_array_equal((pieces[0] + pieces[1] + pieces[2]).astype(np.float32), want)
+        if not f16:
+            pieces = LT.pk_unpack(wp[s], N * HID, in_dim, lb.g.wp[1], 3).astype(np.float64)
+            np.testing.assert_array_equal((pieces[0] + pieces[1] + pieces[2]).astype(np.float32), want)
+        else:
+            pieces = LT.pk_unpack(wp[s], N * HID, in_dim, lb.g.wp[1], 2, f16=True).astype(np.float64)
+            want = want.astype(np.float64) * LT.F16_W_SCALE
+            err = np.abs(pieces[0] + pieces[1] - want)
+            assert np.all(err <= np.maximum(np.spacing(np.abs(want).astype(np.float32)).astype(np.float64), 2.0 ** -25)), float(err.max())
+            assert w_scale is not None or np.mean(err == 0) > 0.6, float(np.mean(err == 0))
     for s in range(S):
         x64 = x[s].astype(np.float64)
         for n in range(N):
             z = x64 @ params[s][n][0].astype(np.float64) + params[s][n][1].astype(np.float64)
             want = np.where(z > 0, z, 0.1 * z)
-            rel_close(a1t[s, n * HID:(n + 1) * HID, :B].T, want, 2e-6, "a1 (lattice)")
+            rel_close(a1t[s, n * HID:(n + 1) * HID, :B].T, want, tol, "a1 (lattice)")
     assert np.isnan(a1t[:, :, B:]).all()                                              # nothing written beyond B
+
+
+def check_lattice_f16_saturation(bk, S=1, N=5, B=70, width=2, nrow=5, ncol=5, lr=0.01, gamma=0.9):
+    """The two-piece f16 form beyond its range (RCMARL_LAT_F16=3): one agent's layer-1 weights are 1e8-scale and its TD targets
+    1e12-scale (a fit that has blown up but is finite in fp32).  Its pieces saturate (MODE.FP16_OVFL: +-65504 each), so its
+    activations equal the float64 model on the CLIPPED weights and its SGD step leaves finite weights; every other agent's
+    forward and fit are what they are without the blown-up neighbour."""
+    assert bk.lib.rcmarl_lattice_f16_mode() == 3
+    rng = np.random.default_rng(77)
+    in_dim = N * width
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    bad = 2
+    for s_ in range(S):
+        params[s_][bad][0] *= np.float32(1e9)
+    theta = pack_rows(params, ldp)
+    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol, True)
+    lb = LatticeBuffers(bk, S, N, in_dim, B)
+    g = lb.g
+    d_x, d_al, d_th = bk.dev(x), bk.dev(alpha), bk.dev(theta)
+    d_a = bk.dev(np.full((S, N * HID, ldb), np.nan, np.float32))
+    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)
+    _layer1_lattice(bk, lb, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+    a1t = bk.host(d_a).copy()
+    assert np.isfinite(a1t[:, :, :B]).all()
+    K = np.rint(x.astype(np.float64) / alpha.astype(np.float64))
+    for s_ in range(S):
+        for n in range(N):
+            w = params[s_][n][0]
+            if n == bad:
+                v = (w * alpha[:, None]).astype(np.float32) * np.float32(LT.F16_W_SCALE)
+                with np.errstate(over="ignore"):
+                    h = np.clip(v, -65504, 65504).astype(np.float16).astype(np.float32)
+                    l = np.clip(v - h, -65504, 65504).astype(np.float16).astype(np.float32)
+                assert np.abs(h).max() == 65504 and np.abs(l).max() == 65504          # the case does saturate
+                z = K[s_] @ ((h.astype(np.float64) + l.astype(np.float64)) / LT.F16_W_SCALE) + params[s_][n][1].astype(np.float64)
+            else:
+                z = x[s_].astype(np.float64) @ w.astype(np.float64) + params[s_][n][1].astype(np.float64)
+            rel_close(a1t[s_, n * HID:(n + 1) * HID, :B].T, np.where(z > 0, z, 0.1 * z), 2e-6, "a1 (saturated f16 pieces)")
+    # one SGD step with 1e12-scale targets for the same agent: dz1 saturates, the weights stay finite; the others fit as usual
+    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    y[:, bad] *= np.float32(1e12)
+    nchunk = (B + 255) // 256
+    L = bk.lib
+    d_y, d_mask = bk.dev(y), bk.dev(np.ones(N, np.int32))
+    d_part = bk.dev(np.zeros((S, N, nchunk, L.rcmarl_fit_partial_size(HID)), np.float32))
+    L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], S, N, B,
+                             in_dim, HID, ldp, ldb, bk.stream)
+    L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_mask), None, S, N, B, in_dim, HID, ldp, lr, bk.stream)
+    L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], bk.ptr(d_al),
+                                         bk.ptr(d_th), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr, bk.ptr(lb.wp), g.wp[0],
+                                         g.wp[1], bk.stream)
+    th = bk.host(d_th)
+    assert np.isfinite(th[:, :, :in_dim * HID]).all()                                     # layer 1 of every agent, the blown-up one included
+    for s_ in range(S):
+        for n in range(N):
+            if n == bad:
+                continue
+            pw = M.copy_params(params[s_][n])
+            M.fit_mse(pw, x[s_], y[s_, n, :B, None], lr, epochs=1)
+            got = unpack_row(th[s_, n], in_dim, 1)
+            for k in range(6):
+                rel_close(got[k], pw[k], 1e-5, "fit param %d beside a saturated agent" % k)
 
 
 def check_lattice_forward_i8(bk, S, N, B, width, nrow, ncol):
@@ -841,13 +930,14 @@ def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamm
                                              bk.ptr(d_al), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
                                              bk.ptr(lb.wp), g.wp[0], g.wp[1], bk.stream)
         if st == steps - 1:                                   # fused pieces == what a fresh split of the result gives
+            npc = 2 if bk.lib.rcmarl_lattice_f16_mode() & 1 else 3
             fused = bk.host(lb.wp).copy()
             L.rcmarl_w1_split(bk.ptr(d_msg), bk.ptr(d_al), bk.ptr(lb.wp), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], bk.stream)
-            fresh = bk.host(lb.wp).reshape(S, -1)
-            fused = fused.reshape(S, -1)
+            fresh = seed_views(bk.host(lb.wp), S, g.wp, npc)
+            fused = seed_views(fused, S, g.wp, npc)
             for s_ in range(S):
-                for pc in range(3):
-                    idx = LT.pk_element_index(N * HID, in_dim, g.wp[1], 3, pc)
+                for pc in range(npc):
+                    idx = LT.pk_element_index(N * HID, in_dim, g.wp[1], npc, pc)
                     np.testing.assert_array_equal(fused[s_][idx], fresh[s_][idx])
     assert bk.host(lb.flag)[0] == 0 and bk.host(lbn.flag)[0] == 0
     msg, y, loss = bk.host(d_msg), bk.host(d_y), bk.host(d_loss)

@@ -177,6 +177,31 @@ def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
     KC.check_lattice_forward(bk, 1, 64, 1000, 2, 16, 16)
 
 
+ENC_CASE, FWD_CASE, FIT_CASE, FIT_STEPS = (1, 64, 700, 3, 16, 16, True), (2, 64, 1000, 2, 16, 16), (2, 20, 777, 3, 7, 9, 4), 5
+@pytest.mark.parametrize("mode", ["0", "1", "3"])
+def test_lattice_operand_forms(bk, mode, monkeypatch):
+    """RCMARL_LAT_F16: 0 = three exact bf16 pieces everywhere, 1 = the forward operand as two f16 pieces of 2^10 alpha W1,
+    3 (default) = the backward operand (2^8 dz1) too -- encode images, piece reconstruction, forward vs float64, whole SGD fits vs
+    the oracle, in every form."""
+    monkeypatch.setenv("RCMARL_LAT_F16", mode)
+    assert bk.lib.rcmarl_lattice_f16_mode() == int(mode)
+    KC.check_lattice_encode(bk, *ENC_CASE)
+    KC.check_lattice_forward(bk, *FWD_CASE)
+    KC.check_lattice_sgd_fit(bk, *FIT_CASE[:-1], steps=FIT_STEPS, masked_agent=FIT_CASE[-1])
+
+
+def test_lattice_f16_pieces_saturate_instead_of_overflowing(bk, monkeypatch):
+    monkeypatch.setenv("RCMARL_LAT_F16", "3")
+    KC.check_lattice_f16_saturation(bk)
+
+
+def test_lattice_f16_pieces_in_the_subnormal_range(bk, monkeypatch):
+    """Weights of 1e-6: every f16 piece of 2^10 alpha W1 is a subnormal (multiples of 2^-24).  The matrix core must not flush
+    them (the result would be zero); what is lost is the form's stated absolute floor (2^-25 of the scaled unit)."""
+    monkeypatch.setenv("RCMARL_LAT_F16", "3")
+    KC.check_lattice_forward(bk, *FWD_CASE, w_scale=1e-6, tol=2e-3)
+
+
 @pytest.mark.parametrize("d,H", [(4, 1), (6, 2), (10, 4), (18, 8), (5, 1), (9, 3)])
 def test_consensus_params_bits_on_awkward_data(bk, d, H):
     """K1 (both kernels on circulant graphs) against a plain NumPy statement of its arithmetic, BIT FOR BIT, on columns of
@@ -201,6 +226,7 @@ def test_mid_fit_bf16_matrix_core_form_sgd_fit(bk, S, N, B, in_dim, masked, monk
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (1, 64, 1000, 3, 16, 16, 5), (1, 20, 777, 2, 7, 9, 3)])
 def test_mid_fit_bf16_matrix_core_form_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
     monkeypatch.setenv("RCMARL_MIDFIT", "7")
+    monkeypatch.setenv("RCMARL_LAT_F16", "1")            # v7 emits the three-piece bf16 operand only
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
 
 
