@@ -323,8 +323,11 @@ def extra_workloads(main_name, tlib, barrier, dev):
             eng = make_engine(w, S, [1000 + k for k in range(S)], tlib)
             t_setup = time.perf_counter() - t_setup
             steps = 2
-            dt, _ = time_blocks(eng, steps, 1, barrier, S, dev, tlib, want_kernels=True)
-            ksum = tlib.summary()
+            # single instances are launch-bound: timed WITHOUT the per-launch events, so the engine's captured epochs
+            # (hipGraph, engine._epoch) run as they do for a user of the drop-in path
+            single = name.endswith("_single")
+            dt, _ = time_blocks(eng, steps, 1, barrier, S, dev, tlib, want_kernels=not single)
+            ksum = {} if single else tlib.summary()
             finite = all(bool(torch.isfinite(eng.theta[k]).all().item()) for k in ("actor", "critic", "tr"))
             c = eng.cfg
             env_steps = c.n_ep_fixed * c.max_ep_len
@@ -332,6 +335,8 @@ def extra_workloads(main_name, tlib, barrier, dev):
                    "agent_steps_per_s": S * w["N"] * env_steps * steps / dt,
                    "consensus_updates_per_s": S * eng.n_coop * c.n_epochs * steps / dt,
                    "weights_finite": finite, "fast_lr": c.fast_lr, "setup_s": round(t_setup, 2)}
+            if single:
+                rec["epochs_replayed_from_hipgraph"] = eng.graph_replays
             if ksum:
                 tot_ms = sum(v[1] for v in ksum.values())
                 top = sorted(ksum.items(), key=lambda kv: -kv[1][1])[:4]
@@ -499,8 +504,8 @@ BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 BF16_SUSTAINED_TFLOPS = 1780.0  # measured on this pool: pure v_mfma_f32_32x32x16_bf16 loops on all SIMDs with operands that
 #                                 change every instruction (tools/micro/mfma_peak.hip; 2100 with constant operands)
 
-# kernel -> (bound, note).  "mfma_bf16x3": fp32-equivalent flops 2MNK against the bf16 dense peak; the kernel
-# EXECUTES 3x those flops (three exact bf16 passes per fp32 product), so its ceiling is peak/3.
+# kernel -> (bound, note).  "mfma_pieces": fp32-equivalent flops 2MNK against the 16-bit dense peak (f16 = bf16 rate); the kernel
+# EXECUTES as many times those flops as the fp32 operand has 16-bit pieces (2 f16, or 3 bf16), so its ceiling is peak / pieces.
 ROOFLINE_KIND = {
     "rcmarl_consensus_params": ("hbm", "algorithmic bytes 8*P_hid per (seed, cooperative agent) (SURVEY 8d). HBM-bound for "
                                 "small d (d=4: ~54% of 8 TB/s); at d=18 the 128-op min/max selection network makes it "
@@ -510,8 +515,8 @@ ROOFLINE_KIND = {
                                           "agent at (18,8) instead of 128) + 18 clamps + 9 packed adds + a 3-instruction "
                                           "division: VALU-bound at d=18 (343 instructions per 4 agents, VALU busy 77 % of the "
                                           "kernel: profiles/r02h_sq_counters_k1_circ_d18.json), toward HBM at d=4"),
-    "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20x3 bf16 "
-                               "dz1 pieces written = 200 B; k_mid_fit_v5: layer 2 (4x4x1 sixteen-block MFMAs, results born row-per-lane) and the "
+    "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20 x 2 f16 "
+                               "dz1 pieces written = 160 B (RCMARL_LAT_F16=0: 20 x 3 bf16 pieces, 200 B); k_mid_fit_v5: layer 2 (4x4x1 sixteen-block MFMAs, results born row-per-lane) and the "
                                "row reductions (32x32x2) as f32-input MFMAs.  Those execute ON the vector ALUs (measured in shader "
                                "cycles: profiles/r03_pipe_overlap_cycles.txt), so the kernel's time is the SUM of its 232 f32 MFMAs, "
                                "~500 VALU and ~190 LDS instructions per 64 rows, not its HBM traffic; the bf16 matrix-core form "
@@ -520,9 +525,9 @@ ROOFLINE_KIND = {
                              "network, one wavefront per network (6 us per step): bound by the latency of one step, not by a pipe; "
                              "flops = 6 per weight per row"),
     "rcmarl_mid_fit": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 read + 20 fp32 written"),
-    "rcmarl_w1_split": ("hbm", "reads W1 (4 B/weight), writes three bf16 pieces (6 B/weight)"),
-    "rcmarl_layer1_forward_lattice": ("mfma_bf16x3", ""),
-    "rcmarl_layer1_backward_sgd_lattice": ("mfma_bf16x3", ""),
+    "rcmarl_w1_split": ("hbm", "reads W1 (4 B/weight), writes two f16 pieces (4 B/weight; three bf16 pieces with RCMARL_LAT_F16=0)"),
+    "rcmarl_layer1_forward_lattice": ("mfma_pieces", ""),
+    "rcmarl_layer1_backward_sgd_lattice": ("mfma_pieces", ""),
 }
 
 
@@ -561,24 +566,25 @@ def rooflines(tlib, ksum, workload=None):
             out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                    "algorithmic_bytes_per_launch": byts / n, "note": note}
-            if name == "rcmarl_mid_fit_lattice":
-                # the 200 B per row count this build's own dz1 representation (3 bf16 pieces = 120 B); with a plain fp32
-                # dz1 (80 B) the same launch moves 160 B per row
-                out["frac_fp32_io"] = out["frac"] * 160.0 / 200.0
             return out
         ach = flops / (tot_ms * 1e-3) / 1e12
-        if kind == "mfma_bf16x3":
+        if kind == "mfma_pieces":
+            from rcmarl_amd.timing import lattice_pieces
+            npc = lattice_pieces(1 if "forward" in name else 2)            # matrix passes = 16-bit pieces of the fp32 operand
+            form = "two f16 pieces of the scaled fp32 operand (the value to one unit in its last place; RCMARL_LAT_F16)" if npc == 2 \
+                else "three exact bf16 pieces of the fp32 operand"
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                     "algorithmic_flops_per_launch": flops / n,
-                    "executed": {"achieved": 3 * ach, "frac": 3 * ach / BF16_PEAK_TFLOPS,
-                                 "frac_of_measured_sustained_peak": 3 * ach / BF16_SUSTAINED_TFLOPS,
-                                 "what": "bf16 MFMA flops actually issued = 3 x algorithmic; sustained peak = %.0f TFLOP/s "
-                                         "measured with tools/micro/mfma_peak.hip" % BF16_SUSTAINED_TFLOPS},
-                    "note": "exact fp32 GEMM as three bf16 passes (integer-lattice operand x bf16 pieces of the fp32 "
-                            "operand, v_mfma_f32_32x32x16_bf16, fp32 accumulate): achieved = fp32-equivalent 2MNK flops; "
-                            "ceiling of the method = bf16 dense peak / 3 = 833 TFLOP/s; the f32-input MFMA it replaces "
-                            "peaks at 157.3"}
+                    "executed": {"achieved": npc * ach, "frac": npc * ach / BF16_PEAK_TFLOPS,
+                                 "frac_of_measured_sustained_peak": npc * ach / BF16_SUSTAINED_TFLOPS,
+                                 "what": "16-bit MFMA flops actually issued = %d x algorithmic; sustained peak = %.0f TFLOP/s "
+                                         "measured with tools/micro/mfma_peak.hip (f16 and bf16 MFMA issue at the same rate)"
+                                         % (npc, BF16_SUSTAINED_TFLOPS)},
+                    "note": "fp32 GEMM as %d passes of v_mfma_f32_32x32x16_%s (integer-lattice operand x %s, fp32 accumulate): "
+                            "achieved = fp32-equivalent 2MNK flops; ceiling of the method = 16-bit dense peak / %d = %.0f TFLOP/s; "
+                            "the f32-input MFMA it replaces peaks at 157.3"
+                            % (npc, "f16" if npc == 2 else "bf16", form, npc, BF16_PEAK_TFLOPS / npc)}
         return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                 "algorithmic_flops_per_launch": flops / n,

@@ -339,12 +339,19 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
   lat_decode(blockIdx.x, mtiles * ntiles, S, s, w);
+#ifdef RC_LAT_STAGGER
+  if (blockIdx.x >= 256 && blockIdx.x < 512) for (int i = 0; i < RC_LAT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int bn = w % ntiles, bm = w / ntiles;                       // n fastest
   LatOperands op;
   op.a = wp + (long)s * wp_rt * wp_kt * (PA * RC_PK_BLOCK); op.a_kt = wp_kt; op.art0 = bm * C::ART;
   op.b = kp + (long)s * kp_rt * kp_kt * (PB * RC_PK_BLOCK); op.b_kt = kp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
+#if defined(RC_LAT_KNOCK) && RC_LAT_KNOCK == 2              // measurement builds only (tools/build_variant.py): no k-loop
+  lat_mainloop<PA, PB, MT, NT, WM, WN, false, F16>(op, ldb == 12345 ? 1 : 0, lds, acc);
+#else
   lat_mainloop<PA, PB, MT, NT, WM, WN, false, F16>(op, (in_dim + 31) >> 5, lds, acc);
+#endif
   // epilogue: a1t[col][b] = lrelu(z + b1[col])
   const int ncols = N * hid;
   const float* theta_s = theta + (long)s * N * ldp;
@@ -377,7 +384,11 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int n = bn * C::BN + wn * 32 * NT + 32 * nt + (lane & 31);
+#if defined(RC_LAT_KNOCK) && RC_LAT_KNOCK == 1              // measurement builds only: no stores
+      if (n < B && ldb == 12345) {
+#else
       if (n < B) {
+#endif
         // byte offset of the lane inside its row block: 32 bits (one seed's a1t is < 4 GiB) -> saddr + voffset stores
         const unsigned lane_byte = ((unsigned)(4 * half) * (unsigned)ldb + (unsigned)n) * 4u;
 #pragma unroll
@@ -414,12 +425,19 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   RCMARL_DYN_SMEM(unsigned char, lds);
   int s, w;
   lat_decode(blockIdx.x, mtiles * ntiles, S, s, w);
+#ifdef RC_LAT_STAGGER
+  if (blockIdx.x >= 256 && blockIdx.x < 512) for (int i = 0; i < RC_LAT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   const int bm = w % mtiles, bn = w / mtiles;                      // m fastest: neighbours share the dz panel
   LatOperands op;
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
+#if defined(RC_LAT_KNOCK) && RC_LAT_KNOCK == 2
+  lat_mainloop<PA, PB, MT, NT, WM, WN, !W8, DZ16>(op, ldp == 12345 ? 1 : 0, lds, acc);
+#else
   lat_mainloop<PA, PB, MT, NT, WM, WN, !W8, DZ16>(op, (B + 31) >> 5, lds, acc);
+#endif
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
@@ -443,7 +461,11 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   for (int nt = 0; nt < NT; ++nt) {
     const int cl = wn * 32 * NT + 32 * nt + (lane & 31);                 // column within the 128-wide tile
     const int col = bn * C::BN + cl;
+#if defined(RC_LAT_KNOCK) && RC_LAT_KNOCK == 1
+    if (col < ncols && ldp == 12345) {
+#else
     if (col < ncols) {
+#endif
       const int ag = col / hid, j = col - ag * hid;
       const bool upd = mask == nullptr || mask[ag];
       // the lane's first row: k = bm*BM + wm*32*MT + 4*half; rows of (mt, gq, e) follow at uniform distances

@@ -132,6 +132,7 @@ class RPBCACEngine:
         self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_t = 0
         self.a1_cached = {"critic": False, "tr": False}
+        self._graphs, self.graph_captures, self.graph_replays = {}, 0, 0       # captured update epochs (see _epoch)
         self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
         self.rp, self.ybuf = None, {k: None for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
         self._alloc_row_buffers(c.buffer_size + self.n_last)
@@ -216,6 +217,7 @@ class RPBCACEngine:
                 self.rp[k][:, :old_B] = old_rp[k][:, :old_B]
         self._init_lattice()
         self._term_rows = {}                  # (row0, nrows) -> device indices of the last row of every episode
+        self._graphs = {}                     # captured epochs point into the buffers replaced here
         if hasattr(self, "adv"):
             self.adv.a1t = torch.zeros_like(self.a1t)
 
@@ -1035,6 +1037,70 @@ class RPBCACEngine:
 
     profile_phases = False
     reuse_activations = True
+
+    def _epoch_body(self, B, t0):
+        """One update epoch: I) local fits of the TR and critic messages, II) resilient consensus."""
+        # I) local fits of TR and critic on a copy (= the transmitted message); live nets untouched
+        if self.shard is not None and not self.shard.shard_tr:
+            self.msg["tr"].copy_(self.theta["tr"])
+        with self._agent_window():
+            if self.shard is None or self.shard.shard_tr:
+                self.msg["tr"].copy_(self.theta["tr"])
+            self.msg["critic"].copy_(self.theta["critic"])
+        # TD target first (it depends on the live critic only), so the adversaries' message generators --
+        # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
+        # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
+        self._td_target(B)
+        join = self._adversary_messages_async(B)
+        self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+        self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+        if join is not None:
+            torch.cuda.current_stream(self.dev).wait_event(join)
+        t0 = self._timed("phase1", t0)
+        # II) resilient consensus (cooperative agents)
+        self._consensus("critic", "s", B)
+        self._consensus("tr", "sa", B)
+        return self._timed("phase2", t0)
+
+    # ---- one epoch as a hipGraph (single instances: an epoch is ~60 launches of a few microseconds each) --------------------
+    # From the second epoch of a block on, every epoch issues the SAME launches with the same arguments (the first differs:
+    # no cached activations yet), and its Python-side state (a1_cached) ends where it began.  That sequence is captured once per
+    # (B, path flags) on torch's capture stream -- the library launches on torch's current stream and calls nothing that a
+    # capture forbids (no allocation, no synchronisation) -- and replayed for the remaining epochs and the following blocks.
+    # RCMARL_GRAPH=1 / 0 forces it on / off; default: on for small instances (S * N <= 256 agent-networks per launch), where
+    # the launches, not the kernels, set the block time.  Never with adversaries that fit mini-batches (side stream, host
+    # permutations), an agent-sharded instance (collectives), a wide critic, phase profiling or a timing wrapper around the library.
+    def _graph_wanted(self):
+        e = os.environ.get("RCMARL_GRAPH")
+        if e is not None:
+            want = e not in ("0", "false")
+        else:
+            want = self.S * self.N <= 256
+        if not want or self.dev.type != "cuda" or self.shard is not None or self.wide or self.profile_phases:
+            return False
+        if hasattr(self, "adv"):                                   # Greedy / Malicious agents present
+            return False
+        return not getattr(self.lib, "enabled", False)            # bench.py's per-kernel timing wrapper records events per launch
+
+    def _epoch(self, B, epoch, t0):
+        if epoch == 0 or not self._graph_wanted() or not (self.a1_cached["critic"] and self.a1_cached["tr"]):
+            return self._epoch_body(B, t0)
+        key = (B, self.lat_active, bool(self.td_shortcut), bool(self.rows_episode_aligned), bool(self.k1_circulant),
+               bool(self.reuse_activations), self.cap, os.environ.get("RCMARL_LAT_F16"), os.environ.get("RCMARL_LAT_W8"),
+               os.environ.get("RCMARL_MIDFIT"))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 8:                             # growing replay buffer: B changes every block until steady state
+                self._graphs.pop(next(iter(self._graphs)))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._epoch_body(B, t0)
+            self._graphs[key] = g
+            self.graph_captures += 1
+        g.replay()
+        self.graph_replays += 1
+        return t0
+
     def update_block(self):
         c, L, S, N, B = self.cfg, self.lib, self.S, self.N, self.B
         assert B >= self.n_last
@@ -1054,27 +1120,7 @@ class RPBCACEngine:
         L.rcmarl_gather_agent_major(rptr, rstride, self.rcoop.data_ptr(), self.fit_mode.data_ptr(),
                                     self.ybuf["r_fit"].data_ptr(), S, N, B, self.ldb, self.stream)
         for epoch in range(c.n_epochs):
-            # I) local fits of TR and critic on a copy (= the transmitted message); live nets untouched
-            if self.shard is not None and not self.shard.shard_tr:
-                self.msg["tr"].copy_(self.theta["tr"])
-            with self._agent_window():
-                if self.shard is None or self.shard.shard_tr:
-                    self.msg["tr"].copy_(self.theta["tr"])
-                self.msg["critic"].copy_(self.theta["critic"])
-            # TD target first (it depends on the live critic only), so the adversaries' message generators --
-            # one latency-bound workgroup per (seed, adversary) -- can run on a side stream UNDER the cooperative
-            # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
-            self._td_target(B)
-            join = self._adversary_messages_async(B)
-            self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
-            self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
-            if join is not None:
-                torch.cuda.current_stream(self.dev).wait_event(join)
-            t0 = self._timed("phase1", t0)
-            # II) resilient consensus (cooperative agents)
-            self._consensus("critic", "s", B)
-            self._consensus("tr", "sa", B)
-            t0 = self._timed("phase2", t0)
+            t0 = self._epoch(B, epoch, t0)
         # III) actor update on the last n_ep_fixed episodes
         self._actor_update(B)
         self._adversary_actor_updates(B)

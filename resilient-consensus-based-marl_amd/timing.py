@@ -15,6 +15,13 @@ def _gemm_flops(a, first):          # (..., S, N, B, in_dim, hid, ...) starting 
     return 2.0 * S * N * hid * B * in_dim, 0.0
 
 
+def lattice_pieces(bit):
+    """16-bit pieces per value of the forward (bit 1) / backward (bit 2) lattice operand under the library's current operand form
+    (RCMARL_LAT_F16, csrc/rcmarl_lattice.h: default 3 = two f16 pieces for both)."""
+    import os
+    return 2 if int(os.environ.get("RCMARL_LAT_F16", "3")) & bit else 3
+
+
 # algorithmic work per launch: name -> f(args) -> (flops, bytes)   (DESIGN.md "Kernels")
 WORK = {
     "rcmarl_layer1_forward": lambda a: _gemm_flops(a, 4),
@@ -26,14 +33,14 @@ WORK = {
     "rcmarl_consensus_params_circulant": lambda a: (0.0, 8.0 * a[3] * a[4] * a[6]),
     # a1t, theta, y, partials, S, N, B, in_dim, hid: layers 2-3 fwd+bwd ~ (8 h^2 + 12 h) flops per (row, agent)
     "rcmarl_mid_fit": lambda a: (a[4] * a[5] * a[6] * (8.0 * a[8] ** 2 + 12.0 * a[8]), 8.0 * a[4] * a[5] * a[6] * a[8]),
-    # lattice path: fp32-EQUIVALENT flops 2*M*N*K (the kernel executes 3x that on the bf16 matrix core)
+    # lattice path: fp32-EQUIVALENT flops 2*M*N*K (the kernel executes 2x that on the f16 matrix core, 3x in the bf16 form)
     "rcmarl_layer1_forward_lattice": lambda a: _gemm_flops(a, 8),
     "rcmarl_layer1_backward_sgd_lattice": lambda a: _gemm_flops(a, 9),
-    # a1t, theta, y, partials, dzp, rt, kt, S, N, B, in_dim, hid: reads a1 (4 B), writes 3 bf16 pieces of dz1 (6 B)
+    # a1t, theta, y, partials, dzp, rt, kt, S, N, B, in_dim, hid: reads a1 (4 B), writes the 16-bit pieces of dz1 (2 x 2 B, or 3 x 2 B)
     "rcmarl_mid_fit_lattice": lambda a: (a[7] * a[8] * a[9] * (8.0 * a[11] ** 2 + 12.0 * a[11]),
-                                         10.0 * a[7] * a[8] * a[9] * a[11]),
-    # theta, alpha, wp, S, N, in_dim, hid: reads W1 (4 B), writes 3 pieces (6 B)
-    "rcmarl_w1_split": lambda a: (0.0, 10.0 * a[3] * a[4] * a[5] * a[6]),
+                                         (4.0 + 2.0 * lattice_pieces(2)) * a[7] * a[8] * a[9] * a[11]),
+    # theta, alpha, wp, S, N, in_dim, hid: reads W1 (4 B), writes its pieces (2 x 2 B, or 3 x 2 B)
+    "rcmarl_w1_split": lambda a: (0.0, (4.0 + 2.0 * lattice_pieces(1)) * a[3] * a[4] * a[5] * a[6]),
     # x, x_seed_stride, theta, agents, n_adv, y, perm, S, N, B, in_dim, hid, ..., batch_size, epochs: whole Keras fit() of
     # n_adv networks per seed: epochs x B rows x (forward + backward ~ 6 flops per weight)
     "rcmarl_minibatch_fit": lambda a: (6.0 * a[7] * a[4] * a[15] * a[9] * (a[10] * a[11] + a[11] * a[11] + a[11]), 0.0),

@@ -116,6 +116,38 @@ def test_engine_run_to_run_bit_identical(labels):
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
 
 
+@pytest.mark.parametrize("n,S,nrow", [(5, 1, 5), (20, 2, 8), (64, 1, 16)])
+def test_engine_epochs_replayed_from_a_hipgraph_are_bit_identical(n, S, nrow, monkeypatch):
+    """RCMARL_GRAPH: from the second epoch of a block on, an epoch is one captured hipGraph (engine._epoch) -- same launches, same
+    arguments, replayed; growing replay buffer (a capture per B) into steady state (the same graph across blocks).  Bits equal
+    the eager run's; the default (on for small instances) actually replays."""
+    import numpy as np
+    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+    in_nodes = EC.CIRC5 if n == 5 else [[(i + k) % n for k in range(4)] for i in range(n)]
+    res = {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("RCMARL_GRAPH", raising=False)
+        else:
+            monkeypatch.setenv("RCMARL_GRAPH", mode)
+        cfg = EngineConfig(n, ["Cooperative"] * n, in_nodes, H=1, n_seeds=S, rng_mode="device", max_ep_len=20, n_ep_fixed=10,
+                           n_epochs=4, buffer_size=400, nrow=nrow, ncol=nrow)
+        eng = RPBCACEngine(cfg, seeds=list(range(100, 100 + S)))
+        eng.init_glorot(base_seed=1)
+        eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(n, 2)) for s in range(S)]))
+        logs = eng.train(50)                       # 5 blocks: B = 200, 400, 600, 600, 600
+        res[mode] = (logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}, eng.graph_captures, eng.graph_replays)
+    assert res["0"][2:] == (0, 0)
+    assert res["1"][2] == 3 and res["1"][3] == 5 * 3, res["1"][2:]          # one capture per distinct B, three replays per block
+    assert res[None][3] == 5 * 3                                              # S * N <= 256: on by default
+    for mode in ("1", None):
+        for k in res["0"][0]:
+            np.testing.assert_array_equal(res["0"][0][k], res[mode][0][k])
+        for k in res["0"][1]:
+            assert np.isfinite(res["0"][1][k]).all()
+            np.testing.assert_array_equal(res["0"][1][k], res[mode][1][k])
+
+
 @pytest.mark.parametrize("n,critic_hid,H,d,rng_mode,lattice", [(5, 64, 1, 4, "device", False), (12, 512, 2, 6, "device", False),
                                                                (5, 128, 0, 4, "numpy", False), (12, 512, 2, 6, "device", True),
                                                                (20, 96, 1, 5, "device", "auto")])

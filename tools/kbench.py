@@ -265,6 +265,51 @@ def mid_ab(L, S=16, N=256, B=3000):
             print("   %-16s dz image identical to product: %s   records max rel diff %.2e" % (name, bool(torch.equal(dz, ref[0])), rel))
 
 
+def lattice_ab(L, S=16, N=256, B=3000):
+    """A/B of the two lattice GEMMs: the product library against the variant builds named in RCMARL_KBENCH_LIB_B (comma-separated
+    paths; tools/build_variant.py), interleaved, on operands produced once by the product library."""
+    from rcmarl_amd import lattice as LT
+    libs = [("product", L)]
+    for pth in [x for x in os.environ.get("RCMARL_KBENCH_LIB_B", "").split(",") if x]:
+        libs.append((os.path.basename(pth).replace("lib", "").replace(".so", ""), capi.CLib(pth)))
+    st = torch.cuda.current_stream().cuda_stream
+    for width in (2, 3):
+        in_dim = width * N
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        g = LT.Geometry(N, in_dim, B)
+        std = float(np.std(np.arange(32)))
+        x = ((torch.randint(0, 32, (S, B, in_dim), device="cuda").float() - 15.5) / std).contiguous()
+        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
+        theta = torch.randn(S, N, ldp, device="cuda") * 0.05
+        a1t = torch.zeros(S, N * HID, ldb, device="cuda")
+        y = torch.randn(S, N, ldb, device="cuda")
+        mask = torch.ones(N, dtype=torch.int32, device="cuda")
+        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
+        kp, ktp, wp, dzp = u8(g.kp, 1), u8(g.ktp, 1), u8(g.wp, 3), u8(g.dzp, 3)
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        part = torch.zeros(S * N * ((B + 255) // 256) * L.rcmarl_fit_partial_size(HID), device="cuda")
+        L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0], g.kp[1], ktp.data_ptr(),
+                                g.ktp[0], g.ktp[1], flag.data_ptr(), st)
+        L.rcmarl_w1_split(theta.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], st)
+        L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], theta.data_ptr(), a1t.data_ptr(),
+                                        S, N, B, in_dim, HID, ldp, ldb, st)
+        L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B,
+                                 in_dim, HID, ldp, ldb, st)
+        ref = None
+        for rnd in range(3):
+            for name, lib in libs:
+                tf = timeit(lambda: lib.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1],
+                                                                      theta.data_ptr(), a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st), iters=20)
+                same = True if ref is None else bool(torch.equal(a1t, ref))
+                if ref is None:
+                    ref = a1t.clone()
+                tb = timeit(lambda: lib.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0], g.dzp[1],
+                                                                           alpha.data_ptr(), theta.data_ptr(), mask.data_ptr(), S, N, B, in_dim,
+                                                                           HID, ldp, 0.0, wp.data_ptr(), g.wp[0], g.wp[1], st), iters=20)
+                print("in=%d round %d  %-16s fwd %8.1f us   bwd %8.1f us   a1 identical: %s" % (in_dim, rnd, name, tf, tb, same))
+
+
 def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
     """the dense-GEMM path at the cfg-5 shape (1024 agents x 512-wide critic, here a 64-agent slice)"""
     st = torch.cuda.current_stream().cuda_stream
@@ -312,4 +357,4 @@ if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "mid_ab": mid_ab, "i8": i8, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "i8": i8, "minibatch": minibatch, "wide": wide}[what](L)
