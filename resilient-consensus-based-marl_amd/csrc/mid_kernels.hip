@@ -107,8 +107,11 @@ template <int HID, bool EMIT, bool DZ16 = false>
 __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restrict__ a1t, const float* __restrict__ theta,
                                                        const float* __restrict__ y, float* __restrict__ partials, int N,
                                                        int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
-                                                       unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
+                                                       unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
+                                                       const int* __restrict__ fix_flags, int fix_gen) {
   static_assert(HID == 20, "panel layout of the reduction product is written for 20 units");
+  // fix-up launch behind k_mid_fit_v8 (rcmarl_mid_fit_lattice): only the agents whose operands left the f16 range there
+  if (fix_flags != nullptr && fix_flags[blockIdx.z * N + blockIdx.y] != fix_gen) return;
   typedef FitPart<HID> PT;
 // (rows per pass of the reduction product: 32; 16 halves the panels -- 22.7 instead of 39 KiB of LDS per workgroup --
 // and measured slower, 877 / 1071 against 857 / 985 us: occupancy is not limited by the LDS here)
@@ -332,13 +335,18 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_mid_fit, bf16 matrix-core form ("v7", round 3).  Why: v_mfma_f32_* (every product of v5) executes on the vector ALUs --
-// measured in shader cycles, its time ADDS to the VALU's (profiles/r03_pipe_overlap_cycles.txt) -- while the bf16 matrix
-// core is a separate pipe that VALU work hides behind and is 16x faster per flop.  Here all three products of the step run
-// as v_mfma_f32_32x32x16_bf16 on bf16 PIECES of their fp32 operands: x = h + m + l exactly (rcmarl_lattice.h), and a
-// product x*y is taken as hh + hm + mh + hl + lh + mm (six exact bf16 x bf16 products, fp32 accumulate, smallest first):
-// the dropped terms ml, lm, ll are <= 2^-23 of the product, the class of one fp32 rounding.  Results therefore differ
-// from v5's fmaf chains in the last bits (same bars vs the oracle: tests), NOT bit-identical to v5.
+// k_mid_fit, f16 matrix-core form ("v8", round 3) -- the default behind rcmarl_mid_fit_lattice when the backward operand is
+// carried as f16 pieces (RCMARL_LAT_F16 bit 1).
+// Why: v_mfma_f32_* (every product of v5) executes on the vector ALUs -- measured in shader cycles, its time ADDS to the VALU's
+// (profiles/r03_pipe_overlap_cycles.txt) -- while the 16-bit matrix core is a separate pipe that VALU work hides behind and is 16x
+// faster per flop.  Here all three products of the step run as v_mfma_f32_32x32x16_f16 on TWO f16 pieces of their (scaled) fp32
+// operands (rcmarl_lattice.h: x = h + l to one unit in the last place of x): a product x*y is hh + hl + lh + ll, four exact
+// f16 x f16 products, fp32 accumulate, smallest first; a split costs 5 VALU per value pair.  Scales: W2'' = 2^10 W2,
+// dz2'' = 2^10 dz2, a1 unscaled; the results are multiplied back (exact).  Results differ from v5's fmaf chains in the last bits
+// (same bars vs the oracle: tests), NOT bit-identical to v5.
+// Range: an agent whose a1, 2^10 dz2 or 2^10 W2 leaves the f16 range (a fit that blew up: clipped operands would feed the blow-up
+// instead of letting fp32 arithmetic saturate it -- measured, profiles/r03r_*) is FLAGGED (ovf_flags[seed][agent] = the call's
+// generation number) and recomputed by k_mid_fit_v5 in a second launch that exits at once for every other agent.
 //
 // Layout.  A wavefront owns 64 replay rows as two blocks of 32.  In a block, lane (j = lane&31, h = lane>>5) works for row
 // j and holds TEN of its 20 units: U_0 = {0..7, 16, 17}, U_1 = {8..15, 18, 19} (local index u = 0..9).  That is exactly the
@@ -348,81 +356,75 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
 // local unit r of row j (r < 10).  So a1 -> z2 -> a2 -> dz2 -> da1 -> dz1 never leave their lanes: no swaps, no LDS.
 //   z2[row][unit]  = sum_m a1[row][m] W2[m][unit]      A = W2^T (permuted rows/slots), B = a1 pieces
 //   da1[row][m]    = sum_j dz2[row][j] W2[m][j]        A = W2   (permuted),            B = dz2 pieces
-// The row REDUCTION gW2 = a1^T dz2 (+ gb2 as its ones row) contracts over ROWS, i.e. over the lane axis: the bf16 pieces the
-// layer products already made are written row-major into per-wavefront LDS planes ([piece][row][unit], one 16-byte + one
-// 4-byte store per piece) and read back TRANSPOSED with ds_read_b64_tr_b16 (a lane = one unit, eight consecutive rows =
-// one MFMA operand): no second split.  The plain row sums (gb1, gW3, gb3, loss: 22 values) are fused-DPP half-wave sums.
-// First form of this kernel (fp32 panels, re-split after the transposed read, g3 inside the product): 1300 VALU per 64 rows,
-// 900 us against v5's 790 (profiles/r03c_*): a 3-piece split costs 9 VALU per value pair and there were 31 pairs per block.
-// This form: 1040 VALU + 200 LDS instructions per 64 rows, matrix pipe 23 % busy, 827 us at two wavefronts per SIMD (975 at
-// three: the wavefronts WAIT 68 % of their cycles -- dependent MFMA chains, LDS round trips, DPP sums --, profiles/r03d_*)
-// against 797 us for v5: the bf16 matrix core removes the 5 k cycles of f32 MFMA from the vector ALUs, and the splits,
-// plane traffic and waits put them back.  Kept as the alternative (RCMARL_MIDFIT=7), not the default.
-__device__ __forceinline__ int v7_unit(int h, int u) { return u < 8 ? u + 8 * h : 16 + 2 * h + (u - 8); }
+// The row REDUCTION gW2 = a1^T dz2 (+ gb2 as its ones row) contracts over ROWS, i.e. over the lane axis: the pieces the layer
+// products already made are written row-major into per-wavefront LDS planes ([piece][row][unit], one 16-byte + one 4-byte
+// store per piece) and read back TRANSPOSED with ds_read_b64_tr_b16 (a lane = one unit, eight consecutive rows = one MFMA
+// operand): no second split.  The plain row sums (gb1, gW3, gb3, loss: 22 values) are fused-DPP half-wave sums.
+// History: the same data flow on three exact bf16 pieces (six products, 9 VALU per split pair; "v7") ran
+// 827 us against v5's 797 at BASELINE configs[3] -- the splits, plane traffic and dependent MFMA chains gave back what the
+// matrix core saved; with two f16 pieces it runs ~600 us against v5's ~715 (profiles/r03n_mid_ab.txt).
+__device__ __forceinline__ int v8_unit(int h, int u) { return u < 8 ? u + 8 * h : 16 + 2 * h + (u - 8); }
 // unit of accumulator / A-operand row i (0..31), or -1 (padding row)
-__device__ __forceinline__ int v7_row_unit(int i) {
+__device__ __forceinline__ int v8_row_unit(int i) {
   const int h = (i >> 2) & 1, q = i >> 3, e = i & 3;
-  if (q < 2) return v7_unit(h, 4 * q + e);
-  return (q == 2 && e < 2) ? v7_unit(h, 8 + e) : -1;
+  if (q < 2) return v8_unit(h, 4 * q + e);
+  return (q == 2 && e < 2) ? v8_unit(h, 8 + e) : -1;
 }
 // unit of contraction slot k (0..31), or -1
-__device__ __forceinline__ int v7_slot_unit(int k) {
-  if (k < 16) return v7_unit(k >> 3, k & 7);
+__device__ __forceinline__ int v8_slot_unit(int k) {
+  if (k < 16) return v8_unit(k >> 3, k & 7);
   const int h = (k - 16) >> 3, u = 8 + ((k - 16) & 7);
-  return u < 10 ? v7_unit(h, u) : -1;
+  return u < 10 ? v8_unit(h, u) : -1;
 }
 
-struct V7Pieces { uint4 h, m, l; };
-// the same for two independent accumulator chains, interleaved: back-to-back MFMAs on ONE accumulator wait for each other
-// (48 instead of 32 cycles per instruction, tools/micro/pipe_overlap_cycles.hip)
-__device__ __forceinline__ void v7_mfma6x2(const V7Pieces& a0, const V7Pieces& b0, rc_f32x16& c0, const V7Pieces& a1,
-                                           const V7Pieces& b1, rc_f32x16& c1) {
-  c0 = rc_mfma_bf16(a0.m, b0.m, c0); c1 = rc_mfma_bf16(a1.m, b1.m, c1);
-  c0 = rc_mfma_bf16(a0.l, b0.h, c0); c1 = rc_mfma_bf16(a1.l, b1.h, c1);
-  c0 = rc_mfma_bf16(a0.h, b0.l, c0); c1 = rc_mfma_bf16(a1.h, b1.l, c1);
-  c0 = rc_mfma_bf16(a0.m, b0.h, c0); c1 = rc_mfma_bf16(a1.m, b1.h, c1);
-  c0 = rc_mfma_bf16(a0.h, b0.m, c0); c1 = rc_mfma_bf16(a1.h, b1.m, c1);
-  c0 = rc_mfma_bf16(a0.h, b0.h, c0); c1 = rc_mfma_bf16(a1.h, b1.h, c1);
-}
-// six exact bf16 products, smallest first
-__device__ __forceinline__ rc_f32x16 v7_mfma6(const V7Pieces& a, const V7Pieces& b, rc_f32x16 c) {
-  c = rc_mfma_bf16(a.m, b.m, c);
-  c = rc_mfma_bf16(a.l, b.h, c);
-  c = rc_mfma_bf16(a.h, b.l, c);
-  c = rc_mfma_bf16(a.m, b.h, c);
-  c = rc_mfma_bf16(a.h, b.m, c);
-  c = rc_mfma_bf16(a.h, b.h, c);
+struct V8Pieces { uint4 h, l; };
+__device__ __forceinline__ rc_f32x16 v8_mfma4(const V8Pieces& a, const V8Pieces& b, rc_f32x16 c) {
+  c = rc_mfma_f16(a.l, b.l, c);
+  c = rc_mfma_f16(a.l, b.h, c);
+  c = rc_mfma_f16(a.h, b.l, c);
+  c = rc_mfma_f16(a.h, b.h, c);
   return c;
 }
-__device__ __forceinline__ V7Pieces v7_split8(const float (&x)[8]) {
-  V7Pieces p;
-  rc_split3_pair(x[0], x[1], p.h.x, p.m.x, p.l.x);
-  rc_split3_pair(x[2], x[3], p.h.y, p.m.y, p.l.y);
-  rc_split3_pair(x[4], x[5], p.h.z, p.m.z, p.l.z);
-  rc_split3_pair(x[6], x[7], p.h.w, p.m.w, p.l.w);
+template <bool SCALED>
+__device__ __forceinline__ V8Pieces v8_split8(const float (&x)[8], float sc) {
+  V8Pieces p;
+  if (SCALED) {
+    rc_split2h_pair(x[0] * sc, x[1] * sc, p.h.x, p.l.x);
+    rc_split2h_pair(x[2] * sc, x[3] * sc, p.h.y, p.l.y);
+    rc_split2h_pair(x[4] * sc, x[5] * sc, p.h.z, p.l.z);
+    rc_split2h_pair(x[6] * sc, x[7] * sc, p.h.w, p.l.w);
+  } else {
+    rc_split2h_pair(x[0], x[1], p.h.x, p.l.x);
+    rc_split2h_pair(x[2], x[3], p.h.y, p.l.y);
+    rc_split2h_pair(x[4], x[5], p.h.z, p.l.z);
+    rc_split2h_pair(x[6], x[7], p.h.w, p.l.w);
+  }
   return p;
 }
-
-#ifndef RC_V7_WAVES
-#define RC_V7_WAVES 2                    // wavefronts per SIMD the register allocation aims at (3: 168 registers, measured 975 us vs 827)
+#ifndef RC_V8_WAVES
+#define RC_V8_WAVES 2                    // wavefronts per SIMD the register allocation aims at
 #endif
+#define RC_V8_S 1024.f                   // scale of W2 and of dz2
+#define RC_V8_US 0.0009765625f
+#define RC_V8_RANGE 65000.f              // a (scaled) operand beyond this would saturate: the agent is flagged and redone by k_mid_fit_v5
 template <int HID, bool EMIT>
-__global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restrict__ a1t, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restrict__ a1t, const float* __restrict__ theta,
                                                     const float* __restrict__ y, float* __restrict__ partials, int N,
                                                     int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
-                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt) {
+                                                    unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
+                                                    int* __restrict__ ovf_flags, int ovf_gen) {
   static_assert(HID == 20, "unit sets and panel layout are written for 20 units");
   typedef FitPart<HID> PT;
   constexpr int LU = 10;                               // units per lane
   constexpr int PC = 24;                               // columns of a plane row (48 bytes): 20 units | 1.0 | 3 spare; a transpose read of
   //                                                      columns 16..31 runs 8 columns into the next row: those only feed elements of G nobody reads
   constexpr int PLANE = 32 * PC;                       // bf16 elements of one piece plane: [32 rows][PC columns]
-  constexpr int PANEL_B = 2 * 3 * PLANE * 2;           // bytes per wavefront: A planes (a1 | 1) then B planes (dz2; later dz transpose, record)
-  __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 3 * 2 * 32];   // [product][k-step][piece][k-group][row i]: 16-byte A fragments
+  constexpr int PANEL_B = 2 * 2 * PLANE * 2;           // bytes per wavefront: A planes (a1 | 1) then B planes (dz2; later dz transpose, record)
+  __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 2 * 2 * 32];   // [product][k-step][piece][k-group][row i]: 16-byte A fragments
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];           // b2 | W3 | b3
   __shared__ __attribute__((aligned(16))) unsigned char sPn[4 * PANEL_B];
-  static_assert(3 * PLANE * 2 >= HID * 3 * 32 * 2, "the dz transpose (HID x 3 pieces x 32 rows of bf16) fits the B planes");
-  static_assert(3 * PLANE * 2 >= (PT::SIZE + 64) * 4, "a staged record (+ one dump word per lane) fits the B planes");
+  static_assert(2 * PLANE * 2 >= HID * 2 * 32 * 2, "the dz transpose (HID x 2 pieces x 32 rows of f16) fits the B planes");
+  static_assert(2 * PLANE * 2 >= (PT::SIZE + 64) * 4, "a staged record (+ one dump word per lane) fits the B planes");
   const int s = blockIdx.z, i = blockIdx.y;
   const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
   const int r = threadIdx.x;
@@ -430,43 +432,43 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
   const NetGeom g = make_geom(in_dim, HID, 1);
   const float* th = theta + ((long)s * N + i) * ldp;
   const long row0 = ((long)s * N + i) * HID;
-  // ---- the agent's W2 as bf16 pieces in A-fragment order, both orientations (once per workgroup)
+  rc_f16_saturate();
+  // ---- the agent's 2^10 W2 as f16 pieces in A-fragment order, both orientations (once per workgroup)
   {
     unsigned short* wf16 = reinterpret_cast<unsigned short*>(sWf);
     for (int e = r; e < 2 * 32 * 32; e += ROWS) {
       const int prod = e >> 10, ri = (e >> 5) & 31, k = e & 31;
-      const int ui = v7_row_unit(ri), uk = v7_slot_unit(k);
+      const int ui = v8_row_unit(ri), uk = v8_slot_unit(k);
       float w = 0.f;
       if (ui >= 0 && uk >= 0) w = prod == 0 ? th[g.o_W2 + uk * HID + ui] : th[g.o_W2 + ui * HID + uk];
-      unsigned ph, pm, pl;
-      rc_split3(w, ph, pm, pl);
+      unsigned ph, pl;
+      rc_split2h_pair(w * RC_V8_S, 0.f, ph, pl);
+      if (fabsf(w) * RC_V8_S > RC_V8_RANGE) ovf_flags[s * N + i] = ovf_gen;
       const int ks = k >> 4, kg = (k >> 3) & 1;
-      const int base = ((((prod * 2 + ks) * 3 + 0) * 2 + kg) * 32 + ri) * 8 + (k & 7);     // in bf16 elements; piece stride 2*32*8
+      const int base = ((((prod * 2 + ks) * 2 + 0) * 2 + kg) * 32 + ri) * 8 + (k & 7);     // in f16 elements; piece stride 2*32*8
       wf16[base] = (unsigned short)ph;
-      wf16[base + 2 * 32 * 8] = (unsigned short)pm;
-      wf16[base + 2 * 2 * 32 * 8] = (unsigned short)pl;
+      wf16[base + 2 * 32 * 8] = (unsigned short)pl;
     }
   }
   if (r < 2 * HID + 1) sV[r] = th[g.o_b2 + r];
   unsigned short* pA = reinterpret_cast<unsigned short*>(sPn + wave * PANEL_B);     // [piece][row][column]: a1 units 0..19 | 1.0 | unused
-  unsigned short* pB = pA + 3 * PLANE;                                              // [piece][row][column]: dz2 units 0..19 | unused
+  unsigned short* pB = pA + 2 * PLANE;                                              // [piece][row][column]: dz2 units 0..19 | unused
   float* sRec = reinterpret_cast<float*>(pB);                                       // the wavefront's record, staged over the B planes
-  // column 20 of the A planes is the constant 1 (-> gb2 = sum dz2): pieces (1.0, 0, 0); written once, nothing else touches it.
+  // column 20 of the A planes is the constant 1 (-> gb2 = sum dz2): pieces (1.0, 0); written once, nothing else touches it.
   // The spare columns of the A planes are zeroed once; columns 20.. of the B planes (and what a transpose read picks up
   // beyond column 23) only feed elements of G nobody reads.
-  for (int e = lane; e < 3 * 32 * (PC - 20); e += 64) {
+  for (int e = lane; e < 2 * 32 * (PC - 20); e += 64) {
     const int pc = e / (32 * (PC - 20)), rw = (e / (PC - 20)) & 31, cl = 20 + e % (PC - 20);
-    pA[pc * PLANE + rw * PC + cl] = (pc == 0 && cl == 20) ? (unsigned short)0x3F80 : (unsigned short)0;
+    pA[pc * PLANE + rw * PC + cl] = (pc == 0 && cl == 20) ? (unsigned short)0x3C00 : (unsigned short)0;
   }
   const float* yrow = y + ((long)s * N + i) * ldb;
   __syncthreads();
   const float b3 = sV[2 * HID];
-  const uint4* wfA = sWf + half * 32 + l31;             // + ((prod*2 + ks)*3 + piece) * 64
+  const uint4* wfA = sWf + half * 32 + l31;             // + ((prod*2 + ks)*2 + piece) * 64
   auto loadA = [&](int prod, int ks) {
-    V7Pieces a;
-    a.h = wfA[((prod * 2 + ks) * 3 + 0) * 64];
-    a.m = wfA[((prod * 2 + ks) * 3 + 1) * 64];
-    a.l = wfA[((prod * 2 + ks) * 3 + 2) * 64];
+    V8Pieces a;
+    a.h = wfA[((prod * 2 + ks) * 2 + 0) * 64];
+    a.l = wfA[((prod * 2 + ks) * 2 + 1) * 64];
     return a;
   };
   // transpose-read address of this lane inside a plane (rcmarl_lattice.h: rc_lds_read_tr16): as MFMA operand lane (i = l31,
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
   const int wr8 = l31 * PC + 8 * half, wr2 = l31 * PC + 16 + 2 * half;
   uint4 z4;
   z4.x = z4.y = z4.z = z4.w = 0u;
+  float amax = 0.f;                                    // largest |operand| this lane split (a1, 2^10 dz2)
   float racc0 = 0.f, racc1 = 0.f;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     rc_f32x16 g1;
@@ -492,35 +495,35 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
       // ---- the lane's ten layer-1 activations of its row
       float a1l[LU];
 #pragma unroll
-      for (int u = 0; u < LU; ++u) a1l[u] = valid ? a1t[(row0 + v7_unit(half, u)) * ldb + b] : 0.f;
+      for (int u = 0; u < LU; ++u) a1l[u] = valid ? a1t[(row0 + v8_unit(half, u)) * ldb + b] : 0.f;
+#pragma unroll
+      for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(a1l[u]), fabsf(a1l[u + 1])));
       const float ycur = valid ? yrow[b] : 0.f;
-      // ---- layer 2 forward on the bf16 matrix core; the a1 pieces also go to the A planes (operand of the row reduction)
-      V7Pieces pa0, pa1;
+      // ---- layer 2 forward on the f16 matrix core; the a1 pieces also go to the A planes (operand of the row reduction)
+      V8Pieces pa0, pa1;
       {
         const float x0[8] = {a1l[0], a1l[1], a1l[2], a1l[3], a1l[4], a1l[5], a1l[6], a1l[7]};
-        pa0 = v7_split8(x0);
-        pa1.h = z4; pa1.m = z4; pa1.l = z4;
-        rc_split3_pair(a1l[8], a1l[9], pa1.h.x, pa1.m.x, pa1.l.x);
+        pa0 = v8_split8<false>(x0, 1.f);
+        pa1.h = z4; pa1.l = z4;
+        rc_split2h_pair(a1l[8], a1l[9], pa1.h.x, pa1.l.x);
       }
       RC_SCHED_FENCE();
       RC_WAVE_SYNC();                                    // the previous block's transpose reads of the planes are done
       *reinterpret_cast<uint4*>(pA + 0 * PLANE + wr8) = pa0.h;
-      *reinterpret_cast<uint4*>(pA + 1 * PLANE + wr8) = pa0.m;
-      *reinterpret_cast<uint4*>(pA + 2 * PLANE + wr8) = pa0.l;
+      *reinterpret_cast<uint4*>(pA + 1 * PLANE + wr8) = pa0.l;
       *reinterpret_cast<unsigned*>(pA + 0 * PLANE + wr2) = pa1.h.x;
-      *reinterpret_cast<unsigned*>(pA + 1 * PLANE + wr2) = pa1.m.x;
-      *reinterpret_cast<unsigned*>(pA + 2 * PLANE + wr2) = pa1.l.x;
+      *reinterpret_cast<unsigned*>(pA + 1 * PLANE + wr2) = pa1.l.x;
       rc_f32x16 zz;
 #pragma unroll
       for (int q = 0; q < 16; ++q) zz[q] = 0.f;
-      zz = v7_mfma6(loadA(0, 1), pa1, zz);
-      zz = v7_mfma6(loadA(0, 0), pa0, zz);
+      zz = v8_mfma4(loadA(0, 1), pa1, zz);
+      zz = v8_mfma4(loadA(0, 0), pa0, zz);
       RC_SCHED_FENCE();
       float a2l[LU], vp = 0.f;
 #pragma unroll
-      for (int u = 0; u < LU; ++u) a2l[u] = rc_lrelu(zz[u] + sV[v7_unit(half, u)]);
+      for (int u = 0; u < LU; ++u) a2l[u] = rc_lrelu(fmaf(zz[u], RC_V8_US, sV[v8_unit(half, u)]));
 #pragma unroll
-      for (int u = 0; u < LU; ++u) vp = fmaf(a2l[u], sV[HID + v7_unit(half, u)], vp);
+      for (int u = 0; u < LU; ++u) vp = fmaf(a2l[u], sV[HID + v8_unit(half, u)], vp);
       float va = vp, vb = vp;
       rc_swap32(va, vb);                                 // va: lanes 32-63 now hold the low half's partial; vb: lanes 0-31 the high half's
       const float v = (vp + (half ? va : vb)) + b3;
@@ -531,92 +534,86 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
 #pragma unroll
       for (int u = 0; u < LU; ++u) {
         gw3l[u] = fmaf(a2l[u], dv, gw3l[u]);
-        dz2l[u] = dv * sV[HID + v7_unit(half, u)] * rc_lrelu_grad_from_act(a2l[u]);
+        dz2l[u] = dv * sV[HID + v8_unit(half, u)] * rc_lrelu_grad_from_act(a2l[u]);
       }
+#pragma unroll
+      for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, RC_V8_S * fmaxf(fabsf(dz2l[u]), fabsf(dz2l[u + 1])));
       // ---- layer 2 backward; the dz2 pieces also go to the B planes
-      V7Pieces pd0, pd1;
+      V8Pieces pd0, pd1;
       {
         const float x0[8] = {dz2l[0], dz2l[1], dz2l[2], dz2l[3], dz2l[4], dz2l[5], dz2l[6], dz2l[7]};
-        pd0 = v7_split8(x0);
-        pd1.h = z4; pd1.m = z4; pd1.l = z4;
-        rc_split3_pair(dz2l[8], dz2l[9], pd1.h.x, pd1.m.x, pd1.l.x);
+        pd0 = v8_split8<true>(x0, RC_V8_S);
+        pd1.h = z4; pd1.l = z4;
+        rc_split2h_pair(dz2l[8] * RC_V8_S, dz2l[9] * RC_V8_S, pd1.h.x, pd1.l.x);
       }
       *reinterpret_cast<uint4*>(pB + 0 * PLANE + wr8) = pd0.h;
-      *reinterpret_cast<uint4*>(pB + 1 * PLANE + wr8) = pd0.m;
-      *reinterpret_cast<uint4*>(pB + 2 * PLANE + wr8) = pd0.l;
+      *reinterpret_cast<uint4*>(pB + 1 * PLANE + wr8) = pd0.l;
       *reinterpret_cast<unsigned*>(pB + 0 * PLANE + wr2) = pd1.h.x;
-      *reinterpret_cast<unsigned*>(pB + 1 * PLANE + wr2) = pd1.m.x;
-      *reinterpret_cast<unsigned*>(pB + 2 * PLANE + wr2) = pd1.l.x;
+      *reinterpret_cast<unsigned*>(pB + 1 * PLANE + wr2) = pd1.l.x;
       rc_f32x16 dd;
 #pragma unroll
       for (int q = 0; q < 16; ++q) dd[q] = 0.f;
-      dd = v7_mfma6(loadA(1, 1), pd1, dd);
-      dd = v7_mfma6(loadA(1, 0), pd0, dd);
+      dd = v8_mfma4(loadA(1, 1), pd1, dd);
+      dd = v8_mfma4(loadA(1, 0), pd0, dd);
       RC_SCHED_FENCE();
       float dz1l[LU];
 #pragma unroll
       for (int u = 0; u < LU; ++u) {
-        dz1l[u] = dd[u] * rc_lrelu_grad_from_act(a1l[u]);
+        dz1l[u] = (dd[u] * (RC_V8_US * RC_V8_US)) * rc_lrelu_grad_from_act(a1l[u]);
         gb1l[u] += dz1l[u];
       }
       if (!EMIT) {
 #pragma unroll
         for (int u = 0; u < LU; ++u)
-          if (valid) a1t[(row0 + v7_unit(half, u)) * ldb + b] = dz1l[u];
+          if (valid) a1t[(row0 + v8_unit(half, u)) * ldb + b] = dz1l[u];
       }
       // ---- the row reduction G = [a1 | 1]^T [dz2] over this block's 32 rows: operands read back TRANSPOSED from the planes
       // (a lane = one column, eight consecutive rows), straight into the MFMA: no second split, no fp32 panels
       RC_WAVE_SYNC();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        V7Pieces ra, rb;
+        V8Pieces ra, rb;
         const int o = tr_off + 16 * PC * ks;
         uint2 t0, t1;
         t0 = rc_lds_read_tr16(pA + 0 * PLANE + o); t1 = rc_lds_read_tr16(pA + 0 * PLANE + o + 4 * PC);
         ra.h.x = t0.x; ra.h.y = t0.y; ra.h.z = t1.x; ra.h.w = t1.y;
         t0 = rc_lds_read_tr16(pA + 1 * PLANE + o); t1 = rc_lds_read_tr16(pA + 1 * PLANE + o + 4 * PC);
-        ra.m.x = t0.x; ra.m.y = t0.y; ra.m.z = t1.x; ra.m.w = t1.y;
-        t0 = rc_lds_read_tr16(pA + 2 * PLANE + o); t1 = rc_lds_read_tr16(pA + 2 * PLANE + o + 4 * PC);
         ra.l.x = t0.x; ra.l.y = t0.y; ra.l.z = t1.x; ra.l.w = t1.y;
         t0 = rc_lds_read_tr16(pB + 0 * PLANE + o); t1 = rc_lds_read_tr16(pB + 0 * PLANE + o + 4 * PC);
         rb.h.x = t0.x; rb.h.y = t0.y; rb.h.z = t1.x; rb.h.w = t1.y;
         t0 = rc_lds_read_tr16(pB + 1 * PLANE + o); t1 = rc_lds_read_tr16(pB + 1 * PLANE + o + 4 * PC);
-        rb.m.x = t0.x; rb.m.y = t0.y; rb.m.z = t1.x; rb.m.w = t1.y;
-        t0 = rc_lds_read_tr16(pB + 2 * PLANE + o); t1 = rc_lds_read_tr16(pB + 2 * PLANE + o + 4 * PC);
         rb.l.x = t0.x; rb.l.y = t0.y; rb.l.z = t1.x; rb.l.w = t1.y;
-        g1 = v7_mfma6(ra, rb, g1);
-        RC_SCHED_FENCE();                              // (keeps the second k-step's twelve reads from being hoisted: registers)
+        g1 = v8_mfma4(ra, rb, g1);
+        RC_SCHED_FENCE();                              // (keeps the second k-step's eight reads from being hoisted: registers)
       }
       if (EMIT) {
-        // packed bf16 pieces (rcmarl_lattice.h): row = i*HID + unit, k = replay row.  The block's 32 rows x 60 (unit, piece)
+        // packed f16 pieces of 2^8 dz1 (rcmarl_lattice.h): row = i*HID + unit, k = replay row.  The block's 32 rows x 40 (unit, piece)
         // values are transposed through the (now idle) B planes so that the stores are 16-byte chunks = 8 consecutive
         // replay rows of one (unit, piece); a block is exactly one k-tile of the packed image.
-        unsigned short* stg = pB;                      // [60 (unit, piece)][32 rows] bf16 = 3840 B
+        unsigned short* stg = pB;                      // [40 (unit, piece)][32 rows] f16 = 2560 B
         RC_WAVE_SYNC();                                // the reduction's transpose reads are done
 #pragma unroll
         for (int q = 0; q < LU / 2; ++q) {
-          unsigned ph, pm, pl;
-          rc_split3_pair(dz1l[2 * q], dz1l[2 * q + 1], ph, pm, pl);          // bits 0-15: local unit 2q, bits 16-31: 2q+1
-          const int u0 = v7_unit(half, 2 * q), u1 = v7_unit(half, 2 * q + 1);
-          stg[(u0 * 3 + 0) * 32 + l31] = (unsigned short)ph;
-          stg[(u0 * 3 + 1) * 32 + l31] = (unsigned short)pm;
-          stg[(u0 * 3 + 2) * 32 + l31] = (unsigned short)pl;
-          stg[(u1 * 3 + 0) * 32 + l31] = (unsigned short)(ph >> 16);
-          stg[(u1 * 3 + 1) * 32 + l31] = (unsigned short)(pm >> 16);
-          stg[(u1 * 3 + 2) * 32 + l31] = (unsigned short)(pl >> 16);
+          unsigned ph, pl;
+          rc_split2h_pair(dz1l[2 * q] * RC_F16_DZ_SCALE, dz1l[2 * q + 1] * RC_F16_DZ_SCALE, ph, pl);   // bits 0-15: local unit 2q, bits 16-31: 2q+1
+          const int u0 = v8_unit(half, 2 * q), u1 = v8_unit(half, 2 * q + 1);
+          stg[(u0 * 2 + 0) * 32 + l31] = (unsigned short)ph;
+          stg[(u0 * 2 + 1) * 32 + l31] = (unsigned short)pl;
+          stg[(u1 * 2 + 0) * 32 + l31] = (unsigned short)(ph >> 16);
+          stg[(u1 * 2 + 1) * 32 + l31] = (unsigned short)(pl >> 16);
         }
         RC_WAVE_SYNC();
-        unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (3 * RC_PK_BLOCK);
+        unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (2 * RC_PK_BLOCK);
         const int kt = (chunk * ROWS + wave * 64 + 32 * blk) >> 5;             // this block's k-tile
 #pragma unroll
-        for (int it = 0; it < (HID * 3 * 4 + 63) / 64; ++it) {
+        for (int it = 0; it < (HID * 2 * 4 + 63) / 64; ++it) {
           const int c = it * 64 + lane;                // chunk index: (unit, piece) = c >> 2, rows 8*(c&3) .. +7
-          if (c < HID * 3 * 4 && kt < dzp_kt) {
+          if (c < HID * 2 * 4 && kt < dzp_kt) {
             const int up = c >> 2, c4 = c & 3;
-            const int unit = up / 3, piece = up - 3 * unit;
+            const int unit = up >> 1, piece = up & 1;
             const int R = i * HID + unit;
             const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 32 + 8 * c4);
-            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 3 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
+            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
                                  (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
             *reinterpret_cast<uint4*>(base + off) = v4;
           }
@@ -638,28 +635,29 @@ __global__ __launch_bounds__(256, RC_V7_WAVES) void k_mid_fit_v7(float* __restri
         const int ii = (q & 3) + 8 * (q >> 2) + 4 * half, jj = l31;
         int idx = -1;
         if (jj < HID) idx = ii < HID ? ii * HID + jj : (ii == HID ? PT::gb2 + jj : -1);
-        sRec[idx >= 0 ? idx : PT::SIZE + lane] = g1[q];                        // (else: a dump word of the lane's own)
+        sRec[idx >= 0 ? idx : PT::SIZE + lane] = g1[q] * RC_V8_US;             // (else: a dump word of the lane's own); dz2 was carried as 2^10 dz2
       }
       if (l31 == 31) {
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
-          sRec[PT::gb1 + v7_unit(half, u)] = sm[u];
-          sRec[PT::gW3 + v7_unit(half, u)] = sm[LU + u];
+          sRec[PT::gb1 + v8_unit(half, u)] = sm[u];
+          sRec[PT::gW3 + v8_unit(half, u)] = sm[LU + u];
         }
         if (half == 0) { sRec[PT::gb3] = sm[2 * LU]; sRec[PT::loss] = sm[2 * LU + 1]; }
       }
     }
     __syncthreads();
     {
-      const float* r0 = reinterpret_cast<const float*>(sPn + 0 * PANEL_B + 3 * PLANE * 2);
-      const float* r1 = reinterpret_cast<const float*>(sPn + 1 * PANEL_B + 3 * PLANE * 2);
-      const float* r2 = reinterpret_cast<const float*>(sPn + 2 * PANEL_B + 3 * PLANE * 2);
-      const float* r3 = reinterpret_cast<const float*>(sPn + 3 * PANEL_B + 3 * PLANE * 2);
+      const float* r0 = reinterpret_cast<const float*>(sPn + 0 * PANEL_B + 2 * PLANE * 2);
+      const float* r1 = reinterpret_cast<const float*>(sPn + 1 * PANEL_B + 2 * PLANE * 2);
+      const float* r2 = reinterpret_cast<const float*>(sPn + 2 * PANEL_B + 2 * PLANE * 2);
+      const float* r3 = reinterpret_cast<const float*>(sPn + 3 * PANEL_B + 2 * PLANE * 2);
       racc0 += (r0[r] + r1[r]) + (r2[r] + r3[r]);                            // the workgroup's running record (as k_mid_fit_v5)
       if (r + ROWS < PT::SIZE) racc1 += (r0[r + ROWS] + r1[r + ROWS]) + (r2[r + ROWS] + r3[r + ROWS]);
     }
     __syncthreads();                                   // records read out before the next chunk's planes land
   }
+  if (amax > RC_V8_RANGE) ovf_flags[s * N + i] = ovf_gen;            // (same value from every lane and workgroup of the agent)
   float* out = partials + (((long)s * N + i) * gridDim.x + blockIdx.x) * PT::SIZE;
   out[r] = racc0;
   if (r + ROWS < PT::SIZE) out[r + ROWS] = racc1;
@@ -1051,10 +1049,35 @@ int midfit_cpw(int nchunk, long columns) {
   return c < 1 ? 1 : c;
 }
 
-// Default: k_mid_fit_v5 (f32-input MFMA forms, fmaf-chain arithmetic).  RCMARL_MIDFIT=7 selects the bf16 matrix-core form
-// (k_mid_fit_v7): measured 825-830 us against 795-800 at the BASELINE configs[3] shape (profiles/r03d_*), so it is the
-// alternative, not the default.  Read at every call (tests switch it inside one process).
-bool midfit_v5() { const char* e = getenv("RCMARL_MIDFIT"); return !(e && atoi(e) == 7); }
+// rcmarl_mid_fit_lattice with the backward operand as f16 pieces (RCMARL_LAT_F16 bit 1, the default): k_mid_fit_v8 (f16 matrix-core
+// form) followed by a fix-up launch of k_mid_fit_v5 for the agents v8 flagged as out of range; RCMARL_MIDFIT=5 forces v5 alone.
+// Everything else -- rcmarl_mid_fit (fp32 dz1 in place: networks off the lattice path), three-piece bf16 operands -- is v5.
+// Read at every call (tests switch it inside one process).
+bool midfit_v8() {
+  const char* e = getenv("RCMARL_MIDFIT");
+  return (rc_lat_f16_mode() & 2) && !(e && atoi(e) == 5);
+}
+
+// Out-of-range flags of k_mid_fit_v8: one int per (seed, agent), owned by the library (the C-ABI hands no workspace over), zeroed at
+// allocation; a launch pair marks and reads them with its own generation number, so nothing is ever cleared.  Allocated at the first
+// call (65536 entries cover every BASELINE shape; a larger S*N reallocates) -- calls are expected from one host thread and one
+// stream at a time, as the engine issues them.
+struct MidFlags { int* buf = nullptr; size_t cap = 0; int gen = 0; };
+MidFlags g_mid_flags;
+int* mid_flags(size_t n, int& gen) {
+  MidFlags& f = g_mid_flags;
+  if (n > f.cap) {
+    const size_t cap = n > 65536 ? n : 65536;
+    int* nb = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&nb), cap * sizeof(int)) != hipSuccess || hipMemset(nb, 0, cap * sizeof(int)) != hipSuccess)
+      return nullptr;
+    if (f.buf) (void)hipFree(f.buf);
+    f.buf = nb; f.cap = cap; f.gen = 0;
+  }
+  f.gen = f.gen >= (1 << 30) ? 1 : f.gen + 1;
+  gen = f.gen;
+  return f.buf;
+}
 
 bool bad_mid(const void* a, const void* b, int S, int N, int B, int in_dim, int hid, int ldp, int ldb) {
   return !a || !b || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) || ldb < B;
@@ -1079,13 +1102,8 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  if (midfit_v5()) {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
-                                     ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
-  } else {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v7<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
-                                     ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0));
-  }
+  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
+                                   ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, (const int*)nullptr, 0));
   return rcmarl_check_launch();
 }
 
@@ -1096,15 +1114,24 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  if (rc_lat_f16_mode() & 2) {                       // the backward operand as two f16 pieces: v5 only
+  if (midfit_v8()) {
+    int gen = 0;
+    int* flags = mid_flags((size_t)S * N, gen);
+    if (!flags) return RCMARL_ERR_LAUNCH;
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v8<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, flags, gen));
+    // the fix-up: same grid, same records, same packed rows -- a workgroup whose agent is not flagged returns at once
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
-  } else if (midfit_v5()) {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
+                                     (const int*)flags, gen));
+  } else if (rc_lat_f16_mode() & 2) {
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
+                                     (const int*)nullptr, 0));
   } else {
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v7<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt));
+    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
+                                     (const int*)nullptr, 0));
   }
   return rcmarl_check_launch();
 }

@@ -27,6 +27,9 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 
 struct dim3 {

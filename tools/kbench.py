@@ -233,7 +233,7 @@ def mid_ab(L, S=16, N=256, B=3000):
     """A/B of rcmarl_mid_fit_lattice: the product library (default kernel = v5, and RCMARL_MIDFIT=7 = the bf16 matrix-core form)
     against the variant builds named in RCMARL_KBENCH_LIB_B (comma-separated paths; tools/build_variant.py), interleaved."""
     from rcmarl_amd import lattice as LT
-    libs = [("product", L, None), ("product-v7", L, "7")]
+    libs = [("product", L, None), ("product-v5", L, "5")]      # default = k_mid_fit_v8 + fix-up launch; RCMARL_MIDFIT=5 = v5 alone
     for pth in [x for x in os.environ.get("RCMARL_KBENCH_LIB_B", "").split(",") if x]:
         libs.append((os.path.basename(pth).replace("lib", "").replace(".so", ""), capi.CLib(pth), None))
     st = torch.cuda.current_stream().cuda_stream
@@ -257,7 +257,7 @@ def mid_ab(L, S=16, N=256, B=3000):
                 t = timeit(lambda: lib.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
                                                               g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st), iters=20)
                 outs[name] = (dzp.clone(), part.clone())
-                print("in=%d round %d  %-16s %8.1f us  (%.0f GB/s of its 200 B per row and agent)" % (in_dim, rnd, name, t, 200.0 * S * N * B / t / 1e3))
+                print("in=%d round %d  %-16s %8.1f us  (%.0f GB/s of its 160 B per row and agent)" % (in_dim, rnd, name, t, 160.0 * S * N * B / t / 1e3))
         os.environ.pop("RCMARL_MIDFIT", None)
         ref = outs["product"]
         for name, (dz, pt) in outs.items():
