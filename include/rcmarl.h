@@ -104,10 +104,11 @@ int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partia
 int rcmarl_lattice_f16_mode(void);
 int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, void* kp,
                           int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag, void* stream);
-/* wp (3 pieces, rows = (agent,unit) column, reduction = feature) <- bf16x3 split of alpha[k]*W1[s][n][k][j] */
+/* wp (rows = (agent,unit) column, reduction = feature) <- the pieces of alpha[k]*W1[s][n][k][j] in the current operand form
+ * (two f16 pieces of 2^10 times it, or three exact bf16 pieces) */
 int rcmarl_w1_split(const float* theta, const float* alpha, void* wp, int S, int N, int in_dim, int hid, int ldp,
                     int wp_rt, int wp_kt, void* stream);
-/* dzp (3 pieces, rows = (agent,unit) column, reduction = replay row, zero beyond B) <- bf16x3 split of the fp32
+/* dzp (rows = (agent,unit) column, reduction = replay row, zero beyond B) <- the pieces (current operand form) of the fp32
  * feature-major dz[S][N*hid][ldb]: the backward operand when dz1 was produced by rcmarl_dense_backward_data */
 int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int N, int B, int hid, int ldb, int dzp_rt, int dzp_kt,
                            void* stream);
@@ -122,8 +123,12 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
                                        const float* alpha, float* theta, const int* mask, int S, int N, int B,
                                        int in_dim, int hid, int ldp, float lr, void* wp_out, int wp_rt, int wp_kt,
                                        void* stream);
-/* = rcmarl_mid_fit, but a1t is left intact and dz1 is written as dzp (3 exact bf16 pieces, rows = (agent,unit)
- * column, reduction = replay row, zero beyond B) for rcmarl_layer1_backward_sgd_lattice. */
+/* = rcmarl_mid_fit, but a1t is left intact and dz1 is written as dzp (its 16-bit pieces in the current operand form --
+ * two f16 pieces of 2^8 dz1, or three exact bf16 pieces --, rows = (agent,unit) column, reduction = replay row, zero
+ * beyond B) for rcmarl_layer1_backward_sgd_lattice.  With f16 backward operands the step itself runs on the f16 matrix
+ * core (two-piece operands, four exact products per fp32 product; RCMARL_MIDFIT=5: the fp32 kernel of rcmarl_mid_fit);
+ * an agent whose activations / gradients leave the f16 range is redone in fp32 arithmetic by a second launch.  The
+ * out-of-range flags live in a device buffer the library allocates at the first call: one host thread, one stream. */
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
                            int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
 
