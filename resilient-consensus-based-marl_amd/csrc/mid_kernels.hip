@@ -363,44 +363,6 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
 // History: the same data flow on three exact bf16 pieces (six products, 9 VALU per split pair; "v7") ran
 // 827 us against v5's 797 at BASELINE configs[3] -- the splits, plane traffic and dependent MFMA chains gave back what the
 // matrix core saved; with two f16 pieces it runs ~600 us against v5's ~715 (profiles/r03n_mid_ab.txt).
-__device__ __forceinline__ int v8_unit(int h, int u) { return u < 8 ? u + 8 * h : 16 + 2 * h + (u - 8); }
-// unit of accumulator / A-operand row i (0..31), or -1 (padding row)
-__device__ __forceinline__ int v8_row_unit(int i) {
-  const int h = (i >> 2) & 1, q = i >> 3, e = i & 3;
-  if (q < 2) return v8_unit(h, 4 * q + e);
-  return (q == 2 && e < 2) ? v8_unit(h, 8 + e) : -1;
-}
-// unit of contraction slot k (0..31), or -1
-__device__ __forceinline__ int v8_slot_unit(int k) {
-  if (k < 16) return v8_unit(k >> 3, k & 7);
-  const int h = (k - 16) >> 3, u = 8 + ((k - 16) & 7);
-  return u < 10 ? v8_unit(h, u) : -1;
-}
-
-struct V8Pieces { uint4 h, l; };
-__device__ __forceinline__ rc_f32x16 v8_mfma4(const V8Pieces& a, const V8Pieces& b, rc_f32x16 c) {
-  c = rc_mfma_f16(a.l, b.l, c);
-  c = rc_mfma_f16(a.l, b.h, c);
-  c = rc_mfma_f16(a.h, b.l, c);
-  c = rc_mfma_f16(a.h, b.h, c);
-  return c;
-}
-template <bool SCALED>
-__device__ __forceinline__ V8Pieces v8_split8(const float (&x)[8], float sc) {
-  V8Pieces p;
-  if (SCALED) {
-    rc_split2h_pair(x[0] * sc, x[1] * sc, p.h.x, p.l.x);
-    rc_split2h_pair(x[2] * sc, x[3] * sc, p.h.y, p.l.y);
-    rc_split2h_pair(x[4] * sc, x[5] * sc, p.h.z, p.l.z);
-    rc_split2h_pair(x[6] * sc, x[7] * sc, p.h.w, p.l.w);
-  } else {
-    rc_split2h_pair(x[0], x[1], p.h.x, p.l.x);
-    rc_split2h_pair(x[2], x[3], p.h.y, p.l.y);
-    rc_split2h_pair(x[4], x[5], p.h.z, p.l.z);
-    rc_split2h_pair(x[6], x[7], p.h.w, p.l.w);
-  }
-  return p;
-}
 #ifndef RC_V8_WAVES
 #define RC_V8_WAVES 2                    // wavefronts per SIMD the register allocation aims at
 #endif

@@ -17,7 +17,7 @@
 // Shuffle: Keras shuffles with TensorFlow's RNG (irreproducible outside TF); the permutation is
 // an INPUT here (perm[S][n_adv][epochs][B], drawn by the host from the stream the oracle defines,
 // oracle/rpbcac_oracle.py::ShuffleStream).  perm == NULL keeps the natural row order.
-#include "rcmarl_common.h"
+#include "rcmarl_lattice.h"
 #include <stdlib.h>
 
 namespace {
@@ -285,12 +285,13 @@ __device__ __forceinline__ float rc_other_half(float v) {
 #endif
 
 template <int INMAX>                                        // inputs padded to INMAX (16 or 20): branch-free loops
-__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
+__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, const int* __restrict__ fix_flags, int fix_gen) {
   constexpr int HID = 20, U = 10, XR = 11;                    // XR: first x row of the P2 panel
   RCMARL_DYN_SMEM(float, smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int net = blockIdx.x * 4 + wave;
+  const int net = blockIdx.x * (blockDim.x >> 6) + wave;
   if (net >= n_nets) return;                               // (wave-uniform; the kernel has no workgroup barrier)
+  if (fix_flags != nullptr && fix_flags[net] != fix_gen) return;   // fix-up launch behind k_minibatch_mx: flagged networks only
   const int s = net / a.n_adv, adv = net - s * a.n_adv;
   float* W = smem + wave * WP_FLOATS;
   float* W2T = W + WP_W;
@@ -504,10 +505,385 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets) {
   for (int e = lane; e < g.P; e += 64) th[e] = W[e];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The MSE fits on the f16 matrix core ("mx", round 3): one wavefront per (seed, adversary) network as above, every product of
+// the step as v_mfma_f32_32x32x16_f16 on two-piece f16 operands (rcmarl_lattice.h; the data flow of k_mid_fit_v8).
+// Why: k_minibatch_wave reads every weight of every layer product from LDS as a broadcast float2 -- 280 ds_read_b64 = 143 KB
+// of LDS return traffic per 32-row step and wavefront; with the 512 x 3 networks of BASELINE configs[1] batched over seeds (six
+// wavefronts per CU) that alone is 3 us per step, and the 2 x 16 f32-input MFMAs of its gradient products run on the vector
+// ALUs.  Here the weights are the STATIONARY matrix operand -- twelve 16-byte fragment reads per step -- and the step is
+//   z1 = x W1, z2 = a1 W2, da1 = dz2 W2^T      3 x (1..2 k-steps) x 4 piece products, lane (row j, half h) = ten units of row j
+//   G1 = [a1 | 1 | 0 | a2_h0]^T [dz2 | dv]     -> gW2, gb2, gW3 (units of half 0), gb3
+//   G2 = [x  | 1 | 0 | a2_h1]^T [dz1 | dv]     -> gW1, gb1, gW3 (units of half 1)
+// with the operands of G1, G2 written row-major into f16 LDS planes and read back transposed (ds_read_b64_tr_b16).  The fp32
+// master copy of every parameter lives in the register of the accumulator slot that owns its gradient (as in k_minibatch_wave);
+// after the SGD step the owner writes the parameter's two f16 pieces straight into the weight fragments (ds_write_b16).
+// Scales: W'' = 2^10 W, dz'' = 2^10 dz, dv'' = 2^10 dv; x, a1, a2 unscaled.  A network whose operands leave the f16 range is NOT
+// written back: its flag is set and k_minibatch_wave redoes the whole fit in fp32 arithmetic (second launch, flagged networks only).
+// Measured (512 seeds x 3 networks, BASELINE configs[1] batched): 2.9 us per step alone against 6.0 for k_minibatch_wave; inside a
+// block, beside the cooperative agents' kernels, 5.2 us (clocks, LDS and L2 shared) -- the block goes 200 -> 163 ms, a single
+// instance 65 -> 35 ms.  Capping a launch at one wavefront per CU (so that the other kernels find LDS) changes nothing: 162-164 ms.
+constexpr int MX_PCA = 32, MX_PCB = 24;                          // plane row strides (f16 elements)
+constexpr int MX_FRAG = 3 * 2 * 2 * 2 * 32 * 8;                  // [product][k-step][piece][k-group][row] x 8 f16
+constexpr int MX_PA = 2 * 32 * MX_PCA, MX_PB = 2 * 32 * MX_PCB;  // one A / B plane pair (two pieces)
+constexpr int MX_F16 = MX_FRAG + 2 * MX_PA + 2 * MX_PB + 32;     // + pad: a transposed read of B columns 24..31 of the last row
+constexpr int MX_PARAMS = 64;                                    // fp32: b1[20] | b2[20] | W3[20] | b3 | two dummy slots
+constexpr size_t MX_BYTES = (size_t)MX_F16 * 2 + MX_PARAMS * 4;  // 26 944 B per wavefront
+#define MX_S 1024.f
+#define MX_US 0.0009765625f
+#define MX_RANGE 65000.f
+
+__device__ __forceinline__ int mx_row_of_unit(int u) { return u < 16 ? 8 * ((u & 7) >> 2) + 4 * (u >> 3) + (u & 3) : 16 + 4 * ((u - 16) >> 1) + ((u - 16) & 1); }
+__device__ __forceinline__ int mx_slot_of_unit(int u) { return u < 16 ? u : 16 + 8 * ((u - 16) >> 1) + ((u - 16) & 1); }
+__device__ __forceinline__ int mx_frag_elem(int prod, int ri, int k) {      // f16 index of piece 0; piece 1 is 2*32*8 further
+  return ((((prod * 2 + (k >> 4)) * 2 + 0) * 2 + ((k >> 3) & 1)) * 32 + ri) * 8 + (k & 7);
+}
+
+#ifdef RCMARL_EMU
+#define RC_MX_OCC
+#else
+#define RC_MX_OCC __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2)))   // <= 256 registers
+#endif
+template <int KS1>                                           // k-steps of layer 1: 1 (<= 16 inputs) or 2 (<= 20)
+__device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned char* smem, int* __restrict__ ovf_flags, int ovf_gen) {
+  constexpr int HID = 20, LU = 10, NX = 8 * KS1;
+  const int lane = threadIdx.x & 63;
+  unsigned short* frag = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* pA1 = frag + MX_FRAG;                      // [piece][row][32]: a1 (0..19) | 1 (20) | 0 (21) | a2 of half 0: local 8,9 (22,23), 0..7 (24..31)
+  unsigned short* pA2 = pA1 + MX_PA;                         // [piece][row][32]: x  (0..19) | 1 (20) | 0 (21) | a2 of half 1
+  unsigned short* pB1 = pA2 + MX_PA;                         // [piece][row][24]: dz2'' (0..19) | dv'' (20)
+  unsigned short* pB2 = pB1 + MX_PB;                         // [piece][row][24]: dz1'' (0..19) | dv'' (20)
+  float* prm = reinterpret_cast<float*>(smem + (size_t)MX_F16 * 2);       // b1 | b2 | W3 | b3
+  const int in = a.in_dim;
+  const NetGeom g = make_geom(in, HID, 1);
+  const int l31 = lane & 31, half = lane >> 5;
+  rc_f16_saturate();
+  const int fdummy = mx_frag_elem(0, 31, 0);
+  const uint4* wfA = reinterpret_cast<const uint4*>(frag) + half * 32 + l31;    // + ((prod*2 + ks)*2 + piece) * 64
+  auto loadA = [&](int prod, int ks) {
+    V8Pieces f;
+    f.h = wfA[((prod * 2 + ks) * 2 + 0) * 64];
+    f.l = wfA[((prod * 2 + ks) * 2 + 1) * 64];
+    return f;
+  };
+  const int trA = (8 * half + ((lane & 15) >> 2)) * MX_PCA + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int trB = (8 * half + ((lane & 15) >> 2)) * MX_PCB + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  auto readT = [&](const unsigned short* plane, int pl_elems, int o, int pc) {
+    V8Pieces r;
+    uint2 t0 = rc_lds_read_tr16(plane + o), t1 = rc_lds_read_tr16(plane + o + 4 * pc);
+    r.h.x = t0.x; r.h.y = t0.y; r.h.z = t1.x; r.h.w = t1.y;
+    t0 = rc_lds_read_tr16(plane + pl_elems + o); t1 = rc_lds_read_tr16(plane + pl_elems + o + 4 * pc);
+    r.l.x = t0.x; r.l.y = t0.y; r.l.z = t1.x; r.l.w = t1.y;
+    return r;
+  };
+  uint4 z4;
+  z4.x = z4.y = z4.z = z4.w = 0u;
+  const int wr8A = l31 * MX_PCA + 8 * half, wr2A = l31 * MX_PCA + 16 + 2 * half;
+  const int wr8B = l31 * MX_PCB + 8 * half, wr2B = l31 * MX_PCB + 16 + 2 * half;
+  unsigned short* pAmine = half ? pA2 : pA1;                 // where this half's a2 values go (columns 22..31)
+  const int tpb = (a.bs + 31) / 32, nbatch = (a.B + a.bs - 1) / a.bs, tpe = tpb * nbatch, T = tpe * a.epochs;
+    const int s = net / a.n_adv, adv = net - s * a.n_adv;
+    const int agent = a.agents[adv];
+    const long row = (long)s * a.N + agent;
+    float* th = a.theta + row * a.ldp;
+    const float* xg = a.x + (long)s * a.x_seed_stride;
+    const float* yv = a.y + row * a.ldb;
+    const int* perm = a.perm ? a.perm + ((long)s * a.n_adv + adv) * a.epochs * a.B : nullptr;
+    float amax = 0.f;                                        // largest |scaled operand| this lane formed
+    // ---- planes: constants once per network (ones column 20 of both A pairs as (1.0, 0); everything else zero)
+    RC_WAVE_SYNC();
+    for (int e = lane; e < MX_FRAG + 2 * MX_PA + 2 * MX_PB + 32; e += 64) frag[e] = 0;
+    RC_WAVE_SYNC();
+    if (lane < 32) { pA1[lane * MX_PCA + 20] = 0x3C00; pA2[lane * MX_PCA + 20] = 0x3C00; }
+    // ---- ownership: accumulator slot q of this lane is G[i = (q&3) + 8(q>>2) + 4 half][jj = l31] of G1 / G2
+    float wr1[16], wr2[16];                                  // fp32 masters of the owned parameters
+    // where the owner publishes them (packed to keep the wavefront under 256 registers): fragment elements (piece 0) of W2 in the
+    // z2 and da operands / of W1 in the z1 operand, fp32 slots in prm.  Slots that own nothing point at DUMMY targets: fragment row
+    // 31 (a padding row of the weight operand: it feeds accumulator rows nobody reads) and prm[62], prm[63].
+    unsigned pk0[16], pk1[16];                               // f1a | f1b << 16;  f2a | p1 << 16 | p2 << 24
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = (q & 3) + 8 * (q >> 2) + 4 * half, jj = l31;
+      int o1 = -1, o2 = -1;                                  // offsets into theta (Keras order)
+      int f1a = fdummy, f1b = fdummy, f2a = fdummy, p1 = 62, p2 = 63;
+      if (jj < HID) {
+        if (i < HID) {                                       // W2[m = i][unit = jj]
+          o1 = g.o_W2 + i * HID + jj;
+          f1a = mx_frag_elem(1, mx_row_of_unit(jj), mx_slot_of_unit(i));      // z2: A[row(unit)][slot(m)]
+          f1b = mx_frag_elem(2, mx_row_of_unit(i), mx_slot_of_unit(jj));      // da: A[row(m)][slot(unit)]
+        } else if (i == HID) { o1 = g.o_b2 + jj; p1 = HID + jj; }
+        if (i < in) { o2 = i * HID + jj; f2a = mx_frag_elem(0, mx_row_of_unit(jj), i); }   // W1[k = i][unit = jj]: slot = feature
+        else if (i == HID) { o2 = g.o_b1 + jj; p2 = jj; }
+      } else if (jj == HID) {
+        if (i == HID) { o1 = g.o_b3; p1 = 3 * HID; }
+        else if (i >= 22) {
+          const int lu = i < 24 ? 8 + (i - 22) : i - 24;
+          o1 = g.o_W3 + v8_unit(0, lu); p1 = 2 * HID + v8_unit(0, lu);
+          o2 = g.o_W3 + v8_unit(1, lu); p2 = 2 * HID + v8_unit(1, lu);
+        }
+      }
+      pk0[q] = (unsigned)f1a | ((unsigned)f1b << 16);
+      pk1[q] = (unsigned)f2a | ((unsigned)p1 << 16) | ((unsigned)p2 << 24);
+      wr1[q] = o1 >= 0 ? th[o1] : 0.f;
+      wr2[q] = o2 >= 0 ? th[o2] : 0.f;
+    }
+    // the owner's view -> fragments and fp32 parameters (also after every SGD step)
+    auto publish = [&]() {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        unsigned h1, l1;
+        rc_split2h_pair(wr1[q] * MX_S, wr2[q] * MX_S, h1, l1);  // low halves: wr1's pieces, high halves: wr2's
+        const int f1a = pk0[q] & 0xffffu, f1b = pk0[q] >> 16, f2a = pk1[q] & 0xffffu;
+        frag[f1a] = (unsigned short)h1; frag[f1a + 2 * 32 * 8] = (unsigned short)l1;
+        frag[f1b] = (unsigned short)h1; frag[f1b + 2 * 32 * 8] = (unsigned short)l1;
+        frag[f2a] = (unsigned short)(h1 >> 16); frag[f2a + 2 * 32 * 8] = (unsigned short)(l1 >> 16);
+        prm[(pk1[q] >> 16) & 0xffu] = wr1[q];
+        prm[pk1[q] >> 24] = wr2[q];
+        amax = fmaxf(amax, fmaxf(fabsf(wr1[q]), fabsf(wr2[q])) * MX_S);   // (biases and W3 too: conservative, branch-free)
+      }
+    };
+    RC_WAVE_SYNC();
+    publish();
+    RC_WAVE_SYNC();
+    rc_f32x16 g1, g2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { g1[q] = 0.f; g2[q] = 0.f; }
+    float loss_part = 0.f;
+    // Two dependent trips to L2 per tile -- its rows' shuffle indices, then the input rows and targets they name -- are taken one
+    // tile apart: while tile t runs, the ROWS of tile t+1 (index known) and the INDEX of tile t+2 are in flight: a single wavefront
+    // has nothing else to hide that latency with, and beside the cooperative agents' kernels it is several microseconds.
+    auto fetch_idx = [&](int t, int& bo, bool& vo) {
+      const int ep = t / tpe, w = t - ep * tpe, bi = w / tpb, lo = bi * a.bs;
+      const int nb = min(a.bs, a.B - lo), nrt = nb - (w - bi * tpb) * 32;
+      vo = l31 < nrt;
+      const int p = lo + (w - bi * tpb) * 32 + (vo ? l31 : 0);
+      bo = vo ? (perm ? perm[(long)ep * a.B + p] : p) : 0;
+    };
+    auto fetch_rows = [&](int b, bool vo, float (&xo)[NX], float& yo) {
+#pragma unroll
+      for (int e = 0; e < NX; ++e) {
+        const int k = 16 * (e >> 3) + 8 * half + (e & 7);   // this lane's contraction slots: features 8 half + e, 16 + 8 half + e
+        xo[e] = (vo && k < in) ? xg[(long)b * in + k] : 0.f;
+      }
+      yo = vo ? yv[b] : 0.f;
+    };
+    float xn[NX], ybn;
+    bool validn, valid2 = false;
+    int bn, b2 = 0;
+    fetch_idx(0, bn, validn);
+    fetch_rows(bn, validn, xn, ybn);
+    if (T > 1) fetch_idx(1, b2, valid2);
+    for (int t = 0; t < T; ++t) {
+      const int ep = t / tpe, w = t - ep * tpe, bi = w / tpb;
+      const int nb = min(a.bs, a.B - bi * a.bs);
+      const bool last_tile = (w - bi * tpb) == tpb - 1, last_of_epoch = w == tpe - 1;
+      float x[NX];
+#pragma unroll
+      for (int e = 0; e < NX; ++e) x[e] = xn[e];
+      const float yb = ybn;
+      const bool valid = validn;
+      if (t + 1 < T) {
+        validn = valid2;
+        fetch_rows(b2, valid2, xn, ybn);
+        if (t + 2 < T) fetch_idx(t + 2, b2, valid2);
+      }
+      // ---- layer 1: B = x pieces (also the main columns of the A2 planes)
+      V8Pieces px0, px1;
+      {
+        const float x0[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+        px0 = v8_split8<false>(x0, 1.f);
+        px1.h = z4; px1.l = z4;
+        if (KS1 == 2) {
+          rc_split2h_pair(x[NX - 8], x[NX - 7], px1.h.x, px1.l.x);
+          rc_split2h_pair(x[NX - 6], x[NX - 5], px1.h.y, px1.l.y);     // features 16..19 (half 0; zeros in half 1 and beyond in_dim)
+        }
+      }
+      RC_WAVE_SYNC();                                        // the previous tile's transposed reads are done
+      *reinterpret_cast<uint4*>(pA2 + wr8A) = px0.h;
+      *reinterpret_cast<uint4*>(pA2 + MX_PA / 2 + wr8A) = px0.l;
+      if (KS1 == 2 && half == 0) {
+        *reinterpret_cast<uint2*>(pA2 + l31 * MX_PCA + 16) = make_uint2(px1.h.x, px1.h.y);
+        *reinterpret_cast<uint2*>(pA2 + MX_PA / 2 + l31 * MX_PCA + 16) = make_uint2(px1.l.x, px1.l.y);
+      }
+      rc_f32x16 zz;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+      if (KS1 == 2) zz = v8_mfma4(loadA(0, 1), px1, zz);
+      zz = v8_mfma4(loadA(0, 0), px0, zz);
+      float a1[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) a1[u] = rc_lrelu(fmaf(zz[u], MX_US, prm[v8_unit(half, u)]));
+      // ---- layer 2
+      V8Pieces pa0, pa1;
+      {
+        const float x0[8] = {a1[0], a1[1], a1[2], a1[3], a1[4], a1[5], a1[6], a1[7]};
+        pa0 = v8_split8<false>(x0, 1.f);
+        pa1.h = z4; pa1.l = z4;
+        rc_split2h_pair(a1[8], a1[9], pa1.h.x, pa1.l.x);
+      }
+      *reinterpret_cast<uint4*>(pA1 + wr8A) = pa0.h;
+      *reinterpret_cast<uint4*>(pA1 + MX_PA / 2 + wr8A) = pa0.l;
+      *reinterpret_cast<unsigned*>(pA1 + wr2A) = pa1.h.x;
+      *reinterpret_cast<unsigned*>(pA1 + MX_PA / 2 + wr2A) = pa1.l.x;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+      zz = v8_mfma4(loadA(1, 1), pa1, zz);
+      zz = v8_mfma4(loadA(1, 0), pa0, zz);
+      float a2[LU], vp = 0.f;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) a2[u] = rc_lrelu(fmaf(zz[u], MX_US, prm[HID + v8_unit(half, u)]));
+#pragma unroll
+      for (int u = 0; u < LU; ++u) vp = fmaf(a2[u], prm[2 * HID + v8_unit(half, u)], vp);
+      float va = vp, vb = vp;
+      rc_swap32(va, vb);                                     // va: lanes 32-63 hold the low half's partial; vb: lanes 0-31 the high half's
+      const float v = (vp + (half ? va : vb)) + prm[3 * HID];
+      const float diff = valid ? v - yb : 0.f;
+      const float dvs = ((2.0f * diff) / (float)nb) * MX_S;   // dv'' = 2^10 dv
+      if (ep == 0 && half == 0) loss_part = fmaf(diff, diff, loss_part);
+      // a2 of this half -> columns 22..31 of its own A planes (local 8, 9 at 22, 23; local 0..7 at 24..31)
+      {
+        V8Pieces q0, q1;
+        const float x0[8] = {a2[0], a2[1], a2[2], a2[3], a2[4], a2[5], a2[6], a2[7]};
+        q0 = v8_split8<false>(x0, 1.f);
+        rc_split2h_pair(a2[8], a2[9], q1.h.x, q1.l.x);
+        *reinterpret_cast<uint4*>(pAmine + l31 * MX_PCA + 24) = q0.h;
+        *reinterpret_cast<uint4*>(pAmine + MX_PA / 2 + l31 * MX_PCA + 24) = q0.l;
+        *reinterpret_cast<unsigned*>(pAmine + l31 * MX_PCA + 22) = q1.h.x;
+        *reinterpret_cast<unsigned*>(pAmine + MX_PA / 2 + l31 * MX_PCA + 22) = q1.l.x;
+      }
+      float dz2[LU];                                           // 2^10 dz2
+#pragma unroll
+      for (int u = 0; u < LU; ++u) dz2[u] = dvs * prm[2 * HID + v8_unit(half, u)] * rc_lrelu_grad_from_act(a2[u]);
+      V8Pieces pd0, pd1;
+      {
+        const float x0[8] = {dz2[0], dz2[1], dz2[2], dz2[3], dz2[4], dz2[5], dz2[6], dz2[7]};
+        pd0 = v8_split8<false>(x0, 1.f);
+        pd1.h = z4; pd1.l = z4;
+        rc_split2h_pair(dz2[8], dz2[9], pd1.h.x, pd1.l.x);
+      }
+      unsigned dvh, dvl;
+      rc_split2h_pair(dvs, 0.f, dvh, dvl);
+      *reinterpret_cast<uint4*>(pB1 + wr8B) = pd0.h;
+      *reinterpret_cast<uint4*>(pB1 + MX_PB / 2 + wr8B) = pd0.l;
+      *reinterpret_cast<unsigned*>(pB1 + wr2B) = pd1.h.x;
+      *reinterpret_cast<unsigned*>(pB1 + MX_PB / 2 + wr2B) = pd1.l.x;
+      if (half == 0) {
+        pB1[l31 * MX_PCB + 20] = (unsigned short)dvh; pB1[MX_PB / 2 + l31 * MX_PCB + 20] = (unsigned short)dvl;
+        pB2[l31 * MX_PCB + 20] = (unsigned short)dvh; pB2[MX_PB / 2 + l31 * MX_PCB + 20] = (unsigned short)dvl;
+      }
+      // ---- layer 2 backward: dd = sum_j dz2''[j] W2''[m][j] = 2^20 da1
+      rc_f32x16 dd;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dd[q] = 0.f;
+      dd = v8_mfma4(loadA(2, 1), pd1, dd);
+      dd = v8_mfma4(loadA(2, 0), pd0, dd);
+      float dz1[LU];                                           // 2^10 dz1
+#pragma unroll
+      for (int u = 0; u < LU; ++u) dz1[u] = (dd[u] * MX_US) * rc_lrelu_grad_from_act(a1[u]);
+      {
+        V8Pieces q0, q1;
+        const float x0[8] = {dz1[0], dz1[1], dz1[2], dz1[3], dz1[4], dz1[5], dz1[6], dz1[7]};
+        q0 = v8_split8<false>(x0, 1.f);
+        rc_split2h_pair(dz1[8], dz1[9], q1.h.x, q1.l.x);
+        *reinterpret_cast<uint4*>(pB2 + wr8B) = q0.h;
+        *reinterpret_cast<uint4*>(pB2 + MX_PB / 2 + wr8B) = q0.l;
+        *reinterpret_cast<unsigned*>(pB2 + wr2B) = q1.h.x;
+        *reinterpret_cast<unsigned*>(pB2 + MX_PB / 2 + wr2B) = q1.l.x;
+      }
+#pragma unroll
+      for (int u = 0; u < LU; u += 2) {
+        amax = fmaxf(amax, fmaxf(fabsf(a1[u]), fabsf(a1[u + 1])));
+        amax = fmaxf(amax, fmaxf(fabsf(a2[u]), fabsf(a2[u + 1])));
+        amax = fmaxf(amax, fmaxf(fabsf(dz2[u]), fabsf(dz2[u + 1])));
+        amax = fmaxf(amax, fmaxf(fabsf(dz1[u]), fabsf(dz1[u + 1])));
+      }
+      amax = fmaxf(amax, fabsf(dvs));
+      // ---- the two gradient products over the tile's 32 rows (operands read back transposed)
+      RC_WAVE_SYNC();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const V8Pieces ra1 = readT(pA1, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb1 = readT(pB1, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);
+        const V8Pieces ra2 = readT(pA2, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb2 = readT(pB2, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);
+        g1 = rc_mfma_f16(ra1.l, rb1.l, g1); g2 = rc_mfma_f16(ra2.l, rb2.l, g2);
+        g1 = rc_mfma_f16(ra1.l, rb1.h, g1); g2 = rc_mfma_f16(ra2.l, rb2.h, g2);
+        g1 = rc_mfma_f16(ra1.h, rb1.l, g1); g2 = rc_mfma_f16(ra2.h, rb2.l, g2);
+        g1 = rc_mfma_f16(ra1.h, rb1.h, g1); g2 = rc_mfma_f16(ra2.h, rb2.h, g2);
+      }
+      if (last_tile) {
+        // ---- SGD step: the owner of a gradient slot holds the parameter's fp32 master and refreshes its broadcast copies
+        const float lrs = a.lr * MX_US;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          wr1[q] = wr1[q] - lrs * g1[q];
+          wr2[q] = wr2[q] - lrs * g2[q];
+          g1[q] = 0.f; g2[q] = 0.f;
+        }
+        RC_WAVE_SYNC();                                      // (the fragment reads of this tile are done)
+        publish();
+        RC_WAVE_SYNC();
+      }
+      if (ep == 0 && last_of_epoch && a.loss_out) {            // Keras History: first-epoch loss
+        float tl = loss_part;
+#pragma unroll
+        for (int mk = 16; mk >= 1; mk >>= 1) tl += __shfl_xor(tl, mk, 64);
+        if (lane == 0) a.loss_out[row] = tl / (float)a.B;
+      }
+    }
+    // ---- write back -- unless an operand left the f16 range anywhere in the wavefront: then the fp32 kernel redoes this network
+    float am = amax;
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) am = fmaxf(am, __shfl_xor(am, mk, 64));
+    if (am > MX_RANGE) {
+      if (lane == 0) ovf_flags[net] = ovf_gen;
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = (q & 3) + 8 * (q >> 2) + 4 * half, jj = l31;
+      int o1 = -1, o2 = -1;
+      if (jj < HID) {
+        if (i < HID) o1 = g.o_W2 + i * HID + jj; else if (i == HID) o1 = g.o_b2 + jj;
+        if (i < in) o2 = i * HID + jj; else if (i == HID) o2 = g.o_b1 + jj;
+      } else if (jj == HID) {
+        if (i == HID) o1 = g.o_b3;
+        else if (i >= 22) { const int lu = i < 24 ? 8 + (i - 22) : i - 24; o1 = g.o_W3 + v8_unit(0, lu); o2 = g.o_W3 + v8_unit(1, lu); }
+      }
+      if (o1 >= 0) th[o1] = wr1[q];
+      if (o2 >= 0) th[o2] = wr2[q];
+    }
+}
+
+template <int KS1>
+__global__ RC_MX_OCC void k_minibatch_mx(MbArgs a, int net0, int* __restrict__ ovf_flags, int ovf_gen) {
+  RCMARL_DYN_SMEM(unsigned char, smem);
+  mx_fit_net<KS1>(a, net0 + (int)blockIdx.x, smem, ovf_flags, ovf_gen);
+}
+
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
   const NetGeom g = make_geom(in_dim, hid, out);
   const int Ppad = (g.P + 3) & ~3;
   return sizeof(float) * ((size_t)2 * Ppad + TR * XLD + 4 * TR * hid + TR * out + TR) + sizeof(int) * TR;
+}
+
+// Out-of-range flags of k_minibatch_mx: one int per network, owned by the library, zeroed at allocation, marked and read with a
+// per-call generation number (as k_mid_fit_v8's, mid_kernels.hip): one host thread, one stream per call sequence... the adversaries'
+// three fits run on three streams, so every call draws a FRESH generation and a network's flag is only ever compared with the
+// generation of the call that may have set it; concurrent calls use disjoint thirds of the buffer (slot = generation % 3).
+struct MbFlags { int* buf = nullptr; size_t cap = 0; int gen = 0; };
+MbFlags g_mb_flags;
+int* mb_flags(size_t n, int& gen) {
+  MbFlags& f = g_mb_flags;
+  if (n > f.cap) {
+    const size_t cap = n > 16384 ? n : 16384;
+    int* nb = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&nb), 3 * cap * sizeof(int)) != hipSuccess || hipMemset(nb, 0, 3 * cap * sizeof(int)) != hipSuccess)
+      return nullptr;
+    if (f.buf) (void)hipFree(f.buf);
+    f.buf = nb; f.cap = cap; f.gen = 0;
+  }
+  f.gen = f.gen >= (1 << 30) ? 1 : f.gen + 1;
+  gen = f.gen;
+  return f.buf + (size_t)(f.gen % 3) * f.cap;
 }
 
 template <class K>
@@ -533,16 +909,34 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
   a.x = x; a.x_seed_stride = x_seed_stride; a.theta = theta; a.agents = agents; a.y = y; a.perm = perm;
   a.loss_out = loss_out; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb;
   a.bs = batch_size < B ? batch_size : B; a.epochs = epochs; a.n_adv = n_adv; a.lr = lr;
-  // <= 20 inputs (the reference's own 5-agent scenarios): one wavefront per network; wider inputs: one workgroup per network
+  // <= 20 inputs (the reference's own 5-agent scenarios): one wavefront per network -- on the f16 matrix core (k_minibatch_mx) with
+  // the fp32 wavefront kernel as the fix-up for networks that leave the f16 range, or (RCMARL_MB_MX=0) the fp32 kernel alone;
+  // wider inputs: one workgroup per network
   if (in_dim <= 20) {
     const int n_nets = n_adv * S;
     const size_t smem = (size_t)4 * WP_FLOATS * sizeof(float);
     static const bool attr_ok = rc_want_lds(k_minibatch_wave<16>, smem) && rc_want_lds(k_minibatch_wave<20>, smem);
     if (!attr_ok) return RCMARL_ERR_LAUNCH;
+    const int* flags = nullptr;
+    int gen = 0;
+    const char* e = getenv("RCMARL_MB_MX");
+    if (!(e && atoi(e) == 0)) {
+      int* fl = mb_flags((size_t)n_nets, gen);
+      if (!fl) return RCMARL_ERR_LAUNCH;
+      flags = fl;
+      if (in_dim <= 16) {
+        RCMARL_LAUNCH((k_minibatch_mx<1>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
+      } else {
+        RCMARL_LAUNCH((k_minibatch_mx<2>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
+      }
+    }
+    // alone: four networks per workgroup; as the fix-up: one (64 threads, 16 KB of LDS: it finds room beside anything and returns at once)
+    const int wpb = flags ? 1 : 4;
+    const size_t smem_w = (size_t)wpb * WP_FLOATS * sizeof(float);
     if (in_dim <= 16) {
-      RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
+      RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + wpb - 1) / wpb), dim3(64 * wpb), smem_w, stream, a, n_nets, flags, gen);
     } else {
-      RCMARL_LAUNCH((k_minibatch_wave<20>), dim3((n_nets + 3) / 4), dim3(256), smem, stream, a, n_nets);
+      RCMARL_LAUNCH((k_minibatch_wave<20>), dim3((n_nets + wpb - 1) / wpb), dim3(64 * wpb), smem_w, stream, a, n_nets, flags, gen);
     }
     return rcmarl_check_launch();
   }

@@ -207,3 +207,46 @@ __device__ __forceinline__ uint2 rc_lds_read_tr16(const unsigned short* p) {
   return __builtin_bit_cast(uint2, v);
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------
+// The "ten units per lane" form of a 20-unit layer on the 32x32x16 matrix core, shared by k_mid_fit_v8 (mid_kernels.hip) and the
+// adversaries' mini-batch fit (minibatch_fit.hip); the layout argument is in k_mid_fit_v8's header.  Lane (row j = lane&31,
+// half h = lane>>5) holds local units u = 0..9 of its row = global units v8_unit(h, u).
+__device__ __forceinline__ int v8_unit(int h, int u) { return u < 8 ? u + 8 * h : 16 + 2 * h + (u - 8); }
+// unit of accumulator / A-operand row i (0..31), or -1 (padding row)
+__device__ __forceinline__ int v8_row_unit(int i) {
+  const int h = (i >> 2) & 1, q = i >> 3, e = i & 3;
+  if (q < 2) return v8_unit(h, 4 * q + e);
+  return (q == 2 && e < 2) ? v8_unit(h, 8 + e) : -1;
+}
+// unit of contraction slot k (0..31), or -1
+__device__ __forceinline__ int v8_slot_unit(int k) {
+  if (k < 16) return v8_unit(k >> 3, k & 7);
+  const int h = (k - 16) >> 3, u = 8 + ((k - 16) & 7);
+  return u < 10 ? v8_unit(h, u) : -1;
+}
+
+struct V8Pieces { uint4 h, l; };
+__device__ __forceinline__ rc_f32x16 v8_mfma4(const V8Pieces& a, const V8Pieces& b, rc_f32x16 c) {
+  c = rc_mfma_f16(a.l, b.l, c);
+  c = rc_mfma_f16(a.l, b.h, c);
+  c = rc_mfma_f16(a.h, b.l, c);
+  c = rc_mfma_f16(a.h, b.h, c);
+  return c;
+}
+template <bool SCALED>
+__device__ __forceinline__ V8Pieces v8_split8(const float (&x)[8], float sc) {
+  V8Pieces p;
+  if (SCALED) {
+    rc_split2h_pair(x[0] * sc, x[1] * sc, p.h.x, p.l.x);
+    rc_split2h_pair(x[2] * sc, x[3] * sc, p.h.y, p.l.y);
+    rc_split2h_pair(x[4] * sc, x[5] * sc, p.h.z, p.l.z);
+    rc_split2h_pair(x[6] * sc, x[7] * sc, p.h.w, p.l.w);
+  } else {
+    rc_split2h_pair(x[0], x[1], p.h.x, p.l.x);
+    rc_split2h_pair(x[2], x[3], p.h.y, p.l.y);
+    rc_split2h_pair(x[4], x[5], p.h.z, p.l.z);
+    rc_split2h_pair(x[6], x[7], p.h.w, p.l.w);
+  }
+  return p;
+}

@@ -536,9 +536,15 @@ def check_rollout(bk, S, N, nrow, ncol, steps=6, mode="device"):
 
 
 # ------------------------------------------------------------------------------------------
-def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shuffle=True):
+def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shuffle=True, knife_edge_nets=0):
     """X1: whole mini-batch fit(batch_size, epochs) of the adversaries' critic/TR in one launch
-    vs oracle mlp_np.fit_mse with the same permutations."""
+    vs oracle mlp_np.fit_mse with the same permutations.
+    knife_edge_nets: that many networks may miss the 2e-5 bar, up to 1e-2.  The fp32 kernel repeats the oracle's fmaf chains, so a
+    pre-activation within rounding of zero takes the same LeakyReLU slope in both; the f16 matrix-core kernel (default) rounds its
+    products differently (operands to one fp32 ulp), so in a chain of hundreds of dependent SGD steps one such row can take the other
+    slope, and plain SGD on random targets amplifies that (tools/diag_mx.py: 1.2e-7 from the fp32 kernel after 282 steps in seven
+    cases of eight, 1.7e-3 in the eighth)."""
+    knife = set()
     rng = np.random.default_rng(S * 31 + N * 7 + B + in_dim)
     P, _ = geom(in_dim, 1)
     ldp, ldb = pad64(P), pad64(B)
@@ -567,9 +573,36 @@ def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shu
                              perms=perm[s, k] if shuffle else np.tile(np.arange(B), (epochs, 1)))
             got = unpack_row(th_new[s, n], in_dim, 1)
             for q in range(6):
-                rel_close(got[q], pw[q], 2e-5, "minibatch fit param %d" % q)
+                try:
+                    rel_close(got[q], pw[q], 2e-5, "minibatch fit param %d" % q)
+                except AssertionError:
+                    knife.add((s, n))
+                    rel_close(got[q], pw[q], 1e-2, "minibatch fit param %d (knife-edge allowance)" % q)
             assert abs(loss[s, n] - hist[0]) <= 2e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+    assert len(knife) <= knife_edge_nets, sorted(knife)
     return th_new, loss
+
+
+def run_minibatch_fit_with_blown_network(bk, S=1, N=5, B=96, in_dim=10, lr=0.01):
+    """One mini-batch fit of two adversaries' networks, the first with layer-2 weights of 100 (2^10 W beyond the f16 range) ->
+    (rows of the blown-up network, rows of the healthy one) after the fit."""
+    rng = np.random.default_rng(5)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    for s_ in range(S):
+        params[s_][1][2] *= np.float32(0) ; params[s_][1][2] += np.float32(100.0) * rng.choice([-1.0, 1.0], size=params[s_][1][2].shape).astype(np.float32)
+    theta = pack_rows(params, ldp)
+    x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    y = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    advs = np.asarray([1, 3], np.int32)
+    perm = np.stack([[[rng.permutation(B) for _ in range(2)] for _ in range(2)] for _ in range(S)]).astype(np.int32)
+    d_x, d_th, d_y, d_adv, d_perm = bk.dev(x), bk.dev(theta), bk.dev(y), bk.dev(advs), bk.dev(perm)
+    bk.lib.rcmarl_minibatch_fit(bk.ptr(d_x), B * in_dim, bk.ptr(d_th), bk.ptr(d_adv), 2, bk.ptr(d_y), bk.ptr(d_perm), S, N, B, in_dim,
+                                HID, ldp, ldb, 32, 2, lr, None, bk.stream)
+    th = bk.host(d_th)
+    assert not np.array_equal(th[:, 1], theta[:, 1]) and not np.array_equal(th[:, 3], theta[:, 3])      # both networks were fitted
+    return th[:, 1].copy(), th[:, 3].copy()
 
 
 def check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=200, lr=0.002, t0=0, shuffle=True):

@@ -89,6 +89,24 @@ def test_minibatch_fit(bk, S, N, B, in_dim, advs, bs, shuffle):
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=shuffle)
 
 
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(1, 5, 70, 15, [1, 3], 32, True), (3, 5, 50, 20, [0], 7, True)])
+def test_minibatch_fit_fp32_wavefront_kernel(bk, S, N, B, in_dim, advs, bs, shuffle, monkeypatch):
+    """RCMARL_MB_MX=0: k_minibatch_wave alone instead of k_minibatch_mx (f16 matrix core) + fix-up"""
+    monkeypatch.setenv("RCMARL_MB_MX", "0")
+    KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=shuffle)
+
+
+def test_minibatch_fit_out_of_range_network_is_redone_in_fp32(bk, monkeypatch):
+    import numpy as np
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RCMARL_MB_MX", mode)
+        res[mode] = KC.run_minibatch_fit_with_blown_network(bk)
+    np.testing.assert_array_equal(res["1"][0], res["0"][0])
+    assert not np.array_equal(res["1"][1], res["0"][1])
+    assert np.abs(res["1"][1] - res["0"][1]).max() <= 1e-5
+
+
 @pytest.mark.parametrize("S,N,B,in_dim,advs,bs,t0", [(2, 5, 100, 10, [4], 40, 0), (1, 3, 60, 6, [0, 2], 200, 7)])
 def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
     KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=B > bs)

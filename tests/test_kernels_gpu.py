@@ -96,7 +96,31 @@ def test_rollout(bk, S, N, nrow, ncol, mode):
                                                           (7, 6, 900, 18, [2, 5], 40, True), (9, 5, 333, 20, [0], 7, True),
                                                           (300, 5, 400, 15, [4], 32, True)])
 def test_minibatch_fit(bk, S, N, B, in_dim, advs, bs, shuffle):
+    """default: <= 20 inputs on the f16 matrix core (k_minibatch_mx + fp32 fix-up for out-of-range networks); one network of the
+    longest chains may sit on a LeakyReLU knife-edge (kernel_checks.check_minibatch_fit)"""
+    KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle, knife_edge_nets=1 if (in_dim <= 20 and B >= 900) else 0)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(2, 5, 1000, 10, [4], 32, True), (1, 5, 3000, 15, [1, 3], 32, True),
+                                                          (9, 5, 333, 20, [0], 7, True)])
+def test_minibatch_fit_fp32_wavefront_kernel(bk, S, N, B, in_dim, advs, bs, shuffle, monkeypatch):
+    """RCMARL_MB_MX=0: k_minibatch_wave alone (the oracle's fmaf chains: every network at the strict bar)"""
+    monkeypatch.setenv("RCMARL_MB_MX", "0")
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle)
+
+
+def test_minibatch_fit_out_of_range_network_is_redone_in_fp32(bk, monkeypatch):
+    """A network whose weights leave the f16 range (2^10 |W| > 65000) is flagged by k_minibatch_mx, not written back, and redone by
+    the fp32 kernel in the fix-up launch: its result equals RCMARL_MB_MX=0 bit for bit; the healthy network beside it is untouched
+    by the fix-up (its result differs from the fp32 kernel's in the last bits only)."""
+    import numpy as np
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RCMARL_MB_MX", mode)
+        res[mode] = KC.run_minibatch_fit_with_blown_network(bk)
+    np.testing.assert_array_equal(res["1"][0], res["0"][0])                       # the blown-up network: the fp32 kernel's bits
+    assert not np.array_equal(res["1"][1], res["0"][1])                           # the healthy one did run on the matrix core ...
+    assert np.abs(res["1"][1] - res["0"][1]).max() <= 1e-5                        # ... and agrees with the fp32 kernel
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,advs,bs,t0", [(2, 5, 1000, 10, [4], 200, 0), (1, 5, 1000, 10, [0, 2], 200, 15),
