@@ -179,7 +179,11 @@ int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float*
  * agents: int[n_adv] agent indices; the rows theta[s][agents[k]] are trained IN PLACE.
  * perm: int[S][n_adv][epochs][B] row permutation per epoch (Keras shuffle; NULL = natural order).
  * rcmarl_minibatch_fit: SGD + MSE against y[S][N][ldb]  -- Greedy/Malicious critic & TR fits,
- *   fit(batch_size=32, epochs=10), agents/adversarial_CAC_agents.py:121-165, 228-253.
+ *   fit(batch_size=32, epochs=10), agents/adversarial_CAC_agents.py:121-165, 228-253.  With <= 20 inputs every
+ *   product of a step runs on the f16 matrix core (two-piece f16 operands, fp32 masters and accumulation); a network
+ *   whose operands leave the f16 range is redone in fp32 arithmetic by a second launch (RCMARL_MB_MX=0: fp32 only).
+ *   The out-of-range flags live in a device buffer the library allocates at the first call; calls from up to three
+ *   streams may be in flight at once (the three fits of a Malicious agent).
  * rcmarl_minibatch_actor: Adam + sample-weighted sparse CE -- the adversaries' actor_update,
  *   fit(batch_size=200, epochs=1), :38-41, :111-117, :221-225.  t0 = Adam steps taken before this call.
  * loss_out[S][N] (or NULL): first-epoch loss. */
