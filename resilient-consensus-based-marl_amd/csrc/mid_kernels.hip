@@ -108,10 +108,10 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
                                                        const float* __restrict__ y, float* __restrict__ partials, int N,
                                                        int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
                                                        unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
-                                                       const int* __restrict__ fix_flags, int fix_gen) {
+                                                       const int* __restrict__ fix_flags, const int* __restrict__ fix_gen) {
   static_assert(HID == 20, "panel layout of the reduction product is written for 20 units");
   // fix-up launch behind k_mid_fit_v8 (rcmarl_mid_fit_lattice): only the agents whose operands left the f16 range there
-  if (fix_flags != nullptr && fix_flags[blockIdx.z * N + blockIdx.y] != fix_gen) return;
+  if (fix_flags != nullptr && fix_flags[blockIdx.z * N + blockIdx.y] != *fix_gen) return;
   typedef FitPart<HID> PT;
 // (rows per pass of the reduction product: 32; 16 halves the panels -- 22.7 instead of 39 KiB of LDS per workgroup --
 // and measured slower, 877 / 1071 against 857 / 985 us: occupancy is not limited by the LDS here)
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
                                                     const float* __restrict__ y, float* __restrict__ partials, int N,
                                                     int B, int in_dim, int ldp, int ldb, int nchunk, int cpw,
                                                     unsigned char* __restrict__ dzp, int dzp_rt, int dzp_kt,
-                                                    int* __restrict__ ovf_flags, int ovf_gen) {
+                                                    int* __restrict__ ovf_flags, const int* __restrict__ ovf_gen_p) {
   static_assert(HID == 20, "unit sets and panel layout are written for 20 units");
   typedef FitPart<HID> PT;
   constexpr int LU = 10;                               // units per lane
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   const float* th = theta + ((long)s * N + i) * ldp;
   const long row0 = ((long)s * N + i) * HID;
   rc_f16_saturate();
+  const int ovf_gen = *ovf_gen_p;                       // this launch pair's generation number (bumped on the device: see mid_flags)
   // ---- the agent's 2^10 W2 as f16 pieces in A-fragment order, both orientations (once per workgroup)
   {
     unsigned short* wf16 = reinterpret_cast<unsigned short*>(sWf);
@@ -1021,23 +1022,26 @@ bool midfit_v8() {
 }
 
 // Out-of-range flags of k_mid_fit_v8: one int per (seed, agent), owned by the library (the C-ABI hands no workspace over), zeroed at
-// allocation; a launch pair marks and reads them with its own generation number, so nothing is ever cleared.  Allocated at the first
-// call (65536 entries cover every BASELINE shape; a larger S*N reallocates) -- calls are expected from one host thread and one
-// stream at a time, as the engine issues them.
-struct MidFlags { int* buf = nullptr; size_t cap = 0; int gen = 0; };
+// allocation.  A launch pair marks and reads them with a GENERATION number that lives on the device beside them and is bumped by a
+// one-thread kernel in front of every pair: nothing is ever cleared, and a pair replayed from a captured hipGraph gets a fresh
+// number like an eager one (a number passed as a kernel argument would be frozen into the graph).  Allocated at the first call
+// (65536 entries cover every BASELINE shape; a larger S*N reallocates) -- calls are expected from one host thread and one stream at a
+// time, as the engine issues them.
+__global__ void k_bump_generation(int* g) { *g = *g >= (1 << 30) ? 1 : *g + 1; }
+struct MidFlags { int* buf = nullptr; size_t cap = 0; };
 MidFlags g_mid_flags;
-int* mid_flags(size_t n, int& gen) {
+int* mid_flags(size_t n, int*& gen_p, void* stream) {
   MidFlags& f = g_mid_flags;
   if (n > f.cap) {
     const size_t cap = n > 65536 ? n : 65536;
     int* nb = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&nb), cap * sizeof(int)) != hipSuccess || hipMemset(nb, 0, cap * sizeof(int)) != hipSuccess)
+    if (hipMalloc(reinterpret_cast<void**>(&nb), (cap + 1) * sizeof(int)) != hipSuccess || hipMemset(nb, 0, (cap + 1) * sizeof(int)) != hipSuccess)
       return nullptr;
     if (f.buf) (void)hipFree(f.buf);
-    f.buf = nb; f.cap = cap; f.gen = 0;
+    f.buf = nb; f.cap = cap;
   }
-  f.gen = f.gen >= (1 << 30) ? 1 : f.gen + 1;
-  gen = f.gen;
+  gen_p = f.buf + f.cap;
+  RCMARL_LAUNCH(k_bump_generation, dim3(1), dim3(1), 0, stream, gen_p);
   return f.buf;
 }
 
@@ -1065,7 +1069,7 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
   const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
   RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, false>), grid, block, 0, stream, a1t, theta, y, partials, N, B, in_dim,
-                                   ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, (const int*)nullptr, 0));
+                                   ldp, ldb, nchunk, cpw, (unsigned char*)nullptr, 0, 0, (const int*)nullptr, (const int*)nullptr));
   return rcmarl_check_launch();
 }
 
@@ -1077,23 +1081,23 @@ RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, c
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
   if (midfit_v8()) {
-    int gen = 0;
-    int* flags = mid_flags((size_t)S * N, gen);
+    int* gen = nullptr;
+    int* flags = mid_flags((size_t)S * N, gen, stream);
     if (!flags) return RCMARL_ERR_LAUNCH;
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v8<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
-                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, flags, gen));
+                                     partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, flags, (const int*)gen));
     // the fix-up: same grid, same records, same packed rows -- a workgroup whose agent is not flagged returns at once
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
                                      partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
-                                     (const int*)flags, gen));
+                                     (const int*)flags, (const int*)gen));
   } else if (rc_lat_f16_mode() & 2) {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
                                      partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
-                                     (const int*)nullptr, 0));
+                                     (const int*)nullptr, (const int*)nullptr));
   } else {
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v5<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
                                      partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt,
-                                     (const int*)nullptr, 0));
+                                     (const int*)nullptr, (const int*)nullptr));
   }
   return rcmarl_check_launch();
 }

@@ -521,6 +521,10 @@ class RPBCACEngine:
                           "sa": torch.tensor(LT.column_alpha(self.N, 3, c.nrow, c.ncol, c.scaling), **f32)}
         self.lat_alpha["ns"] = self.lat_alpha["s"]
         self.lat_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # the last next-state row of every episode (the TD target's own forward pass, _value_next_cached): a small image of its own
+        self.lat_geom_term = LT.Geometry(self.N, self.in_c, max(1, -(-self.cap // max(c.max_ep_len, 1))), self.hid["critic"])
+        self.lat_kp_term = u8(self.lat_geom_term.kp, 1)
+        self.lat_flag_term = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
     def _lattice_encode(self, B):
         """Once per update block: integer-lattice images of the replay tensors (rows 0..B)."""
@@ -981,8 +985,20 @@ class RPBCACEngine:
             idx = self._term_rows[key] = torch.arange(ep - 1, nrows, ep, device=self.dev)
         nt = idx.numel()
         ns_term = self.rp["ns"][:, row0:row0 + nrows].index_select(1, idx).contiguous()
-        L.rcmarl_layer1_forward(ns_term.data_ptr(), nt * self.in_c, th.data_ptr(), self.a1t.data_ptr(), S, N, nt, self.in_c, HID,
-                                self.ldp["critic"], self.ldb, self.stream)
+        if self.lat_active and self.shard is None and "s" in self.lat_wp_f and self.a1_cached["critic"]:
+            # on the lattice GEMM: the live critic's layer-1 pieces are what the consensus step's forward left in the weight operand
+            # (its hidden layers have not moved since), the rows are a subset of the ns rows _lattice_encode verified -- 60 us
+            # instead of 283 for the f32 kernel, which reads all of W1 for 150 rows
+            gt, gs = self.lat_geom_term, self.lat_geom["s"]
+            L.rcmarl_lattice_encode(ns_term.data_ptr(), nt * self.in_c, self.lat_alpha["s"].data_ptr(), S, nt, self.in_c,
+                                    self.lat_kp_term.data_ptr(), gt.kp[0], gt.kp[1], None, 0, 0, self.lat_flag_term.data_ptr(),
+                                    self.stream)
+            L.rcmarl_layer1_forward_lattice(self.lat_kp_term.data_ptr(), gt.kp[0], gt.kp[1], self.lat_wp_f["s"].data_ptr(), gs.wp[0],
+                                            gs.wp[1], th.data_ptr(), self.a1t.data_ptr(), S, N, nt, self.in_c, HID,
+                                            self.ldp["critic"], self.ldb, self.stream)
+        else:
+            L.rcmarl_layer1_forward(ns_term.data_ptr(), nt * self.in_c, th.data_ptr(), self.a1t.data_ptr(), S, N, nt, self.in_c, HID,
+                                    self.ldp["critic"], self.ldb, self.stream)
         L.rcmarl_mid_value(self.a1t.data_ptr(), th.data_ptr(), None, c.gamma, scratch.data_ptr(), S, N, nt, self.in_c, HID,
                            self.ldp["critic"], self.ldb, self.stream)
         if r_applied is None:
