@@ -8,17 +8,20 @@ import bench
 from rcmarl_amd import capi
 import torch
 
-w = bench.WORKLOADS[os.environ.get("WORKLOAD", "cfg4_shard")]
+w = dict(bench.WORKLOADS[os.environ.get("WORKLOAD", "cfg4_shard")])
+if os.environ.get("FAST_LR"):
+    w["fast_lr"] = float(os.environ["FAST_LR"])
 S = int(os.environ.get("SEEDS", w["S"]))
 blocks = int(os.environ.get("BLOCKS", "8"))
 lib = capi.load()
 for mode in os.environ.get("MODES", "3,0").split(","):
     os.environ["RCMARL_LAT_F16"] = mode
-    eng = bench.make_engine(w, S, list(range(1000, 1000 + S)), lib)
+    seed0 = int(os.environ.get("SEED0", "1000"))
+    eng = bench.make_engine(w, S, list(range(seed0, seed0 + S)), lib)
     for b in range(blocks):
         team, adv, est = eng.run_block()
         torch.cuda.synchronize()
-        line = "mode=%s block=%d B=%d lat=%s ret=%.3f" % (mode, b, eng.B, eng.lat_active, float(np.mean(team)))
+        line = "seed0=%d " % seed0 + "mode=%s block=%d B=%d lat=%s ret=%.3f" % (mode, b, eng.B, eng.lat_active, float(np.mean(team)))
         for net in ("critic", "tr", "actor"):
             x = eng.theta[net] if hasattr(eng, "theta") else None
             x = x.detach().float().cpu().numpy()
