@@ -519,11 +519,13 @@ ROOFLINE_KIND = {
                                           "division: VALU-bound at d=18 (343 instructions per 4 agents, VALU busy 77 % of the "
                                           "kernel: profiles/r02h_sq_counters_k1_circ_d18.json), toward HBM at d=4"),
     "rcmarl_mid_fit_lattice": ("hbm", "algorithmic bytes per (seed, agent, replay row): 20 fp32 activations read + 20 x 2 f16 "
-                               "dz1 pieces written = 160 B (RCMARL_LAT_F16=0: 20 x 3 bf16 pieces, 200 B); k_mid_fit_v5: layer 2 (4x4x1 sixteen-block MFMAs, results born row-per-lane) and the "
-                               "row reductions (32x32x2) as f32-input MFMAs.  Those execute ON the vector ALUs (measured in shader "
-                               "cycles: profiles/r03_pipe_overlap_cycles.txt), so the kernel's time is the SUM of its 232 f32 MFMAs, "
-                               "~500 VALU and ~190 LDS instructions per 64 rows, not its HBM traffic; the bf16 matrix-core form "
-                               "(k_mid_fit_v7, RCMARL_MIDFIT=7) measured 4 % slower (DESIGN.md section 5, Round 3)"),
+                               "dz1 pieces written = 160 B (RCMARL_LAT_F16=0: 20 x 3 bf16 pieces, 200 B); one API call = k_mid_fit_v8 (layers 2-3 "
+                               "and the row reduction as v_mfma_f32_32x32x16_f16 on two-piece f16 operands, four exact products per fp32 "
+                               "product) + a fix-up launch of the fp32 kernel k_mid_fit_v5 for agents whose operands left the f16 range "
+                               "(returns at once otherwise) + a one-thread generation bump.  Not HBM-bound: ~890 VALU + 48 MFMA + ~150 LDS "
+                               "instructions per 64 rows and wavefront, VALU ~57 % busy, wavefronts waiting 43 % of their cycles "
+                               "(profiles/r03u_sq_k_mid_fit_v8.json); the f32-input MFMA form it replaced (v5, RCMARL_MIDFIT=5) ran on the "
+                               "vector ALUs: 715-770 us (DESIGN.md section 5, Round 3)"),
     "rcmarl_minibatch_fit": ("mfma_f32", "the adversaries' fit(batch_size=32, epochs=10): 940 sequentially DEPENDENT SGD steps per "
                              "network, one wavefront per network (6 us per step): bound by the latency of one step, not by a pipe; "
                              "flops = 6 per weight per row"),

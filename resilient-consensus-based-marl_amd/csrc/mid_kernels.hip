@@ -492,22 +492,23 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
       const float v = (vp + (half ? va : vb)) + b3;
       const float diff = valid ? v - ycur : 0.f;
       const float dv = (2.0f * diff) / (float)B;
+      const float dvs = dv * RC_V8_S;
       if (half == 0) { gb3a += dv; lossa = fmaf(diff, diff, lossa); }   // (both lanes of a row hold the same v: count it once)
       float dz2l[LU];
 #pragma unroll
       for (int u = 0; u < LU; ++u) {
         gw3l[u] = fmaf(a2l[u], dv, gw3l[u]);
-        dz2l[u] = dv * sV[HID + v8_unit(half, u)] * rc_lrelu_grad_from_act(a2l[u]);
+        dz2l[u] = dvs * sV[HID + v8_unit(half, u)] * rc_lrelu_grad_from_act(a2l[u]);      // 2^10 dz2 (power-of-two scale: same bits as scaling afterwards)
       }
 #pragma unroll
-      for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, RC_V8_S * fmaxf(fabsf(dz2l[u]), fabsf(dz2l[u + 1])));
+      for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(dz2l[u]), fabsf(dz2l[u + 1])));
       // ---- layer 2 backward; the dz2 pieces also go to the B planes
       V8Pieces pd0, pd1;
       {
         const float x0[8] = {dz2l[0], dz2l[1], dz2l[2], dz2l[3], dz2l[4], dz2l[5], dz2l[6], dz2l[7]};
-        pd0 = v8_split8<true>(x0, RC_V8_S);
+        pd0 = v8_split8<false>(x0, 1.f);
         pd1.h = z4; pd1.l = z4;
-        rc_split2h_pair(dz2l[8] * RC_V8_S, dz2l[9] * RC_V8_S, pd1.h.x, pd1.l.x);
+        rc_split2h_pair(dz2l[8], dz2l[9], pd1.h.x, pd1.l.x);
       }
       *reinterpret_cast<uint4*>(pB + 0 * PLANE + wr8) = pd0.h;
       *reinterpret_cast<uint4*>(pB + 1 * PLANE + wr8) = pd0.l;
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
       float dz1l[LU];
 #pragma unroll
       for (int u = 0; u < LU; ++u) {
-        dz1l[u] = (dd[u] * (RC_V8_US * RC_V8_US)) * rc_lrelu_grad_from_act(a1l[u]);
+        dz1l[u] = (dd[u] * (RC_V8_US * RC_V8_US * (EMIT ? RC_F16_DZ_SCALE : 1.f))) * rc_lrelu_grad_from_act(a1l[u]);   // EMIT: 2^8 dz1, what the packed operand carries
         gb1l[u] += dz1l[u];
       }
       if (!EMIT) {
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
 #pragma unroll
         for (int q = 0; q < LU / 2; ++q) {
           unsigned ph, pl;
-          rc_split2h_pair(dz1l[2 * q] * RC_F16_DZ_SCALE, dz1l[2 * q + 1] * RC_F16_DZ_SCALE, ph, pl);   // bits 0-15: local unit 2q, bits 16-31: 2q+1
+          rc_split2h_pair(dz1l[2 * q], dz1l[2 * q + 1], ph, pl);             // bits 0-15: local unit 2q, bits 16-31: 2q+1
           const int u0 = v8_unit(half, 2 * q), u1 = v8_unit(half, 2 * q + 1);
           stg[(u0 * 2 + 0) * 32 + l31] = (unsigned short)ph;
           stg[(u0 * 2 + 1) * 32 + l31] = (unsigned short)pl;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
     {
       float sm[2 * LU + 4];
 #pragma unroll
-      for (int u = 0; u < LU; ++u) { sm[u] = gb1l[u]; sm[LU + u] = gw3l[u]; }
+      for (int u = 0; u < LU; ++u) { sm[u] = gb1l[u] * (EMIT ? RC_F16_DZ_UNSCALE : 1.f); sm[LU + u] = gw3l[u]; }
       sm[2 * LU] = gb3a; sm[2 * LU + 1] = lossa; sm[2 * LU + 2] = sm[2 * LU + 3] = 0.f;
 #pragma unroll
       for (int q = 0; q < (2 * LU + 4) / 3; ++q) rc_half_sum3_lane31(sm[3 * q], sm[3 * q + 1], sm[3 * q + 2]);
