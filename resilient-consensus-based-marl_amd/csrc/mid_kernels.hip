@@ -455,13 +455,18 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
     for (int blk = 0; blk < 2; ++blk) {
       const int b = chunk * ROWS + wave * 64 + 32 * blk + l31;
       const bool valid = b < B;
+      const int bc = valid ? b : B - 1;
       // ---- the lane's ten layer-1 activations of its row
       float a1l[LU];
 #pragma unroll
-      for (int u = 0; u < LU; ++u) a1l[u] = valid ? a1t[(row0 + v8_unit(half, u)) * ldb + b] : 0.f;
+      for (int u = 0; u < LU; ++u) {                       // unconditional loads from a clamped row (ten loads in flight, no exec-mask
+        const float av = a1t[(row0 + v8_unit(half, u)) * ldb + bc];      // branches), then the rows beyond B are zeroed
+        a1l[u] = valid ? av : 0.f;
+      }
 #pragma unroll
       for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(a1l[u]), fabsf(a1l[u + 1])));
-      const float ycur = valid ? yrow[b] : 0.f;
+      const float yv = yrow[bc];
+      const float ycur = valid ? yv : 0.f;
       // ---- layer 2 forward on the f16 matrix core; the a1 pieces also go to the A planes (operand of the row reduction)
       V8Pieces pa0, pa1;
       {
