@@ -866,9 +866,10 @@ size_t mb_smem_bytes(int in_dim, int hid, int out) {
 }
 
 // Out-of-range flags of k_minibatch_mx: one int per network, owned by the library, zeroed at allocation, marked and read with a
-// per-call generation number (as k_mid_fit_v8's, mid_kernels.hip): one host thread, one stream per call sequence... the adversaries'
-// three fits run on three streams, so every call draws a FRESH generation and a network's flag is only ever compared with the
-// generation of the call that may have set it; concurrent calls use disjoint thirds of the buffer (slot = generation % 3).
+// per-call generation number: one host thread.  The adversaries' three fits run on three streams beside the cooperative agents'
+// two, so every call draws a FRESH generation, a network's flag is only ever compared with the generation of the call that may have
+// set it, and up to eight calls in flight use disjoint slices of the buffer (slot = generation % 8).
+constexpr int MB_SLOTS = 8;
 struct MbFlags { int* buf = nullptr; size_t cap = 0; int gen = 0; };
 MbFlags g_mb_flags;
 int* mb_flags(size_t n, int& gen) {
@@ -876,14 +877,14 @@ int* mb_flags(size_t n, int& gen) {
   if (n > f.cap) {
     const size_t cap = n > 16384 ? n : 16384;
     int* nb = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&nb), 3 * cap * sizeof(int)) != hipSuccess || hipMemset(nb, 0, 3 * cap * sizeof(int)) != hipSuccess)
+    if (hipMalloc(reinterpret_cast<void**>(&nb), MB_SLOTS * cap * sizeof(int)) != hipSuccess || hipMemset(nb, 0, MB_SLOTS * cap * sizeof(int)) != hipSuccess)
       return nullptr;
     if (f.buf) (void)hipFree(f.buf);
     f.buf = nb; f.cap = cap; f.gen = 0;
   }
   f.gen = f.gen >= (1 << 30) ? 1 : f.gen + 1;
   gen = f.gen;
-  return f.buf + (size_t)(f.gen % 3) * f.cap;
+  return f.buf + (size_t)(f.gen % MB_SLOTS) * f.cap;
 }
 
 template <class K>

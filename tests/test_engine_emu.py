@@ -28,6 +28,17 @@ def test_engine_with_adversaries(labels):
     EC.compare(eng, logs, o_logs, o_w)
 
 
+@pytest.mark.parametrize("labels", [["Cooperative"] * 5, ["Cooperative"] * 4 + ["Malicious"], ["Cooperative", "Faulty", "Cooperative", "Cooperative", "Cooperative"]])
+def test_engine_local_fits_as_matrix_core_chains(labels, monkeypatch):
+    """RCMARL_FIT_CHAINS=1: the cooperative agents' 5-step full-batch local fits of the small networks through rcmarl_minibatch_fit
+    (batch_size = B, no shuffle: one matrix-core wavefront per network; the default from 1024 networks per launch on) vs the oracle."""
+    monkeypatch.setenv("RCMARL_FIT_CHAINS", "1")
+    args = EC.make_args(labels, H=1, n_episodes=6, max_ep_len=4, n_ep_fixed=2, n_epochs=2, buffer_size=16, seed=31)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(31, 32))
+    assert eng._fit_as_chains("critic", eng.coop) and eng._fit_as_chains("tr", eng.coop)
+    EC.compare(eng, logs, o_logs, o_w)
+
+
 @pytest.mark.parametrize("labels,nrow,ncol", [(["Cooperative"] * 5, 5, 5), (["Cooperative"] * 4 + ["Malicious"], 7, 4)])
 def test_engine_lattice_path_matches_oracle(labels, nrow, ncol):
     """Same end-to-end check with the layer-1 GEMMs forced onto the exact bf16x3 (lattice) kernels."""

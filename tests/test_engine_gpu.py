@@ -21,6 +21,18 @@ def test_engine_coop_H0_common_reward():
     EC.compare(eng, logs, o_logs, o_w)
 
 
+@pytest.mark.parametrize("labels", [["Cooperative"] * 5, ["Cooperative"] * 4 + ["Malicious"], ["Cooperative", "Faulty", "Cooperative", "Cooperative", "Cooperative"]])
+def test_engine_local_fits_as_matrix_core_chains(labels, monkeypatch):
+    """RCMARL_FIT_CHAINS=1: the cooperative agents' 5-step full-batch local fits of the small networks through rcmarl_minibatch_fit
+    (batch_size = B, no shuffle: one matrix-core wavefront per network, activations never leave the registers; the default from
+    1024 networks per launch on -- the batched BASELINE configs[0] / [1] workloads) vs the oracle, steady-state buffer included."""
+    monkeypatch.setenv("RCMARL_FIT_CHAINS", "1")
+    args = EC.make_args(labels, H=1, n_episodes=45, max_ep_len=20, n_ep_fixed=10, n_epochs=3, buffer_size=400, seed=100)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cuda", None, seeds=(100, 200, 300))
+    assert eng._fit_as_chains("critic", eng.coop) and eng._fit_as_chains("tr", eng.coop)
+    EC.compare(eng, logs, o_logs, o_w)
+
+
 def test_engine_12_agents_H2():
     n = 12
     in_nodes = [[(i + k) % n for k in range(6)] for i in range(n)]
