@@ -1093,8 +1093,24 @@ class RPBCACEngine:
         # agents' local fits: they touch disjoint parameter rows and meet again at the consensus step
         self._td_target(B)
         join = self._adversary_messages_async(B)
-        self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
-        self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+        if self.dev.type == "cuda" and self._fit_as_chains("tr", self.coop) and self._fit_as_chains("critic", self.coop):
+            # both fits are chains of one wavefront per network (disjoint buffers): side by side they fill the GPU's wavefront
+            # slots in 3.3 rounds instead of 2 + 2
+            if getattr(self, "chain_stream", None) is None:
+                self.chain_stream = torch.cuda.Stream(device=self.dev)
+            main = torch.cuda.current_stream(self.dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self.chain_stream.wait_event(fork)
+            with torch.cuda.stream(self.chain_stream):
+                self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+                tr_done = torch.cuda.Event()
+                tr_done.record(self.chain_stream)
+            self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
+            main.wait_event(tr_done)
+        else:
+            self._local_fit("tr", "sa", self.ybuf["r_fit"], B, self.coop)
+            self._local_fit("critic", "s", self.ybuf["y_c"], B, self.coop)
         if join is not None:
             torch.cuda.current_stream(self.dev).wait_event(join)
         t0 = self._timed("phase1", t0)
