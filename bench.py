@@ -449,7 +449,10 @@ def main(argv=None):
             "value": agent_steps / dt, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if one_instance else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not stub else "STUB ENGINE (control-path test, not a measurement)",
+            "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "fp32 parameters, activations and accumulation throughout; the matrix-core products of Phase I take their fp32 "
+                          "operands as two f16 pieces (the value to one unit in its last place, RCMARL_LAT_F16) or, =0, three exact bf16 pieces",
+            "data": "synthetic" if not stub else "STUB ENGINE (control-path test, not a measurement)",
             "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
                        "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady, "fast_lr": c.fast_lr, "slow_lr": c.slow_lr, "weights_finite": finite,
                        "env_steps_per_block": env_steps, "n_epochs": c.n_epochs, "hidden": 20, "critic_hidden": c.critic_hid,
