@@ -28,7 +28,7 @@ def test_engine_with_adversaries(labels):
     EC.compare(eng, logs, o_logs, o_w)
 
 
-@pytest.mark.parametrize("labels", [["Cooperative"] * 5, ["Cooperative"] * 4 + ["Malicious"], ["Cooperative", "Faulty", "Cooperative", "Cooperative", "Cooperative"]])
+@pytest.mark.parametrize("labels", [["Cooperative"] * 5, ["Cooperative", "Faulty", "Cooperative", "Cooperative", "Malicious"]])
 def test_engine_local_fits_as_matrix_core_chains(labels, monkeypatch):
     """RCMARL_FIT_CHAINS=1: the cooperative agents' 5-step full-batch local fits of the small networks through rcmarl_minibatch_fit
     (batch_size = B, no shuffle: one matrix-core wavefront per network; the default from 1024 networks per launch on) vs the oracle."""
@@ -83,7 +83,8 @@ def test_engine_wide_critic_with_greedy_and_malicious_agents_matches_oracle(labe
 
 @pytest.mark.parametrize("labels,rng_mode", [(["Cooperative"] * 4 + ["Greedy"], "device"), (["Cooperative"] * 5, "numpy")])
 def test_checkpoint_resume_is_bit_identical(labels, rng_mode, tmp_path):
-    EC.check_checkpoint_resume(labels, rng_mode, "cpu", emu_lib(), str(tmp_path / "ck.pt"), blocks=(1, 1))     # (1, 2) on the GPU
+    # (the emulated lattice GEMMs are slow and have their own tests: one of the two runs stays off them; (1, 2) blocks on the GPU)
+    EC.check_checkpoint_resume(labels, rng_mode, "cpu", emu_lib(), str(tmp_path / "ck.pt"), blocks=(1, 1), lattice=rng_mode == "device")
 
 
 def test_engine_buffer_not_a_multiple_of_the_episode_length():
