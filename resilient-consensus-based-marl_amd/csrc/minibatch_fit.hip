@@ -528,42 +528,73 @@ constexpr int MX_FRAG = 3 * 2 * 2 * 2 * 32 * 8;                  // [product][k-
 constexpr int MX_PA = 2 * 32 * MX_PCA, MX_PB = 2 * 32 * MX_PCB;  // one A / B plane pair (two pieces)
 constexpr int MX_F16 = MX_FRAG + 2 * MX_PA + 2 * MX_PB + 32;     // + pad: a transposed read of B columns 24..31 of the last row
 constexpr int MX_PARAMS = 64;                                    // fp32: b1[20] | b2[20] | W3[20] | b3 | two dummy slots
-constexpr size_t MX_BYTES = (size_t)MX_F16 * 2 + MX_PARAMS * 4;  // 26 944 B per wavefront
+constexpr size_t MX_BYTES = (size_t)MX_F16 * 2 + MX_PARAMS * 4;  // 26 944 B per wavefront: six per CU
+// COMPACT form (more networks than the GPU has wavefront slots: the cooperative agents' full-batch fits of 512 seeds): k-step 1 of
+// the weight operands holds 4 (z1: features 16..19) or 2 (z2, da: local units 8, 9) slots per k-group and is stored as such, and
+// the B planes of G2 overwrite those of G1 -> 19 264 B: EIGHT wavefronts per CU, at the price of G1 and G2 no longer interleaving.
+constexpr int MX_CF0 = 3 * 2 * 2 * 32 * 8;                       // k-step 0: [product][piece][k-group][row] x 8 f16
+constexpr int MX_CF1 = 2 * 32 * 4;                               // k-step 1 of z1: [piece][row] x 4 f16 (k-group 0 only)
+constexpr int MX_CF2 = 2 * 2 * 2 * 32 * 2;                       // k-step 1 of z2, da: [product][piece][k-group][row] x 2 f16
+constexpr int MX_CFRAG = MX_CF0 + MX_CF1 + MX_CF2;
+constexpr int MX_CF16 = MX_CFRAG + 2 * MX_PA + MX_PB + 32;
+constexpr size_t MX_CBYTES = (size_t)MX_CF16 * 2 + MX_PARAMS * 4;
 #define MX_S 1024.f
 #define MX_US 0.0009765625f
 #define MX_RANGE 65000.f
 
 __device__ __forceinline__ int mx_row_of_unit(int u) { return u < 16 ? 8 * ((u & 7) >> 2) + 4 * (u >> 3) + (u & 3) : 16 + 4 * ((u - 16) >> 1) + ((u - 16) & 1); }
 __device__ __forceinline__ int mx_slot_of_unit(int u) { return u < 16 ? u : 16 + 8 * ((u - 16) >> 1) + ((u - 16) & 1); }
-__device__ __forceinline__ int mx_frag_elem(int prod, int ri, int k) {      // f16 index of piece 0; piece 1 is 2*32*8 further
-  return ((((prod * 2 + (k >> 4)) * 2 + 0) * 2 + ((k >> 3) & 1)) * 32 + ri) * 8 + (k & 7);
+template <bool COMPACT>
+__device__ __forceinline__ int mx_frag_elem(int prod, int ri, int k) {      // f16 index of piece 0; piece 1: mx_piece1() further
+  const int kg = (k >> 3) & 1;
+  if (!COMPACT) return ((((prod * 2 + (k >> 4)) * 2 + 0) * 2 + kg) * 32 + ri) * 8 + (k & 7);
+  if (k < 16) return (((prod * 2 + 0) * 2 + kg) * 32 + ri) * 8 + (k & 7);
+  if (prod == 0) return MX_CF0 + ri * 4 + (k & 3);                             // features 16..19
+  return MX_CF0 + MX_CF1 + ((((prod - 1) * 2 + 0) * 2 + kg) * 32 + ri) * 2 + (k & 1);
 }
+template <bool COMPACT>
+__device__ __forceinline__ int mx_piece1(int elem) { return !COMPACT ? 2 * 32 * 8 : (elem < MX_CF0 ? 2 * 32 * 8 : 128); }
 
 #ifdef RCMARL_EMU
 #define RC_MX_OCC
 #else
 #define RC_MX_OCC __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2)))   // <= 256 registers
 #endif
-template <int KS1>                                           // k-steps of layer 1: 1 (<= 16 inputs) or 2 (<= 20)
+template <int KS1, bool COMPACT>                             // k-steps of layer 1: 1 (<= 16 inputs) or 2 (<= 20)
 __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned char* smem, int* __restrict__ ovf_flags, int ovf_gen) {
   constexpr int HID = 20, LU = 10, NX = 8 * KS1;
   const int lane = threadIdx.x & 63;
   unsigned short* frag = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* pA1 = frag + MX_FRAG;                      // [piece][row][32]: a1 (0..19) | 1 (20) | 0 (21) | a2 of half 0: local 8,9 (22,23), 0..7 (24..31)
+  constexpr int NFRAG = COMPACT ? MX_CFRAG : MX_FRAG;
+  unsigned short* pA1 = frag + NFRAG;                        // [piece][row][32]: a1 (0..19) | 1 (20) | 0 (21) | a2 of half 0: local 8,9 (22,23), 0..7 (24..31)
   unsigned short* pA2 = pA1 + MX_PA;                         // [piece][row][32]: x  (0..19) | 1 (20) | 0 (21) | a2 of half 1
   unsigned short* pB1 = pA2 + MX_PA;                         // [piece][row][24]: dz2'' (0..19) | dv'' (20)
-  unsigned short* pB2 = pB1 + MX_PB;                         // [piece][row][24]: dz1'' (0..19) | dv'' (20)
-  float* prm = reinterpret_cast<float*>(smem + (size_t)MX_F16 * 2);       // b1 | b2 | W3 | b3
+  unsigned short* pB2 = COMPACT ? pB1 : pB1 + MX_PB;         // [piece][row][24]: dz1'' (0..19) | dv'' (20)   (COMPACT: over G1's)
+  float* prm = reinterpret_cast<float*>(smem + (size_t)(COMPACT ? MX_CF16 : MX_F16) * 2);       // b1 | b2 | W3 | b3
   const int in = a.in_dim;
   const NetGeom g = make_geom(in, HID, 1);
   const int l31 = lane & 31, half = lane >> 5;
   rc_f16_saturate();
-  const int fdummy = mx_frag_elem(0, 31, 0);
-  const uint4* wfA = reinterpret_cast<const uint4*>(frag) + half * 32 + l31;    // + ((prod*2 + ks)*2 + piece) * 64
+  const int fdummy = mx_frag_elem<COMPACT>(0, 31, 0);
+  const uint4* wfA = reinterpret_cast<const uint4*>(frag) + half * 32 + l31;    // + ((prod*2 + ks)*2 + piece) * 64  (COMPACT: (prod*2 + piece) * 64)
   auto loadA = [&](int prod, int ks) {
     V8Pieces f;
-    f.h = wfA[((prod * 2 + ks) * 2 + 0) * 64];
-    f.l = wfA[((prod * 2 + ks) * 2 + 1) * 64];
+    if (!COMPACT) {
+      f.h = wfA[((prod * 2 + ks) * 2 + 0) * 64];
+      f.l = wfA[((prod * 2 + ks) * 2 + 1) * 64];
+    } else if (ks == 0) {
+      f.h = wfA[(prod * 2 + 0) * 64];
+      f.l = wfA[(prod * 2 + 1) * 64];
+    } else if (prod == 0) {                                  // features 16..19: k-group 0 only
+      const uint2* q = reinterpret_cast<const uint2*>(frag + MX_CF0) + l31;
+      const uint2 vh = q[0], vl = q[32];
+      f.h.x = half ? 0u : vh.x; f.h.y = half ? 0u : vh.y; f.h.z = 0u; f.h.w = 0u;
+      f.l.x = half ? 0u : vl.x; f.l.y = half ? 0u : vl.y; f.l.z = 0u; f.l.w = 0u;
+    } else {                                                 // local units 8, 9 of the k-group
+      const unsigned* q = reinterpret_cast<const unsigned*>(frag + MX_CF0 + MX_CF1) + (((prod - 1) * 2 + 0) * 2 + half) * 32 + l31;
+      f.h.x = q[0]; f.h.y = 0u; f.h.z = 0u; f.h.w = 0u;
+      f.l.x = q[64]; f.l.y = 0u; f.l.z = 0u; f.l.w = 0u;
+    }
     return f;
   };
   const int trA = (8 * half + ((lane & 15) >> 2)) * MX_PCA + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -592,7 +623,7 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
     float amax = 0.f;                                        // largest |scaled operand| this lane formed
     // ---- planes: constants once per network (ones column 20 of both A pairs as (1.0, 0); everything else zero)
     RC_WAVE_SYNC();
-    for (int e = lane; e < MX_FRAG + 2 * MX_PA + 2 * MX_PB + 32; e += 64) frag[e] = 0;
+    for (int e = lane; e < (COMPACT ? MX_CF16 : MX_F16); e += 64) frag[e] = 0;
     RC_WAVE_SYNC();
     if (lane < 32) { pA1[lane * MX_PCA + 20] = 0x3C00; pA2[lane * MX_PCA + 20] = 0x3C00; }
     // ---- ownership: accumulator slot q of this lane is G[i = (q&3) + 8(q>>2) + 4 half][jj = l31] of G1 / G2
@@ -609,10 +640,10 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
       if (jj < HID) {
         if (i < HID) {                                       // W2[m = i][unit = jj]
           o1 = g.o_W2 + i * HID + jj;
-          f1a = mx_frag_elem(1, mx_row_of_unit(jj), mx_slot_of_unit(i));      // z2: A[row(unit)][slot(m)]
-          f1b = mx_frag_elem(2, mx_row_of_unit(i), mx_slot_of_unit(jj));      // da: A[row(m)][slot(unit)]
+          f1a = mx_frag_elem<COMPACT>(1, mx_row_of_unit(jj), mx_slot_of_unit(i));      // z2: A[row(unit)][slot(m)]
+          f1b = mx_frag_elem<COMPACT>(2, mx_row_of_unit(i), mx_slot_of_unit(jj));      // da: A[row(m)][slot(unit)]
         } else if (i == HID) { o1 = g.o_b2 + jj; p1 = HID + jj; }
-        if (i < in) { o2 = i * HID + jj; f2a = mx_frag_elem(0, mx_row_of_unit(jj), i); }   // W1[k = i][unit = jj]: slot = feature
+        if (i < in) { o2 = i * HID + jj; f2a = mx_frag_elem<COMPACT>(0, mx_row_of_unit(jj), i); }   // W1[k = i][unit = jj]: slot = feature
         else if (i == HID) { o2 = g.o_b1 + jj; p2 = jj; }
       } else if (jj == HID) {
         if (i == HID) { o1 = g.o_b3; p1 = 3 * HID; }
@@ -634,9 +665,9 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
         unsigned h1, l1;
         rc_split2h_pair(wr1[q] * MX_S, wr2[q] * MX_S, h1, l1);  // low halves: wr1's pieces, high halves: wr2's
         const int f1a = pk0[q] & 0xffffu, f1b = pk0[q] >> 16, f2a = pk1[q] & 0xffffu;
-        frag[f1a] = (unsigned short)h1; frag[f1a + 2 * 32 * 8] = (unsigned short)l1;
-        frag[f1b] = (unsigned short)h1; frag[f1b + 2 * 32 * 8] = (unsigned short)l1;
-        frag[f2a] = (unsigned short)(h1 >> 16); frag[f2a + 2 * 32 * 8] = (unsigned short)(l1 >> 16);
+        frag[f1a] = (unsigned short)h1; frag[f1a + mx_piece1<COMPACT>(f1a)] = (unsigned short)l1;
+        frag[f1b] = (unsigned short)h1; frag[f1b + mx_piece1<COMPACT>(f1b)] = (unsigned short)l1;
+        frag[f2a] = (unsigned short)(h1 >> 16); frag[f2a + mx_piece1<COMPACT>(f2a)] = (unsigned short)(l1 >> 16);
         prm[(pk1[q] >> 16) & 0xffu] = wr1[q];
         prm[pk1[q] >> 24] = wr2[q];
         amax = fmaxf(amax, fmaxf(fabsf(wr1[q]), fabsf(wr2[q])) * MX_S);   // (biases and W3 too: conservative, branch-free)
@@ -780,16 +811,19 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
       float dz1[LU];                                           // 2^10 dz1
 #pragma unroll
       for (int u = 0; u < LU; ++u) dz1[u] = (dd[u] * MX_US) * rc_lrelu_grad_from_act(a1[u]);
+      V8Pieces qd0, qd1;
       {
-        V8Pieces q0, q1;
         const float x0[8] = {dz1[0], dz1[1], dz1[2], dz1[3], dz1[4], dz1[5], dz1[6], dz1[7]};
-        q0 = v8_split8<false>(x0, 1.f);
-        rc_split2h_pair(dz1[8], dz1[9], q1.h.x, q1.l.x);
-        *reinterpret_cast<uint4*>(pB2 + wr8B) = q0.h;
-        *reinterpret_cast<uint4*>(pB2 + MX_PB / 2 + wr8B) = q0.l;
-        *reinterpret_cast<unsigned*>(pB2 + wr2B) = q1.h.x;
-        *reinterpret_cast<unsigned*>(pB2 + MX_PB / 2 + wr2B) = q1.l.x;
+        qd0 = v8_split8<false>(x0, 1.f);
+        rc_split2h_pair(dz1[8], dz1[9], qd1.h.x, qd1.l.x);
       }
+      auto write_dz1 = [&]() {
+        *reinterpret_cast<uint4*>(pB2 + wr8B) = qd0.h;
+        *reinterpret_cast<uint4*>(pB2 + MX_PB / 2 + wr8B) = qd0.l;
+        *reinterpret_cast<unsigned*>(pB2 + wr2B) = qd1.h.x;
+        *reinterpret_cast<unsigned*>(pB2 + MX_PB / 2 + wr2B) = qd1.l.x;
+      };
+      if (!COMPACT) write_dz1();
 #pragma unroll
       for (int u = 0; u < LU; u += 2) {
         amax = fmaxf(amax, fmaxf(fabsf(a1[u]), fabsf(a1[u + 1])));
@@ -800,14 +834,28 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
       amax = fmaxf(amax, fabsf(dvs));
       // ---- the two gradient products over the tile's 32 rows (operands read back transposed)
       RC_WAVE_SYNC();
+      if (!COMPACT) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const V8Pieces ra1 = readT(pA1, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb1 = readT(pB1, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);
-        const V8Pieces ra2 = readT(pA2, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb2 = readT(pB2, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);
-        g1 = rc_mfma_f16(ra1.l, rb1.l, g1); g2 = rc_mfma_f16(ra2.l, rb2.l, g2);
-        g1 = rc_mfma_f16(ra1.l, rb1.h, g1); g2 = rc_mfma_f16(ra2.l, rb2.h, g2);
-        g1 = rc_mfma_f16(ra1.h, rb1.l, g1); g2 = rc_mfma_f16(ra2.h, rb2.l, g2);
-        g1 = rc_mfma_f16(ra1.h, rb1.h, g1); g2 = rc_mfma_f16(ra2.h, rb2.h, g2);
+        for (int ks = 0; ks < 2; ++ks) {
+          const V8Pieces ra1 = readT(pA1, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb1 = readT(pB1, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);
+          const V8Pieces ra2 = readT(pA2, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb2 = readT(pB2, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);
+          g1 = rc_mfma_f16(ra1.l, rb1.l, g1); g2 = rc_mfma_f16(ra2.l, rb2.l, g2);
+          g1 = rc_mfma_f16(ra1.l, rb1.h, g1); g2 = rc_mfma_f16(ra2.l, rb2.h, g2);
+          g1 = rc_mfma_f16(ra1.h, rb1.l, g1); g2 = rc_mfma_f16(ra2.h, rb2.l, g2);
+          g1 = rc_mfma_f16(ra1.h, rb1.h, g1); g2 = rc_mfma_f16(ra2.h, rb2.h, g2);
+        }
+      } else {
+        V8Pieces rb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) rb[ks] = readT(pB1, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);   // G1's B operand leaves the LDS ...
+        RC_WAVE_SYNC();
+        write_dz1();                                                                                       // ... before G2's takes its place
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) g1 = v8_mfma4(readT(pA1, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb[ks], g1);
+        RC_WAVE_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          g2 = v8_mfma4(readT(pA2, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), readT(pB2, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB), g2);
       }
       if (last_tile) {
         // ---- SGD step: the owner of a gradient slot holds the parameter's fp32 master and refreshes its broadcast copies
@@ -853,10 +901,10 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
     }
 }
 
-template <int KS1>
+template <int KS1, bool COMPACT>
 __global__ RC_MX_OCC void k_minibatch_mx(MbArgs a, int net0, int* __restrict__ ovf_flags, int ovf_gen) {
   RCMARL_DYN_SMEM(unsigned char, smem);
-  mx_fit_net<KS1>(a, net0 + (int)blockIdx.x, smem, ovf_flags, ovf_gen);
+  mx_fit_net<KS1, COMPACT>(a, net0 + (int)blockIdx.x, smem, ovf_flags, ovf_gen);
 }
 
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
@@ -925,10 +973,19 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
       int* fl = mb_flags((size_t)n_nets, gen);
       if (!fl) return RCMARL_ERR_LAUNCH;
       flags = fl;
-      if (in_dim <= 16) {
-        RCMARL_LAUNCH((k_minibatch_mx<1>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
+      // more networks than wavefront slots at six per CU: the compact form (eight per CU)
+      const char* ce = getenv("RCMARL_MB_MX_COMPACT");
+      const bool compact = ce ? atoi(ce) != 0 : n_nets > 1536;
+      if (compact) {
+        if (in_dim <= 16) {
+          RCMARL_LAUNCH((k_minibatch_mx<1, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl, gen);
+        } else {
+          RCMARL_LAUNCH((k_minibatch_mx<2, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl, gen);
+        }
+      } else if (in_dim <= 16) {
+        RCMARL_LAUNCH((k_minibatch_mx<1, false>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
       } else {
-        RCMARL_LAUNCH((k_minibatch_mx<2>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
+        RCMARL_LAUNCH((k_minibatch_mx<2, false>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
       }
     }
     // alone: four networks per workgroup; as the fix-up: one (64 threads, 16 KB of LDS: it finds room beside anything and returns at once)

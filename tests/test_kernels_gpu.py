@@ -109,6 +109,15 @@ def test_minibatch_fit_fp32_wavefront_kernel(bk, S, N, B, in_dim, advs, bs, shuf
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle)
 
 
+@pytest.mark.parametrize("S,N,B,in_dim,advs,bs,shuffle", [(2, 5, 1000, 10, [4], 32, True), (9, 5, 333, 20, [0], 7, True), (300, 5, 400, 15, [0, 1, 2, 3, 4], 400, False), (7, 6, 900, 18, [2, 5], 900, False)])
+def test_minibatch_fit_compact_form(bk, S, N, B, in_dim, advs, bs, shuffle, monkeypatch):
+    """RCMARL_MB_MX_COMPACT=1: k_minibatch_mx with the short k-step-1 weight fragments and ONE B plane pair for both gradient
+    products (eight wavefronts per CU; the default from 1537 networks per launch on), mini-batches and full batches (bs = B:
+    the cooperative agents' local fit, engine._fit_as_chains)."""
+    monkeypatch.setenv("RCMARL_MB_MX_COMPACT", "1")
+    KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle, knife_edge_nets=1 if B >= 900 else 0)
+
+
 def test_minibatch_fit_out_of_range_network_is_redone_in_fp32(bk, monkeypatch):
     """A network whose weights leave the f16 range (2^10 |W| > 65000) is flagged by k_minibatch_mx, not written back, and redone by
     the fp32 kernel in the fix-up launch: its result equals RCMARL_MB_MX=0 bit for bit; the healthy network beside it is untouched
