@@ -583,6 +583,23 @@ def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shu
     return th_new, loss
 
 
+def check_shuffle_perms(bk, seeds, calls, epochs, B):
+    """rcmarl_shuffle_perms (csrc/shuffle.hip: per permutation a bucket sort of the Philox keys) against the oracle's ShuffleStream
+    (argsort of the same keys, ties to the lower row): every entry equal."""
+    from oracle.rpbcac_oracle import ShuffleStream
+    S, n = len(seeds), len(calls)
+    d_seeds = bk.dev(np.asarray(seeds, np.uint64))
+    d_calls = bk.dev(np.asarray(calls, np.int32))
+    d_perm = bk.dev(np.full((S, n, epochs, B), -1, np.int32))
+    assert bk.lib.rcmarl_shuffle_perms(bk.ptr(d_seeds), bk.ptr(d_calls), n, epochs, B, bk.ptr(d_perm), S, bk.stream) in (0, None)
+    perm = bk.host(d_perm)
+    for si, seed in enumerate(seeds):
+        for qi, call in enumerate(calls):
+            st = ShuffleStream(seed)
+            st.calls = int(call)
+            np.testing.assert_array_equal(perm[si, qi], st.perms(epochs, B))
+
+
 def run_minibatch_fit_with_blown_network(bk, S=1, N=5, B=96, in_dim=10, lr=0.01):
     """One mini-batch fit of two adversaries' networks, the first with layer-2 weights of 100 (2^10 W beyond the f16 range) ->
     (rows of the blown-up network, rows of the healthy one) after the fit."""

@@ -105,6 +105,11 @@ def test_minibatch_fit_compact_form(bk, S, N, B, in_dim, advs, bs, shuffle, monk
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=2, shuffle=shuffle, knife_edge_nets=1 if B >= 900 else 0)
 
 
+@pytest.mark.parametrize("seeds,calls,epochs,B", [((3, 77), (0, 5), 2, 70), ((11,), (2,), 1, 1), ((1000,), (0, 1, 2), 2, 300)])
+def test_shuffle_perms_equal_the_oracle_stream(bk, seeds, calls, epochs, B):
+    KC.check_shuffle_perms(bk, seeds, calls, epochs, B)
+
+
 def test_minibatch_fit_out_of_range_network_is_redone_in_fp32(bk, monkeypatch):
     import numpy as np
     res = {}

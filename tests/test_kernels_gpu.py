@@ -118,6 +118,11 @@ def test_minibatch_fit_compact_form(bk, S, N, B, in_dim, advs, bs, shuffle, monk
     KC.check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=bs, epochs=3, shuffle=shuffle, knife_edge_nets=1 if B >= 900 else 0)
 
 
+@pytest.mark.parametrize("seeds,calls,epochs,B", [((3, 77, 1000, 12345678901), (0, 5, 29), 10, 3000), ((11,), (2,), 1, 1), (tuple(range(64)), (0, 1, 2), 3, 777), ((5,), (7,), 2, 8192)])
+def test_shuffle_perms_equal_the_oracle_stream(bk, seeds, calls, epochs, B):
+    KC.check_shuffle_perms(bk, seeds, calls, epochs, B)
+
+
 def test_minibatch_fit_out_of_range_network_is_redone_in_fp32(bk, monkeypatch):
     """A network whose weights leave the f16 range (2^10 |W| > 65000) is flagged by k_minibatch_mx, not written back, and redone by
     the fp32 kernel in the fix-up launch: its result equals RCMARL_MB_MX=0 bit for bit; the healthy network beside it is untouched
