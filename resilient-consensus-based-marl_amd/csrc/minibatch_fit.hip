@@ -631,11 +631,10 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
     // where the owner publishes them (packed to keep the wavefront under 256 registers): fragment elements (piece 0) of W2 in the
     // z2 and da operands / of W1 in the z1 operand, fp32 slots in prm.  Slots that own nothing point at DUMMY targets: fragment row
     // 31 (a padding row of the weight operand: it feeds accumulator rows nobody reads) and prm[62], prm[63].
-    unsigned pk0[16], pk1[16];                               // f1a | f1b << 16;  f2a | p1 << 16 | p2 << 24
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    // COMPACT keeps none of them: it recomputes them when it publishes (once per epoch in a full-batch fit) and has 32 registers more.
+    auto targets = [&](int q, int& o1, int& o2, unsigned& k0, unsigned& k1) {
       const int i = (q & 3) + 8 * (q >> 2) + 4 * half, jj = l31;
-      int o1 = -1, o2 = -1;                                  // offsets into theta (Keras order)
+      o1 = -1; o2 = -1;                                      // offsets into theta (Keras order)
       int f1a = fdummy, f1b = fdummy, f2a = fdummy, p1 = 62, p2 = 63;
       if (jj < HID) {
         if (i < HID) {                                       // W2[m = i][unit = jj]
@@ -653,8 +652,16 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
           o2 = g.o_W3 + v8_unit(1, lu); p2 = 2 * HID + v8_unit(1, lu);
         }
       }
-      pk0[q] = (unsigned)f1a | ((unsigned)f1b << 16);
-      pk1[q] = (unsigned)f2a | ((unsigned)p1 << 16) | ((unsigned)p2 << 24);
+      k0 = (unsigned)f1a | ((unsigned)f1b << 16);            // f1a | f1b << 16
+      k1 = (unsigned)f2a | ((unsigned)p1 << 16) | ((unsigned)p2 << 24);      // f2a | p1 << 16 | p2 << 24
+    };
+    unsigned pk0[COMPACT ? 1 : 16], pk1[COMPACT ? 1 : 16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      int o1, o2;
+      unsigned k0, k1;
+      targets(q, o1, o2, k0, k1);
+      if (!COMPACT) { pk0[q] = k0; pk1[q] = k1; }
       wr1[q] = o1 >= 0 ? th[o1] : 0.f;
       wr2[q] = o2 >= 0 ? th[o2] : 0.f;
     }
@@ -664,12 +671,14 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
       for (int q = 0; q < 16; ++q) {
         unsigned h1, l1;
         rc_split2h_pair(wr1[q] * MX_S, wr2[q] * MX_S, h1, l1);  // low halves: wr1's pieces, high halves: wr2's
-        const int f1a = pk0[q] & 0xffffu, f1b = pk0[q] >> 16, f2a = pk1[q] & 0xffffu;
+        unsigned k0, k1;
+        if (COMPACT) { int o1, o2; targets(q, o1, o2, k0, k1); } else { k0 = pk0[q]; k1 = pk1[q]; }
+        const int f1a = k0 & 0xffffu, f1b = k0 >> 16, f2a = k1 & 0xffffu;
         frag[f1a] = (unsigned short)h1; frag[f1a + mx_piece1<COMPACT>(f1a)] = (unsigned short)l1;
         frag[f1b] = (unsigned short)h1; frag[f1b + mx_piece1<COMPACT>(f1b)] = (unsigned short)l1;
         frag[f2a] = (unsigned short)(h1 >> 16); frag[f2a + mx_piece1<COMPACT>(f2a)] = (unsigned short)(l1 >> 16);
-        prm[(pk1[q] >> 16) & 0xffu] = wr1[q];
-        prm[pk1[q] >> 24] = wr2[q];
+        prm[(k1 >> 16) & 0xffu] = wr1[q];
+        prm[k1 >> 24] = wr2[q];
         amax = fmaxf(amax, fmaxf(fabsf(wr1[q]), fabsf(wr2[q])) * MX_S);   // (biases and W3 too: conservative, branch-free)
       }
     };
@@ -808,6 +817,12 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
       for (int q = 0; q < 16; ++q) dd[q] = 0.f;
       dd = v8_mfma4(loadA(2, 1), pd1, dd);
       dd = v8_mfma4(loadA(2, 0), pd0, dd);
+      if (COMPACT) {                                           // G1 now: its B planes are about to be overwritten by G2's
+        RC_WAVE_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          g1 = v8_mfma4(readT(pA1, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), readT(pB1, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB), g1);
+      }
       float dz1[LU];                                           // 2^10 dz1
 #pragma unroll
       for (int u = 0; u < LU; ++u) dz1[u] = (dd[u] * MX_US) * rc_lrelu_grad_from_act(a1[u]);
@@ -845,13 +860,7 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
           g1 = rc_mfma_f16(ra1.h, rb1.h, g1); g2 = rc_mfma_f16(ra2.h, rb2.h, g2);
         }
       } else {
-        V8Pieces rb[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) rb[ks] = readT(pB1, MX_PB / 2, trB + 16 * MX_PCB * ks, MX_PCB);   // G1's B operand leaves the LDS ...
-        RC_WAVE_SYNC();
-        write_dz1();                                                                                       // ... before G2's takes its place
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) g1 = v8_mfma4(readT(pA1, MX_PA / 2, trA + 16 * MX_PCA * ks, MX_PCA), rb[ks], g1);
+        write_dz1();                                         // (G1's transposed reads were issued above: the LDS executes a wavefront's instructions in order)
         RC_WAVE_SYNC();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
