@@ -132,6 +132,28 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
                            int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
 
+/* ---- the whole local fit in ONE launch ("fused fit", csrc/fused_fit.hip) --------------------------------------------
+ * Replaces the per-agent Keras fit  self.critic.fit(s, TD_target, epochs=5, batch_size=B)  /  self.TR.fit(sa, r, ...)
+ * (agents/resilient_CAC_agents.py:118,136) for ALL agents of all seeds: `nsteps` full-batch SGD steps on theta (the message
+ * copy), every array of every network with mask[agent] != 0.  One workgroup owns three consecutive agents of a seed and runs
+ * all steps by itself; layer-1 activations and dz1 stay in registers / LDS (the three-launch path above moves them through HBM
+ * twice per step).  Arithmetic: that of the two-piece f16 operand form (rcmarl_lattice_f16_mode() == 3), element for element.
+ * Operand images (device buffers owned by the caller, sizes from rcmarl_fit_fused_geometry, per seed, seeds contiguous):
+ *   kf, ktf  the lattice integers of the replay rows as f16 MFMA fragments, rows x features and features x rows; written by
+ *            rcmarl_fit_encode (same x / alpha contract as rcmarl_lattice_encode, whose flag tells whether x is on the lattice)
+ *   wf       scratch for the f16 pieces of 2^10 alpha W1 (written and read by the fit itself)
+ * rows_alloc: replay rows the images are laid out for (a multiple of 256, >= B).
+ * flags[S][N] (int32, zeroed by the caller): set to 1 for an agent whose operands left the f16 range -- its row of theta is
+ * then NOT the reference's result and must be recomputed from the pre-fit weights on the three-launch path (which redoes such
+ * agents in fp32); all other agents are unaffected.  loss_out[S][N] (or NULL): the MSE before the first step.
+ * Shapes: hid == 20, in_dim <= 768; otherwise RCMARL_ERR_UNSUPPORTED (use the three-launch path). */
+int rcmarl_fit_fused_geometry(int N, int in_dim, int hid, int rows_alloc, long* kf_bytes, long* ktf_bytes, long* wf_bytes);
+int rcmarl_fit_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, int rows_alloc,
+                      void* kf, void* ktf, void* stream);
+int rcmarl_fit_fused(const void* kf, const void* ktf, void* wf, const float* alpha, float* theta, const float* y,
+                     const int* mask, float* loss_out, int* flags, int S, int N, int B, int in_dim, int hid, int ldp,
+                     int ldb, int rows_alloc, int nsteps, float lr, void* stream);
+
 /* Shuffle permutations of the adversaries' mini-batch fits (Keras fit(shuffle=True) inside
  * agents/adversarial_CAC_agents.py:38-41,131-135,163-165,237-253).  TensorFlow's shuffle RNG is not reproducible
  * outside TensorFlow; the shuffle is DEFINED here (csrc/shuffle.hip; same statement in the oracle):

@@ -62,6 +62,14 @@ SIGNATURES = {
     # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_stream],
+    # fused local fit, csrc/fused_fit.hip ---------------------------------------------------------------------
+    # N, in_dim, hid, rows_alloc, kf_bytes(long*, host), ktf_bytes, wf_bytes
+    "rcmarl_fit_fused_geometry": [c_int, c_int, c_int, c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    # x, x_seed_stride, alpha, S, B, in_dim, rows_alloc, kf, ktf, stream
+    "rcmarl_fit_encode": [c_f32p, c_long, c_f32p, c_int, c_int, c_int, c_int, c_u8p, c_u8p, c_stream],
+    # kf, ktf, wf, alpha, theta, y, mask, loss_out, flags, S, N, B, in_dim, hid, ldp, ldb, rows_alloc, nsteps, lr, stream
+    "rcmarl_fit_fused": [c_u8p, c_u8p, c_u8p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int,
+                         c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     # seeds(u64[S]), calls(int[n]), n, epochs, B, perm(int[S][n][epochs][B]), S, stream
     "rcmarl_shuffle_perms": [C.c_void_p, c_i32p, c_int, c_int, c_int, c_i32p, c_int, c_stream],
     # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream

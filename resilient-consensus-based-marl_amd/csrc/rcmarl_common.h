@@ -268,6 +268,17 @@ __device__ __forceinline__ bool rc_all(bool v) {
 #define RC_SCHED_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
 
+// A value the optimiser must treat as unknown: address arithmetic that depends on it stays where it is written (loop-invariant
+// code motion otherwise hoists every per-lane address of a big unrolled epilogue out of the enclosing loops and keeps
+// hundreds of registers alive across them).
+#ifdef RCMARL_EMU
+__device__ __forceinline__ int rc_opaque_v(int v) { return v; }
+__device__ __forceinline__ int rc_opaque_s(int v) { return v; }
+#else
+__device__ __forceinline__ int rc_opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int rc_opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+#endif
+
 // v_permlane32_swap on two floats: lanes 32-63 of `a` swap with lanes 0-31 of `b`
 __device__ __forceinline__ void rc_swap32(float& a, float& b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);

@@ -88,6 +88,7 @@ inline int wave_size_here() {   // lanes present in this (possibly partial) wave
 #define warpSize 64
 
 inline void __syncthreads() { hipemu::block_barrier(); }
+inline void __threadfence() {}
 
 // ---- cross-lane ----------------------------------------------------------------
 template <typename T> inline T __hipemu_xch(T v, int src_lane) {

@@ -226,3 +226,20 @@ def test_lattice_forward_int8_limbs_prototype(bk, S, N, B, width, nrow, ncol):
     """csrc/lattice_i8.hip: the layer-1 forward on the int8 matrix core (four balanced base-256 limbs of alpha*W1 under one scale per
     column, exact int32 dot products) holds the bf16x3 path's bar against float64."""
     KC.check_lattice_forward_i8(bk, S, N, B, width, nrow, ncol)
+
+
+@pytest.mark.parametrize("S,n_agents,B,width", [(2, 5, 70, 2), (1, 12, 300, 3), (1, 40, 40, 3)])
+def test_fit_encode(bk, S, n_agents, B, width):
+    KC.check_fit_encode(bk, S, n_agents, B, width, 5, 5)
+
+
+@pytest.mark.parametrize("S,N,B,width,masked,steps", [(1, 5, 70, 2, None, 2), (2, 4, 300, 3, 1, 2), (1, 7, 40, 2, None, 3)])
+def test_fused_fit(bk, S, N, B, width, masked, steps):
+    KC.check_fused_fit(bk, S, N, B, width, 5, 5, steps=steps, masked_agent=masked)
+
+
+def test_fused_fit_reproduces_itself(bk):
+    """no atomics, fixed summation order: two runs give the same bits"""
+    a = KC.check_fused_fit(bk, 1, 5, 100, 2, 5, 5, steps=2, vs_unfused=False)
+    b = KC.check_fused_fit(bk, 1, 5, 100, 2, 5, 5, steps=2, vs_unfused=False)
+    np.testing.assert_array_equal(a, b)

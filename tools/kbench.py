@@ -186,6 +186,74 @@ def lattice(L, S=16, N=256, B=3000):
                                                                                                    3 * flops / t / 1e6))
 
 
+def fused(L, S=16, N=256, B=3000, steps=5):
+    """the whole local fit as ONE launch (csrc/fused_fit.hip) against the three-launch path, same inputs; RCMARL_FUSED_NU=1|2"""
+    import ctypes
+    from rcmarl_amd import lattice as LT
+    st = torch.cuda.current_stream().cuda_stream
+    S, N, B = int(os.environ.get("KB_S", S)), int(os.environ.get("KB_N", N)), int(os.environ.get("KB_B", B))
+    for width in (2, 3):
+        in_dim = width * N
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        g = LT.Geometry(N, in_dim, B)
+        std = float(np.std(np.arange(32)))
+        x = ((torch.randint(0, 32, (S, B, in_dim), device="cuda").float() - 15.5) / std).contiguous()
+        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
+        lim = float(np.sqrt(6.0 / (in_dim + HID)))
+        theta0 = (torch.rand(S, N, ldp, device="cuda") * 2 - 1) * lim
+        y = torch.randn(S, N, ldb, device="cuda")
+        mask = torch.ones(N, dtype=torch.int32, device="cuda")
+        lr = 1e-3
+        # ---- three launches per step
+        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
+        kp, ktp, wp, dzp = u8(g.kp, 1), u8(g.ktp, 1), u8(g.wp, 3), u8(g.dzp, 3)
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        a1t = torch.zeros(S, N * HID, ldb, device="cuda")
+        part = torch.zeros(S * N * ((B + 255) // 256) * L.rcmarl_fit_partial_size(HID), device="cuda")
+        L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0], g.kp[1], ktp.data_ptr(),
+                                g.ktp[0], g.ktp[1], flag.data_ptr(), st)
+        th_a = theta0.clone()
+
+        def unfused():
+            th_a.copy_(theta0)
+            for k in range(steps):
+                if k == 0:
+                    L.rcmarl_w1_split(th_a.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], st)
+                L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], th_a.data_ptr(),
+                                                a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st)
+                L.rcmarl_mid_fit_lattice(a1t.data_ptr(), th_a.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1],
+                                         S, N, B, in_dim, HID, ldp, ldb, st)
+                L.rcmarl_small_sgd(part.data_ptr(), th_a.data_ptr(), mask.data_ptr(), None, S, N, B, in_dim, HID, ldp, lr, st)
+                L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0], g.dzp[1], alpha.data_ptr(),
+                                                     th_a.data_ptr(), mask.data_ptr(), S, N, B, in_dim, HID, ldp, lr,
+                                                     wp.data_ptr() if k + 1 < steps else None, g.wp[0], g.wp[1], st)
+        # ---- one launch
+        rows_alloc = (B + 255) // 256 * 256
+        nb = [ctypes.c_long() for _ in range(3)]
+        L.rcmarl_fit_fused_geometry(N, in_dim, HID, rows_alloc, *[ctypes.byref(v) for v in nb])
+        kf, ktf, wf = (torch.zeros(S * v.value, dtype=torch.uint8, device="cuda") for v in nb)
+        flags = torch.zeros(S, N, dtype=torch.int32, device="cuda")
+        loss = torch.zeros(S, N, device="cuda")
+        t_enc = timeit(lambda: L.rcmarl_fit_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, rows_alloc, kf.data_ptr(),
+                                                   ktf.data_ptr(), st))
+        th_b = theta0.clone()
+
+        def fusedfit():
+            th_b.copy_(theta0)
+            L.rcmarl_fit_fused(kf.data_ptr(), ktf.data_ptr(), wf.data_ptr(), alpha.data_ptr(), th_b.data_ptr(), y.data_ptr(),
+                               mask.data_ptr(), loss.data_ptr(), flags.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, rows_alloc, steps, lr, st)
+        for rnd in range(2):
+            tu = timeit(unfused, iters=3, warm=1)
+            tf = timeit(fusedfit, iters=3, warm=1)
+            print("in=%4d S=%d N=%d B=%d round %d: three-launch fit %9.1f us (%7.1f per step)   fused fit %9.1f us (%7.1f per step)   x%.2f"
+                  % (in_dim, S, N, B, rnd, tu, tu / steps, tf, tf / steps, tu / tf))
+        d = float(((th_a - th_b).abs().max() / th_a.abs().max()).item())
+        print("in=%4d fit_encode %.1f us; max |fused - three-launch| / max|theta| = %.2e; flags %d; finite %s; moved %.3e"
+              % (in_dim, t_enc, d, int(flags.sum().item()), bool(torch.isfinite(th_b).all().item()),
+                 float((th_b - theta0).abs().max().item())))
+
+
 def i8(L, S=16, N=256, B=3000):
     """the int8-limb forward prototype (csrc/lattice_i8.hip) against the bf16x3 forward, on random lattice inputs"""
     from rcmarl_amd import lattice as LT
@@ -357,4 +425,4 @@ if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "i8": i8, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "i8": i8, "fused": fused, "minibatch": minibatch, "wide": wide}[what](L)
