@@ -332,7 +332,8 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
   const int ag0 = g * G, N = A.N, B = A.B, KS = A.KS, in_dim = A.in_dim, ldp = A.ldp;
   const NetGeom geo = make_geom(in_dim, HID, 1);
   float* theta_s = A.theta + (long)s * N * ldp;
-  unsigned char* wf_wg = A.wf + (long)s * A.wf_seed + (long)g * KS * WSTEP;
+  const int NS = (KS + KC - 1) / KC, KSP = NS * KC;       // stages; k16 steps incl. the zero padding of the last stage
+  unsigned char* wf_wg = A.wf + (long)s * A.wf_seed + (long)g * KSP * WSTEP;
   const unsigned char* kf_s = A.kf + (long)s * A.kf_seed;
   const unsigned char* ktf_s = A.ktf + (long)s * A.ktf_seed;
   const int ntiles = (B + TILE - 1) / TILE;
@@ -409,23 +410,31 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
     }
   };
   w1_pass(std::false_type{});
+  for (int e = r; e < (KSP - KS) * (WSTEP / 16); e += 256) {        // W' is zero on the padding steps of the last stage
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0u;
+    *reinterpret_cast<uint4*>(wf_wg + (long)KS * WSTEP + (long)e * 16) = z;
+  }
   // feature tiles beyond the last wavefront's share but inside KS (KS = 2 FTILES: none) -- nothing to zero
   __threadfence();
 
   const int lane16 = lane * 16;
   const rc_lds_t zaddr = rc_lds_addr(Z);
   auto issue_stage = [&](int st) {
-    const int n = min(KC, KS - st * KC);
 #pragma unroll
     for (int i = 0; i < KC; ++i)
-      if (i < n)
-        RC_GLDS16S(wf_wg + ((long)(st * KC + i) * 4 + wave) * FRAG, lane16, zaddr + (st & 1) * STAGE + (i * 4 + wave) * FRAG);
+      RC_GLDS16S(wf_wg + ((long)(st * KC + i) * 4 + wave) * FRAG, lane16, zaddr + (st & 1) * STAGE + (i * 4 + wave) * FRAG);
   };
-  const int NS = (KS + KC - 1) / KC;
   float amax[G];
 #pragma unroll
   for (int a = 0; a < G; ++a) amax[a] = 0.f;
 
+#ifdef FF_TIMING
+  long long tmF = 0, tmM = 0, tmB = 0, tmE = 0, tm0 = wall_clock64(), tm1;
+#define FF_TICK(acc) do { tm1 = wall_clock64(); acc += tm1 - tm0; tm0 = tm1; } while (0)
+#else
+#define FF_TICK(acc) ((void)0)
+#endif
   for (int step = 0; step < A.nsteps; ++step) {
     // ---- the agents' small arrays: W2 as f16 pieces in A-fragment order (both orientations), b2 | W3 | b3, b1
     __syncthreads();
@@ -480,24 +489,28 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
           for (int q = 0; q < 16; ++q) acc[t][rb][q] = 0.f;
-      const unsigned char* kf_w = kf_s + ((long)(tile * (TILE / 32) + wave * RB) * KS * 64 + lane) * 16;
+      const int lane_f = rc_opaque_v(lane);
+      const unsigned char* kf_w = kf_s + ((long)(tile * (TILE / 32) + wave * RB) * KS * 64 + lane_f) * 16;
+      // No branch inside the reduction loop (hipcc's s_waitcnt pass gives up its load bookkeeping at every control-flow join and
+      // waits for vmcnt(0)): the reduction runs over KSP = NS * KC steps -- Wf is zero beyond KS --, and a fragment request past
+      // the end re-reads the last one.
       uint4 xb[PD][RB];
 #pragma unroll
       for (int d = 0; d < PD; ++d)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-          if (d < KS) xb[d][rb] = ld_u4(kf_w + ((long)rb * KS + d) * FRAG);
+        for (int rb = 0; rb < RB; ++rb) xb[d][rb] = ld_u4(kf_w + ((long)rb * KS + min(d, KS - 1)) * FRAG);
       issue_stage(0);
       for (int st = 0; st < NS; ++st) {
         // this wavefront's bursts of stage st have landed: they are older than the PD * RB fragment loads issued behind them
-        // (when all of those were issued: not near the end of the reduction)
-        if (st > 0 && st * KC - 1 + PD < KS) { RC_WAIT_VMEM_N(PD * RB); } else { RC_WAIT_VMEM(); }
+        if (st > 0) { RC_WAIT_VMEM_N(PD * RB); } else { RC_WAIT_VMEM(); }
         __syncthreads();                                 // ... and everybody's; all reads of the other buffer are done
         if (st + 1 < NS) issue_stage(st + 1);
-        const unsigned char* stg = Z + (st & 1) * STAGE + lane16;
-        // One k16 step: the NEXT step's W' fragments are requested from LDS and the step-after-PD's row fragments from L2 before
-        // this step's eight matrix-core instructions, so that with one wavefront per SIMD the loads run under them; the
-        // scheduling fence keeps hipcc from hoisting more than that (it would lift every load of the unrolled stage to its top).
+        const unsigned char* stg = Z + (st & 1) * STAGE + lane_f * 16;
+        // One k16 step: the NEXT step's W' fragments are requested from LDS before this step's eight matrix-core instructions
+        // and the step-after-PD's row fragments from L2 behind them, so that with one wavefront per SIMD the loads run under
+        // the matrix core; the scheduling fences keep hipcc from hoisting more than that (it would lift every load of the
+        // unrolled stage to its top).  The row fragments go straight into the slot their readers have just been issued from
+        // (requested ahead of them, hipcc loads into temporaries and waits for vmcnt(0) in every step to copy them home).
         uint4 afA[2][UT], afB[2][UT];
         auto ldsA = [&](int ksl, uint4 (&af)[2][UT]) {
 #pragma unroll
@@ -507,22 +520,17 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
         };
         auto kstep = [&](int ksl, uint4 (&cur)[2][UT], uint4 (&nxt)[2][UT]) {
           const int ks = st * KC + ksl;
-          if (ksl + 1 < KC && ks + 1 < KS) ldsA(ksl + 1, nxt);
-          if (ks < KS) {
-            uint4 xf[RB];
+          if (ksl + 1 < KC) ldsA(ksl + 1, nxt);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) xf[rb] = xb[ksl % PD][rb];
-            if (ks + PD < KS) {
+          for (int p = 1; p >= 0; --p)                   // smallest pieces first
 #pragma unroll
-              for (int rb = 0; rb < RB; ++rb) xb[ksl % PD][rb] = ld_u4(kf_w + ((long)rb * KS + ks + PD) * FRAG);
-            }
+            for (int t = 0; t < UT; ++t)
 #pragma unroll
-            for (int p = 1; p >= 0; --p)                 // smallest pieces first
+              for (int rb = 0; rb < RB; ++rb) acc[t][rb] = rc_mfma_f16(cur[p][t], xb[ksl % PD][rb], acc[t][rb]);
+          RC_SCHED_FENCE();
+          const int kn = min(ks + PD, KS - 1);
 #pragma unroll
-              for (int t = 0; t < UT; ++t)
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) acc[t][rb] = rc_mfma_f16(cur[p][t], xf[rb], acc[t][rb]);
-          }
+          for (int rb = 0; rb < RB; ++rb) xb[ksl % PD][rb] = ld_u4(kf_w + ((long)rb * KS + kn) * FRAG);
           RC_SCHED_FENCE();
         };
         ldsA(0, afA);
@@ -533,9 +541,14 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
         }
       }
       __syncthreads();                                   // the W' stages are read out: Z becomes this tile's dz planes
+      FF_TICK(tmF);
 
       // ================= M: layers 2-3 of the three agents on this wavefront's two row blocks ===========================
       {
+        // (lane-derived addresses and predicates of this phase are formed per tile from an opaque copy of the lane id: left to
+        // loop-invariant code motion they would all be lifted out of the tile loop and held in registers through F and B)
+        const int lane_m = rc_opaque_v(lane);
+        const int lane = lane_m, l31 = lane_m & 31, half = lane_m >> 5;
         const int brow = tile * TILE + wave * (RB * 32);
         bool valid[RB];
         unsigned char* zrow[RB];
@@ -618,18 +631,23 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
         agent(std::integral_constant<int, 2>{});
       }
       __syncthreads();                                   // every wavefront's dz1 pieces are in the planes
+      FF_TICK(tmM);
 
       // ================= B: gW1 += K^T dz1 over this tile's 256 rows ====================================================
       {
-        const int ft0 = wave * FTW;
+        // (no branches here either: a feature tile beyond the last one re-reads the last one, and its accumulators are never
+        // looked at; a request past the tile's last row step re-reads that step)
+        int ftc[FTW];
+#pragma unroll
+        for (int f = 0; f < FTW; ++f) ftc[f] = min(wave * FTW + f, A.FTILES - 1);
         uint4 kb[PD][FTW];
-        const unsigned char* ktf_w = ktf_s + ((long)tile * (TILE / 16) * 64 + lane) * 16;     // + (ft * RS + rs) * FRAG
+        const int lane_b = rc_opaque_v(lane);
+        const unsigned char* ktf_w = ktf_s + ((long)tile * (TILE / 16) * 64 + lane_b) * 16;     // + (ft * RS + rs) * FRAG
 #pragma unroll
         for (int d = 0; d < PD; ++d)
 #pragma unroll
-          for (int f = 0; f < FTW; ++f)
-            if (ft0 + f < A.FTILES) kb[d][f] = ld_u4(ktf_w + ((long)(ft0 + f) * A.RS + d) * FRAG);
-        const unsigned char* zl = Z + lane16;
+          for (int f = 0; f < FTW; ++f) kb[d][f] = ld_u4(ktf_w + ((long)ftc[f] * A.RS + d) * FRAG);
+        const unsigned char* zl = Z + lane_b * 16;
         uint4 bfA[2][UT], bfB[2][UT];
         auto ldsB = [&](int rs, uint4 (&bf)[2][UT]) {
 #pragma unroll
@@ -639,23 +657,17 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
         };
         auto bstep = [&](int rs0, int j, uint4 (&cur)[2][UT], uint4 (&nxt)[2][UT]) {      // row step rs0 + j, j = its prefetch slot
           const int rs = rs0 + j;
-          if (rs + 1 < TILE / 16) ldsB(rs + 1, nxt);
-          uint4 kfr[FTW];
-#pragma unroll
-          for (int f = 0; f < FTW; ++f) kfr[f] = kb[j][f];
-          if (rs + PD < TILE / 16) {
-#pragma unroll
-            for (int f = 0; f < FTW; ++f)
-              if (ft0 + f < A.FTILES) kb[j][f] = ld_u4(ktf_w + ((long)(ft0 + f) * A.RS + rs + PD) * FRAG);
-          }
+          ldsB(min(rs + 1, TILE / 16 - 1), nxt);
 #pragma unroll
           for (int p = 1; p >= 0; --p)
 #pragma unroll
             for (int f = 0; f < FTW; ++f)
-              if (ft0 + f < A.FTILES) {
 #pragma unroll
-                for (int t = 0; t < UT; ++t) gacc[f][t] = rc_mfma_f16(kfr[f], cur[p][t], gacc[f][t]);
-              }
+              for (int t = 0; t < UT; ++t) gacc[f][t] = rc_mfma_f16(kb[j][f], cur[p][t], gacc[f][t]);
+          RC_SCHED_FENCE();
+          const int rn = min(rs + PD, TILE / 16 - 1);    // (behind its readers, straight into the slot: see the forward loop)
+#pragma unroll
+          for (int f = 0; f < FTW; ++f) kb[j][f] = ld_u4(ktf_w + ((long)ftc[f] * A.RS + rn) * FRAG);
           RC_SCHED_FENCE();
         };
         static_assert(PD == 4, "the row-step loop is unrolled by the prefetch distance");
@@ -668,6 +680,7 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
         }
       }
       __syncthreads();                                   // the planes are read out: Z takes the next tile's W' stages
+      FF_TICK(tmB);
     }
 
     // ================= step end: records -> small gradients, SGD on every array of the three agents ========================
@@ -705,9 +718,17 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
       }
       w1_pass(std::true_type{});
       __threadfence();                                   // the next step's loads (other lanes, LDS-DMA) see these stores
+      FF_TICK(tmE);
     }
   }
   __syncthreads();
+#ifdef FF_TIMING
+  if (r == 0 && A.loss_out && ag0 + 2 < N) {            // measurement builds only: 10-ns ticks per phase, all steps (E includes the small-array loads)
+    float* o = A.loss_out + (long)s * N + ag0;
+    o[0] = (float)tmF; o[1] = (float)tmM; o[2] = (float)tmB;
+    if (g == 0) o[3] = (float)tmE;
+  }
+#endif
 #pragma unroll
   for (int a = 0; a < G; ++a)
     if (live[a] && amax[a] > RANGE) A.flags[s * N + ag0 + a] = 1;
@@ -744,7 +765,7 @@ RCMARL_EXPORT int rcmarl_fit_fused_geometry(int N, int in_dim, int hid, int rows
   const long ftiles = rc_ceil_div(in_dim, 32), ks = 2 * ftiles, ng = rc_ceil_div(N, ff::G);
   if (kf_bytes) *kf_bytes = (long)(rows_alloc / 32) * ks * ff::FRAG;
   if (ktf_bytes) *ktf_bytes = ftiles * (rows_alloc / 16) * ff::FRAG;
-  if (wf_bytes) *wf_bytes = ng * ks * ff::WSTEP;
+  if (wf_bytes) *wf_bytes = ng * ((ks + ff::KC - 1) / ff::KC * ff::KC) * ff::WSTEP;
   return RCMARL_OK;
 }
 
@@ -772,7 +793,7 @@ RCMARL_EXPORT int rcmarl_fit_fused(const void* kf, const void* ktf, void* wf, co
   a.KS = 2 * ftiles; a.RS = rows_alloc / 16; a.FTILES = ftiles; a.NG = rc_ceil_div(N, ff::G);
   a.kf = (const unsigned char*)kf; a.kf_seed = (long)(rows_alloc / 32) * a.KS * ff::FRAG;
   a.ktf = (const unsigned char*)ktf; a.ktf_seed = (long)ftiles * a.RS * ff::FRAG;
-  a.wf = (unsigned char*)wf; a.wf_seed = (long)a.NG * a.KS * ff::WSTEP;
+  a.wf = (unsigned char*)wf; a.wf_seed = (long)a.NG * ((a.KS + ff::KC - 1) / ff::KC * ff::KC) * ff::WSTEP;
   a.alpha = alpha; a.theta = theta; a.y = y; a.mask = mask; a.loss_out = loss_out; a.flags = flags;
   a.S = S; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb; a.nsteps = nsteps; a.lr = lr;
   const int ftw = rc_ceil_div(ftiles, ff::NW);

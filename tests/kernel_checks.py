@@ -1059,8 +1059,9 @@ def check_fit_encode(bk, S, n_agents, B, width, nrow, ncol):
     in_dim = n_agents * width
     rows_alloc = (B + 255) // 256 * 256 + 256
     fb = FusedBuffers(bk, S, n_agents, in_dim, rows_alloc)
-    bk.lib.rcmarl_fit_encode(bk.ptr(bk.dev(x)), B * in_dim, bk.ptr(bk.dev(alpha)), S, B, in_dim, rows_alloc, bk.ptr(fb.kf),
-                             bk.ptr(fb.ktf), bk.stream)
+    d_x, d_al = bk.dev(x), bk.dev(alpha)                  # (named: a temporary would be freed, and reused, before the launch)
+    bk.lib.rcmarl_fit_encode(bk.ptr(d_x), B * in_dim, bk.ptr(d_al), S, B, in_dim, rows_alloc, bk.ptr(fb.kf), bk.ptr(fb.ktf),
+                             bk.stream)
     K = np.rint(x.astype(np.float64) / alpha.astype(np.float64)).astype(np.float32)
     ftiles = (in_dim + 31) // 32
     KS, RS, b_pad = 2 * ftiles, rows_alloc // 16, (B + 255) // 256 * 256

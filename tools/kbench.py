@@ -248,6 +248,10 @@ def fused(L, S=16, N=256, B=3000, steps=5):
             tf = timeit(fusedfit, iters=3, warm=1)
             print("in=%4d S=%d N=%d B=%d round %d: three-launch fit %9.1f us (%7.1f per step)   fused fit %9.1f us (%7.1f per step)   x%.2f"
                   % (in_dim, S, N, B, rnd, tu, tu / steps, tf, tf / steps, tu / tf))
+        if os.environ.get("KB_FF_TIMING"):                 # a -DFF_TIMING build leaves 10-ns ticks per phase in loss_out
+            lo = loss.cpu().numpy().reshape(S, N)[:, :N // 3 * 3].reshape(S, -1, 3)
+            print("in=%4d phase time per workgroup over %d steps (us): F %.1f  M %.1f  B %.1f   (max F %.1f M %.1f B %.1f)"
+                  % ((in_dim, steps) + tuple(lo[:, 1:, k].mean() / 100 for k in range(3)) + tuple(lo[:, 1:, k].max() / 100 for k in range(3))))
         d = float(((th_a - th_b).abs().max() / th_a.abs().max()).item())
         print("in=%4d fit_encode %.1f us; max |fused - three-launch| / max|theta| = %.2e; flags %d; finite %s; moved %.3e"
               % (in_dim, t_enc, d, int(flags.sum().item()), bool(torch.isfinite(th_b).all().item()),
