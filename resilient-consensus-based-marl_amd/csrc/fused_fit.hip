@@ -45,19 +45,25 @@ constexpr int NW = 4;                      // wavefronts per workgroup, one per 
 constexpr int RB = 2;                      // 32-row blocks per wavefront and tile
 constexpr int TILE = NW * RB * 32;         // replay rows per tile
 constexpr int KC = 8;                      // k16 steps per W' stage
-constexpr int PD = 4;                      // prefetch distance (steps) of the straight-from-L2 fragments
+constexpr int PD = 4;                      // prefetch distance (row steps) of the backward's straight-from-L2 fragments
+#ifndef FF_PDF
+#define FF_PDF 8
+#endif
+constexpr int PDF = FF_PDF;                // ... of the forward's (k16 steps)
 constexpr int FRAG = 1024;                 // bytes of one operand fragment
 constexpr int WSTEP = 2 * UT * FRAG;       // W' bytes per k16 step: [piece][slot tile]
 constexpr int STAGE = KC * WSTEP;
 constexpr int ZBYTES = 2 * STAGE;          // two W' stages during F; the dz1 planes of a tile during M and B
 static_assert((TILE / 16) * WSTEP == ZBYTES, "the dz1 planes of one tile fill the region of the two W' stages");
-static_assert(KC % PD == 0 && (TILE / 16) % PD == 0, "prefetch slots rotate with a fixed period");
+static_assert(KC % PDF == 0 && (TILE / 16) % PD == 0, "prefetch slots rotate with a fixed period");
 constexpr int PC = 24, PLANE = 32 * PC, PANEL_B = 2 * 2 * PLANE * 2;     // per (wavefront, row block): k_mid_fit_v8's A and B planes
 constexpr int WF_AGENT = 2 * 2 * 2 * 2 * 32;                             // uint4 of one agent's W2 fragments (both orientations)
 constexpr int SV = 44;                     // floats per agent: b2 | W3 | b3 | pad
 constexpr int SUMREC = 48;                 // floats per (wavefront, agent): gb1[20] | gW3[20] | gb3 | loss | pad
 constexpr int GREC = HID * HID + HID;      // floats per (wavefront, agent): gW2 | gb2, the matrix-core row reduction
 constexpr int MAX_K = 768;                 // features (4 wavefronts x 6 feature tiles)
+constexpr int SMALL = 3 * HID + HID * HID + 1;      // b1 | W2 | b2 | W3 | b3: the 461 floats behind W1 in a parameter row
+constexpr int SMP = 464;                   // ... padded
 struct FitRec { static constexpr int gb2 = HID * HID, gW3 = gb2 + HID, gb3 = gW3 + HID, gb1 = gb3 + 1, loss = gb1 + HID, SIZE = loss + 1; };
 constexpr float S2 = 1024.f, US2 = 0.0009765625f, RANGE = 65000.f;        // k_mid_fit_v8's scale of W2 / dz2 and its range bound
 
@@ -70,6 +76,7 @@ constexpr int LDS_SUM = LDS_B1 + 64 * 4;
 constexpr int LDS_G = LDS_SUM + NW * G * SUMREC * 4;
 constexpr int LDS_BYTES = LDS_G + NW * G * GREC * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+static_assert(G * SMP * 4 <= ZBYTES, "the small arrays are staged in the Z region between steps");
 
 // accumulator row of register q in lane half h (v_mfma_f32_32x32x*: D[(q&3) + 8*(q>>2) + 4*h][lane&31])
 __host__ __device__ constexpr int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
@@ -317,6 +324,7 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
   float* sB1 = reinterpret_cast<float*>(lds + LDS_B1);
   float* sSum = reinterpret_cast<float*>(lds + LDS_SUM);
   float* sG = reinterpret_cast<float*>(lds + LDS_G);
+  float* sSm = reinterpret_cast<float*>(lds + LDS_Z);     // (the Z region is idle between the last tile of a step and the first of the next)
 
   int s, g;
   if ((A.S & 7) == 0) {                                  // all groups of a seed on one XCD (workgroup b -> XCD b % 8)
@@ -332,7 +340,8 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
   const int ag0 = g * G, N = A.N, B = A.B, KS = A.KS, in_dim = A.in_dim, ldp = A.ldp;
   const NetGeom geo = make_geom(in_dim, HID, 1);
   float* theta_s = A.theta + (long)s * N * ldp;
-  const int NS = (KS + KC - 1) / KC, KSP = NS * KC;       // stages; k16 steps incl. the zero padding of the last stage
+  const int NS = 2 * ((KS + 2 * KC - 1) / (2 * KC)), KSP = NS * KC;      // stages (an even number: they alternate between two
+  //                                                                         register sets); k16 steps incl. the zero padding
   unsigned char* wf_wg = A.wf + (long)s * A.wf_seed + (long)g * KSP * WSTEP;
   const unsigned char* kf_s = A.kf + (long)s * A.kf_seed;
   const unsigned char* ktf_s = A.ktf + (long)s * A.ktf_seed;
@@ -365,35 +374,46 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
     // every address below is formed from these two, which the optimiser cannot see through: otherwise loop-invariant code
     // motion lifts the whole address arithmetic of this pass (hundreds of registers) out of the step loop and keeps it alive
     const int wv = rc_opaque_s(wave), hf = rc_opaque_v(half);
+    // Two phases: ALL old weights of the wavefront's tiles are requested first (independent loads, one round trip), then the
+    // updates are computed and stored.
+    float wold[FTW][UT][16];
+#pragma unroll
+    for (int f = 0; f < FTW; ++f) {
+      const int ft = wv * FTW + f, k0 = 32 * ft + 4 * hf;
+#pragma unroll
+      for (int t = 0; t < UT; ++t) {
+        const float* th = theta_s + (long)(ag0 + (col_ok[t] ? col_a[t] : 0)) * ldp + col_unit[t] + (long)k0 * HID;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          wold[f][t][q] = (ft < A.FTILES && col_ok[t] && k0 + acc_row(q, 0) < in_dim) ? th[acc_row(q, 0) * HID] : 0.f;
+      }
+    }
 #pragma unroll
     for (int f = 0; f < FTW; ++f) {
       const int ft = wv * FTW + f;
       if (ft < A.FTILES) {
+        const int k0 = 32 * ft + 4 * hf;                 // the lane's first feature of this tile; register q adds acc_row(q, 0)
+        float alq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) alq[q] = k0 + acc_row(q, 0) < in_dim ? A.alpha[k0 + acc_row(q, 0)] : 0.f;
 #pragma unroll
         for (int t = 0; t < UT; ++t) {
-          float* th = theta_s + (long)(ag0 + (col_ok[t] ? col_a[t] : 0)) * ldp + col_unit[t] + (32 * ft + 4 * hf) * HID;
+          float* th = theta_s + (long)(ag0 + (col_ok[t] ? col_a[t] : 0)) * ldp + col_unit[t] + (long)k0 * HID;
           unsigned char* wf_t = wf_wg + (long)(2 * ft) * WSTEP + t * FRAG + l31 * 16 + 8 * hf;
-          const int k0 = 32 * ft + 4 * hf;               // the lane's first feature of this tile; register q adds acc_row(q, 0)
-          float wold[16];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) wold[q] = (col_ok[t] && k0 + acc_row(q, 0) < in_dim) ? th[acc_row(q, 0) * HID] : 0.f;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            float alv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) alv[e] = k0 + 8 * gq + e < in_dim ? A.alpha[k0 + 8 * gq + e] : 0.f;
             float wn4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int q = 4 * gq + e;
-              float w = wold[q];
+              float w = wold[f][t][q];
               if (UPDATE) {
                 if (col_upd[t] && k0 + acc_row(q, 0) < in_dim) {
-                  w = w - lr_dz * (alv[e] * gacc[f][t][q]);
+                  w = w - lr_dz * (alq[q] * gacc[f][t][q]);
                   th[acc_row(q, 0) * HID] = w;
                 }
               }
-              wn4[e] = (w * alv[e]) * RC_F16_W_SCALE;
+              wn4[e] = (w * alq[q]) * RC_F16_W_SCALE;
               if (fabsf(wn4[e]) > RANGE) wflag = true;
             }
             unsigned h0, l0, h1, l1;
@@ -404,12 +424,15 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
             *reinterpret_cast<uint2*>(q8) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(q8 + UT * FRAG) = make_uint2(l0, l1);
           }
-          RC_SCHED_FENCE();                              // (one tile's 16 loads in flight, not every tile's)
         }
       }
     }
   };
   w1_pass(std::false_type{});
+  for (int e = r; e < G * SMP; e += 256) {
+    const int a = e / SMP, i = e - a * SMP;
+    sSm[e] = (i < SMALL && ag0 + a < N) ? theta_s[(long)(ag0 + a) * ldp + geo.o_b1 + i] : 0.f;
+  }
   for (int e = r; e < (KSP - KS) * (WSTEP / 16); e += 256) {        // W' is zero on the padding steps of the last stage
     uint4 z;
     z.x = z.y = z.z = z.w = 0u;
@@ -418,12 +441,26 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
   // feature tiles beyond the last wavefront's share but inside KS (KS = 2 FTILES: none) -- nothing to zero
   __threadfence();
 
-  const int lane16 = lane * 16;
-  const rc_lds_t zaddr = rc_lds_addr(Z);
-  auto issue_stage = [&](int st) {
+  // W' reaches LDS through registers: a wavefront carries its quarter of TWO stages (wreg[0]: the next even stage, wreg[1]: the
+  // next odd one); a set is requested from L2 two stages before it is written to LDS.  (LDS-DMA was measured slower here: an
+  // LDS-DMA instruction blocks the wavefront's issue for 60-180 cycles, and with one wavefront per SIMD nobody fills them.)
+  uint4 wreg[2][KC];
+  uint4 xb[PDF][RB];                                     // the row fragments of the next PDF steps of the forward reduction
+  auto load_wset = [&](auto set_tag, int st, int lane_x) {
+    constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
-    for (int i = 0; i < KC; ++i)
-      RC_GLDS16S(wf_wg + ((long)(st * KC + i) * 4 + wave) * FRAG, lane16, zaddr + (st & 1) * STAGE + (i * 4 + wave) * FRAG);
+    for (int i = 0; i < KC; ++i) wreg[SET][i] = ld_u4(wf_wg + (((long)(st * KC + i) * 4 + wave) * 64 + lane_x) * 16);
+  };
+  // what the forward phase of `tile` starts from: stages 0 and 1 of W' and the row fragments of its first PD steps
+  auto f_prefetch = [&](int tile) {
+    const int lane_x = rc_opaque_v(lane);
+    load_wset(std::integral_constant<int, 0>{}, 0, lane_x);
+    load_wset(std::integral_constant<int, 1>{}, 1, lane_x);
+    const unsigned char* kf_w = kf_s + ((long)(tile * (TILE / 32) + wave * RB) * KS * 64 + lane_x) * 16;
+#pragma unroll
+    for (int d = 0; d < PDF; ++d)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) xb[d][rb] = ld_u4(kf_w + ((long)rb * KS + min(d, KS - 1)) * FRAG);
   };
   float amax[G];
 #pragma unroll
@@ -436,16 +473,14 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
 #define FF_TICK(acc) ((void)0)
 #endif
   for (int step = 0; step < A.nsteps; ++step) {
-    // ---- the agents' small arrays: W2 as f16 pieces in A-fragment order (both orientations), b2 | W3 | b3, b1
+    // ---- the agents' small arrays, from their image in LDS (sSm: b1 | W2 | b2 | W3 | b3 per agent; loaded once before the first
+    // step, kept current by the step end): W2 as f16 pieces in A-fragment order (both orientations), b2 | W3 | b3, b1
     __syncthreads();
     for (int e = r; e < G * 2 * 32 * 32; e += 256) {
       const int a = e >> 11, e2 = e & 2047, prod = e2 >> 10, ri = (e2 >> 5) & 31, k = e2 & 31;
       const int ui = v8_row_unit(ri), uk = v8_slot_unit(k);
       float w = 0.f;
-      if (ui >= 0 && uk >= 0 && ag0 + a < N) {
-        const float* th = theta_s + (long)(ag0 + a) * ldp;
-        w = prod == 0 ? th[geo.o_W2 + uk * HID + ui] : th[geo.o_W2 + ui * HID + uk];
-      }
+      if (ui >= 0 && uk >= 0) w = sSm[a * SMP + HID + (prod == 0 ? uk * HID + ui : ui * HID + uk)];
       unsigned ph, pl;
       rc_split2h_pair(w * S2, 0.f, ph, pl);
       if (fabsf(w) * S2 > RANGE) A.flags[s * N + ag0 + a] = 1;
@@ -457,12 +492,9 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
     }
     for (int e = r; e < G * SV; e += 256) {
       const int a = e / SV, i = e - a * SV;
-      sV[e] = (i < 2 * HID + 1 && ag0 + a < N) ? theta_s[(long)(ag0 + a) * ldp + geo.o_b2 + i] : 0.f;
+      sV[e] = i < 2 * HID + 1 ? sSm[a * SMP + HID + HID * HID + i] : 0.f;
     }
-    if (r < 64) {
-      const int a = r / HID, i = r - a * HID;
-      sB1[r] = (r < G * HID && ag0 + a < N) ? theta_s[(long)(ag0 + a) * ldp + geo.o_b1 + i] : 0.f;
-    }
+    if (r < 64) sB1[r] = r < G * HID ? sSm[(r / HID) * SMP + r % HID] : 0.f;
     for (int e = r; e < NW * G * SUMREC; e += 256) sSum[e] = 0.f;
     // column 20 of the A planes is the constant 1 (-> gb2), the other spare columns are zero (as k_mid_fit_v8)
     for (int e = lane; e < RB * 2 * 32 * (PC - 20); e += 64) {
@@ -478,7 +510,8 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) gacc[f][t][q] = 0.f;
     for (int e = r; e < NW * G * GREC; e += 256) sG[e] = 0.f;
-    __syncthreads();
+    __syncthreads();                                     // (also: sSm is read out, the Z region belongs to the tiles again)
+    f_prefetch(0);
 
     for (int tile = 0; tile < ntiles; ++tile) {
       // ================= F: z1^T = W' K^T for this wavefront's 64 rows ===================================================
@@ -494,23 +527,13 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
       // No branch inside the reduction loop (hipcc's s_waitcnt pass gives up its load bookkeeping at every control-flow join and
       // waits for vmcnt(0)): the reduction runs over KSP = NS * KC steps -- Wf is zero beyond KS --, and a fragment request past
       // the end re-reads the last one.
-      uint4 xb[PD][RB];
-#pragma unroll
-      for (int d = 0; d < PD; ++d)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) xb[d][rb] = ld_u4(kf_w + ((long)rb * KS + min(d, KS - 1)) * FRAG);
-      issue_stage(0);
-      for (int st = 0; st < NS; ++st) {
-        // this wavefront's bursts of stage st have landed: they are older than the PD * RB fragment loads issued behind them
-        if (st > 0) { RC_WAIT_VMEM_N(PD * RB); } else { RC_WAIT_VMEM(); }
-        __syncthreads();                                 // ... and everybody's; all reads of the other buffer are done
-        if (st + 1 < NS) issue_stage(st + 1);
-        const unsigned char* stg = Z + (st & 1) * STAGE + lane_f * 16;
-        // One k16 step: the NEXT step's W' fragments are requested from LDS before this step's eight matrix-core instructions
-        // and the step-after-PD's row fragments from L2 behind them, so that with one wavefront per SIMD the loads run under
-        // the matrix core; the scheduling fences keep hipcc from hoisting more than that (it would lift every load of the
-        // unrolled stage to its top).  The row fragments go straight into the slot their readers have just been issued from
-        // (requested ahead of them, hipcc loads into temporaries and waits for vmcnt(0) in every step to copy them home).
+      // One stage: KC k16 steps from LDS buffer BUF while this wavefront's quarter of the NEXT stage goes from register set
+      // 1 - BUF to the other buffer, one 1-KiB burst per step, each register then re-requested with the stage after that.
+      unsigned char* zst = Z + (wave * 64 + lane_f) * 16;                // + buffer * STAGE + burst * 4 KiB
+      auto stage = [&](auto buf_tag, int st) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        const unsigned char* stg = Z + BUF * STAGE + lane_f * 16;
+        const int st2 = (st + 3) % NS;                                 // (past the end: next tile's stages -- same W')
         uint4 afA[2][UT], afB[2][UT];
         auto ldsA = [&](int ksl, uint4 (&af)[2][UT]) {
 #pragma unroll
@@ -518,6 +541,9 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
 #pragma unroll
             for (int t = 0; t < UT; ++t) af[p][t] = ld_u4(stg + ((ksl * 2 + p) * UT + t) * FRAG);
         };
+        // One k16 step: the NEXT step's W' fragments are requested from LDS before this step's eight matrix-core instructions
+        // and the step-after-PD's row fragments from L2 behind them (straight into the slot their readers were just issued
+        // from); the scheduling fences keep hipcc from hoisting every load of the unrolled stage to its top.
         auto kstep = [&](int ksl, uint4 (&cur)[2][UT], uint4 (&nxt)[2][UT]) {
           const int ks = st * KC + ksl;
           if (ksl + 1 < KC) ldsA(ksl + 1, nxt);
@@ -526,11 +552,13 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
 #pragma unroll
             for (int t = 0; t < UT; ++t)
 #pragma unroll
-              for (int rb = 0; rb < RB; ++rb) acc[t][rb] = rc_mfma_f16(cur[p][t], xb[ksl % PD][rb], acc[t][rb]);
+              for (int rb = 0; rb < RB; ++rb) acc[t][rb] = rc_mfma_f16(cur[p][t], xb[ksl % PDF][rb], acc[t][rb]);
           RC_SCHED_FENCE();
-          const int kn = min(ks + PD, KS - 1);
+          const int kn = min(ks + PDF, KS - 1);
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) xb[ksl % PD][rb] = ld_u4(kf_w + ((long)rb * KS + kn) * FRAG);
+          for (int rb = 0; rb < RB; ++rb) xb[ksl % PDF][rb] = ld_u4(kf_w + ((long)rb * KS + kn) * FRAG);
+          *reinterpret_cast<uint4*>(zst + (1 - BUF) * STAGE + ksl * (4 * FRAG)) = wreg[1 - BUF][ksl];
+          wreg[1 - BUF][ksl] = ld_u4(wf_wg + (((long)(st2 * KC + ksl) * 4 + wave) * 64 + lane_f) * 16);
           RC_SCHED_FENCE();
         };
         ldsA(0, afA);
@@ -539,9 +567,22 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
           kstep(ksl, afA, afB);
           kstep(ksl + 1, afB, afA);
         }
+        __syncthreads();                                 // buffer 1 - BUF is written, buffer BUF is read out
+      };
+      // stage 0 of W' into buffer 0; its registers then take stage 2
+#pragma unroll
+      for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(zst + i * (4 * FRAG)) = wreg[0][i];
+      {
+        const int st2 = 2 % NS;
+#pragma unroll
+        for (int i = 0; i < KC; ++i) wreg[0][i] = ld_u4(wf_wg + (((long)(st2 * KC + i) * 4 + wave) * 64 + lane_f) * 16);
       }
-      __syncthreads();                                   // the W' stages are read out: Z becomes this tile's dz planes
-      FF_TICK(tmF);
+      __syncthreads();
+      for (int st = 0; st < NS; st += 2) {
+        stage(std::integral_constant<int, 0>{}, st);
+        stage(std::integral_constant<int, 1>{}, st + 1);
+      }
+      FF_TICK(tmF);                                      // (the last stage ended with a barrier: Z becomes this tile's dz planes)
 
       // ================= M: layers 2-3 of the three agents on this wavefront's two row blocks ===========================
       {
@@ -637,6 +678,7 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
       {
         // (no branches here either: a feature tile beyond the last one re-reads the last one, and its accumulators are never
         // looked at; a request past the tile's last row step re-reads that step)
+        f_prefetch(min(tile + 1, ntiles - 1));           // what the next tile's forward phase starts from (registers; harmless after the last tile)
         int ftc[FTW];
 #pragma unroll
         for (int f = 0; f < FTW; ++f) ftc[f] = min(wave * FTW + f, A.FTILES - 1);
@@ -701,19 +743,21 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
           for (int w = 0; w < NW; ++w) sum += sSum[(w * G + a) * SUMREC + si];
         }
         const bool up = a == 0 ? upd[0] : (a == 1 ? upd[1] : upd[2]);      // (no dynamic index into a register array)
-        if (up) {
-          float* th = theta_s + (long)(ag0 + a) * ldp;
-          if (idx == FitRec::loss) {
-            if (step == 0 && A.loss_out) A.loss_out[(long)s * N + ag0 + a] = sum / (float)B;
-          } else {
-            int o;
-            if (idx < FitRec::gb2) o = geo.o_W2 + idx;
-            else if (idx < FitRec::gW3) o = geo.o_b2 + (idx - FitRec::gb2);
-            else if (idx < FitRec::gb3) o = geo.o_W3 + (idx - FitRec::gW3);
-            else if (idx < FitRec::gb1) o = geo.o_b3;
-            else o = geo.o_b1 + (idx - FitRec::gb1);
-            th[o] = th[o] - lr * sum;
-          }
+        if (idx == FitRec::loss) {
+          if (up && step == 0 && A.loss_out) A.loss_out[(long)s * N + ag0 + a] = sum / (float)B;
+        } else {
+          int o;                                         // offset behind W1: b1 | W2 | b2 | W3 | b3
+          if (idx < FitRec::gb2) o = HID + idx;
+          else if (idx < FitRec::gW3) o = HID + HID * HID + (idx - FitRec::gb2);
+          else if (idx < FitRec::gb3) o = 2 * HID + HID * HID + (idx - FitRec::gW3);
+          else if (idx < FitRec::gb1) o = 3 * HID + HID * HID;
+          else o = idx - FitRec::gb1;
+          // the new value goes to global memory and to the image in LDS the next step builds its operands from (the Z region is
+          // idle from here to the next step's first tile)
+          float* th = theta_s + (long)(ag0 + a) * ldp + geo.o_b1 + o;
+          float v = ag0 + a < N ? *th : 0.f;
+          if (up) { v = v - lr * sum; *th = v; }
+          sSm[a * SMP + o] = v;
         }
       }
       w1_pass(std::true_type{});
@@ -765,7 +809,7 @@ RCMARL_EXPORT int rcmarl_fit_fused_geometry(int N, int in_dim, int hid, int rows
   const long ftiles = rc_ceil_div(in_dim, 32), ks = 2 * ftiles, ng = rc_ceil_div(N, ff::G);
   if (kf_bytes) *kf_bytes = (long)(rows_alloc / 32) * ks * ff::FRAG;
   if (ktf_bytes) *ktf_bytes = ftiles * (rows_alloc / 16) * ff::FRAG;
-  if (wf_bytes) *wf_bytes = ng * ((ks + ff::KC - 1) / ff::KC * ff::KC) * ff::WSTEP;
+  if (wf_bytes) *wf_bytes = ng * ((ks + 2 * ff::KC - 1) / (2 * ff::KC) * (2 * ff::KC)) * ff::WSTEP;
   return RCMARL_OK;
 }
 
@@ -793,7 +837,7 @@ RCMARL_EXPORT int rcmarl_fit_fused(const void* kf, const void* ktf, void* wf, co
   a.KS = 2 * ftiles; a.RS = rows_alloc / 16; a.FTILES = ftiles; a.NG = rc_ceil_div(N, ff::G);
   a.kf = (const unsigned char*)kf; a.kf_seed = (long)(rows_alloc / 32) * a.KS * ff::FRAG;
   a.ktf = (const unsigned char*)ktf; a.ktf_seed = (long)ftiles * a.RS * ff::FRAG;
-  a.wf = (unsigned char*)wf; a.wf_seed = (long)a.NG * ((a.KS + ff::KC - 1) / ff::KC * ff::KC) * ff::WSTEP;
+  a.wf = (unsigned char*)wf; a.wf_seed = (long)a.NG * ((a.KS + 2 * ff::KC - 1) / (2 * ff::KC) * (2 * ff::KC)) * ff::WSTEP;
   a.alpha = alpha; a.theta = theta; a.y = y; a.mask = mask; a.loss_out = loss_out; a.flags = flags;
   a.S = S; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb; a.nsteps = nsteps; a.lr = lr;
   const int ftw = rc_ceil_div(ftiles, ff::NW);
