@@ -154,6 +154,27 @@ int rcmarl_fit_fused(const void* kf, const void* ktf, void* wf, const float* alp
                      const int* mask, float* loss_out, int* flags, int S, int N, int B, int in_dim, int hid, int ldp,
                      int ldb, int rows_alloc, int nsteps, float lr, void* stream);
 
+/* ---- forward + mid in ONE launch (csrc/fused_fit.hip, namespace fm): steps 2.. of the same Keras fit
+ * (agents/resilient_CAC_agents.py:118,136) without the a1t round trip.  rcmarl_forward_mid = rcmarl_layer1_forward_lattice +
+ * rcmarl_mid_fit_lattice: from Kf (rcmarl_fit_encode), Wf (the f16 pieces of 2^10 alpha W1 in fragment order: rcmarl_fit_wf_split
+ * from theta, or left by rcmarl_layer1_backward_sgd_lattice_wf) and w2f (rcmarl_fit_w2_frags: the agents' 2^10 W2 as f16 MFMA
+ * fragments, [S][N][8 KiB]) it writes dzp (the packed f16 pieces of 2^8 dz1, bit-identical to rcmarl_mid_fit_lattice's) and
+ * partials[S][N][ceil(B/256)][rcmarl_fit_partial_size] -- one record per 256-row tile, to be applied with
+ * rcmarl_small_sgd_records(nrec = ceil(B/256)).  flags[S][N] (int32, zeroed by the caller): 1 for an agent whose operands left
+ * the f16 range (its outputs are then not to be used: redo the step through rcmarl_mid_fit_lattice, which has the fp32 fix-up).
+ * Wf bytes per seed: rcmarl_fit_fused_geometry's wf_bytes.  f16 operand form only (rcmarl_lattice_f16_mode() == 3). */
+int rcmarl_fit_w2_frags(const float* theta, void* w2f, int* flags, int S, int N, int in_dim, int hid, int ldp, void* stream);
+int rcmarl_fit_wf_split(const float* theta, const float* alpha, void* wf, int* flags, int S, int N, int in_dim, int hid, int ldp,
+                        void* stream);
+int rcmarl_forward_mid(const void* kf, const void* wf, const void* w2f, const float* theta, const float* y, float* partials,
+                       void* dzp, int dzp_rt, int dzp_kt, int* flags, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                       int rows_alloc, void* stream);
+int rcmarl_small_sgd_records(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N, int B,
+                             int in_dim, int hid, int ldp, int nrec, float lr, void* stream);
+int rcmarl_layer1_backward_sgd_lattice_wf(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt, int dzp_kt,
+                                          const float* alpha, float* theta, const int* mask, int S, int N, int B, int in_dim,
+                                          int hid, int ldp, float lr, void* wf_out, void* stream);
+
 /* Shuffle permutations of the adversaries' mini-batch fits (Keras fit(shuffle=True) inside
  * agents/adversarial_CAC_agents.py:38-41,131-135,163-165,237-253).  TensorFlow's shuffle RNG is not reproducible
  * outside TensorFlow; the shuffle is DEFINED here (csrc/shuffle.hip; same statement in the oracle):

@@ -157,12 +157,14 @@ __global__ __launch_bounds__(256) void k_fit_encode(const float* __restrict__ x,
 // layout argument).  z1: the lane's ten layer-1 pre-activations (x 2^10, without bias) per block, straight out of the forward
 // accumulators.  Outputs: dz1 pieces into the dz planes (zrow[n] = the lane's base address: row step, k-group, element and lane
 // half already applied), the row reduction G = [a1 | 1]^T dz2 into g1, the per-lane partial sums of gb1 / gW3 / gb3 / loss.
-template <int NU, int AG>
+// TOZ: dz1 goes to the dz planes (the fused fit); otherwise 2^8 dz1 is handed back in dz1o (rcmarl_forward_mid packs it for the
+// backward GEMM of the three-launch path).
+template <int NU, int AG, bool TOZ = true>
 __device__ __forceinline__ void mid_units(const float (&z1)[NU][LU], const bool (&valid)[NU], const float (&ycur)[NU], int B,
                                           const uint4* __restrict__ wfA, const float* __restrict__ sVa,
                                           const float* __restrict__ sB1a, unsigned short* __restrict__ planes,
                                           unsigned char* const (&zrow)[NU], int lane, rc_f32x16& g1, float (&gb1l)[LU],
-                                          float (&gw3l)[LU], float& gb3a, float& lossa, float& amax) {
+                                          float (&gw3l)[LU], float& gb3a, float& lossa, float& amax, float (&dz1o)[NU][LU]) {
   const int l31 = lane & 31, half = lane >> 5;
   auto loadA = [&](int prod, int ks) {
     V8Pieces a;
@@ -292,6 +294,10 @@ __device__ __forceinline__ void mid_units(const float (&z1)[NU][LU], const bool 
     }
 #pragma unroll
     for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(dz1l[u]), fabsf(dz1l[u + 1])));
+    if constexpr (!TOZ) {
+#pragma unroll
+      for (int u = 0; u < LU; ++u) dz1o[n][u] = dz1l[u];
+    } else
 #pragma unroll
     for (int qq = 0; qq < LU / 2; ++qq) {
       unsigned ph, pl;
@@ -625,8 +631,9 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
 #pragma unroll
               for (int u = 0; u < LU; ++u) z1[rb][u] = acc[(LU * AG + u) >> 4][rb][(LU * AG + u) & 15];
             const float yc[2] = {yv[AG][0], yv[AG][1]};
+            float nodz[2][LU];
             mid_units<2, AG>(z1, valid, yc, B, wfA, sV + AG * SV, sB1 + AG * HID, planes, zrow, lane, g1, gb1l, gw3l, gb3a,
-                             lossa, amax[AG]);
+                             lossa, amax[AG], nodz);
           } else {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -636,8 +643,9 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
               const bool v1[1] = {valid[rb]};
               const float yc[1] = {yv[AG][rb]};
               unsigned char* const zr[1] = {zrow[rb]};
+              float nodz[1][LU];
               mid_units<1, AG>(z1, v1, yc, B, wfA, sV + AG * SV, sB1 + AG * HID, planes, zr, lane, g1, gb1l, gw3l, gb3a,
-                               lossa, amax[AG]);
+                               lossa, amax[AG], nodz);
             }
           }
           // the row reduction of this tile joins the wavefront's running record (element q of the lane's accumulator tile is
@@ -781,6 +789,360 @@ __global__ RC_FF_OCC void k_fit_fused(const Args A) {
     if (wflag && col_ok[t]) A.flags[s * N + ag0 + col_a[t]] = 1;
 }
 
+
+// =============================================================================================================================
+// Forward + mid in one launch ("rcmarl_forward_mid"): the F and M phases above as a kernel of their own, one workgroup per
+// (seed, three agents, 256 replay rows), SEVERAL workgroups per CU -- while one workgroup's wavefronts run the reduction loop
+// (matrix core, LDS, L2) another's run layers 2-3 (vector ALUs): the layer-1 activations never reach HBM (a1t: 1 GB written and
+// read back per step at BASELINE configs[3]) and the two phases overlap across workgroups.  Outputs are those of
+// rcmarl_mid_fit_lattice: dz1 as two f16 pieces of 2^8 dz1 in the packed layout the backward GEMM reads, and one
+// partial-gradient record per (seed, agent, 256-row tile).  Operands: Kf (rcmarl_fit_encode), Wf (rcmarl_fit_wf_split, or the
+// backward GEMM's epilogue: rcmarl_layer1_backward_sgd_lattice_wf), the agents' W2 fragments (rcmarl_fit_w2_frags).
+namespace fm {
+#ifndef RC_FM_WAVES
+#define RC_FM_WAVES 2
+#endif
+constexpr int RC_FM_WAVES_ = RC_FM_WAVES;
+#ifndef FM_KC2
+#define FM_KC2 4
+#endif
+#ifndef FM_RECS_PER_WAVE
+#define FM_RECS_PER_WAVE 0
+#endif
+constexpr int KC2 = FM_KC2;                             // k16 steps per W' stage (two LDS buffers of KC2 * 4 KiB)
+constexpr bool RECS_PER_WAVE = FM_RECS_PER_WAVE != 0;   // every wavefront leaves its own record (no staging in LDS: 4 x the records)
+constexpr int STAGE2 = KC2 * WSTEP;
+constexpr int PD2 = KC2 < 4 ? KC2 : 4;
+constexpr int REC = 464;                                // floats of one staged record (>= FitRec::SIZE)
+constexpr int LDS_A = 0;                                // F: the two W' stages; M: the wavefronts' planes, then the staged records
+constexpr int A_BYTES = NW * PANEL_B + (RECS_PER_WAVE ? 0 : NW * G * REC * 4);
+static_assert(A_BYTES >= 2 * STAGE2, "the stage buffers fit the aliased region");
+constexpr int LDS_WF2 = LDS_A + A_BYTES;
+constexpr int LDS_SV2 = LDS_WF2 + G * WF_AGENT * 16;
+constexpr int LDS_B12 = LDS_SV2 + G * SV * 4;
+constexpr int LDS_BYTES2 = LDS_B12 + 64 * 4;
+static_assert(RC_FM_WAVES_ * LDS_BYTES2 <= 160 * 1024, "the workgroups of a CU fit its LDS");
+
+struct Args2 {
+  const unsigned char* kf; long kf_seed;
+  const unsigned char* wf; long wf_seed;
+  const uint4* w2f;                                     // [S][N][WF_AGENT]
+  const float* theta;
+  const float* y;
+  float* partials;                                      // [S][N][ntiles][FitRec::SIZE]
+  unsigned char* dzp; int dzp_rt, dzp_kt;
+  int* flags;
+  int S, N, B, in_dim, ldp, ldb, KS, NG, ntiles;
+};
+
+// the agents' 2^10 W2 as f16 pieces in A-fragment order, both orientations (k_mid_fit_v8's sWf image): 8 KiB per agent
+__global__ __launch_bounds__(256) void k_w2_frags(const float* __restrict__ theta, uint4* __restrict__ w2f, int* __restrict__ flags,
+                                                  int N, int in_dim, int ldp) {
+  const int s = blockIdx.y, i = blockIdx.x, r = threadIdx.x;
+  const NetGeom geo = make_geom(in_dim, HID, 1);
+  const float* th = theta + ((long)s * N + i) * ldp;
+  unsigned short* wf16 = reinterpret_cast<unsigned short*>(w2f + ((long)s * N + i) * WF_AGENT);
+  rc_f16_saturate();
+  for (int e = r; e < 2 * 32 * 32; e += 256) {
+    const int prod = e >> 10, ri = (e >> 5) & 31, k = e & 31;
+    const int ui = v8_row_unit(ri), uk = v8_slot_unit(k);
+    float w = 0.f;
+    if (ui >= 0 && uk >= 0) w = prod == 0 ? th[geo.o_W2 + uk * HID + ui] : th[geo.o_W2 + ui * HID + uk];
+    unsigned ph, pl;
+    rc_split2h_pair(w * S2, 0.f, ph, pl);
+    if (fabsf(w) * S2 > RANGE) flags[s * N + i] = 1;
+    const int ks = k >> 4, kg = (k >> 3) & 1;
+    const int base = ((((prod * 2 + ks) * 2 + 0) * 2 + kg) * 32 + ri) * 8 + (k & 7);
+    wf16[base] = (unsigned short)ph;
+    wf16[base + 2 * 32 * 8] = (unsigned short)pl;
+  }
+}
+
+// theta -> Wf: the two f16 pieces of 2^10 alpha_k W1 of every agent group in fragment order (what the fused fit's prologue writes)
+__global__ __launch_bounds__(256) void k_wf_split(const float* __restrict__ theta, const float* __restrict__ alpha,
+                                                  unsigned char* __restrict__ wf, long wf_seed, int* __restrict__ flags, int N,
+                                                  int in_dim, int ldp, int KS, int KSP, int FTILES) {
+  const int s = blockIdx.y, g = blockIdx.x, r = threadIdx.x, lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
+  const int ag0 = g * G;
+  unsigned char* wf_wg = wf + (long)s * wf_seed + (long)g * KSP * WSTEP;
+  rc_f16_saturate();
+  bool wflag = false;
+  int col_a[UT], col_unit[UT];
+#pragma unroll
+  for (int t = 0; t < UT; ++t) slot_decode(t, l31, col_a[t], col_unit[t]);
+  for (int ft = wave; ft < FTILES; ft += NW) {
+    const int k0 = 32 * ft + 4 * half;
+#pragma unroll
+    for (int t = 0; t < UT; ++t) {
+      const bool ok = col_a[t] >= 0 && ag0 + col_a[t] < N;
+      const float* th = theta + ((long)s * N + ag0 + (ok ? col_a[t] : 0)) * ldp + col_unit[t] + (long)k0 * HID;
+      unsigned char* wf_t = wf_wg + (long)(2 * ft) * WSTEP + t * FRAG + l31 * 16 + 8 * half;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float wn4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = k0 + 8 * gq + e;
+          const float w = (ok && k < in_dim) ? th[(8 * gq + e) * HID] : 0.f;
+          wn4[e] = (w * (k < in_dim ? alpha[k] : 0.f)) * RC_F16_W_SCALE;
+          if (fabsf(wn4[e]) > RANGE) wflag = true;
+        }
+        unsigned h0, l0, h1, l1;
+        rc_split2h_pair(wn4[0], wn4[1], h0, l0);
+        rc_split2h_pair(wn4[2], wn4[3], h1, l1);
+        unsigned char* q8 = wf_t + (gq >> 1) * WSTEP + (gq & 1) * 512;
+        *reinterpret_cast<uint2*>(q8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(q8 + UT * FRAG) = make_uint2(l0, l1);
+      }
+      if (wflag && ok) flags[s * N + ag0 + col_a[t]] = 1;
+    }
+  }
+  for (int e = r; e < (KSP - KS) * (WSTEP / 16); e += 256) {
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0u;
+    *reinterpret_cast<uint4*>(wf_wg + (long)KS * WSTEP + (long)e * 16) = z;
+  }
+}
+
+#ifdef RCMARL_EMU
+#define RC_FM_OCC
+#else
+#define RC_FM_OCC __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(RC_FM_WAVES, RC_FM_WAVES)))
+#endif
+
+__global__ RC_FM_OCC void k_forward_mid(const Args2 A) {
+  RCMARL_DYN_SMEM(unsigned char, lds);
+  unsigned char* Z = lds + LDS_A;
+  uint4* sWf = reinterpret_cast<uint4*>(lds + LDS_WF2);
+  float* sV = reinterpret_cast<float*>(lds + LDS_SV2);
+  float* sB1 = reinterpret_cast<float*>(lds + LDS_B12);
+  const int per_seed = A.NG * A.ntiles;
+  int s, w;
+  if ((A.S & 7) == 0) {                                  // all workgroups of a seed on one XCD (workgroup b -> XCD b % 8)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    s = xcd + 8 * (q / per_seed);
+    w = q % per_seed;
+  } else {
+    s = blockIdx.x / per_seed;
+    w = blockIdx.x - s * per_seed;
+  }
+  const int g = w % A.NG, tile = w / A.NG;               // neighbours share the rows' fragments
+  const int r = threadIdx.x, lane = r & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ag0 = g * G, N = A.N, B = A.B, KS = A.KS, in_dim = A.in_dim, ldp = A.ldp;
+  const int NS = 2 * ((KS + 2 * KC - 1) / (2 * KC)) * (KC / KC2);          // stages of KC2 steps over the padded reduction (even)
+  const NetGeom geo = make_geom(in_dim, HID, 1);
+  const float* theta_s = A.theta + (long)s * N * ldp;
+  // (uniform 64-bit bases + one 32-bit lane offset: the loads take their address as SGPR pair + VGPR offset, no 64-bit vector adds)
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned char* wf_u = A.wf + (long)s * A.wf_seed + (long)g * (NS * KC2) * WSTEP + (long)wave * FRAG;
+  const unsigned char* kf_u = A.kf + (long)s * A.kf_seed + (long)(tile * (TILE / 32) + wave * RB) * KS * FRAG;
+  rc_f16_saturate();
+#ifdef RC_FM_STAGGER                                     // de-phase the workgroups that share a CU (their phases use different pipes)
+  if ((blockIdx.x >> RC_FM_STAGGER_BIT) & 1) rc_sleep(RC_FM_STAGGER);
+#endif
+  // ---- requests first: W' stages 0 and 1 and the first row fragments (registers), the small arrays (LDS)
+  uint4 wreg[2][KC2], xb[PD2][RB];
+#pragma unroll
+  for (int i = 0; i < KC2; ++i) {
+    wreg[0][i] = ld_u4(wf_u + (long)(0 * KC2 + i) * (4 * FRAG) + lane16);
+    wreg[1][i] = ld_u4(wf_u + (long)(1 * KC2 + i) * (4 * FRAG) + lane16);
+  }
+#pragma unroll
+  for (int d = 0; d < PD2; ++d)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) xb[d][rb] = ld_u4(kf_u + ((long)rb * KS + min(d, KS - 1)) * FRAG + lane16);
+  for (int e = r; e < G * WF_AGENT; e += 256) {
+    const int a = e / WF_AGENT;
+    uint4 v;
+    v.x = v.y = v.z = v.w = 0u;
+    if (ag0 + a < N) v = A.w2f[((long)s * N + ag0) * WF_AGENT + e];
+    sWf[e] = v;
+  }
+  for (int e = r; e < G * SV; e += 256) {
+    const int a = e / SV, i = e - a * SV;
+    sV[e] = (i < 2 * HID + 1 && ag0 + a < N) ? theta_s[(long)(ag0 + a) * ldp + geo.o_b2 + i] : 0.f;
+  }
+  if (r < 64) {
+    const int a = r / HID, i = r - a * HID;
+    sB1[r] = (r < G * HID && ag0 + a < N) ? theta_s[(long)(ag0 + a) * ldp + geo.o_b1 + i] : 0.f;
+  }
+  bool live[G];
+#pragma unroll
+  for (int a = 0; a < G; ++a) live[a] = ag0 + a < N;
+
+  // ================= F (the fused fit's forward phase with 16-KiB stages) =====================================================
+  rc_f32x16 acc[UT][RB];
+#pragma unroll
+  for (int t = 0; t < UT; ++t)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][rb][q] = 0.f;
+  {
+    unsigned char* zst = Z + (wave * 64 + lane) * 16;
+    auto stage = [&](auto buf_tag, int st) {
+      constexpr int BUF = decltype(buf_tag)::value;
+      const unsigned char* stg = Z + BUF * STAGE2 + lane * 16;
+      const int st2 = (st + 3) % NS;
+      uint4 afA[2][UT], afB[2][UT];
+      auto ldsA = [&](int ksl, uint4 (&af)[2][UT]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int t = 0; t < UT; ++t) af[p][t] = ld_u4(stg + ((ksl * 2 + p) * UT + t) * FRAG);
+      };
+      auto kstep = [&](int ksl, uint4 (&cur)[2][UT], uint4 (&nxt)[2][UT]) {
+        const int ks = st * KC2 + ksl;
+        if (ksl + 1 < KC2) ldsA(ksl + 1, nxt);
+#pragma unroll
+        for (int p = 1; p >= 0; --p)
+#pragma unroll
+          for (int t = 0; t < UT; ++t)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[t][rb] = rc_mfma_f16(cur[p][t], xb[ksl % PD2][rb], acc[t][rb]);
+        RC_SCHED_FENCE();
+        const int kn = min(ks + PD2, KS - 1);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xb[ksl % PD2][rb] = ld_u4(kf_u + ((long)rb * KS + kn) * FRAG + lane16);
+        *reinterpret_cast<uint4*>(zst + (1 - BUF) * STAGE2 + ksl * (4 * FRAG)) = wreg[1 - BUF][ksl];
+        wreg[1 - BUF][ksl] = ld_u4(wf_u + (long)(st2 * KC2 + ksl) * (4 * FRAG) + lane16);
+        RC_SCHED_FENCE();
+      };
+      static_assert(KC2 % PD2 == 0 && KC2 % 2 == 0, "prefetch slots rotate with the stage");
+      ldsA(0, afA);
+#pragma unroll
+      for (int ksl = 0; ksl < KC2; ksl += 2) {
+        kstep(ksl, afA, afB);
+        kstep(ksl + 1, afB, afA);
+      }
+      __syncthreads();
+    };
+#pragma unroll
+    for (int i = 0; i < KC2; ++i) *reinterpret_cast<uint4*>(zst + i * (4 * FRAG)) = wreg[0][i];
+#pragma unroll
+    for (int i = 0; i < KC2; ++i) wreg[0][i] = ld_u4(wf_u + (long)((2 % NS) * KC2 + i) * (4 * FRAG) + lane16);
+    __syncthreads();
+#if !defined(FM_KNOCK) || FM_KNOCK != 1                  // (measurement builds only: 1 = no reduction loop, 2 = no mid step)
+    for (int st = 0; st < NS; st += 2) {
+      stage(std::integral_constant<int, 0>{}, st);
+      stage(std::integral_constant<int, 1>{}, st + 1);
+    }
+#endif
+  }
+
+  // ================= M: layers 2-3 of the three agents on this wavefront's two row blocks; dz1 packed for the backward GEMM ====
+  unsigned short* planes = reinterpret_cast<unsigned short*>(Z + wave * PANEL_B);
+  float* recs = reinterpret_cast<float*>(Z + NW * PANEL_B);              // [wavefront][agent][REC]
+  for (int e = lane; e < 2 * 32 * (PC - 20); e += 64) {                  // column 20 of the A planes = 1 (-> gb2), other spares 0
+    const int pc = e / (32 * (PC - 20)), rw = (e / (PC - 20)) & 31, cl = 20 + e % (PC - 20);
+    planes[pc * PLANE + rw * PC + cl] = (pc == 0 && cl == 20) ? (unsigned short)0x3C00 : (unsigned short)0;
+  }
+  const int brow = tile * TILE + wave * (RB * 32);
+  float amax[G];
+  auto agent = [&](auto ag_tag) {
+    constexpr int AG = decltype(ag_tag)::value;
+    amax[AG] = 0.f;
+    float* rec = RECS_PER_WAVE ? A.partials + (((long)s * N + (live[AG] ? ag0 + AG : 0)) * (A.ntiles * NW) + tile * NW + wave) * FitRec::SIZE
+                               : recs + (wave * G + AG) * REC;
+    float gb1l[LU], gw3l[LU], gb3a = 0.f, lossa = 0.f;
+#pragma unroll
+    for (int u = 0; u < LU; ++u) gb1l[u] = gw3l[u] = 0.f;
+    rc_f32x16 g1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g1[q] = 0.f;
+    const uint4* wfA = sWf + AG * WF_AGENT + half * 32 + l31;
+    const long R0 = (long)(ag0 + AG) * HID;               // the agent's first row of the packed dz image
+    unsigned char* dz_s = A.dzp + (long)s * A.dzp_rt * A.dzp_kt * (2 * RC_PK_BLOCK);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int b = brow + rb * 32 + l31;
+      float z1[1][LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) z1[0][u] = acc[(LU * AG + u) >> 4][rb][(LU * AG + u) & 15];
+      const bool v1[1] = {b < B};
+      const float yc[1] = {(live[AG] && b < B) ? A.y[((long)s * N + ag0 + AG) * A.ldb + b] : 0.f};
+      unsigned char* const zr[1] = {nullptr};
+      float dz1l[1][LU];
+      mid_units<1, AG, false>(z1, v1, yc, B, wfA, sV + AG * SV, sB1 + AG * HID, planes, zr, lane, g1, gb1l, gw3l, gb3a, lossa,
+                              amax[AG], dz1l);
+      // packed f16 pieces of 2^8 dz1 (rcmarl_lattice.h): row = agent*HID + unit, k = replay row; the block's 32 rows x 40
+      // (unit, piece) values are transposed through the (now idle) B planes so that the stores are 16-byte chunks (k_mid_fit_v8)
+      unsigned short* stg = planes + 2 * PLANE;
+      RC_WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < LU / 2; ++q) {
+        unsigned ph, pl;
+        rc_split2h_pair(dz1l[0][2 * q], dz1l[0][2 * q + 1], ph, pl);
+        const int u0 = v8_unit(half, 2 * q), u1 = v8_unit(half, 2 * q + 1);
+        stg[(u0 * 2 + 0) * 32 + l31] = (unsigned short)ph;
+        stg[(u0 * 2 + 1) * 32 + l31] = (unsigned short)pl;
+        stg[(u1 * 2 + 0) * 32 + l31] = (unsigned short)(ph >> 16);
+        stg[(u1 * 2 + 1) * 32 + l31] = (unsigned short)(pl >> 16);
+      }
+      RC_WAVE_SYNC();
+      const int kt = (brow + 32 * rb) >> 5;
+#pragma unroll
+      for (int it = 0; it < (HID * 2 * 4 + 63) / 64; ++it) {
+        const int c = it * 64 + lane;
+        if (c < HID * 2 * 4 && kt < A.dzp_kt && live[AG]) {
+          const int up = c >> 2, c4 = c & 3;
+          const int unit = up >> 1, piece = up & 1;
+          const int R = (int)R0 + unit;
+          const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 32 + 8 * c4);
+          const unsigned off = (unsigned)(((R >> 7) * A.dzp_kt + kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
+                               (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
+          *reinterpret_cast<uint4*>(dz_s + off) = v4;
+        }
+      }
+    }
+    // the wavefront's record of this agent: row sums by fused DPP adds, the row reduction from the accumulator tile
+    float sm[2 * LU + 4];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) { sm[u] = gb1l[u] * RC_F16_DZ_UNSCALE; sm[LU + u] = gw3l[u]; }
+    sm[2 * LU] = gb3a; sm[2 * LU + 1] = lossa; sm[2 * LU + 2] = sm[2 * LU + 3] = 0.f;
+#pragma unroll
+    for (int q = 0; q < (2 * LU + 4) / 3; ++q) rc_half_sum3_lane31(sm[3 * q], sm[3 * q + 1], sm[3 * q + 2]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ii = acc_row(q, half);
+      if (ii <= HID && l31 < HID && (!RECS_PER_WAVE || live[AG])) rec[ii * HID + l31] = g1[q] * US2;     // rows 0..19 = gW2, row 20 = gb2
+    }
+    if (l31 == 31 && (!RECS_PER_WAVE || live[AG])) {
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        rec[FitRec::gb1 + v8_unit(half, u)] = sm[u];
+        rec[FitRec::gW3 + v8_unit(half, u)] = sm[LU + u];
+      }
+      if (half == 0) { rec[FitRec::gb3] = sm[2 * LU]; rec[FitRec::loss] = sm[2 * LU + 1]; }
+    }
+  };
+#if defined(FM_KNOCK) && FM_KNOCK == 2
+  if (B == 12345) {
+#endif
+  agent(std::integral_constant<int, 0>{});
+  agent(std::integral_constant<int, 1>{});
+  agent(std::integral_constant<int, 2>{});
+#if defined(FM_KNOCK) && FM_KNOCK == 2
+  } else { recs[r] = acc[0][0][0] + acc[1][1][3] + acc[0][1][7] + acc[1][0][15]; amax[0] = amax[1] = amax[2] = 0.f; }
+#endif
+  if (!RECS_PER_WAVE) {
+    __syncthreads();
+    for (int e = r; e < G * FitRec::SIZE; e += 256) {
+      const int a = e / FitRec::SIZE, idx = e - a * FitRec::SIZE;
+      if (ag0 + a < N) {
+        const float v = (recs[(0 * G + a) * REC + idx] + recs[(1 * G + a) * REC + idx]) +
+                        (recs[(2 * G + a) * REC + idx] + recs[(3 * G + a) * REC + idx]);
+        A.partials[(((long)s * N + ag0 + a) * A.ntiles + tile) * FitRec::SIZE + idx] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < G; ++a)
+    if (live[a] && amax[a] > RANGE) A.flags[s * N + ag0 + a] = 1;
+}
+}  // namespace fm
+
 template <int FTW, int NU>
 int launch(const Args& a, void* stream) {
   static const bool ok = rc_want_lds(k_fit_fused<FTW, NU>, (size_t)LDS_BYTES);
@@ -857,4 +1219,47 @@ RCMARL_EXPORT int rcmarl_fit_fused(const void* kf, const void* ktf, void* wf, co
   }
 #endif
 #undef RC_FF
+}
+
+// ---- forward + mid in one launch (see namespace fm above) -----------------------------------------------------------------------
+RCMARL_EXPORT int rcmarl_fit_w2_frags(const float* theta, void* w2f, int* flags, int S, int N, int in_dim, int hid, int ldp,
+                                      void* stream) {
+  if (!theta || !w2f || !flags || S <= 0 || N <= 0 || in_dim <= 0 || (ldp & 63) || ldp < in_dim * hid + hid) return RCMARL_ERR_ARG;
+  if (hid != ff::HID) return RCMARL_ERR_UNSUPPORTED;
+  RCMARL_LAUNCH(ff::fm::k_w2_frags, dim3(N, S), dim3(256), 0, stream, theta, (uint4*)w2f, flags, N, in_dim, ldp);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_fit_wf_split(const float* theta, const float* alpha, void* wf, int* flags, int S, int N, int in_dim, int hid,
+                                      int ldp, void* stream) {
+  if (!theta || !alpha || !wf || !flags || S <= 0 || N <= 0 || in_dim <= 0 || (ldp & 63) || ldp < in_dim * hid + hid)
+    return RCMARL_ERR_ARG;
+  if (hid != ff::HID || in_dim > ff::MAX_K) return RCMARL_ERR_UNSUPPORTED;
+  const int ftiles = rc_ceil_div(in_dim, 32), ks = 2 * ftiles, ksp = (ks + 2 * ff::KC - 1) / (2 * ff::KC) * (2 * ff::KC);
+  const int ng = rc_ceil_div(N, ff::G);
+  RCMARL_LAUNCH(ff::fm::k_wf_split, dim3(ng, S), dim3(256), 0, stream, theta, alpha, (unsigned char*)wf, (long)ng * ksp * ff::WSTEP,
+                flags, N, in_dim, ldp, ks, ksp, ftiles);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_forward_mid(const void* kf, const void* wf, const void* w2f, const float* theta, const float* y,
+                                     float* partials, void* dzp, int dzp_rt, int dzp_kt, int* flags, int S, int N, int B,
+                                     int in_dim, int hid, int ldp, int ldb, int rows_alloc, void* stream) {
+  if (!kf || !wf || !w2f || !theta || !y || !partials || !dzp || !flags || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 ||
+      (ldp & 63) || ldp < in_dim * hid + hid || ldb < B || rows_alloc < B || (rows_alloc % ff::TILE))
+    return RCMARL_ERR_ARG;
+  if (hid != ff::HID || in_dim > ff::MAX_K) return RCMARL_ERR_UNSUPPORTED;
+  ff::fm::Args2 a;
+  const int ftiles = rc_ceil_div(in_dim, 32);
+  a.KS = 2 * ftiles; a.NG = rc_ceil_div(N, ff::G); a.ntiles = rc_ceil_div(B, ff::TILE);
+  if (dzp_rt * 128 < N * hid || dzp_kt * 32 < a.ntiles * ff::TILE) return RCMARL_ERR_ARG;
+  a.kf = (const unsigned char*)kf; a.kf_seed = (long)(rows_alloc / 32) * a.KS * ff::FRAG;
+  a.wf = (const unsigned char*)wf; a.wf_seed = (long)a.NG * ((a.KS + 2 * ff::KC - 1) / (2 * ff::KC) * (2 * ff::KC)) * ff::WSTEP;
+  a.w2f = (const uint4*)w2f; a.theta = theta; a.y = y; a.partials = partials;
+  a.dzp = (unsigned char*)dzp; a.dzp_rt = dzp_rt; a.dzp_kt = dzp_kt; a.flags = flags;
+  a.S = S; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb;
+  static const bool ok = rc_want_lds(ff::fm::k_forward_mid, (size_t)ff::fm::LDS_BYTES2);
+  if (!ok) return RCMARL_ERR_LAUNCH;
+  RCMARL_LAUNCH(ff::fm::k_forward_mid, dim3((unsigned)(S * a.NG * a.ntiles)), dim3(256), (size_t)ff::fm::LDS_BYTES2, stream, a);
+  return rcmarl_check_launch();
 }

@@ -209,6 +209,28 @@ __device__ __forceinline__ uint2 rc_lds_read_tr16(const unsigned short* p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// "Wf": the forward operand of the fused kernels (fused_fit.hip) -- the two f16 pieces of 2^10 alpha_k W1 of THREE consecutive
+// agents (one group) as ready-made MFMA A fragments:  [group][k16 step][piece][slot tile 0/1][lane 64][8 x f16], lane =
+// (slot row i = lane & 31, k-group = lane >> 5).  Slot sigma = 10 * (agent % 3) + local unit u lives in tile sigma >> 4, row
+// acc_row(sigma & 15, h) = (q & 3) + 8 * (q >> 2) + 4 * h, where unit = v8_unit(h, u): the accumulator layout of the product then IS
+// k_mid_fit_v8's "ten units per lane" layout.  Four of the 64 slots are padding (zero).
+#define RC_WF_FRAG 1024
+#define RC_WF_UT 2
+#define RC_WF_STEP (2 * RC_WF_UT * RC_WF_FRAG)
+#define RC_WF_KC 8                     // the reduction is padded to a multiple of 2 * RC_WF_KC k16 steps (zeros)
+__host__ __device__ static inline int rc_wf_ksp(int in_dim) {
+  const int ks = 2 * ((in_dim + 31) / 32);
+  return (ks + 2 * RC_WF_KC - 1) / (2 * RC_WF_KC) * (2 * RC_WF_KC);
+}
+// byte offset, inside one seed's Wf, of the 16-byte chunk row of (agent, unit) at k16 step 0, piece 0, k-group 0
+__host__ __device__ static inline long rc_wf_row_offset(int agent, int unit, int ksp) {
+  const int g = agent / 3, a = agent - 3 * g;
+  const int h = unit < 16 ? (unit >> 3) : ((unit - 16) >> 1), u = unit < 16 ? (unit & 7) : 8 + ((unit - 16) & 1);
+  const int sg = 10 * a + u, t = sg >> 4, q = sg & 15, i = (q & 3) + 8 * (q >> 2) + 4 * h;
+  return (long)g * ksp * RC_WF_STEP + t * RC_WF_FRAG + i * 16;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The "ten units per lane" form of a 20-unit layer on the 32x32x16 matrix core, shared by k_mid_fit_v8 (mid_kernels.hip) and the
 // adversaries' mini-batch fit (minibatch_fit.hip); the layout argument is in k_mid_fit_v8's header.  Lane (row j = lane&31,
 // half h = lane>>5) holds local units u = 0..9 of its row = global units v8_unit(h, u).

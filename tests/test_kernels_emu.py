@@ -243,3 +243,8 @@ def test_fused_fit_reproduces_itself(bk):
     a = KC.check_fused_fit(bk, 1, 5, 100, 2, 5, 5, steps=2, vs_unfused=False)
     b = KC.check_fused_fit(bk, 1, 5, 100, 2, 5, 5, steps=2, vs_unfused=False)
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("S,N,B,width,masked,steps", [(1, 5, 70, 2, None, 2), (2, 4, 300, 3, 1, 2), (1, 7, 40, 2, None, 3)])
+def test_forward_mid_fit(bk, S, N, B, width, masked, steps):
+    KC.check_forward_mid_fit(bk, S, N, B, width, 5, 5, steps=steps, masked_agent=masked)

@@ -288,3 +288,11 @@ def test_fused_fit_reproduces_itself(bk):
     a = KC.check_fused_fit(bk, 2, 23, 800, 3, 5, 5, steps=3, vs_unfused=False)
     b = KC.check_fused_fit(bk, 2, 23, 800, 3, 5, 5, steps=3, vs_unfused=False)
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("S,N,B,width,masked,steps", [(2, 5, 1000, 2, None, 5), (1, 64, 700, 3, 7, 3), (1, 47, 270, 3, 5, 2),
+                                                      (2, 256, 600, 2, None, 2), (1, 256, 300, 3, 100, 2), (8, 20, 3000, 3, None, 3)])
+def test_forward_mid_fit(bk, S, N, B, width, masked, steps):
+    """forward + mid in one launch: dz1 image bit-identical to the three-launch path, the same fit, the oracle's fit"""
+    KC.check_forward_mid_fit(bk, S, N, B, width, 16 if N > 30 else 5, 16 if N > 30 else 5, steps=steps, masked_agent=masked,
+                             lr=0.01 if N < 100 else 0.002)

@@ -258,6 +258,67 @@ def fused(L, S=16, N=256, B=3000, steps=5):
                  float((th_b - theta0).abs().max().item())))
 
 
+def fwdmid(L, S=16, N=256, B=3000):
+    """forward + mid in ONE launch (rcmarl_forward_mid) against rcmarl_layer1_forward_lattice + rcmarl_mid_fit_lattice, same inputs"""
+    import ctypes
+    from rcmarl_amd import lattice as LT
+    st = torch.cuda.current_stream().cuda_stream
+    S, N, B = int(os.environ.get("KB_S", S)), int(os.environ.get("KB_N", N)), int(os.environ.get("KB_B", B))
+    for width in [int(w) for w in os.environ.get("KB_WIDTHS", "2,3").split(",")]:
+        in_dim = width * N
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        g = LT.Geometry(N, in_dim, B)
+        std = float(np.std(np.arange(32)))
+        x = ((torch.randint(0, 32, (S, B, in_dim), device="cuda").float() - 15.5) / std).contiguous()
+        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
+        lim = float(np.sqrt(6.0 / (in_dim + HID)))
+        theta = (torch.rand(S, N, ldp, device="cuda") * 2 - 1) * lim
+        y = torch.randn(S, N, ldb, device="cuda")
+        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
+        kp, wp, dzp_a, dzp_b = u8(g.kp, 1), u8(g.wp, 3), u8(g.dzp, 3), u8(g.dzp, 3)
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        a1t = torch.zeros(S, N * HID, ldb, device="cuda")
+        ntiles = (B + 255) // 256
+        psz = L.rcmarl_fit_partial_size(HID)
+        part_a, part_b = (torch.zeros(S * N * ntiles * psz * 4, device="cuda") for _ in range(2))     # (x4: variants with one record per wavefront)
+        L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0], g.kp[1], None, 0, 0,
+                                flag.data_ptr(), st)
+        L.rcmarl_w1_split(theta.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], st)
+        rows_alloc = ntiles * 256
+        nb = [ctypes.c_long() for _ in range(3)]
+        L.rcmarl_fit_fused_geometry(N, in_dim, HID, rows_alloc, *[ctypes.byref(v) for v in nb])
+        kf, ktf, wf = (torch.zeros(S * v.value, dtype=torch.uint8, device="cuda") for v in nb)
+        w2f = torch.zeros(S * N * 8192, dtype=torch.uint8, device="cuda")
+        flags = torch.zeros(S, N, dtype=torch.int32, device="cuda")
+        L.rcmarl_fit_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, rows_alloc, kf.data_ptr(), ktf.data_ptr(), st)
+        t_wf = timeit(lambda: L.rcmarl_fit_wf_split(theta.data_ptr(), alpha.data_ptr(), wf.data_ptr(), flags.data_ptr(), S, N, in_dim, HID, ldp, st))
+        t_w2 = timeit(lambda: L.rcmarl_fit_w2_frags(theta.data_ptr(), w2f.data_ptr(), flags.data_ptr(), S, N, in_dim, HID, ldp, st))
+
+        def two():
+            L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], theta.data_ptr(),
+                                            a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st)
+            L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part_a.data_ptr(), dzp_a.data_ptr(), g.dzp[0],
+                                     g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st)
+
+        def one():
+            L.rcmarl_forward_mid(kf.data_ptr(), wf.data_ptr(), w2f.data_ptr(), theta.data_ptr(), y.data_ptr(), part_b.data_ptr(),
+                                 dzp_b.data_ptr(), g.dzp[0], g.dzp[1], flags.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, rows_alloc, st)
+        libs = [("product", L)]
+        for pth in [q for q in os.environ.get("RCMARL_KBENCH_LIB_B", "").split(",") if q]:
+            libs.append((os.path.basename(pth).replace("lib", "").replace(".so", ""), capi.CLib(pth)))
+        for rnd in range(2):
+            ta = timeit(two, iters=10)
+            for name, lib in libs:
+                def one_v(lib=lib):
+                    lib.rcmarl_forward_mid(kf.data_ptr(), wf.data_ptr(), w2f.data_ptr(), theta.data_ptr(), y.data_ptr(), part_b.data_ptr(),
+                                           dzp_b.data_ptr(), g.dzp[0], g.dzp[1], flags.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, rows_alloc, st)
+                tb = timeit(one_v, iters=10)
+                print("in=%4d round %d: forward + mid (2 launches) %8.1f us   forward_mid [%s] %8.1f us   x%.2f" % (in_dim, rnd, ta, name, tb, ta / tb))
+        print("in=%4d wf_split %.1f us, w2_frags %.1f us; dz image identical: %s; flags %d" %
+              (in_dim, t_wf, t_w2, bool(torch.equal(dzp_a, dzp_b)), int(flags.sum().item())))
+
+
 def i8(L, S=16, N=256, B=3000):
     """the int8-limb forward prototype (csrc/lattice_i8.hip) against the bf16x3 forward, on random lattice inputs"""
     from rcmarl_amd import lattice as LT
@@ -429,4 +490,4 @@ if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "i8": i8, "fused": fused, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "i8": i8, "fused": fused, "fwdmid": fwdmid, "minibatch": minibatch, "wide": wide}[what](L)
