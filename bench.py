@@ -145,7 +145,7 @@ def cpu_baseline(w, budget_s=25.0):
     rng = np.random.default_rng(0)
     in_nodes = build_graph(w["graph"], N, d)
     chid = w.get("critic_hid", 20)
-    k = (4 if chid == 20 else 2) if N >= 64 else min(N, 5)           # agents whose update phases are timed
+    k = (8 if chid == 20 else 2) if N >= 64 else min(N, 5)           # agents whose update phases are timed
     # only the k sampled agents need a critic of their own (a 512-unit critic at N = 1024 is 4 MB per agent)
     critics = [M.init_mlp(rng, 2 * N, chid, 1) for _ in range(k)]
     agents = [O.CoopAgent(M.init_mlp(rng, 2 * N, 20, 5), critics[i] if i < k else critics[0], M.init_mlp(rng, 3 * N, 20, 1),
@@ -155,15 +155,28 @@ def cpu_baseline(w, budget_s=25.0):
     # (a) rollout: per-agent batch-of-one policy forward + numpy RNG draws + python env step
     env.reset(episode=0)
     state, _ = env.get_data()
-    n_steps = 3
-    t0 = time.perf_counter()
-    for j in range(n_steps):
-        action = np.zeros(N)
-        for i in range(N):
-            action[i] = agents[i].act_numpy(state[None])
-        env.step(action)
-        state, _ = env.get_data()
-    t_step = (time.perf_counter() - t0) / n_steps
+    n_steps = 20 if N <= 256 else 6
+    reps = 3
+
+    def timed(fn):
+        """min and median of `reps` repeats (the host is shared with nobody, but BLAS thread start-up and page faults land on
+        the first repeat)"""
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts), sorted(ts)[len(ts) // 2]
+
+    def roll():
+        nonlocal state
+        for j in range(n_steps):
+            action = np.zeros(N)
+            for i in range(N):
+                action[i] = agents[i].act_numpy(state[None])
+            env.step(action)
+            state, _ = env.get_data()
+    t_step, t_step_med = (t / n_steps for t in timed(roll))
     # (b) phases I-III on a sample of agents
     s = rng.normal(size=(B, N, 2)).astype(np.float32)
     ns = rng.normal(size=(B, N, 2)).astype(np.float32)
@@ -171,40 +184,49 @@ def cpu_baseline(w, budget_s=25.0):
     r = -rng.integers(0, 9, size=(B, N, 1)).astype(np.float32) / 5
     sa = np.concatenate([s, a], axis=-1)
     sample = list(range(k))
-    t0 = time.perf_counter()
     msgs_c, msgs_t = [], []
-    for i in sample:
-        x, _ = agents[i].local_fit_tr(sa, r[:, i])
-        y, _ = agents[i].local_fit_critic(s, ns, r[:, i])
-        msgs_t.append(x)
-        msgs_c.append(y)
-    t_fit = (time.perf_counter() - t0) / k
-    t0 = time.perf_counter()
-    for i in sample:
-        c_in = [msgs_c[j % k] for j in range(d)]
-        t_in = [msgs_t[j % k] for j in range(d)]
-        ag = agents[i]
-        ag.consensus_hidden_critic(c_in)
-        ag.consensus_hidden_tr(t_in)
-        c_agg = ag.consensus_estimates_critic(s, c_in)
-        t_agg = ag.consensus_estimates_tr(sa, t_in)
-        ag.projection_step_critic(s, c_agg)
-        ag.projection_step_tr(sa, t_agg)
-    t_cons = (time.perf_counter() - t0) / k
-    t0 = time.perf_counter()
-    for i in sample:
-        agents[i].actor_step(s[-n_last:], ns[-n_last:], sa[-n_last:], a[-n_last:, i])
-    t_actor = (time.perf_counter() - t0) / k
-    block = steps_per_block * t_step + n_epochs * N * (t_fit + t_cons) + N * t_actor
+
+    def fits():
+        msgs_c.clear()
+        msgs_t.clear()
+        for i in sample:
+            x, _ = agents[i].local_fit_tr(sa, r[:, i])
+            y, _ = agents[i].local_fit_critic(s, ns, r[:, i])
+            msgs_t.append(x)
+            msgs_c.append(y)
+
+    def cons():
+        for i in sample:
+            c_in = [msgs_c[j % k] for j in range(d)]
+            t_in = [msgs_t[j % k] for j in range(d)]
+            ag = agents[i]
+            ag.consensus_hidden_critic(c_in)
+            ag.consensus_hidden_tr(t_in)
+            c_agg = ag.consensus_estimates_critic(s, c_in)
+            t_agg = ag.consensus_estimates_tr(sa, t_in)
+            ag.projection_step_critic(s, c_agg)
+            ag.projection_step_tr(sa, t_agg)
+
+    def actor():
+        for i in sample:
+            agents[i].actor_step(s[-n_last:], ns[-n_last:], sa[-n_last:], a[-n_last:, i])
+    (t_fit, t_fit_med), (t_cons, t_cons_med), (t_actor, t_actor_med) = (tuple(t / k for t in timed(f)) for f in (fits, cons, actor))
+
+    def block_of(ts, tf, tc, ta):
+        return steps_per_block * ts + n_epochs * N * (tf + tc) + N * ta
+    block = block_of(t_step_med, t_fit_med, t_cons_med, t_actor_med)              # the reported value: medians
+    block_fast = block_of(t_step, t_fit, t_cons, t_actor)                         # ... and the spread: minima
     return {
         "value": N * steps_per_block / block, "unit": "agent-steps/s", "cores": _blas_threads(),
         "host_cpus": os.cpu_count(), "kind": "port",
-        "consensus_updates_per_s": 1.0 / t_cons,
+        "value_from_minima": N * steps_per_block / block_fast, "repeats": reps,
+        "consensus_updates_per_s": 1.0 / t_cons_med,
         "sample": "oracle/rpbcac_oracle.py (reference loop structure, numpy fp32), one seed: %d env steps with all %d agents; "
-                  "local fits, consensus b/c/d and actor step of %d sample agents at B=%d; extrapolated linearly to one "
-                  "block (1000 env steps + 10 epochs x %d agents + actor step)" % (n_steps, N, k, B, N),
-        "seconds": {"env_step_all_agents": t_step, "local_fit_per_agent_epoch": t_fit,
-                    "consensus_per_agent_epoch": t_cons, "actor_per_agent": t_actor, "block_extrapolated": block},
+                  "local fits, consensus b/c/d and actor step of %d sample agents at B=%d; each part %d times, median (value) and "
+                  "minimum (value_from_minima); extrapolated linearly to one block (1000 env steps + 10 epochs x %d agents + "
+                  "actor step)" % (n_steps, N, k, B, reps, N),
+        "seconds": {"env_step_all_agents": t_step_med, "local_fit_per_agent_epoch": t_fit_med,
+                    "consensus_per_agent_epoch": t_cons_med, "actor_per_agent": t_actor_med, "block_extrapolated": block},
     }
 
 
@@ -300,6 +322,26 @@ def time_blocks(eng, steps, warmup, barrier, S, dev, tlib=None, want_kernels=Tru
     return dt, curve
 
 
+def _self_hash():
+    import hashlib
+    with open(os.path.abspath(__file__), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def _speedup(out):
+    """GPU line / CPU port, to the two digits the bounded CPU sample supports, with the spread of the CPU measurement"""
+    cb = out["cpu_baseline"]
+    return {"x": float("%.2g" % (out["value"] / cb["value"])),
+            "x_against_the_fastest_cpu_repeat": float("%.2g" % (out["value"] / cb.get("value_from_minima", cb["value"])))}
+
+
+def _lat_mode(tlib):
+    try:
+        return int(tlib.rcmarl_lattice_f16_mode()) if tlib is not None else 0
+    except Exception:
+        return 0
+
+
 def phase_split(eng):
     """one extra, untimed block with a synchronisation at every phase boundary"""
     eng.profile_phases = True
@@ -315,12 +357,20 @@ def extra_workloads(main_name, tlib, barrier, dev):
     bench line also carries BASELINE configs[1], [2], [4] and the north-star target shape; K1's roofline on the target
     shape is measured here with HIP events (`roofline_consensus_target`)."""
     out, k1_target = {}, None
-    for name in ("target_N256_H1", "cfg3", "cfg2_batched", "cfg1_batched", "cfg0_H0_batched", "cfg0_H0_single", "cfg2_single",
+    exact = main_name + "_exact"           # the headline workload again in the EXACT operand form (three bf16 pieces, fp32 mid kernels)
+    for name in (exact, "target_N256_H1", "cfg3", "cfg2_batched", "cfg1_batched", "cfg0_H0_batched", "cfg0_H0_single", "cfg2_single",
                  "cfg3_single", "cfg5_1gpu"):
         if name == main_name:
             continue
-        w = WORKLOADS[name]
+        w = WORKLOADS[main_name if name == exact else name]
+        saved_env = None
         try:
+            if name == exact:
+                # every fp32 operand of the matrix-core products as three bf16 pieces whose sum IS the fp32 value, layers 2-3 and
+                # the adversaries' chains on the fp32-arithmetic kernels: no operand narrower than the reference's fp32
+                saved_env = {k: os.environ.get(k) for k in ("RCMARL_LAT_F16", "RCMARL_MIDFIT", "RCMARL_MB_MX")}
+                os.environ.update(RCMARL_LAT_F16="0", RCMARL_MIDFIT="5", RCMARL_MB_MX="0")
+                tlib.rcmarl_lattice_set_f16_mode(0)
             S = w["S"]
             t_setup = time.perf_counter()
             eng = make_engine(w, S, [1000 + k for k in range(S)], tlib)
@@ -352,11 +402,22 @@ def extra_workloads(main_name, tlib, barrier, dev):
                                                                     "traffic", "traffic_source")}
                     if name == "target_N256_H1":
                         k1_target = k1
+            if name == exact:
+                rec["operand_form"] = ("exact: RCMARL_LAT_F16=0 (three bf16 pieces whose sum is the fp32 operand, bit for bit), "
+                                       "RCMARL_MIDFIT=5 and RCMARL_MB_MX=0 (fp32-arithmetic mid / mini-batch kernels)")
             out[name] = rec
             del eng
             torch.cuda.empty_cache()
         except Exception as e:                                  # an extra must never kill the bench line
             out[name] = {"error": repr(e)}
+        finally:
+            if saved_env is not None:
+                for k, v in saved_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                tlib.rcmarl_lattice_set_f16_mode(-1)
     return out, k1_target
 
 
@@ -449,9 +510,12 @@ def main(argv=None):
             "value": agent_steps / dt, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if one_instance else "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None,
+            "dtype": "f32 (matrix-core operands as 2 x f16 pieces: each fp32 operand to <= 1 ulp)" if _lat_mode(tlib) else "f32",
             "dtype_note": "fp32 parameters, activations and accumulation throughout; the matrix-core products of Phase I take their fp32 "
-                          "operands as two f16 pieces (the value to one unit in its last place, RCMARL_LAT_F16) or, =0, three exact bf16 pieces",
+                          "operands as two f16 pieces (the value to one unit in its last place: 22-23 significand bits where fp32 has 24; "
+                          "RCMARL_LAT_F16=3, the default) or, =0, as three bf16 pieces whose sum is the fp32 value bit for bit -- that form "
+                          "is timed in extra.<workload>_exact of this same line",
             "data": "synthetic" if not stub else "STUB ENGINE (control-path test, not a measurement)",
             "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
                        "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady, "fast_lr": c.fast_lr, "slow_lr": c.slow_lr, "weights_finite": finite,
@@ -486,17 +550,20 @@ def main(argv=None):
         if not args.no_cpu_baseline and world == 1 and not stub:
             try:
                 out["cpu_baseline"] = cpu_baseline(w)
-                out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+                out["speedup_vs_cpu_port"] = _speedup(out)
                 with open(cache, "w") as f:                            # the N > 1 lines of the same box sit beside it
-                    json.dump(out["cpu_baseline"], f)
+                    json.dump(dict(out["cpu_baseline"], bench_py_sha=_self_hash(), workload=args.workload), f)
             except Exception as e:                                     # the baseline must never kill the bench line
                 out["cpu_baseline"] = {"error": repr(e)}
         elif not args.no_cpu_baseline and not stub and os.path.exists(cache):
             # timed on rank 0 at N = 1 only (a few tens of CPU-seconds); the N > 1 lines of the same box carry that record
             try:
                 with open(cache) as f:
-                    out["cpu_baseline"] = dict(json.load(f), carried_from="the N=1 run of this workload on this box")
-                out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+                    rec = json.load(f)
+                if rec.get("bench_py_sha") != _self_hash():            # written by another bench.py: not this measurement's baseline
+                    raise ValueError("stale CPU-baseline cache (another bench.py wrote it)")
+                out["cpu_baseline"] = dict(rec, carried_from="the N=1 run of this workload on this box")
+                out["speedup_vs_cpu_port"] = _speedup(out)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

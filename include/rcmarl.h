@@ -102,6 +102,11 @@ int rcmarl_mid_fit(float* a1t, const float* theta, const float* y, float* partia
  *   epilogues multiply the scale out; finite while |alpha W1| < 64 and |dz1| < 256.  0 = three exact bf16 pieces
  *   everywhere.  Buffers are sized for three pieces in either form; producer and consumer calls must see the same mode. */
 int rcmarl_lattice_f16_mode(void);
+/* The form is read from RCMARL_LAT_F16 ONCE, at the first call that needs it; a process that switches forms (tests, a benchmark
+ * that reports both) says so here: mode 0..3, or -1 = read the environment again.  Host-side state only.  A packed buffer remembers
+ * the form it was last written in (by base pointer): handing a consumer (rcmarl_layer1_forward_lattice,
+ * rcmarl_layer1_backward_sgd_lattice) a buffer written in the other form returns RCMARL_ERR_ARG. */
+int rcmarl_lattice_set_f16_mode(int mode);
 int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, void* kp,
                           int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag, void* stream);
 /* wp (rows = (agent,unit) column, reduction = feature) <- the pieces of alpha[k]*W1[s][n][k][j] in the current operand form
@@ -127,10 +132,12 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
  * two f16 pieces of 2^8 dz1, or three exact bf16 pieces --, rows = (agent,unit) column, reduction = replay row, zero
  * beyond B) for rcmarl_layer1_backward_sgd_lattice.  With f16 backward operands the step itself runs on the f16 matrix
  * core (two-piece operands, four exact products per fp32 product; RCMARL_MIDFIT=5: the fp32 kernel of rcmarl_mid_fit);
- * an agent whose activations / gradients leave the f16 range is redone in fp32 arithmetic by a second launch.  The
- * out-of-range flags live in a device buffer the library allocates at the first call: one host thread, one stream. */
+ * an agent whose activations / gradients leave the f16 range is redone in fp32 arithmetic by a second launch.
+ * ovf_flags: int32[S*N + 1] owned by the caller, ZERO before its first use and not touched by anybody else while a call is in
+ * flight (one buffer per stream / call site): [0, S*N) the call generation in which an agent was last flagged, [S*N] the
+ * generation counter (bumped on the device: a hipGraph replay draws a fresh one).  NULL: the fp32-arithmetic kernel alone. */
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
-                           int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+                           int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, int* ovf_flags, void* stream);
 
 /* ---- the whole local fit in ONE launch ("fused fit", csrc/fused_fit.hip) --------------------------------------------
  * Replaces the per-agent Keras fit  self.critic.fit(s, TD_target, epochs=5, batch_size=B)  /  self.TR.fit(sa, r, ...)
@@ -225,14 +232,15 @@ int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float*
  *   fit(batch_size=32, epochs=10), agents/adversarial_CAC_agents.py:121-165, 228-253.  With <= 20 inputs every
  *   product of a step runs on the f16 matrix core (two-piece f16 operands, fp32 masters and accumulation); a network
  *   whose operands leave the f16 range is redone in fp32 arithmetic by a second launch (RCMARL_MB_MX=0: fp32 only).
- *   The out-of-range flags live in a device buffer the library allocates at the first call; calls from up to three
- *   streams may be in flight at once (the three fits of a Malicious agent).
+ *   ovf_flags: int32[S * n_adv] owned by the caller, ZERO before its first use (the fix-up clears what it consumes, so the
+ *   buffer is zero again when the call has run; safe under hipGraph replay); one buffer per call in flight.  NULL: the fp32
+ *   kernel alone.
  * rcmarl_minibatch_actor: Adam + sample-weighted sparse CE -- the adversaries' actor_update,
  *   fit(batch_size=200, epochs=1), :38-41, :111-117, :221-225.  t0 = Adam steps taken before this call.
  * loss_out[S][N] (or NULL): first-epoch loss. */
 int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float* theta, const int* agents, int n_adv,
                          const float* y, const int* perm, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
-                         int batch_size, int epochs, float lr, float* loss_out, void* stream);
+                         int batch_size, int epochs, float lr, float* loss_out, int* ovf_flags, void* stream);
 int rcmarl_minibatch_actor(const float* x, long x_seed_stride, float* theta, float* adam_m, float* adam_v,
                            const int* agents, int n_adv, const float* act_t, const float* delta, const int* perm, int S,
                            int N, int B, int in_dim, int hid, int n_actions, int ldp, int ldb, int batch_size,

@@ -26,6 +26,7 @@ SIGNATURES = {
     "rcmarl_actor_partial_size": [c_int, c_int],
     "rcmarl_rows_per_chunk": [],
     "rcmarl_lattice_f16_mode": [],
+    "rcmarl_lattice_set_f16_mode": [c_int],
     # msg, theta, nbr, coop, S, N, ldp, P_hid, d, H, lo_dbg, hi_dbg, stream
     "rcmarl_consensus_params": [c_f32p, c_f32p, c_i32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_f32p, c_f32p, c_stream],
@@ -59,9 +60,9 @@ SIGNATURES = {
     # stream
     "rcmarl_layer1_backward_sgd_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_u8p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_float, c_u8p, c_int, c_int, c_stream],
-    # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, stream
+    # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, ovf_flags, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_stream],
+                               c_int, c_int, c_i32p, c_stream],
     # fused local fit, csrc/fused_fit.hip ---------------------------------------------------------------------
     # N, in_dim, hid, rows_alloc, kf_bytes(long*, host), ktf_bytes, wf_bytes
     "rcmarl_fit_fused_geometry": [c_int, c_int, c_int, c_int, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -107,9 +108,9 @@ SIGNATURES = {
     "rcmarl_projection_residual": [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_stream],
     # x, x_seed_stride, theta, agents, n_adv, y, perm, S, N, B, in_dim, hid, ldp, ldb, batch_size, epochs, lr,
-    # loss_out, stream
+    # loss_out, ovf_flags, stream
     "rcmarl_minibatch_fit": [c_f32p, c_long, c_f32p, c_i32p, c_int, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int,
-                             c_int, c_int, c_int, c_int, c_float, c_f32p, c_stream],
+                             c_int, c_int, c_int, c_int, c_float, c_f32p, c_i32p, c_stream],
     # x, x_seed_stride, theta, adam_m, adam_v, agents, n_adv, act_t, delta, perm, S, N, B, in_dim, hid, n_actions,
     # ldp, ldb, batch_size, epochs, lr, beta1, beta2, eps, t0, loss_out, stream
     "rcmarl_minibatch_actor": [c_f32p, c_long, c_f32p, c_f32p, c_f32p, c_i32p, c_int, c_f32p, c_f32p, c_i32p, c_int,
@@ -185,7 +186,7 @@ SIGNATURES = {
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
              "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
              "rcmarl_consensus_params_circulant_supported"}
 

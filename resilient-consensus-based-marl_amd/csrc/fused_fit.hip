@@ -1258,6 +1258,7 @@ RCMARL_EXPORT int rcmarl_forward_mid(const void* kf, const void* wf, const void*
   a.w2f = (const uint4*)w2f; a.theta = theta; a.y = y; a.partials = partials;
   a.dzp = (unsigned char*)dzp; a.dzp_rt = dzp_rt; a.dzp_kt = dzp_kt; a.flags = flags;
   a.S = S; a.N = N; a.B = B; a.in_dim = in_dim; a.ldp = ldp; a.ldb = ldb;
+  rc_form_set(dzp, 1);
   static const bool ok = rc_want_lds(ff::fm::k_forward_mid, (size_t)ff::fm::LDS_BYTES2);
   if (!ok) return RCMARL_ERR_LAUNCH;
   RCMARL_LAUNCH(ff::fm::k_forward_mid, dim3((unsigned)(S * a.NG * a.ntiles)), dim3(256), (size_t)ff::fm::LDS_BYTES2, stream, a);

@@ -571,7 +571,6 @@ int launch_backward(unsigned nblocks, void* stream, const unsigned char* ktp, in
 
 // 0: exact bf16x3 everywhere; bit 0: forward operand (W', and K of the forward image) as f16x2; bit 1: backward operand (dz1, and
 // K^T) as f16x2.  Callers that decode packed buffers (tests) ask here; the buffers are always sized for three pieces.
-RCMARL_EXPORT int rcmarl_lattice_f16_mode(void) { return rc_lat_f16_mode(); }
 
 RCMARL_EXPORT int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim,
                                         void* kp, int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag,
@@ -586,6 +585,8 @@ RCMARL_EXPORT int rcmarl_lattice_encode(const float* x, long x_seed_stride, cons
   if (ktp) c_ext = ktp_rt * 128 > c_ext ? ktp_rt * 128 : c_ext;
   const dim3 grid(rc_ceil_div(c_ext, 128), b_pad / 32, S), block(256);
   const int mode = rc_lat_f16_mode();
+  rc_form_set(kp, mode & 1);
+  rc_form_set(ktp, (mode >> 1) & 1);
   RCMARL_LAUNCH(k_lattice_encode, grid, block, 0, stream, x, x_seed_stride, alpha, B, in_dim, (unsigned char*)kp, kp_rt,
                 kp_kt, (unsigned char*)ktp, ktp_rt, ktp_kt, flag, mode & 1, (mode >> 1) & 1);
   return rcmarl_check_launch();
@@ -598,6 +599,7 @@ RCMARL_EXPORT int rcmarl_w1_split(const float* theta, const float* alpha, void* 
   if (hid <= 0) return RCMARL_ERR_ARG;
   if ((long)wp_rt * 128 < (long)N * hid || wp_kt * 32 < in_dim) return RCMARL_ERR_ARG;
   const dim3 grid(rc_ceil_div(in_dim, 32), rc_ceil_div(N * hid, 128), S), block(256);
+  rc_form_set(wp, rc_lat_f16_mode() & 1);
   if (rc_lat_f16_mode() & 1) {
     RCMARL_LAUNCH(k_w1_split<true>, grid, block, 0, stream, theta, alpha, (unsigned char*)wp, N, in_dim, ldp, wp_rt, wp_kt, hid);
   } else {
@@ -613,6 +615,7 @@ RCMARL_EXPORT int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int 
     return RCMARL_ERR_ARG;
   const int rts = rc_ceil_div(N * hid, 128), kts = rc_ceil_div(B, 32);
   if (dzp_rt < rts || dzp_kt < kts) return RCMARL_ERR_ARG;
+  rc_form_set(dzp, (rc_lat_f16_mode() >> 1) & 1);
   if (rc_lat_f16_mode() & 2) {
     RCMARL_LAUNCH(k_dz_pack<true>, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
   } else {
@@ -632,6 +635,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
   const unsigned nb = (unsigned)(S * mtiles * ntiles);
   const bool w8 = lat_w8(true), f16 = rc_lat_f16_mode() & 1;
+  if (!rc_form_ok(kp, f16) || !rc_form_ok(wp, f16)) return RCMARL_ERR_ARG;       // written in the other operand form
 #define RC_FWD(W8, F16)                                                                                                       \
   launch_forward<W8, F16>(nb, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp, kp_rt, kp_kt, theta, \
                           a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid)
@@ -653,6 +657,8 @@ static int backward_sgd_lattice_impl(const void* ktp, int ktp_rt, int ktp_kt, co
   const unsigned nb = (unsigned)(S * mtiles * ntiles);
   const int mode = rc_lat_f16_mode();
   const bool w8 = lat_w8(false);
+  if (!rc_form_ok(ktp, (mode >> 1) & 1) || !rc_form_ok(dzp, (mode >> 1) & 1)) return RCMARL_ERR_ARG;   // written in the other operand form
+  rc_form_set(wp_out, mode & 1);
   if (wf_out && (mode != 3 || hid != 20)) return RCMARL_ERR_UNSUPPORTED;      // the fragment-order output exists for f16 pieces only
 #define RC_BWD(W8, DZ16, WP16)                                                                                              \
   launch_backward<W8, DZ16, WP16>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, \

@@ -1034,23 +1034,6 @@ bool midfit_v8() {
 // (65536 entries cover every BASELINE shape; a larger S*N reallocates) -- calls are expected from one host thread and one stream at a
 // time, as the engine issues them.
 __global__ void k_bump_generation(int* g) { *g = *g >= (1 << 30) ? 1 : *g + 1; }
-struct MidFlags { int* buf = nullptr; size_t cap = 0; };
-MidFlags g_mid_flags;
-int* mid_flags(size_t n, int*& gen_p, void* stream) {
-  MidFlags& f = g_mid_flags;
-  if (n > f.cap) {
-    const size_t cap = n > 65536 ? n : 65536;
-    int* nb = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&nb), (cap + 1) * sizeof(int)) != hipSuccess || hipMemset(nb, 0, (cap + 1) * sizeof(int)) != hipSuccess)
-      return nullptr;
-    if (f.buf) (void)hipFree(f.buf);
-    f.buf = nb; f.cap = cap;
-  }
-  gen_p = f.buf + f.cap;
-  RCMARL_LAUNCH(k_bump_generation, dim3(1), dim3(1), 0, stream, gen_p);
-  return f.buf;
-}
-
 bool bad_mid(const void* a, const void* b, int S, int N, int B, int in_dim, int hid, int ldp, int ldb) {
   return !a || !b || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) || (ldb & 63) || ldb < B;
 }
@@ -1081,15 +1064,18 @@ RCMARL_EXPORT int rcmarl_mid_fit(float* a1t, const float* theta, const float* y,
 
 RCMARL_EXPORT int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials,
                                          void* dzp, int dzp_rt, int dzp_kt, int S, int N, int B, int in_dim, int hid,
-                                         int ldp, int ldb, void* stream) {
+                                         int ldp, int ldb, int* ovf_flags, void* stream) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !y || !partials || !dzp) return RCMARL_ERR_ARG;
   const int nchunk = rc_ceil_div(B, ROWS), cpw = midfit_cpw(nchunk, (long)S * N);
   if (dzp_rt * 128 < N * hid || dzp_kt * 32 < nchunk * ROWS) return RCMARL_ERR_ARG;   // every lane of every chunk stores
   const dim3 grid(rc_ceil_div(nchunk, cpw), N, S), block(ROWS);
-  if (midfit_v8()) {
-    int* gen = nullptr;
-    int* flags = mid_flags((size_t)S * N, gen, stream);
-    if (!flags) return RCMARL_ERR_LAUNCH;
+  rc_form_set(dzp, (rc_lat_f16_mode() >> 1) & 1);
+  if (midfit_v8() && ovf_flags != nullptr) {               // (no flag buffer: the fp32-arithmetic kernel alone)
+    // ovf_flags[0 .. S*N) = the generation in which an agent was last flagged, ovf_flags[S*N] = the generation counter,
+    // bumped on the device so that a launch pair replayed from a hipGraph draws a fresh one
+    int* flags = ovf_flags;
+    int* gen = ovf_flags + (size_t)S * N;
+    RCMARL_LAUNCH(k_bump_generation, dim3(1), dim3(1), 0, stream, gen);
     RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_fit_v8<HID_, true>), grid, block, 0, stream, const_cast<float*>(a1t), theta, y,
                                      partials, N, B, in_dim, ldp, ldb, nchunk, cpw, (unsigned char*)dzp, dzp_rt, dzp_kt, flags, (const int*)gen));
     // the fix-up: same grid, same records, same packed rows -- a workgroup whose agent is not flagged returns at once

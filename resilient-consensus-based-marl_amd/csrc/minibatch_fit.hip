@@ -285,13 +285,19 @@ __device__ __forceinline__ float rc_other_half(float v) {
 #endif
 
 template <int INMAX>                                        // inputs padded to INMAX (16 or 20): branch-free loops
-__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, const int* __restrict__ fix_flags, int fix_gen) {
+__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, int* __restrict__ fix_flags) {
   constexpr int HID = 20, U = 10, XR = 11;                    // XR: first x row of the P2 panel
   RCMARL_DYN_SMEM(float, smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int net = blockIdx.x * (blockDim.x >> 6) + wave;
   if (net >= n_nets) return;                               // (wave-uniform; the kernel has no workgroup barrier)
-  if (fix_flags != nullptr && fix_flags[net] != fix_gen) return;   // fix-up launch behind k_minibatch_mx: flagged networks only
+  // fix-up launch behind k_minibatch_mx: flagged networks only.  The wavefront that redoes a network is the flag's one reader: it
+  // clears it (nothing host-side to go stale when the launch pair is replayed from a hipGraph)
+  if (fix_flags != nullptr) {
+    if (fix_flags[net] == 0) return;
+    RC_WAVE_SYNC();
+    if ((threadIdx.x & 63) == 0) fix_flags[net] = 0;
+  }
   const int s = net / a.n_adv, adv = net - s * a.n_adv;
   float* W = smem + wave * WP_FLOATS;
   float* W2T = W + WP_W;
@@ -561,7 +567,7 @@ __device__ __forceinline__ int mx_piece1(int elem) { return !COMPACT ? 2 * 32 * 
 #define RC_MX_OCC __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2)))   // <= 256 registers
 #endif
 template <int KS1, bool COMPACT>                             // k-steps of layer 1: 1 (<= 16 inputs) or 2 (<= 20)
-__device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned char* smem, int* __restrict__ ovf_flags, int ovf_gen) {
+__device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned char* smem, int* __restrict__ ovf_flags) {
   constexpr int HID = 20, LU = 10, NX = 8 * KS1;
   const int lane = threadIdx.x & 63;
   unsigned short* frag = reinterpret_cast<unsigned short*>(smem);
@@ -891,7 +897,7 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
 #pragma unroll
     for (int mk = 32; mk >= 1; mk >>= 1) am = fmaxf(am, __shfl_xor(am, mk, 64));
     if (am > MX_RANGE) {
-      if (lane == 0) ovf_flags[net] = ovf_gen;
+      if (lane == 0) ovf_flags[net] = 1;
       return;
     }
 #pragma unroll
@@ -911,37 +917,15 @@ __device__ __forceinline__ void mx_fit_net(const MbArgs& a, int net, unsigned ch
 }
 
 template <int KS1, bool COMPACT>
-__global__ RC_MX_OCC void k_minibatch_mx(MbArgs a, int net0, int* __restrict__ ovf_flags, int ovf_gen) {
+__global__ RC_MX_OCC void k_minibatch_mx(MbArgs a, int net0, int* __restrict__ ovf_flags) {
   RCMARL_DYN_SMEM(unsigned char, smem);
-  mx_fit_net<KS1, COMPACT>(a, net0 + (int)blockIdx.x, smem, ovf_flags, ovf_gen);
+  mx_fit_net<KS1, COMPACT>(a, net0 + (int)blockIdx.x, smem, ovf_flags);
 }
 
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
   const NetGeom g = make_geom(in_dim, hid, out);
   const int Ppad = (g.P + 3) & ~3;
   return sizeof(float) * ((size_t)2 * Ppad + TR * XLD + 4 * TR * hid + TR * out + TR) + sizeof(int) * TR;
-}
-
-// Out-of-range flags of k_minibatch_mx: one int per network, owned by the library, zeroed at allocation, marked and read with a
-// per-call generation number: one host thread.  The adversaries' three fits run on three streams beside the cooperative agents'
-// two, so every call draws a FRESH generation, a network's flag is only ever compared with the generation of the call that may have
-// set it, and up to eight calls in flight use disjoint slices of the buffer (slot = generation % 8).
-constexpr int MB_SLOTS = 8;
-struct MbFlags { int* buf = nullptr; size_t cap = 0; int gen = 0; };
-MbFlags g_mb_flags;
-int* mb_flags(size_t n, int& gen) {
-  MbFlags& f = g_mb_flags;
-  if (n > f.cap) {
-    const size_t cap = n > 16384 ? n : 16384;
-    int* nb = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&nb), MB_SLOTS * cap * sizeof(int)) != hipSuccess || hipMemset(nb, 0, MB_SLOTS * cap * sizeof(int)) != hipSuccess)
-      return nullptr;
-    if (f.buf) (void)hipFree(f.buf);
-    f.buf = nb; f.cap = cap; f.gen = 0;
-  }
-  f.gen = f.gen >= (1 << 30) ? 1 : f.gen + 1;
-  gen = f.gen;
-  return f.buf + (size_t)(f.gen % MB_SLOTS) * f.cap;
 }
 
 template <class K>
@@ -958,7 +942,7 @@ int mb_launch(K kernel, const MbArgs& a, int S, size_t smem, void* stream) {
 RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float* theta, const int* agents, int n_adv,
                                        const float* y, const int* perm, int S, int N, int B, int in_dim, int hid,
                                        int ldp, int ldb, int batch_size, int epochs, float lr, float* loss_out,
-                                       void* stream) {
+                                       int* ovf_flags, void* stream) {
   if (!x || !theta || !agents || !y || n_adv <= 0 || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || batch_size <= 0 ||
       epochs <= 0 || (ldp & 63) || ldb < B)
     return RCMARL_ERR_ARG;
@@ -975,35 +959,33 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
     const size_t smem = (size_t)4 * WP_FLOATS * sizeof(float);
     static const bool attr_ok = rc_want_lds(k_minibatch_wave<16>, smem) && rc_want_lds(k_minibatch_wave<20>, smem);
     if (!attr_ok) return RCMARL_ERR_LAUNCH;
-    const int* flags = nullptr;
-    int gen = 0;
+    int* flags = nullptr;
     const char* e = getenv("RCMARL_MB_MX");
-    if (!(e && atoi(e) == 0)) {
-      int* fl = mb_flags((size_t)n_nets, gen);
-      if (!fl) return RCMARL_ERR_LAUNCH;
+    if (ovf_flags != nullptr && !(e && atoi(e) == 0)) {       // (no flag buffer: the fp32 kernel alone)
+      int* fl = ovf_flags;
       flags = fl;
       // more networks than wavefront slots at six per CU: the compact form (eight per CU)
       const char* ce = getenv("RCMARL_MB_MX_COMPACT");
       const bool compact = ce ? atoi(ce) != 0 : n_nets > 1536;
       if (compact) {
         if (in_dim <= 16) {
-          RCMARL_LAUNCH((k_minibatch_mx<1, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl, gen);
+          RCMARL_LAUNCH((k_minibatch_mx<1, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl);
         } else {
-          RCMARL_LAUNCH((k_minibatch_mx<2, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl, gen);
+          RCMARL_LAUNCH((k_minibatch_mx<2, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl);
         }
       } else if (in_dim <= 16) {
-        RCMARL_LAUNCH((k_minibatch_mx<1, false>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
+        RCMARL_LAUNCH((k_minibatch_mx<1, false>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl);
       } else {
-        RCMARL_LAUNCH((k_minibatch_mx<2, false>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl, gen);
+        RCMARL_LAUNCH((k_minibatch_mx<2, false>), dim3(n_nets), dim3(64), MX_BYTES, stream, a, 0, fl);
       }
     }
     // alone: four networks per workgroup; as the fix-up: one (64 threads, 16 KB of LDS: it finds room beside anything and returns at once)
     const int wpb = flags ? 1 : 4;
     const size_t smem_w = (size_t)wpb * WP_FLOATS * sizeof(float);
     if (in_dim <= 16) {
-      RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + wpb - 1) / wpb), dim3(64 * wpb), smem_w, stream, a, n_nets, flags, gen);
+      RCMARL_LAUNCH((k_minibatch_wave<16>), dim3((n_nets + wpb - 1) / wpb), dim3(64 * wpb), smem_w, stream, a, n_nets, flags);
     } else {
-      RCMARL_LAUNCH((k_minibatch_wave<20>), dim3((n_nets + wpb - 1) / wpb), dim3(64 * wpb), smem_w, stream, a, n_nets, flags, gen);
+      RCMARL_LAUNCH((k_minibatch_wave<20>), dim3((n_nets + wpb - 1) / wpb), dim3(64 * wpb), smem_w, stream, a, n_nets, flags);
     }
     return rcmarl_check_launch();
   }

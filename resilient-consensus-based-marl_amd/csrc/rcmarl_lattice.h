@@ -89,10 +89,11 @@ __device__ __forceinline__ void rc_split3_pair(float w0, float w1, unsigned& h, 
 #ifndef RC_LAT_F16_DEFAULT
 #define RC_LAT_F16_DEFAULT 3
 #endif
-static inline int rc_lat_f16_mode() {               // read at every call: tests switch it
-  const char* e = getenv("RCMARL_LAT_F16");
-  return e ? (atoi(e) & 3) : RC_LAT_F16_DEFAULT;
-}
+// (csrc/abi.hip) the operand form -- RCMARL_LAT_F16 read once, then rcmarl_lattice_set_f16_mode -- and the form each packed
+// buffer was last WRITTEN in: producers record it, consumers refuse a buffer written in the other form (RCMARL_ERR_ARG)
+int rc_lat_f16_mode();
+void rc_form_set(const void* buf, int f16_form);
+bool rc_form_ok(const void* buf, int f16_form);
 
 // Saturation.  Kernels that form f16 pieces call rc_f16_saturate() first: MODE.FP16_OVFL (bit 23) makes a f32 -> f16 conversion
 // of a FINITE value beyond +-65504 return +-65504 instead of infinity (true infinities and NaNs pass).  A value beyond the form's

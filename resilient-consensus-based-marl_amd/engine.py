@@ -890,7 +890,8 @@ class RPBCACEngine:
             ptr, stride = self._x(xkey)
             L.rcmarl_minibatch_fit(ptr, stride, msg.data_ptr(), self.coop_idx.data_ptr(), self.n_coop, y.data_ptr(), None, S, N, B,
                                    self.in_dim[net], HID, self.ldp[net], self.ldb, B, self.cfg.local_fit_steps, self.cfg.fast_lr,
-                                   self.loss[net].data_ptr(), self.stream)
+                                   self.loss[net].data_ptr(), self.ovf_flags(("chain", net), S * max(self.n_coop, 1)).data_ptr(),
+                                   self.stream)
             self.a1_cached[net] = False
             return
         a1 = self.a1net[net]
@@ -906,7 +907,7 @@ class RPBCACEngine:
             if lat:
                 L.rcmarl_mid_fit_lattice(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), partials.data_ptr(),
                                          dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B, self.in_dim[net], HID,
-                                         self.ldp[net], self.ldb, self.stream)
+                                         self.ldp[net], self.ldb, self.ovf_flags(("mid", net), S * N + 1).data_ptr(), self.stream)
             else:
                 L.rcmarl_mid_fit(a1.data_ptr(), msg.data_ptr(), y.data_ptr(), partials.data_ptr(), S, N, B,
                                  self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
@@ -927,6 +928,16 @@ class RPBCACEngine:
                 L.rcmarl_layer1_backward_sgd(ptr, stride, a1.data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B,
                                              self.in_dim[net], HID, self.ldp[net], self.ldb, self.cfg.fast_lr, self.stream)
         self.a1_cached[net] = False
+
+    def ovf_flags(self, key, n):
+        """Out-of-range flag buffer of one call site (int32, zero at first use; the library's f16 kernels flag an agent / network
+        whose operands leave the f16 range and their fp32 fix-up consumes the flag).  Owned by THIS engine, one per call site and
+        stream: nothing is shared between engines, host threads or launches in flight (include/rcmarl.h)."""
+        d = self.__dict__.setdefault("_ovf_flags", {})
+        t = d.get(key)
+        if t is None or t.numel() < n:
+            t = d[key] = torch.zeros(int(n), dtype=torch.int32, device=self.dev)
+        return t
 
     def _fit_as_chains(self, net, mask):
         """Local fits through rcmarl_minibatch_fit (one wavefront per network)?  RCMARL_FIT_CHAINS=1 / 0 forces it on / off; default:
@@ -1143,7 +1154,7 @@ class RPBCACEngine:
         if epoch == 0 or not self._graph_wanted() or not (self.a1_cached["critic"] and self.a1_cached["tr"]):
             return self._epoch_body(B, t0)
         key = (B, self.lat_active, bool(self.td_shortcut), bool(self.rows_episode_aligned), bool(self.k1_circulant),
-               bool(self.reuse_activations), self.cap, os.environ.get("RCMARL_LAT_F16"), os.environ.get("RCMARL_LAT_W8"),
+               bool(self.reuse_activations), self.cap, self.lib.rcmarl_lattice_f16_mode(), os.environ.get("RCMARL_LAT_W8"),
                os.environ.get("RCMARL_MIDFIT"))
         g = self._graphs.get(key)
         if g is None:

@@ -89,7 +89,8 @@ class AdversaryPath:
         if hid == HID:
             L.rcmarl_minibatch_fit(xptr, xstride, theta.data_ptr(), agents_t.data_ptr(), len(agents), y.data_ptr(),
                                    perm.data_ptr(), e.S, e.N, B, e.in_c, HID, e.ldp["critic"], e.ldb, FIT_BATCH, FIT_EPOCHS,
-                                   e.cfg.fast_lr, None if loss_out is None else loss_out.data_ptr(), e.stream)
+                                   e.cfg.fast_lr, None if loss_out is None else loss_out.data_ptr(),
+                                   e.ovf_flags(("adv", theta.data_ptr()), e.S * len(agents)).data_ptr(), e.stream)
             return
         # wide critic: one SGD step = forward L1, forward L2, head fit (dz3, dz2 in place, gW3/gb3/gb2), backward-data L2
         # (-> dz1), bias grad, backward-SGD W2, backward-SGD W1, small SGD -- every gradient from the pre-step weights, as
@@ -189,7 +190,8 @@ class AdversaryPath:
             xptr, xstride = e._x("sa")
             L.rcmarl_minibatch_fit(xptr, xstride, e.theta["tr"].data_ptr(), self.fit_t.data_ptr(), len(self.fit),
                                    e.ybuf["r_fit"].data_ptr(), perms["tr"].data_ptr(), S, N, B, e.in_r, HID, e.ldp["tr"],
-                                   e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(), e.stream)
+                                   e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(),
+                                   e.ovf_flags(("adv", "tr"), S * len(self.fit)).data_ptr(), e.stream)
             e.msg["tr"].index_copy_(1, self.fit_idx, e.theta["tr"].index_select(1, self.fit_idx))   # the fitted net IS the message
             done(1)
         # transmitted critic: targets y_c = r_fit + gamma*V_theta(ns), computed from the pre-fit weights

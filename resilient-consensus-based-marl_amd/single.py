@@ -78,6 +78,7 @@ class RowOps:
     def __init__(self, lib, device):
         self.lib = lib
         self.dev = torch.device(device)
+        self._mb_flags = torch.zeros(8, dtype=torch.int32, device=self.dev)      # out-of-range flags of rcmarl_minibatch_fit (one network)
 
     # ---- plumbing ----------------------------------------------------------------------------
     @property
@@ -295,7 +296,7 @@ class RowOps:
         loss = self._zeros(1, 1)
         self.lib.rcmarl_minibatch_fit(xd.data_ptr(), B * in_dim, theta.data_ptr(), agents.data_ptr(), 1, yd.data_ptr(),
                                       None if pd is None else pd.data_ptr(), 1, 1, B, in_dim, HID, ldp, ldb, int(batch_size),
-                                      int(epochs), float(lr), loss.data_ptr(), self.stream)
+                                      int(epochs), float(lr), loss.data_ptr(), self._mb_flags.data_ptr(), self.stream)
         return unflat(self._host(theta)[0, 0], in_dim, 1), float(self._host(loss)[0, 0])
 
     def minibatch_actor(self, params, adam, x, labels, weights, lr, batch_size=200, epochs=1, perms=None):

@@ -18,8 +18,7 @@ def _gemm_flops(a, first):          # (..., S, N, B, in_dim, hid, ...) starting 
 def lattice_pieces(bit):
     """16-bit pieces per value of the forward (bit 1) / backward (bit 2) lattice operand under the library's current operand form
     (RCMARL_LAT_F16, csrc/rcmarl_lattice.h: default 3 = two f16 pieces for both)."""
-    import os
-    return 2 if int(os.environ.get("RCMARL_LAT_F16", "3")) & bit else 3
+    return 2 if int(capi.load().rcmarl_lattice_f16_mode()) & bit else 3
 
 
 # algorithmic work per launch: name -> f(args) -> (flops, bytes)   (DESIGN.md "Kernels")

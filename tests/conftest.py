@@ -31,3 +31,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def lattice_form(monkeypatch):
+    """Switch the operand form of the lattice path inside one process: the library reads RCMARL_LAT_F16 once, so the switch goes
+    through rcmarl_lattice_set_f16_mode(); the environment variable is set too (host-side helpers read it).  Restored afterwards."""
+    done = []
+
+    def set_form(bk, mode):
+        done.append((bk.lib, bk.lib.rcmarl_lattice_f16_mode()))
+        monkeypatch.setenv("RCMARL_LAT_F16", str(mode))
+        bk.lib.rcmarl_lattice_set_f16_mode(int(mode))
+    yield set_form
+    for lib, prev in reversed(done):
+        lib.rcmarl_lattice_set_f16_mode(prev)

@@ -15,6 +15,25 @@ from oracle import rpbcac_oracle as O
 HID = 20
 
 
+_FLAG_BUFS = {}
+
+
+def _mid_flags(bk, S, N):
+    """caller-owned out-of-range flags of rcmarl_mid_fit_lattice: int32[S*N + 1], zero at first use, reused across calls"""
+    key = ("mid", id(bk), S, N)
+    if key not in _FLAG_BUFS:
+        _FLAG_BUFS[key] = bk.dev(np.zeros(S * N + 1, np.int32))
+    return _FLAG_BUFS[key]
+
+
+def _mb_flags(bk, n=4096):
+    """... of rcmarl_minibatch_fit: int32[S * n_adv], zero at first use (the fix-up clears what it consumes)"""
+    key = ("mb", id(bk), n)
+    if key not in _FLAG_BUFS:
+        _FLAG_BUFS[key] = bk.dev(np.zeros(n, np.int32))
+    return _FLAG_BUFS[key]
+
+
 def pad64(n):
     return (n + 63) // 64 * 64
 
@@ -560,7 +579,7 @@ def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shu
     d_loss = bk.dev(np.zeros((S, N), np.float32))
     bk.lib.rcmarl_minibatch_fit(bk.ptr(d_x), cap * in_dim, bk.ptr(d_th), bk.ptr(d_adv), nA, bk.ptr(d_y),
                                 bk.ptr(d_perm) if shuffle else None, S, N, B, in_dim, HID, ldp, ldb, bs, epochs, lr,
-                                bk.ptr(d_loss), bk.stream)
+                                bk.ptr(d_loss), bk.ptr(_mb_flags(bk)), bk.stream)
     th_new, loss = bk.host(d_th), bk.host(d_loss)
     for s in range(S):
         for n in range(N):
@@ -616,7 +635,7 @@ def run_minibatch_fit_with_blown_network(bk, S=1, N=5, B=96, in_dim=10, lr=0.01)
     perm = np.stack([[[rng.permutation(B) for _ in range(2)] for _ in range(2)] for _ in range(S)]).astype(np.int32)
     d_x, d_th, d_y, d_adv, d_perm = bk.dev(x), bk.dev(theta), bk.dev(y), bk.dev(advs), bk.dev(perm)
     bk.lib.rcmarl_minibatch_fit(bk.ptr(d_x), B * in_dim, bk.ptr(d_th), bk.ptr(d_adv), 2, bk.ptr(d_y), bk.ptr(d_perm), S, N, B, in_dim,
-                                HID, ldp, ldb, 32, 2, lr, None, bk.stream)
+                                HID, ldp, ldb, 32, 2, lr, None, bk.ptr(_mb_flags(bk)), bk.stream)
     th = bk.host(d_th)
     assert not np.array_equal(th[:, 1], theta[:, 1]) and not np.array_equal(th[:, 3], theta[:, 3])      # both networks were fitted
     return th[:, 1].copy(), th[:, 3].copy()
@@ -881,13 +900,13 @@ def check_lattice_f16_saturation(bk, S=1, N=5, B=70, width=2, nrow=5, ncol=5, lr
     d_part5 = bk.dev(np.zeros((S, N, nchunk, L.rcmarl_fit_partial_size(HID)), np.float32))
     lb5 = LatticeBuffers(bk, S, N, in_dim, B)
     L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part5), bk.ptr(lb5.dzp), g.dzp[0], g.dzp[1], S, N, B,
-                             in_dim, HID, ldp, ldb, bk.stream)
+                             in_dim, HID, ldp, ldb, bk.ptr(_mid_flags(bk, S, N)), bk.stream)
     if prev is None:
         del os.environ["RCMARL_MIDFIT"]
     else:
         os.environ["RCMARL_MIDFIT"] = prev
     L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], S, N, B,
-                             in_dim, HID, ldp, ldb, bk.stream)
+                             in_dim, HID, ldp, ldb, bk.ptr(_mid_flags(bk, S, N)), bk.stream)
     part, part5 = bk.host(d_part), bk.host(d_part5)
     np.testing.assert_array_equal(part[:, bad], part5[:, bad])
     dz, dz5 = seed_views(bk.host(lb.dzp), S, g.dzp, 2), seed_views(bk.host(lb5.dzp), S, g.dzp, 2)
@@ -1001,7 +1020,7 @@ def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamm
         _layer1_lattice(bk, lb, d_al, d_msg, d_a, S, N, B, in_dim, ldp, ldb, split=(st == 0))
         a_before = bk.host(d_a).copy() if st == 0 else None
         L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_msg), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
-                                 S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+                                 S, N, B, in_dim, HID, ldp, ldb, bk.ptr(_mid_flags(bk, S, N)), bk.stream)
         if st == 0:
             np.testing.assert_array_equal(bk.host(d_a), a_before)                    # activations left intact
         L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_msg), bk.ptr(d_mask), bk.ptr(d_loss) if st == 0 else None, S, N, B,
@@ -1120,7 +1139,7 @@ def check_fused_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamma=0.9,
         for st in range(steps):
             _layer1_lattice(bk, lb, d_al, d_ref, d_a, S, N, B, in_dim, ldp, ldb, split=(st == 0))
             L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_ref), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
-                                     S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+                                     S, N, B, in_dim, HID, ldp, ldb, bk.ptr(_mid_flags(bk, S, N)), bk.stream)
             L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_ref), bk.ptr(d_mask), None, S, N, B, in_dim, HID, ldp, lr, bk.stream)
             L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
                                                  bk.ptr(d_al), bk.ptr(d_ref), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
@@ -1193,7 +1212,7 @@ def check_forward_mid_fit(bk, S, N, B, width, nrow, ncol, steps=3, lr=0.01, mask
         # --- three launches
         _layer1_lattice(bk, lb, d_al, d_ref, d_a, S, N, B, in_dim, ldp, ldb, split=(st == 0))
         L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_ref), bk.ptr(d_y), bk.ptr(d_part_ref), bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
-                                 S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+                                 S, N, B, in_dim, HID, ldp, ldb, bk.ptr(_mid_flags(bk, S, N)), bk.stream)
         L.rcmarl_small_sgd(bk.ptr(d_part_ref), bk.ptr(d_ref), bk.ptr(d_mask), None, S, N, B, in_dim, HID, ldp, lr, bk.stream)
         L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1],
                                              bk.ptr(d_al), bk.ptr(d_ref), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, lr,
@@ -1236,6 +1255,35 @@ def check_forward_mid_fit(bk, S, N, B, width, nrow, ncol, steps=3, lr=0.01, mask
     return msg
 
 
+def check_lattice_form_mismatch(bk, lattice_form):
+    from rcmarl_amd.capi import RcmarlError
+    import pytest
+    S, N, B, width = 1, 5, 70, 2
+    rng = np.random.default_rng(3)
+    in_dim = N * width
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    theta = pack_rows(random_params(rng, S, N, in_dim, 1), ldp)
+    x, alpha = lattice_rows(rng, S, B, N, width, 5, 5)
+    lb = LatticeBuffers(bk, S, N, in_dim, B)
+    d_x, d_al, d_th = bk.dev(x), bk.dev(alpha), bk.dev(theta)
+    d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
+    d_mask = bk.dev(np.ones(N, np.int32))
+    lattice_form(bk, 3)
+    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)
+    _layer1_lattice(bk, lb, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb)                    # produced and consumed in form 3: fine
+    lattice_form(bk, 0)
+    g = lb.g
+    with pytest.raises(RcmarlError, match="RCMARL_ERR_ARG"):                                # f16 pieces, bf16 consumer
+        bk.lib.rcmarl_layer1_forward_lattice(bk.ptr(lb.kp), g.kp[0], g.kp[1], bk.ptr(lb.wp), g.wp[0], g.wp[1], bk.ptr(d_th),
+                                             bk.ptr(d_a), S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+    with pytest.raises(RcmarlError, match="RCMARL_ERR_ARG"):
+        bk.lib.rcmarl_layer1_backward_sgd_lattice(bk.ptr(lb.ktp), g.ktp[0], g.ktp[1], bk.ptr(lb.dzp), g.dzp[0], g.dzp[1], bk.ptr(d_al),
+                                                  bk.ptr(d_th), bk.ptr(d_mask), S, N, B, in_dim, HID, ldp, 0.01, None, 0, 0, bk.stream)
+    _encode(bk, lb, d_x, B * in_dim, d_al, S, B, in_dim)                                    # re-produced in form 0: accepted again
+    _layer1_lattice(bk, lb, d_al, d_th, d_a, S, N, B, in_dim, ldp, ldb)
+
+
 def check_lattice_vs_f32(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01):
     rng = np.random.default_rng(N + B + width)
     in_dim = N * width
@@ -1272,7 +1320,7 @@ def check_lattice_vs_f32(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01):
                 L.rcmarl_mid_fit(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), S, N, B, in_dim, HID, ldp, ldb, bk.stream)
             else:
                 L.rcmarl_mid_fit_lattice(bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_y), bk.ptr(d_part), bk.ptr(lb.dzp), g.dzp[0],
-                                         g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, bk.stream)
+                                         g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, bk.ptr(_mid_flags(bk, S, N)), bk.stream)
             L.rcmarl_small_sgd(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_mask), None, S, N, B, in_dim, HID, ldp, lr, bk.stream)
             if path == "f32":
                 L.rcmarl_layer1_backward_sgd(bk.ptr(d_x), B * in_dim, bk.ptr(d_a), bk.ptr(d_th), bk.ptr(d_mask), S, N, B,

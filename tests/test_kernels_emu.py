@@ -177,26 +177,26 @@ def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
 
 ENC_CASE, FWD_CASE, FIT_CASE, FIT_STEPS = (1, 7, 33, 3, 9, 9, True), (2, 5, 70, 2, 5, 5), (1, 7, 130, 3, 16, 16, 2), 2
 @pytest.mark.parametrize("mode", ["0", "1", "3"])
-def test_lattice_operand_forms(bk, mode, monkeypatch):
+def test_lattice_operand_forms(bk, mode, monkeypatch, lattice_form):
     """RCMARL_LAT_F16: 0 = three exact bf16 pieces everywhere, 1 = the forward operand as two f16 pieces of 2^10 alpha W1,
     3 (default) = the backward operand (2^8 dz1) too -- encode images, piece reconstruction, forward vs float64, whole SGD fits vs
     the oracle, in every form."""
-    monkeypatch.setenv("RCMARL_LAT_F16", mode)
+    lattice_form(bk, mode)
     assert bk.lib.rcmarl_lattice_f16_mode() == int(mode)
     KC.check_lattice_encode(bk, *ENC_CASE)
     KC.check_lattice_forward(bk, *FWD_CASE)
     KC.check_lattice_sgd_fit(bk, *FIT_CASE[:-1], steps=FIT_STEPS, masked_agent=FIT_CASE[-1])
 
 
-def test_lattice_f16_pieces_saturate_instead_of_overflowing(bk, monkeypatch):
-    monkeypatch.setenv("RCMARL_LAT_F16", "3")
+def test_lattice_f16_pieces_saturate_instead_of_overflowing(bk, monkeypatch, lattice_form):
+    lattice_form(bk, "3")
     KC.check_lattice_f16_saturation(bk)
 
 
-def test_lattice_f16_pieces_in_the_subnormal_range(bk, monkeypatch):
+def test_lattice_f16_pieces_in_the_subnormal_range(bk, monkeypatch, lattice_form):
     """Weights of 1e-6: every f16 piece of 2^10 alpha W1 is a subnormal (multiples of 2^-24).  The matrix core must not flush
     them (the result would be zero); what is lost is the form's stated absolute floor (2^-25 of the scaled unit)."""
-    monkeypatch.setenv("RCMARL_LAT_F16", "3")
+    lattice_form(bk, "3")
     KC.check_lattice_forward(bk, *FWD_CASE, w_scale=1e-6, tol=2e-3)
 
 
@@ -248,3 +248,9 @@ def test_fused_fit_reproduces_itself(bk):
 @pytest.mark.parametrize("S,N,B,width,masked,steps", [(1, 5, 70, 2, None, 2), (2, 4, 300, 3, 1, 2), (1, 7, 40, 2, None, 3)])
 def test_forward_mid_fit(bk, S, N, B, width, masked, steps):
     KC.check_forward_mid_fit(bk, S, N, B, width, 5, 5, steps=steps, masked_agent=masked)
+
+
+def test_lattice_operand_form_mismatch_is_refused(bk, lattice_form):
+    """A packed buffer remembers the operand form it was written in: switching the form between producer (rcmarl_w1_split,
+    rcmarl_lattice_encode, rcmarl_mid_fit_lattice) and consumer (the two lattice GEMMs) is an RCMARL_ERR_ARG, not a garbage result."""
+    KC.check_lattice_form_mismatch(bk, lattice_form)

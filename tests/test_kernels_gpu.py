@@ -217,26 +217,26 @@ def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
 
 ENC_CASE, FWD_CASE, FIT_CASE, FIT_STEPS = (1, 64, 700, 3, 16, 16, True), (2, 64, 1000, 2, 16, 16), (2, 20, 777, 3, 7, 9, 4), 5
 @pytest.mark.parametrize("mode", ["0", "1", "3"])
-def test_lattice_operand_forms(bk, mode, monkeypatch):
+def test_lattice_operand_forms(bk, mode, monkeypatch, lattice_form):
     """RCMARL_LAT_F16: 0 = three exact bf16 pieces everywhere, 1 = the forward operand as two f16 pieces of 2^10 alpha W1,
     3 (default) = the backward operand (2^8 dz1) too -- encode images, piece reconstruction, forward vs float64, whole SGD fits vs
     the oracle, in every form."""
-    monkeypatch.setenv("RCMARL_LAT_F16", mode)
+    lattice_form(bk, mode)
     assert bk.lib.rcmarl_lattice_f16_mode() == int(mode)
     KC.check_lattice_encode(bk, *ENC_CASE)
     KC.check_lattice_forward(bk, *FWD_CASE)
     KC.check_lattice_sgd_fit(bk, *FIT_CASE[:-1], steps=FIT_STEPS, masked_agent=FIT_CASE[-1])
 
 
-def test_lattice_f16_pieces_saturate_instead_of_overflowing(bk, monkeypatch):
-    monkeypatch.setenv("RCMARL_LAT_F16", "3")
+def test_lattice_f16_pieces_saturate_instead_of_overflowing(bk, monkeypatch, lattice_form):
+    lattice_form(bk, "3")
     KC.check_lattice_f16_saturation(bk)
 
 
-def test_lattice_f16_pieces_in_the_subnormal_range(bk, monkeypatch):
+def test_lattice_f16_pieces_in_the_subnormal_range(bk, monkeypatch, lattice_form):
     """Weights of 1e-6: every f16 piece of 2^10 alpha W1 is a subnormal (multiples of 2^-24).  The matrix core must not flush
     them (the result would be zero); what is lost is the form's stated absolute floor (2^-25 of the scaled unit)."""
-    monkeypatch.setenv("RCMARL_LAT_F16", "3")
+    lattice_form(bk, "3")
     KC.check_lattice_forward(bk, *FWD_CASE, w_scale=1e-6, tol=2e-3)
 
 
@@ -296,3 +296,9 @@ def test_forward_mid_fit(bk, S, N, B, width, masked, steps):
     """forward + mid in one launch: dz1 image bit-identical to the three-launch path, the same fit, the oracle's fit"""
     KC.check_forward_mid_fit(bk, S, N, B, width, 16 if N > 30 else 5, 16 if N > 30 else 5, steps=steps, masked_agent=masked,
                              lr=0.01 if N < 100 else 0.002)
+
+
+def test_lattice_operand_form_mismatch_is_refused(bk, lattice_form):
+    """A packed buffer remembers the operand form it was written in: switching the form between producer (rcmarl_w1_split,
+    rcmarl_lattice_encode, rcmarl_mid_fit_lattice) and consumer (the two lattice GEMMs) is an RCMARL_ERR_ARG, not a garbage result."""
+    KC.check_lattice_form_mismatch(bk, lattice_form)

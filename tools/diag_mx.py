@@ -25,8 +25,9 @@ for in_dim in (10, 15):
             for mode in ("1", "0"):
                 os.environ["RCMARL_MB_MX"] = mode
                 th = theta0.clone()
+                fl = torch.zeros(S * len(advs), dtype=torch.int32, device="cuda")
                 L.rcmarl_minibatch_fit(x.data_ptr(), B * in_dim, th.data_ptr(), agents.data_ptr(), len(advs), y.data_ptr(), perm.data_ptr(),
-                                       S, N, B, in_dim, HID, ldp, ldb, 32, epochs, 0.01, None, st)
+                                       S, N, B, in_dim, HID, ldp, ldb, 32, epochs, 0.01, None, fl.data_ptr(), st)
                 torch.cuda.synchronize()
                 out[mode] = th[:, advs, :P].double().cpu().numpy()
             d = np.abs(out["1"] - out["0"]).max()

@@ -22,6 +22,17 @@ def pad64(n):
     return (n + 63) // 64 * 64
 
 
+_FL = None
+
+
+def _flags():
+    """caller-owned out-of-range flag buffer of the f16 mid / mini-batch kernels (int32, zero at first use)"""
+    global _FL
+    if _FL is None:
+        _FL = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+    return _FL.data_ptr()
+
+
 def timeit(fn, iters=10, warm=3):
     for _ in range(warm):
         fn()
@@ -114,7 +125,7 @@ def minibatch(L, S=512, N=5, B=3000):
         agents = torch.tensor([N - 1], dtype=torch.int32, device="cuda")
         perm = torch.stack([torch.stack([torch.randperm(B, device="cuda") for _ in range(10)]) for _ in range(S)]).to(torch.int32).reshape(S, 1, 10, B).contiguous()
         t = timeit(lambda: L.rcmarl_minibatch_fit(x.data_ptr(), B * in_dim, theta.data_ptr(), agents.data_ptr(), 1, y.data_ptr(), perm.data_ptr(),
-                                                  S, N, B, in_dim, HID, ldp, ldb, 32, 10, 1e-4, None, st), iters=3, warm=1)
+                                                  S, N, B, in_dim, HID, ldp, ldb, 32, 10, 1e-4, None, _flags(), st), iters=3, warm=1)
         print("minibatch_fit in=%3d S=%d: %9.1f us per launch, %.2f us per SGD step" % (in_dim, S, t, t / (10 * ((B + 31) // 32))))
 
 
@@ -177,7 +188,7 @@ def lattice(L, S=16, N=256, B=3000):
         print("fwd_lat   in=%4d  %8.1f us  %6.1f TF/s fp32-equivalent (%.0f TF/s bf16 executed)" % (in_dim, t, flops / t / 1e6,
                                                                                                    3 * flops / t / 1e6))
         t = timeit(lambda: L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
-                                                    g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st))
+                                                    g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, _flags(), st))
         print("mid_fit_l in=%4d  %8.1f us" % (in_dim, t))
         t = timeit(lambda: L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0],
                                                                 g.dzp[1], alpha.data_ptr(), theta.data_ptr(), mask.data_ptr(), S, N,
@@ -223,7 +234,7 @@ def fused(L, S=16, N=256, B=3000, steps=5):
                 L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], th_a.data_ptr(),
                                                 a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st)
                 L.rcmarl_mid_fit_lattice(a1t.data_ptr(), th_a.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1],
-                                         S, N, B, in_dim, HID, ldp, ldb, st)
+                                         S, N, B, in_dim, HID, ldp, ldb, _flags(), st)
                 L.rcmarl_small_sgd(part.data_ptr(), th_a.data_ptr(), mask.data_ptr(), None, S, N, B, in_dim, HID, ldp, lr, st)
                 L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0], g.dzp[1], alpha.data_ptr(),
                                                      th_a.data_ptr(), mask.data_ptr(), S, N, B, in_dim, HID, ldp, lr,
@@ -299,7 +310,7 @@ def fwdmid(L, S=16, N=256, B=3000):
             L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], theta.data_ptr(),
                                             a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st)
             L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part_a.data_ptr(), dzp_a.data_ptr(), g.dzp[0],
-                                     g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st)
+                                     g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, _flags(), st)
 
         def one():
             L.rcmarl_forward_mid(kf.data_ptr(), wf.data_ptr(), w2f.data_ptr(), theta.data_ptr(), y.data_ptr(), part_b.data_ptr(),
@@ -388,7 +399,7 @@ def mid_ab(L, S=16, N=256, B=3000):
                     os.environ["RCMARL_MIDFIT"] = midfit
                 dzp.zero_()
                 t = timeit(lambda: lib.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(),
-                                                              g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, st), iters=20)
+                                                              g.dzp[0], g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, _flags(), st), iters=20)
                 outs[name] = (dzp.clone(), part.clone())
                 print("in=%d round %d  %-16s %8.1f us  (%.0f GB/s of its 160 B per row and agent)" % (in_dim, rnd, name, t, 160.0 * S * N * B / t / 1e3))
         os.environ.pop("RCMARL_MIDFIT", None)
@@ -428,7 +439,7 @@ def lattice_ab(L, S=16, N=256, B=3000):
         L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], theta.data_ptr(), a1t.data_ptr(),
                                         S, N, B, in_dim, HID, ldp, ldb, st)
         L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], S, N, B,
-                                 in_dim, HID, ldp, ldb, st)
+                                 in_dim, HID, ldp, ldb, _flags(), st)
         ref = None
         for rnd in range(3):
             for name, lib in libs:
