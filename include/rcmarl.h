@@ -254,6 +254,15 @@ int rcmarl_team_reward(const float* r, long seed_stride, const int* coop, int n_
  * the r_applied selection of training/train_agents.py:106-116 and the a[:,node] slices of :151-153 */
 int rcmarl_gather_agent_major(const float* src, long seed_stride, const float* rcoop, const int* mode, float* out,
                               int S, int N, int B, int ldb, void* stream);
+/* The TD target's own forward pass (agents/resilient_CAC_agents.py:114-115) only concerns the LAST next-state row of every episode
+ * (inside an episode ns[b] = s[b+1], training/train_agents.py:66-80): rcmarl_gather_rows collects every `step`-th row of a replay
+ * tensor, dst[s][k][:] = src[s][first + k*step][:]; rcmarl_scatter_values puts their values back into an agent-major vector,
+ * out[s][n][first + k*step] = v[s][n][k]  (r_applied == NULL)  or  r_applied[s][n][first + k*step] + gamma * v[s][n][k]. */
+int rcmarl_gather_rows(const float* src, long seed_stride, int first, int step, int n_rows, int width, float* dst, int S,
+                       void* stream);
+int rcmarl_scatter_values(const float* v, const float* r_applied, float gamma, float* out, int first, int step, int n_rows,
+                          int S, int N, int ldb, void* stream);
+
 /* delta = r_team + gamma*nV - V   (global_TD_error, agents/resilient_CAC_agents.py:98) */
 int rcmarl_td_error(const float* r_team, const float* v_next, const float* v_cur, float gamma, float* delta,
                     long n_total, void* stream);
@@ -347,18 +356,6 @@ int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float
 int rcmarl_wide_head_apply(const float* grads, float* theta, const int* coop, int S, int N, int B, int in_dim, int hid,
                            int ldp, void* stream);
 
-/* PROTOTYPE (round 3, not used by the engine): layer-1 forward on the INT8 matrix core.  K as int8 (|K| <= 127), alpha*W1 as
- * four balanced base-256 limbs under one power-of-two scale per W1 column (csrc/lattice_i8.hip has the arithmetic): exact
- * int32 dot products, three fp32 roundings per output.  Same contract as rcmarl_lattice_encode (kp only) / rcmarl_w1_split /
- * rcmarl_layer1_forward_lattice, i.e. the forward pass inside the Keras fit at agents/resilient_CAC_agents.py:118,136;
- * packed int8 images: 8-KiB blocks [rows/128][k/64][planes][128 rows][64 k]; scale: float[S][wp_rt*128]. */
-int rcmarl_lattice_encode_i8(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, void* kp, int kp_rt,
-                             int kp_kt, int* flag, void* stream);
-int rcmarl_w1_split_i8(const float* theta, const float* alpha, void* wp, float* scale, int S, int N, int in_dim, int hid, int ldp,
-                       int wp_rt, int wp_kt, void* stream);
-int rcmarl_layer1_forward_i8(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt, const float* scale,
-                             const float* theta, float* a1t, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
-                             void* stream);
 
 /* C2 (one instance over several GPUs): the pack / unpack pass of the two all-to-all transposes of the message
  * matrix, which replace the reference's in-process gather `[critic_weights[i] for i in in_nodes[node]]`

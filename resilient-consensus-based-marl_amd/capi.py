@@ -118,6 +118,10 @@ SIGNATURES = {
                                C.c_double, C.c_double, c_int, c_f32p, c_stream],
     # src, seed_stride, rcoop, mode, out, S, N, B, ldb, stream
     "rcmarl_gather_agent_major": [c_f32p, c_long, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_stream],
+    # src, seed_stride, first, step, n_rows, width, dst, S, stream
+    "rcmarl_gather_rows": [c_f32p, c_long, c_int, c_int, c_int, c_int, c_f32p, c_int, c_stream],
+    # v, r_applied, gamma, out, first, step, n_rows, S, N, ldb, stream
+    "rcmarl_scatter_values": [c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # r_team, v_next, v_cur, gamma, delta, n_total, stream
     "rcmarl_td_error": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_long, c_stream],
     # xs, theta, probs, S, N, in_dim, hid, n_actions, ldp, stream
@@ -174,14 +178,6 @@ SIGNATURES = {
                                    c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # grads, theta, coop, S, N, B, in_dim, hid, ldp, stream
     "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # ---- int8-limb forward prototype (csrc/lattice_i8.hip) -------------------------------------------------
-    # x, x_seed_stride, alpha, S, B, in_dim, kp, kp_rt, kp_kt, flag, stream
-    "rcmarl_lattice_encode_i8": [c_f32p, c_long, c_f32p, c_int, c_int, c_int, c_u8p, c_int, c_int, c_i32p, c_stream],
-    # theta, alpha, wp, scale, S, N, in_dim, hid, ldp, wp_rt, wp_kt, stream
-    "rcmarl_w1_split_i8": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, scale, theta, a1t, S, N, B, in_dim, hid, ldp, ldb, stream
-    "rcmarl_layer1_forward_i8": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
-                                 c_int, c_int, c_int, c_stream],
     # ---- sharded instance (csrc/shard_pack.hip) ----------------------------------------------------------
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],

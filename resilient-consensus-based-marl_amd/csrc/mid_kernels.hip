@@ -1000,6 +1000,31 @@ __global__ __launch_bounds__(256) void k_gather_agent_major(const float* __restr
   out[((long)s * N + n) * ldb + b] = v;
 }
 
+// every `step`-th replay row, starting at `first`, gathered into a dense block: dst[s][k][c] = src[s][first + k*step][c]
+// (the last next-state row of every episode: the only rows of a TD target that need a forward pass of their own)
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, long seed_stride, int first, int step,
+                                                     int n_rows, int width, float* __restrict__ dst) {
+  const int s = blockIdx.z, k = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < width) dst[((long)s * n_rows + k) * width + c] = src[(long)s * seed_stride + (long)(first + k * step) * width + c];
+}
+
+// ... and their values scattered back: out[s][n][first + k*step] = v[s][n][k]  or  r_applied[s][n][first + k*step] + gamma * v
+// (multiply, then add: the two roundings of k_mid_value's TD target)
+__global__ __launch_bounds__(256) void k_scatter_values(const float* __restrict__ v, const float* __restrict__ r_applied, float gamma,
+                                                        float* __restrict__ out, int first, int step, int n_rows, int ldb) {
+  const long row = blockIdx.y;                            // (seed, agent)
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_rows) return;
+  const int b = first + k * step;
+  const float val = v[row * ldb + k];
+  if (r_applied == nullptr) {
+    out[row * ldb + b] = val;
+  } else {
+    const float gv = gamma * val;
+    out[row * ldb + b] = r_applied[row * ldb + b] + gv;
+  }
+}
+
 // delta = r_team + gamma*V(ns) - V(s)            (agents/resilient_CAC_agents.py:98)
 __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_team, const float* __restrict__ v_next,
                                                   const float* __restrict__ v_cur, float gamma,
@@ -1209,6 +1234,22 @@ RCMARL_EXPORT int rcmarl_gather_agent_major(const float* src, long seed_stride, 
   if (!src || !out || S <= 0 || N <= 0 || B <= 0 || ldb < B || (mode && !rcoop)) return RCMARL_ERR_ARG;
   const dim3 grid(rc_ceil_div(B, 256), N, S), block(256);
   RCMARL_LAUNCH(k_gather_agent_major, grid, block, 0, stream, src, seed_stride, rcoop, mode, out, N, B, ldb);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_gather_rows(const float* src, long seed_stride, int first, int step, int n_rows, int width, float* dst,
+                                     int S, void* stream) {
+  if (!src || !dst || S <= 0 || n_rows <= 0 || width <= 0 || first < 0 || step <= 0) return RCMARL_ERR_ARG;
+  RCMARL_LAUNCH(k_gather_rows, dim3(rc_ceil_div(width, 256), n_rows, S), dim3(256), 0, stream, src, seed_stride, first, step, n_rows,
+                width, dst);
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_scatter_values(const float* v, const float* r_applied, float gamma, float* out, int first, int step,
+                                        int n_rows, int S, int N, int ldb, void* stream) {
+  if (!v || !out || S <= 0 || N <= 0 || n_rows <= 0 || first < 0 || step <= 0 || first + (n_rows - 1) * step >= ldb) return RCMARL_ERR_ARG;
+  RCMARL_LAUNCH(k_scatter_values, dim3(rc_ceil_div(n_rows, 256), S * N), dim3(256), 0, stream, v, r_applied, gamma, out, first, step,
+                n_rows, ldb);
   return rcmarl_check_launch();
 }
 

@@ -217,7 +217,7 @@ class RPBCACEngine:
             for k in self.rp:
                 self.rp[k][:, :old_B] = old_rp[k][:, :old_B]
         self._init_lattice()
-        self._term_rows = {}                  # (row0, nrows) -> device indices of the last row of every episode
+        self._ns_term = None                  # scratch: the last next-state row of every episode, gathered (rcmarl_gather_rows)
         self._graphs = {}                     # captured epochs point into the buffers replaced here
         if hasattr(self, "adv"):
             self.adv.a1t = torch.zeros_like(self.a1t)
@@ -1015,12 +1015,13 @@ class RPBCACEngine:
         ep, th = c.max_ep_len, self.theta["critic"]
         L.rcmarl_mid_value(self.a1net["critic"].data_ptr() + 4 * (row0 + 1), th.data_ptr(), self._p(r_applied), c.gamma,
                            out.data_ptr(), S, N, nrows - 1, self.in_c, HID, self.ldp["critic"], self.ldb, self.stream)
-        key = (row0, nrows)
-        idx = self._term_rows.get(key)
-        if idx is None:
-            idx = self._term_rows[key] = torch.arange(ep - 1, nrows, ep, device=self.dev)
-        nt = idx.numel()
-        ns_term = self.rp["ns"][:, row0:row0 + nrows].index_select(1, idx).contiguous()
+        nt = nrows // ep
+        ns_w = self.rp["ns"].shape[2]
+        if self._ns_term is None or self._ns_term.numel() < S * nt * ns_w:
+            self._ns_term = torch.empty(S * nt * ns_w, dtype=torch.float32, device=self.dev)
+        ns_term = self._ns_term
+        nptr, nstride = self._x("ns", row0)
+        L.rcmarl_gather_rows(nptr, nstride, ep - 1, ep, nt, ns_w, ns_term.data_ptr(), S, self.stream)
         if self.lat_active and self.shard is None and "s" in self.lat_wp_f and self.a1_cached["critic"]:
             # on the lattice GEMM: the live critic's layer-1 pieces are what the consensus step's forward left in the weight operand
             # (its hidden layers have not moved since), the rows are a subset of the ns rows _lattice_encode verified -- 60 us
@@ -1037,10 +1038,10 @@ class RPBCACEngine:
                                     self.ldp["critic"], self.ldb, self.stream)
         L.rcmarl_mid_value(self.a1t.data_ptr(), th.data_ptr(), None, c.gamma, scratch.data_ptr(), S, N, nt, self.in_c, HID,
                            self.ldp["critic"], self.ldb, self.stream)
-        if r_applied is None:
-            out[:, :, idx] = scratch[:, :, :nt]
-        else:        # r + gamma*v in fp32, multiply then add like the kernel (no fused multiply-add)
-            out[:, :, idx] = r_applied[:, :, idx] + torch.mul(scratch[:, :, :nt], np.float32(c.gamma))
+        # back into the agent-major vector (r + gamma*v in fp32: multiply, then add, like the kernel): one small launch, no
+        # framework kernels inside an update epoch (they kept larger instances out of hipGraph capture)
+        L.rcmarl_scatter_values(scratch.data_ptr(), self._p(r_applied), c.gamma, out.data_ptr(), ep - 1, ep, nt, S, N, self.ldb,
+                                self.stream)
 
     def _td_target(self, B):
         """y = r_applied + gamma * V_critic(ns)   (agents/resilient_CAC_agents.py:114-115), all agents, all rows: from the

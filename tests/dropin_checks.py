@@ -29,10 +29,15 @@ def make_models(n_agents, weights=None):
     return trio
 
 
+WORST = {}           # label -> worst |a - b| / max(1, |b|max) seen by close(): printed by the callers as "[parity]" lines
+
+
 def close(a, b, rtol, what=""):
     a, b = np.asarray(a), np.asarray(b)
     scale = max(1.0, float(np.abs(b).max()))
     err = float(np.abs(a - b).max())
+    key = what.split(" agent")[0].split(" after")[-1].strip() or "?"
+    WORST[what[:24]] = max(WORST.get(what[:24], 0.0), err / scale)
     assert err <= rtol * scale, "%s: %.3e > %.1e*%.3g" % (what, err, rtol, scale)
 
 
@@ -190,7 +195,7 @@ def check_env_golden(golden):
                 t += 1
 
 
-def check_train_golden(golden, name, engine_hook, rtol_w=3e-4):
+def check_train_golden(golden, name, engine_hook, rtol_w=1e-4):
     """train_RPBCAC drop-in vs the golden run of the REFERENCE's own train_RPBCAC source
     (tests/golden/make_golden.py): same seeds, same NumPy stream, same initial weights."""
     args, desired, init, final, sim = helpers.golden_scenario(golden, name)
@@ -220,6 +225,7 @@ def check_train_golden(golden, name, engine_hook, rtol_w=3e-4):
     np.testing.assert_array_equal(df["True_adv_returns"].to_numpy(), sim["True_adv_returns"])
     np.testing.assert_allclose(df["Estimated_team_returns"].to_numpy(), sim["Estimated_team_returns"], rtol=1e-4, atol=1e-5)
     np.testing.assert_array_equal(env.state, golden[f"train/{name}/final_env_state"])
+    worst, fails = {}, []
     for i in range(5):
         names = ["actor", "critic", "tr"] + (["critic_local"] if len(weights[i]) == 4 else [])
         assert len(weights[i]) == (4 if args["agent_label"][i] == "Malicious" else 3)
@@ -228,7 +234,14 @@ def check_train_golden(golden, name, engine_hook, rtol_w=3e-4):
             want = final[i][net]
             scale = max(1.0, float(np.abs(want).max()))
             tol = rtol_w * scale if net != "actor" else 0.05 * args["slow_lr"] * 12 + 1e-5
-            assert float(np.abs(got - want).max()) <= tol, (name, i, net, float(np.abs(got - want).max()), tol)
+            err = float(np.abs(got - want).max())
+            if net != "actor":
+                worst[net] = max(worst.get(net, 0.0), err / scale)
+            if err > tol:
+                fails.append((name, i, args["agent_label"][i], net, err, tol))
+    print("[parity] drop-in train_RPBCAC vs the reference's golden run '%s': worst |w - w_ref| / max(1,|w|max) %s  (bar %.0e)"
+          % (name, "  ".join("%s %.2e" % kv for kv in sorted(worst.items())), rtol_w))
+    assert not fails, fails
 
 
 def check_train_wide_critic(engine_hook, critic_hid=32, seed=5):
@@ -343,7 +356,7 @@ def check_main_roundtrip(golden, tmp_path, engine_hook, n_episodes=100, n_ep_fix
         for i in range(5):
             for k in (1, 2) + ((3,) if len(ow[i]) == 4 else ()):
                 for a, b in zip(weights[i][k], ow[i][k]):
-                    close(a, b, 5e-4, "agent %d net %d after warm start" % (i, k))
+                    close(a, b, 1e-4, "agent %d net %d after warm start" % (i, k))
         # a policy trained for 8000 episodes by the reference: its first block (before any update of ours) must already be good
         first = float(df["True_team_returns"].to_numpy()[:n_ep_fixed].mean())
         assert first > -6.5, "shipped policy's return on the new engine: %.3f (reference phase-2 band: -5.3 .. -5.6)" % first

@@ -932,57 +932,6 @@ def check_lattice_f16_saturation(bk, S=1, N=5, B=70, width=2, nrow=5, ncol=5, lr
                 rel_close(got[k], pw[k], 1e-5, "fit param %d beside a saturated agent" % k)
 
 
-def check_lattice_forward_i8(bk, S, N, B, width, nrow, ncol):
-    """The int8-limb forward prototype (csrc/lattice_i8.hip): encode_i8 -> w1_split_i8 -> layer1_forward_i8 against float64,
-    at the bar of the bf16x3 path (2e-6 of the output scale); limbs and scale reconstruct alpha*W1 to 2^-30 of the column max."""
-    rng = np.random.default_rng(B + N * 5 + width)
-    in_dim = N * width
-    P, _ = geom(in_dim, 1)
-    ldp, ldb = pad64(P), pad64(B)
-    params = random_params(rng, S, N, in_dim, 1)
-    theta = pack_rows(params, ldp)
-    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol, True)
-    kp_rt, kt = -(-B // 128), -(-in_dim // 64)
-    wp_rt = -(-(N * HID) // 128)
-    d_x, d_al, d_th = bk.dev(x), bk.dev(alpha), bk.dev(theta)
-    d_kp = bk.dev(np.zeros(S * kp_rt * kt * 8192, np.uint8))
-    d_wp = bk.dev(np.zeros(S * wp_rt * kt * 4 * 8192, np.uint8))
-    d_sc = bk.dev(np.zeros(S * wp_rt * 128, np.float32))
-    d_flag = bk.dev(np.zeros(1, np.int32))
-    d_a = bk.dev(np.full((S, N * HID, ldb), np.nan, np.float32))
-    L = bk.lib
-    L.rcmarl_lattice_encode_i8(bk.ptr(d_x), B * in_dim, bk.ptr(d_al), S, B, in_dim, bk.ptr(d_kp), kp_rt, kt, bk.ptr(d_flag), bk.stream)
-    L.rcmarl_w1_split_i8(bk.ptr(d_th), bk.ptr(d_al), bk.ptr(d_wp), bk.ptr(d_sc), S, N, in_dim, HID, ldp, wp_rt, kt, bk.stream)
-    L.rcmarl_layer1_forward_i8(bk.ptr(d_kp), kp_rt, kt, bk.ptr(d_wp), wp_rt, kt, bk.ptr(d_sc), bk.ptr(d_th), bk.ptr(d_a), S, N, B, in_dim,
-                               HID, ldp, ldb, bk.stream)
-    assert bk.host(d_flag)[0] == 0
-    # limbs + scale reconstruct alpha*W1
-    wp = bk.host(d_wp).reshape(S, wp_rt, kt, 4, 128, 64).view(np.int8)
-    sc = bk.host(d_sc).reshape(S, wp_rt * 128)
-    rows = np.arange(128)
-    for s in range(S):
-        w1 = np.stack([params[s][n][0] for n in range(N)], axis=0)                                  # [N][in][HID]
-        want = (w1 * alpha[None, :, None]).astype(np.float32).transpose(0, 2, 1).reshape(N * HID, in_dim).astype(np.float64)
-        got = np.zeros((wp_rt * 128, kt * 64))
-        for k in range(kt * 64):
-            chunk = ((k & 63) >> 4) ^ ((rows >> 2) & 3)
-            byte = chunk * 16 + (k & 15)
-            limbs = wp[s, :, k >> 6, :, rows, byte]                                              # [128 rows][wp_rt][4]
-            q = sum(limbs[:, :, l].astype(np.float64) * 256.0 ** l for l in range(4))           # [128][wp_rt]
-            got[:, k] = q.T.reshape(-1)
-        got = got[:N * HID, :in_dim] * sc[s, :N * HID, None].astype(np.float64)
-        colmax = np.abs(want).max(axis=1, keepdims=True)
-        assert np.all(np.abs(got - want) <= colmax * 2.0 ** -30 + 1e-300), float(np.abs(got - want).max())     # half a unit of 2^(E-30), 2^E <= 2 max
-    a1t = bk.host(d_a)
-    for s in range(S):
-        x64 = x[s].astype(np.float64)
-        for n in range(N):
-            z = x64 @ params[s][n][0].astype(np.float64) + params[s][n][1].astype(np.float64)
-            want = np.where(z > 0, z, 0.1 * z)
-            rel_close(a1t[s, n * HID:(n + 1) * HID, :B].T, want, 2e-6, "a1 (int8 limbs)")
-    assert np.isnan(a1t[:, :, B:]).all()
-
-
 def check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, lr=0.01, gamma=0.9, masked_agent=None):
     """check_sgd_fit on the lattice path: encode -> [w1_split -> forward_lattice -> mid_fit_lattice ->
     small_sgd -> backward_sgd_lattice] x steps, against the same oracle fit."""

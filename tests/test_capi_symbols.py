@@ -72,9 +72,6 @@ def test_argument_validation_needs_no_gpu():
                                         1472, 128, 4, 1, None)),
         ("rcmarl_wide_head_apply", (None, None, None, 1, 5, 100, 10, 32, 1472, None)),
         ("rcmarl_copy3d", (None, 0, 64, None, 0, 64, 1, 5, 40, None, None)),
-        ("rcmarl_lattice_encode_i8", (None, 0, None, 1, 100, 10, None, 1, 1, None, None)),
-        ("rcmarl_w1_split_i8", (None, None, None, None, 1, 5, 10, 20, 704, 1, 1, None)),
-        ("rcmarl_layer1_forward_i8", (None, 0, 0, None, 0, 0, None, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
     ]
     for name, args in bad:
         with pytest.raises(capi.RcmarlError, match="RCMARL_ERR_ARG|RCMARL_ERR_UNSUPPORTED"):

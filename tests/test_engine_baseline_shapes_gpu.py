@@ -1,11 +1,11 @@
 """Engine vs ORACLE (oracle.train, not another HIP path) at the shapes of BASELINE.json configs[2..4]:
    (a) configs[2]: 64 agents, 16x16 grid, random 9-regular in-graph + self (d = 10), H = 4
-   (b) configs[3] reduced in seeds/epochs only: 256 agents, 32x32 grid, circulant d = 18, H = 8, one seed, one
-       50-episode block (B = 1000), lattice layer-1 path, circulant K1 -- with the TD-target row-shift shortcut and the
-       cached-activation reuse ON and OFF (engine.py:_value_next_cached / _cached_rows_ok)
+   (b) configs[3] reduced in seeds/epochs only: 256 agents, 32x32 grid, circulant d = 18, H = 8, two seeds, two 50-episode
+       blocks (B = 1000, then 2000 with the replay trim), the bench's fast_lr, lattice layer-1 path, circulant K1 -- with the
+       TD-target row-shift shortcut and the cached-activation reuse ON and OFF (engine.py:_value_next_cached / _cached_rows_ok)
    (c) configs[4] in width/degree: a wide critic with circulant d = 66, H = 32 on 72 agents
 Same tolerances as the small-N engine tests (tests/engine_checks.py:compare): returns bit-identical, start-state
-values rtol 1e-4, end-of-block weights rtol 1e-4 * max(1, |w|max) (2e-4 for the 256-agent run: measured 9.3e-5)."""
+values rtol 1e-4, end-of-block weights rtol 1e-4 * max(1, |w|max)."""
 import numpy as np
 import pytest
 
@@ -30,12 +30,19 @@ def test_engine_cfg3_shape_vs_oracle():
 
 @pytest.fixture(scope="module")
 def cfg4_oracle():
+    """BASELINE configs[3] at the hyper-parameters bench.py runs it with (fast_lr = 0.001: the reference's 0.01 diverges to NaN at
+    768 inputs and 0.0025 still loses single fits -- bench.py header; the oracle agrees), TWO seeds batched, TWO update blocks: the
+    second one fits on B = 2000 rows with the replay trim (buffer_size 1000), the TD-target shortcut and the cached activations
+    live.  slow_lr = 0: the actors stay where they are, so the SECOND block's rollout draws the same actions on both sides and
+    its replay rows can be compared at all -- with a live actor, Adam turns the 1e-7 differences of the first block into policy
+    differences of 1e-4 and one of the 256 000 action draws of the second block flips (measured: 2 of 100 episode returns off by
+    0.01, profiles/r04l_*), after which the two runs train on different data.  The actor step at 256 agents has its own
+    deterministic test (test_actor_gradient_at_256_agents_vs_oracle).  ~4 CPU-minutes of oracle time on the GPU box."""
     n, d = 256, 18
     in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
-    # fast_lr 0.0025: the reference's 0.01 diverges to NaN at 768 inputs (bench.py header); the oracle agrees
-    args = EC.make_args(["Cooperative"] * n, H=8, n_episodes=50, max_ep_len=20, n_ep_fixed=50, n_epochs=2, buffer_size=2000,
-                        seed=1000, in_nodes=in_nodes, fast_lr=0.0025)
-    seeds = (1000,)
+    args = EC.make_args(["Cooperative"] * n, H=8, n_episodes=100, max_ep_len=20, n_ep_fixed=50, n_epochs=2, buffer_size=1000,
+                        seed=1000, in_nodes=in_nodes, fast_lr=0.001, slow_lr=0.0)
+    seeds = (1000, 1001)
     W, goals = EC.make_inputs(args, 32, seeds)
     o_logs, o_w = EC.run_oracle(args, 32, 32, "device", seeds, W, goals)
     return args, seeds, W, goals, o_logs, o_w
@@ -50,12 +57,12 @@ def test_engine_cfg4_shape_vs_oracle(cfg4_oracle, shortcut):
         eng.reuse_activations = shortcut      # step 0 of a local fit reuses the activations the consensus step left
 
     eng, logs = EC.run_engine(args, 32, 32, "device", "cuda", None, seeds, W, goals, tweak=tweak)
-    assert eng.lat_active and eng.k1_circulant
+    assert eng.lat_active and eng.k1_circulant and eng.S == 2
     for df in o_logs:
         assert np.isfinite(df["Estimated_team_returns"].to_numpy()).all()
-    # 2.8 M actor parameters: statistical bar, see EC.compare; weights: measured worst case 9.3e-5 (team-reward net) -- inside
-    # SURVEY 8c's 1e-4 but without margin for another summation order, so this one run is held to 2e-4
-    EC.compare(eng, logs, o_logs, o_w, rtol_w=2e-4, actor="stat")
+    # 2.8 M actor parameters: statistical bar, see EC.compare; weights: SURVEY 8c's 1e-4 (round 4: at the bench's learning rate the
+    # team-reward net no longer sits at the edge of the plain-SGD stability range; the worst case is printed)
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="stat")
 
 
 def test_engine_wide_critic_d66_vs_oracle():

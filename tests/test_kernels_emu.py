@@ -221,12 +221,6 @@ def test_mid_fit_fp32_form_behind_the_f16_operand(bk, monkeypatch):
     KC.check_lattice_sgd_fit(bk, 1, 5, 300, 2, 5, 5, steps=2, masked_agent=2)
 
 
-@pytest.mark.parametrize("S,N,B,width,nrow,ncol", [(2, 3, 150, 2, 5, 5), (1, 7, 70, 3, 16, 16)])
-def test_lattice_forward_int8_limbs_prototype(bk, S, N, B, width, nrow, ncol):
-    """csrc/lattice_i8.hip: the layer-1 forward on the int8 matrix core (four balanced base-256 limbs of alpha*W1 under one scale per
-    column, exact int32 dot products) holds the bf16x3 path's bar against float64."""
-    KC.check_lattice_forward_i8(bk, S, N, B, width, nrow, ncol)
-
 
 @pytest.mark.parametrize("S,n_agents,B,width", [(2, 5, 70, 2), (1, 12, 300, 3), (1, 40, 40, 3)])
 def test_fit_encode(bk, S, n_agents, B, width):

@@ -262,12 +262,6 @@ def test_mid_fit_fp32_form_behind_the_f16_operand(bk, S, N, B, width, nrow, ncol
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
 
 
-@pytest.mark.parametrize("S,N,B,width,nrow,ncol", [(2, 5, 1000, 2, 5, 5), (1, 64, 700, 3, 16, 16), (2, 256, 3000, 2, 32, 32)])
-def test_lattice_forward_int8_limbs_prototype(bk, S, N, B, width, nrow, ncol):
-    """csrc/lattice_i8.hip: the layer-1 forward on the int8 matrix core (four balanced base-256 limbs of alpha*W1 under one scale per
-    column, exact int32 dot products) holds the bf16x3 path's bar against float64."""
-    KC.check_lattice_forward_i8(bk, S, N, B, width, nrow, ncol)
-
 
 @pytest.mark.parametrize("S,n_agents,B,width", [(2, 5, 1000, 2), (1, 64, 700, 3), (2, 256, 300, 3)])
 def test_fit_encode(bk, S, n_agents, B, width):

@@ -4,6 +4,8 @@
     python tools/kbench.py gemm      # layer-1 GEMMs (variant via RCMARL_GEMM=0|1|2)
     python tools/kbench.py k1        # consensus_params at (d,H) = (4,1), (10,4), (18,8)
     python tools/kbench.py mid       # mid_fit / consensus_head / mid_value
+    python tools/kbench.py fused     # the whole local fit in one launch vs the three-launch path (csrc/fused_fit.hip)
+    python tools/kbench.py fwdmid    # forward + mid in one launch vs two
 """
 import os
 import sys
@@ -330,49 +332,6 @@ def fwdmid(L, S=16, N=256, B=3000):
               (in_dim, t_wf, t_w2, bool(torch.equal(dzp_a, dzp_b)), int(flags.sum().item())))
 
 
-def i8(L, S=16, N=256, B=3000):
-    """the int8-limb forward prototype (csrc/lattice_i8.hip) against the bf16x3 forward, on random lattice inputs"""
-    from rcmarl_amd import lattice as LT
-    st = torch.cuda.current_stream().cuda_stream
-    for width in (2, 3):
-        in_dim = width * N
-        P = in_dim * HID + HID + HID * HID + HID + HID + 1
-        ldp, ldb = pad64(P), pad64(B)
-        g = LT.Geometry(N, in_dim, B)
-        pos = torch.randint(0, 32, (S, B, in_dim), device="cuda").float()
-        std = float(np.std(np.arange(32)))
-        x = ((pos - 15.5) / std).contiguous()
-        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
-        theta = torch.randn(S, N, ldp, device="cuda") * 0.05
-        a_ref, a_i8 = torch.zeros(S, N * HID, ldb, device="cuda"), torch.zeros(S, N * HID, ldb, device="cuda")
-        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
-        kp, wp = u8(g.kp, 1), u8(g.wp, 3)
-        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-        kp_rt, kt, wp_rt = -(-B // 128), -(-in_dim // 64), -(-(N * HID) // 128)
-        kp8 = torch.zeros(S * kp_rt * kt * 8192, dtype=torch.uint8, device="cuda")
-        wp8 = torch.zeros(S * wp_rt * kt * 4 * 8192, dtype=torch.uint8, device="cuda")
-        sc = torch.zeros(S * wp_rt * 128, device="cuda")
-        flops = 2.0 * S * N * HID * B * in_dim
-        L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0], g.kp[1], None, 0, 0,
-                                flag.data_ptr(), st)
-        t = timeit(lambda: L.rcmarl_w1_split(theta.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], st))
-        print("in=%4d  w1_split (bf16x3)   %8.1f us" % (in_dim, t))
-        t = timeit(lambda: L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], theta.data_ptr(),
-                                                           a_ref.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st))
-        print("in=%4d  forward bf16x3      %8.1f us  %6.1f TF/s fp32-equivalent (3 passes: %.0f TF/s bf16 executed)" % (in_dim, t, flops / t / 1e6, 3 * flops / t / 1e6))
-        t = timeit(lambda: L.rcmarl_lattice_encode_i8(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp8.data_ptr(), kp_rt, kt,
-                                                      flag.data_ptr(), st))
-        print("in=%4d  encode int8         %8.1f us  flag=%d" % (in_dim, t, int(flag.item())))
-        t = timeit(lambda: L.rcmarl_w1_split_i8(theta.data_ptr(), alpha.data_ptr(), wp8.data_ptr(), sc.data_ptr(), S, N, in_dim, HID, ldp, wp_rt,
-                                                kt, st))
-        print("in=%4d  w1_split int8 limbs %8.1f us" % (in_dim, t))
-        t = timeit(lambda: L.rcmarl_layer1_forward_i8(kp8.data_ptr(), kp_rt, kt, wp8.data_ptr(), wp_rt, kt, sc.data_ptr(), theta.data_ptr(),
-                                                      a_i8.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st))
-        print("in=%4d  forward int8 limbs  %8.1f us  %6.1f TF/s fp32-equivalent (4 passes: %.0f TOP/s int8 executed)" % (in_dim, t, flops / t / 1e6, 4 * flops / t / 1e6))
-        d = (a_i8[:, :, :B] - a_ref[:, :, :B]).abs().max().item() / a_ref[:, :, :B].abs().max().item()
-        print("in=%4d  max |a1(int8) - a1(bf16x3)| / max|a1| = %.2e" % (in_dim, d))
-
-
 def mid_ab(L, S=16, N=256, B=3000):
     """A/B of rcmarl_mid_fit_lattice: the product library (default kernel = v5, and RCMARL_MIDFIT=7 = the bf16 matrix-core form)
     against the variant builds named in RCMARL_KBENCH_LIB_B (comma-separated paths; tools/build_variant.py), interleaved."""
@@ -501,4 +460,4 @@ if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "i8": i8, "fused": fused, "fwdmid": fwdmid, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "fused": fused, "fwdmid": fwdmid, "minibatch": minibatch, "wide": wide}[what](L)

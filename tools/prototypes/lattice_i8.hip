@@ -1,3 +1,6 @@
+// NOT PART OF THE PRODUCT LIBRARY (moved out of csrc/ in round 4): a measured-slower prototype kept for the record -- DESIGN.md section 5,
+// Round 3 item 3; profiles/r03e_int8_limb_forward_prototype.txt.  It built against csrc/rcmarl_lattice.h and exported three entry points
+// (rcmarl_lattice_encode_i8, rcmarl_w1_split_i8, rcmarl_layer1_forward_i8) that no longer exist in include/rcmarl.h.
 // Layer-1 FORWARD GEMM on the int8 matrix core ("int8 limbs"), a measured PROTOTYPE of VERDICT r02 item 1(d).
 //
 // The lattice path (rcmarl_lattice.h) multiplies the small-integer replay operand K (|K| <= 127 here: grids up to 64 x 64)
