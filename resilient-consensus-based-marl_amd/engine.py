@@ -1137,8 +1137,8 @@ class RPBCACEngine:
     # (B, path flags) on torch's capture stream -- the library launches on torch's current stream and calls nothing that a
     # capture forbids (no allocation, no synchronisation) -- and replayed for the remaining epochs and the following blocks.
     # RCMARL_GRAPH=1 / 0 forces it on / off; default: on for small instances (S * N <= 256 agent-networks per launch), where
-    # the launches, not the kernels, set the block time.  Never with adversaries that fit mini-batches (side stream, host
-    # permutations), an agent-sharded instance (collectives), a wide critic, phase profiling or a timing wrapper around the library.
+    # the launches, not the kernels, set the block time.  Never with an agent-sharded instance (collectives), a wide critic, phase
+    # profiling or a timing wrapper around the library.  Greedy / Malicious agents are captured with their side streams (round 4).
     def _graph_wanted(self):
         e = os.environ.get("RCMARL_GRAPH")
         if e is not None:
@@ -1147,8 +1147,8 @@ class RPBCACEngine:
             want = self.S * self.N <= 256
         if not want or self.dev.type != "cuda" or self.shard is not None or self.wide or self.profile_phases:
             return False
-        if hasattr(self, "adv"):                                   # Greedy / Malicious agents present
-            return False
+        # (Greedy / Malicious agents: their message generators fork onto side streams and join again inside the captured epoch, the
+        # shuffle stream's call counter lives on the device -- engine_adversaries._draw; a wide critic keeps them eager, see above)
         return not getattr(self.lib, "enabled", False)            # bench.py's per-kernel timing wrapper records events per launch
 
     def _epoch(self, B, epoch, t0):
@@ -1162,11 +1162,18 @@ class RPBCACEngine:
             if len(self._graphs) >= 8:                             # growing replay buffer: B changes every block until steady state
                 self._graphs.pop(next(iter(self._graphs)))
             g = torch.cuda.CUDAGraph()
+            calls0 = list(self.adv.calls) if hasattr(self, "adv") else None
             with torch.cuda.graph(g):
                 self._epoch_body(B, t0)
+            if calls0 is not None:                                 # the capture advanced the host's shuffle-call counter by one epoch
+                g.rcmarl_draws = self.adv.calls[0] - calls0[0]     # ... without running anything: take it back, the replay below counts
+                self.adv.calls = calls0
+                self.adv.base_dev.fill_(int(calls0[0]))
             self._graphs[key] = g
             self.graph_captures += 1
         g.replay()
+        if hasattr(self, "adv"):
+            self.adv.replayed(getattr(g, "rcmarl_draws", 0))
         self.graph_replays += 1
         return t0
 

@@ -46,6 +46,7 @@ class AdversaryPath:
         self.fit_idx = torch.tensor(self.fit, dtype=torch.long, device=dev) if self.fit else None
         self.mal_idx = torch.tensor(self.mal, dtype=torch.long, device=dev) if self.mal else None
         self.calls = [0] * eng.S                       # ShuffleStream.calls per seed
+        self.base_dev, self._draw_bufs, self.last_draw = None, {}, 0
         self.adam_t = 0                                # Adam steps every adversary's actor has taken
         f32 = dict(dtype=torch.float32, device=dev)
         for k in ("r_own", "y_l", "y_adv", "delta_adv", "v_next_adv", "v_cur_adv"):
@@ -62,22 +63,43 @@ class AdversaryPath:
     # -- the shuffle stream (csrc/shuffle.hip; oracle: ShuffleStream), all seeds in one launch ------------
     def _draw(self, plan, epochs, B):
         """plan: list of (agent, key) in the reference's call order -> {key: int32 tensor [S][n_key][epochs][B]}.
-        Every seed makes the same sequence of fit calls, so the call numbers are shared."""
+        Every seed makes the same sequence of fit calls, so the call numbers are shared.
+        hipGraph-safe: the call counter also lives on the device (base_dev), the call numbers of a draw are formed there (constant
+        offsets + base_dev) and the counter is advanced by an in-stream add, the permutation buffers are persistent -- a replayed
+        epoch draws the NEXT permutations; the host counter follows through replayed()."""
         e = self.e
-        base = self.calls[0]
-        by_key = {}
-        for pos, (agent, key) in enumerate(plan):
-            by_key.setdefault(key, []).append(base + pos)
+        dev = e.dev
+        if self.base_dev is None:
+            self.base_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.base_dev.fill_(int(self.calls[0]))          # (eager: the host counter is the truth, e.g. after load_state_dict)
+        sig = (tuple(plan), int(epochs), int(B))
+        bufs = self._draw_bufs.get(sig)
+        if bufs is None:
+            by_key = {}
+            for pos, (agent, key) in enumerate(plan):
+                by_key.setdefault(key, []).append(pos)
+            bufs = {}
+            for key, offs in by_key.items():
+                bufs[key] = (torch.tensor(offs, dtype=torch.int32, device=dev), torch.empty(len(offs), dtype=torch.int32, device=dev),
+                             torch.empty(e.S, len(offs), epochs, B, dtype=torch.int32, device=dev))
+            if len(self._draw_bufs) >= 16:                    # growing replay buffer: B changes every block until steady state
+                self._draw_bufs.pop(next(iter(self._draw_bufs)))
+            self._draw_bufs[sig] = bufs
         out = {}
-        for key, call_ids in by_key.items():
-            calls = torch.tensor(call_ids, dtype=torch.int32, device=e.dev)
-            perm = torch.empty(e.S, len(call_ids), epochs, B, dtype=torch.int32, device=e.dev)
-            e.lib.rcmarl_shuffle_perms(e.seeds_dev.data_ptr(), calls.data_ptr(), len(call_ids), epochs, B, perm.data_ptr(),
-                                       e.S, e.stream)
+        for key, (offs, calls, perm) in bufs.items():
+            torch.add(offs, self.base_dev, out=calls)
+            e.lib.rcmarl_shuffle_perms(e.seeds_dev.data_ptr(), calls.data_ptr(), offs.numel(), epochs, B, perm.data_ptr(), e.S, e.stream)
             out[key] = perm
-            self._keep = (calls, perm)                 # keep the small call table alive until the launch has run
+        self.base_dev.add_(len(plan))
         self.calls = [c + len(plan) for c in self.calls]
+        self.last_draw = len(plan)
         return out
+
+    def replayed(self, draws):
+        """an epoch that drew `draws` permutations was replayed from a hipGraph: the device-side counter moved, the host's follows"""
+        self.calls = [c + draws for c in self.calls]
 
     # -- Keras fit(batch_size=32, epochs=10) of a critic-family network, any width ----------------------------
     def _fit_critic_family(self, theta, agents_t, agents, y, perm, B, loss_out):
@@ -150,7 +172,6 @@ class AdversaryPath:
             plan.append((i, "tr"))
             plan.append((i, "critic"))
         perms = self._draw(plan, FIT_EPOCHS, B)
-        self._keep_perms = perms                       # other streams read them: keep the memory until the next call
         S, N = e.S, e.N
         # The (up to) three fits are independent networks and each is ONE latency-bound workgroup per (seed, adversary):
         # on a GPU they run side by side on three streams (forked from / joined to the current one).

@@ -160,6 +160,36 @@ def test_engine_epochs_replayed_from_a_hipgraph_are_bit_identical(n, S, nrow, mo
             np.testing.assert_array_equal(res["0"][1][k], res[mode][1][k])
 
 
+@pytest.mark.parametrize("labels,S", [(["Cooperative"] * 4 + ["Malicious"], 1), (["Greedy", "Cooperative", "Cooperative", "Malicious", "Faulty"], 2)])
+def test_engine_epochs_with_adversaries_replayed_from_a_hipgraph_are_bit_identical(labels, S, monkeypatch):
+    """The reference's own headline scenario (main.py:88-104 with a Malicious agent) as captured epochs: the adversaries' mini-batch
+    fits fork onto their side streams and join again INSIDE the graph, the shuffle stream's call counter lives on the device
+    (engine_adversaries._draw), the out-of-range flags are consumed by the fix-up launch -- weights, logs and the shuffle-call
+    count equal the eager run's bit for bit, and epochs really are replayed."""
+    import numpy as np
+    from rcmarl_amd.engine import EngineConfig, RPBCACEngine
+    n = len(labels)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RCMARL_GRAPH", mode)
+        cfg = EngineConfig(n, labels, EC.CIRC5, H=1, n_seeds=S, rng_mode="device", max_ep_len=20, n_ep_fixed=10, n_epochs=4,
+                           buffer_size=400, nrow=5, ncol=5)
+        eng = RPBCACEngine(cfg, seeds=list(range(200, 200 + S)))
+        eng.init_glorot(base_seed=2)
+        eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(n, 2)) for s in range(S)]))
+        logs = eng.train(50)                       # 5 blocks: B = 200, 400, 600, 600, 600
+        res[mode] = (logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}, eng.graph_captures, eng.graph_replays,
+                     list(eng.adv.calls))
+    assert res["0"][2:4] == (0, 0)
+    assert res["1"][2] == 3 and res["1"][3] == 5 * 3, res["1"][2:4]
+    assert res["0"][4] == res["1"][4]                                         # the same number of shuffle draws was consumed
+    for k in res["0"][0]:
+        np.testing.assert_array_equal(res["0"][0][k], res["1"][0][k])
+    for k in res["0"][1]:
+        assert np.isfinite(res["0"][1][k]).all()
+        np.testing.assert_array_equal(res["0"][1][k], res["1"][1][k])
+
+
 @pytest.mark.parametrize("n,critic_hid,H,d,rng_mode,lattice", [(5, 64, 1, 4, "device", False), (12, 512, 2, 6, "device", False),
                                                                (5, 128, 0, 4, "numpy", False), (12, 512, 2, 6, "device", True),
                                                                (20, 96, 1, 5, "device", "auto")])
