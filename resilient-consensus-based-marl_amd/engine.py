@@ -1138,7 +1138,7 @@ class RPBCACEngine:
     # capture forbids (no allocation, no synchronisation) -- and replayed for the remaining epochs and the following blocks.
     # RCMARL_GRAPH=1 / 0 forces it on / off; default: on for small instances (S * N <= 256 agent-networks per launch), where
     # the launches, not the kernels, set the block time.  Never with an agent-sharded instance (collectives), a wide critic, phase
-    # profiling or a timing wrapper around the library.  Greedy / Malicious agents are captured with their side streams (round 4).
+    # profiling or a timing wrapper around the library; with Greedy / Malicious agents only when their fits run inline (see below).
     def _graph_wanted(self):
         e = os.environ.get("RCMARL_GRAPH")
         if e is not None:
@@ -1147,8 +1147,14 @@ class RPBCACEngine:
             want = self.S * self.N <= 256
         if not want or self.dev.type != "cuda" or self.shard is not None or self.wide or self.profile_phases:
             return False
-        # (Greedy / Malicious agents: their message generators fork onto side streams and join again inside the captured epoch, the
-        # shuffle stream's call counter lives on the device -- engine_adversaries._draw; a wide critic keeps them eager, see above)
+        if hasattr(self, "adv") and self.adv.fit and os.environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false"):
+            # Greedy / Malicious agents: their three 940-step chains run side by side on three streams, and capturing that fork/join
+            # SEGFAULTS inside the HIP runtime of this ROCm (7.2; reproduced with tools/diag_graph_adversaries.py, round 4).  Inline on
+            # the capture stream (RCMARL_ADV_ASYNC=0) the capture works -- the shuffle-call counter lives on the device for that,
+            # engine_adversaries._draw -- but then the chains run one after the other (3 x 2.7 ms per epoch instead of 2.7 ms) and that
+            # costs more than the ~50 launches the graph saves.  A block of BASELINE configs[1] as one instance is 10 epochs x 2.7 ms
+            # of chain latency + rollout: its 32 ms are at that floor, graph or not.
+            return False
         return not getattr(self.lib, "enabled", False)            # bench.py's per-kernel timing wrapper records events per launch
 
     def _epoch(self, B, epoch, t0):

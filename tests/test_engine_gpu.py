@@ -160,34 +160,41 @@ def test_engine_epochs_replayed_from_a_hipgraph_are_bit_identical(n, S, nrow, mo
             np.testing.assert_array_equal(res["0"][1][k], res[mode][1][k])
 
 
-@pytest.mark.parametrize("labels,S", [(["Cooperative"] * 4 + ["Malicious"], 1), (["Greedy", "Cooperative", "Cooperative", "Malicious", "Faulty"], 2)])
+@pytest.mark.parametrize("labels,S", [(["Cooperative"] * 4 + ["Malicious"], 1), (["Greedy", "Cooperative", "Cooperative", "Malicious", "Faulty"], 2),
+                                      (["Cooperative", "Faulty", "Cooperative", "Cooperative", "Faulty"], 1)])
 def test_engine_epochs_with_adversaries_replayed_from_a_hipgraph_are_bit_identical(labels, S, monkeypatch):
-    """The reference's own headline scenario (main.py:88-104 with a Malicious agent) as captured epochs: the adversaries' mini-batch
-    fits fork onto their side streams and join again INSIDE the graph, the shuffle stream's call counter lives on the device
-    (engine_adversaries._draw), the out-of-range flags are consumed by the fix-up launch -- weights, logs and the shuffle-call
-    count equal the eager run's bit for bit, and epochs really are replayed."""
+    """The reference's own headline scenario (main.py:88-104 with a Malicious agent) as captured epochs, the adversaries' mini-batch
+    fits INLINE on the capture stream (RCMARL_ADV_ASYNC=0; on their side streams the capture crashes this ROCm's runtime, so the
+    engine's default keeps such instances eager -- asserted below): the shuffle stream's call counter lives on the device
+    (engine_adversaries._draw), the out-of-range flags are consumed by the fix-up launch.  Weights, logs and the number of shuffle
+    draws equal the eager run's bit for bit, and epochs really are replayed."""
     import numpy as np
     from rcmarl_amd.engine import EngineConfig, RPBCACEngine
     n = len(labels)
+    fits = any(l in ("Greedy", "Malicious") for l in labels)
     res = {}
-    for mode in ("0", "1"):
+    for mode, asyn in (("0", "1"), ("1", "0"), ("1", "1")):
         monkeypatch.setenv("RCMARL_GRAPH", mode)
+        monkeypatch.setenv("RCMARL_ADV_ASYNC", asyn)
         cfg = EngineConfig(n, labels, EC.CIRC5, H=1, n_seeds=S, rng_mode="device", max_ep_len=20, n_ep_fixed=10, n_epochs=4,
                            buffer_size=400, nrow=5, ncol=5)
         eng = RPBCACEngine(cfg, seeds=list(range(200, 200 + S)))
         eng.init_glorot(base_seed=2)
         eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(n, 2)) for s in range(S)]))
         logs = eng.train(50)                       # 5 blocks: B = 200, 400, 600, 600, 600
-        res[mode] = (logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}, eng.graph_captures, eng.graph_replays,
-                     list(eng.adv.calls))
-    assert res["0"][2:4] == (0, 0)
-    assert res["1"][2] == 3 and res["1"][3] == 5 * 3, res["1"][2:4]
-    assert res["0"][4] == res["1"][4]                                         # the same number of shuffle draws was consumed
-    for k in res["0"][0]:
-        np.testing.assert_array_equal(res["0"][0][k], res["1"][0][k])
-    for k in res["0"][1]:
-        assert np.isfinite(res["0"][1][k]).all()
-        np.testing.assert_array_equal(res["0"][1][k], res["1"][1][k])
+        res[(mode, asyn)] = (logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}, eng.graph_captures,
+                             eng.graph_replays, list(eng.adv.calls))
+    eager, inline, dflt = res[("0", "1")], res[("1", "0")], res[("1", "1")]
+    assert eager[2:4] == (0, 0)
+    assert inline[2] == 3 and inline[3] == 5 * 3, inline[2:4]
+    assert dflt[2:4] == ((0, 0) if fits else (3, 15))                         # side-stream fits: the engine stays eager
+    for other in (inline, dflt):
+        assert eager[4] == other[4]                                           # the same number of shuffle draws was consumed
+        for k in eager[0]:
+            np.testing.assert_array_equal(eager[0][k], other[0][k])
+        for k in eager[1]:
+            assert np.isfinite(eager[1][k]).all()
+            np.testing.assert_array_equal(eager[1][k], other[1][k])
 
 
 @pytest.mark.parametrize("n,critic_hid,H,d,rng_mode,lattice", [(5, 64, 1, 4, "device", False), (12, 512, 2, 6, "device", False),
