@@ -4,7 +4,7 @@ RCMARL_ADV_ASYNC=0 it prints "ok 3 15".   python -X faulthandler tools/diag_grap
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("RCMARL_DIAG_FORCE_CAPTURE", "1")
+
 os.environ["RCMARL_GRAPH"] = "1"
 import numpy as np
 import engine_checks as EC
