@@ -13,7 +13,7 @@ import csv, glob, collections, json, re
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
 for f in glob.glob('$R/gpurun_out/pmckb/${WHAT}_*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+        k = re.sub(r'\(.*', '', r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', ''))
         if k.startswith('at::') or 'rocclr' in k: continue
         tot[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[k][r['Counter_Name']] += 1
 out = {}
