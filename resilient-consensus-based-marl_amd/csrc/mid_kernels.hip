@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, EMIT ? 3 : 4) void k_mid_fit_v5(float* __restr
 // 827 us against v5's 797 at BASELINE configs[3] -- the splits, plane traffic and dependent MFMA chains gave back what the
 // matrix core saved; with two f16 pieces it runs ~600 us against v5's ~715 (profiles/r03n_mid_ab.txt).
 #ifndef RC_V8_WAVES
-#define RC_V8_WAVES 2                    // wavefronts per SIMD the register allocation aims at
+#define RC_V8_WAVES 3                    // wavefronts per SIMD the register allocation aims at
 #endif
 #define RC_V8_S 1024.f                   // scale of W2 and of dz2
 #define RC_V8_US 0.0009765625f
@@ -443,30 +443,65 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   uint4 z4;
   z4.x = z4.y = z4.z = z4.w = 0u;
   float amax = 0.f;                                    // largest |operand| this lane split (a1, 2^10 dz2)
-  float racc0 = 0.f, racc1 = 0.f;
+  // Everything summed over rows accumulates per wavefront over ALL the workgroup's chunks -- the row reduction in the accumulator
+  // tile g1, the plain sums per lane -- and is reduced ONCE at the end (round 4: the per-chunk reduction, 120 fused-DPP adds + the
+  // record staging + two workgroup barriers per 64 rows, was a fifth of this kernel's instructions).
+  rc_f32x16 g1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) g1[q] = 0.f;
+  float gb1l[LU], gw3l[LU], gb3a = 0.f, lossa = 0.f;    // per-lane partial sums over this wavefront's blocks
+#pragma unroll
+  for (int u = 0; u < LU; ++u) gb1l[u] = gw3l[u] = 0.f;
+  // The lane's ten layer-1 activations + target of a block are loaded ONE BLOCK AHEAD (round 4: a block is one dependent chain --
+  // loads, split, matrix core, vector ALU, matrix core, ... -- and with three wavefronts per SIMD nothing else covered the ~2 us
+  // an HBM load takes under load: the wavefronts sat 43 % of their cycles waiting).  Unconditional loads from a clamped row
+  // (ten in flight, no exec-mask branches); rows beyond B are zeroed when the values are used.
+  float nxa[LU], nxy;
+  auto fetch = [&](int bfirst) {
+    const int bc = min(bfirst + l31, B - 1);
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      nxa[u] = a1t[(row0 + v8_unit(half, u)) * ldb + bc];
+      RC_SCHED_FENCE();                                  // the same issue order at both call sites: the wait at the top of a block then
+    }                                                    // counts only the loads, not the dz1 stores issued behind them (vmcnt is in order)
+    nxy = yrow[bc];
+    RC_SCHED_FENCE();
+  };
+  // A block's packed dz1 chunks leave the staging planes at the TOP of the next block, behind that block's wait for its prefetched
+  // loads: the memory counter is in order, so stores issued at the end of a block would be waited for -- a round trip to L2 -- at
+  // the top of the next one; issued there, everything outstanding at a wait is one block old.
+  int kt_staged = -1;
+  auto store_staged = [&](int kt) {
+    const unsigned short* stg = pB;                    // [40 (unit, piece)][32 rows] f16 = 2560 B, written at the end of the block
+    unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (2 * RC_PK_BLOCK);
+#pragma unroll
+    for (int it = 0; it < (HID * 2 * 4 + 63) / 64; ++it) {
+      const int c = it * 64 + lane;                    // chunk index: (unit, piece) = c >> 2, rows 8*(c&3) .. +7
+      if (c < HID * 2 * 4 && kt < dzp_kt) {
+        const int up = c >> 2, c4 = c & 3;
+        const int unit = up >> 1, piece = up & 1;
+        const int R = i * HID + unit;
+        const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 32 + 8 * c4);
+        const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
+                             (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
+        *reinterpret_cast<uint4*>(base + off) = v4;
+      }
+    }
+  };
+  fetch(c_begin * ROWS + wave * 64);
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
-    rc_f32x16 g1;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) g1[q] = 0.f;
-    float gb1l[LU], gw3l[LU], gb3a = 0.f, lossa = 0.f;  // per-lane partial sums over this wavefront's two blocks
-#pragma unroll
-    for (int u = 0; u < LU; ++u) gb1l[u] = gw3l[u] = 0.f;
 #pragma unroll 1
     for (int blk = 0; blk < 2; ++blk) {
       const int b = chunk * ROWS + wave * 64 + 32 * blk + l31;
       const bool valid = b < B;
-      const int bc = valid ? b : B - 1;
-      // ---- the lane's ten layer-1 activations of its row
       float a1l[LU];
 #pragma unroll
-      for (int u = 0; u < LU; ++u) {                       // unconditional loads from a clamped row (ten loads in flight, no exec-mask
-        const float av = a1t[(row0 + v8_unit(half, u)) * ldb + bc];      // branches), then the rows beyond B are zeroed
-        a1l[u] = valid ? av : 0.f;
-      }
+      for (int u = 0; u < LU; ++u) a1l[u] = valid ? nxa[u] : 0.f;
+      const float ycur = valid ? nxy : 0.f;
+      fetch(chunk * ROWS + wave * 64 + (blk ? ROWS : 32));  // the next block of this wavefront (past the workgroup's last: a clamped, unused read)
+      if (EMIT && kt_staged >= 0) store_staged(kt_staged);
 #pragma unroll
       for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(a1l[u]), fabsf(a1l[u + 1])));
-      const float yv = yrow[bc];
-      const float ycur = valid ? yv : 0.f;
       // ---- layer 2 forward on the f16 matrix core; the a1 pieces also go to the A planes (operand of the row reduction)
       V8Pieces pa0, pa1;
       {
@@ -572,24 +607,13 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
           stg[(u1 * 2 + 1) * 32 + l31] = (unsigned short)(pl >> 16);
         }
         RC_WAVE_SYNC();
-        unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (2 * RC_PK_BLOCK);
-        const int kt = (chunk * ROWS + wave * 64 + 32 * blk) >> 5;             // this block's k-tile
-#pragma unroll
-        for (int it = 0; it < (HID * 2 * 4 + 63) / 64; ++it) {
-          const int c = it * 64 + lane;                // chunk index: (unit, piece) = c >> 2, rows 8*(c&3) .. +7
-          if (c < HID * 2 * 4 && kt < dzp_kt) {
-            const int up = c >> 2, c4 = c & 3;
-            const int unit = up >> 1, piece = up & 1;
-            const int R = i * HID + unit;
-            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 32 + 8 * c4);
-            const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
-                                 (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
-            *reinterpret_cast<uint4*>(base + off) = v4;
-          }
-        }
+        kt_staged = (chunk * ROWS + wave * 64 + 32 * blk) >> 5;               // this block's k-tile: stored at the top of the next block
       }
     }
-    // ---- what is summed over rows outside the matrix core: gb1, gW3 (per unit), gb3, loss -- both blocks were added above per
+  }
+  if (EMIT && kt_staged >= 0) store_staged(kt_staged);
+  {
+    // ---- what is summed over rows outside the matrix core: gb1, gW3 (per unit), gb3, loss -- all blocks were added above per
     // lane; now over the 32 lanes of each half (results in lanes 31 and 63)
     {
       float sm[2 * LU + 4];
@@ -615,21 +639,18 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
         if (half == 0) { sRec[PT::gb3] = sm[2 * LU]; sRec[PT::loss] = sm[2 * LU + 1]; }
       }
     }
-    __syncthreads();
-    {
-      const float* r0 = reinterpret_cast<const float*>(sPn + 0 * PANEL_B + 2 * PLANE * 2);
-      const float* r1 = reinterpret_cast<const float*>(sPn + 1 * PANEL_B + 2 * PLANE * 2);
-      const float* r2 = reinterpret_cast<const float*>(sPn + 2 * PANEL_B + 2 * PLANE * 2);
-      const float* r3 = reinterpret_cast<const float*>(sPn + 3 * PANEL_B + 2 * PLANE * 2);
-      racc0 += (r0[r] + r1[r]) + (r2[r] + r3[r]);                            // the workgroup's running record (as k_mid_fit_v5)
-      if (r + ROWS < PT::SIZE) racc1 += (r0[r + ROWS] + r1[r + ROWS]) + (r2[r + ROWS] + r3[r + ROWS]);
-    }
-    __syncthreads();                                   // records read out before the next chunk's planes land
   }
+  __syncthreads();
   if (amax > RC_V8_RANGE) ovf_flags[s * N + i] = ovf_gen;            // (same value from every lane and workgroup of the agent)
-  float* out = partials + (((long)s * N + i) * gridDim.x + blockIdx.x) * PT::SIZE;
-  out[r] = racc0;
-  if (r + ROWS < PT::SIZE) out[r + ROWS] = racc1;
+  {
+    const float* r0 = reinterpret_cast<const float*>(sPn + 0 * PANEL_B + 2 * PLANE * 2);
+    const float* r1 = reinterpret_cast<const float*>(sPn + 1 * PANEL_B + 2 * PLANE * 2);
+    const float* r2 = reinterpret_cast<const float*>(sPn + 2 * PANEL_B + 2 * PLANE * 2);
+    const float* r3 = reinterpret_cast<const float*>(sPn + 3 * PANEL_B + 2 * PLANE * 2);
+    float* out = partials + (((long)s * N + i) * gridDim.x + blockIdx.x) * PT::SIZE;          // the workgroup's record
+    out[r] = (r0[r] + r1[r]) + (r2[r] + r3[r]);
+    if (r + ROWS < PT::SIZE) out[r + ROWS] = (r0[r + ROWS] + r1[r + ROWS]) + (r2[r + ROWS] + r3[r + ROWS]);
+  }
 }
 
 // theta(small arrays) -= lr * sum_chunks partial; optional loss_out[s][n] = sum(diff^2)/B.
