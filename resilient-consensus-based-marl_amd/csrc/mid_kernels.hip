@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   const int s = blockIdx.z, i = blockIdx.y;
   const int c_begin = blockIdx.x * cpw, c_end = min(nchunk, c_begin + cpw);
   const int r = threadIdx.x;
-  const int lane = r & 63, wave = r >> 6, l31 = lane & 31, half = lane >> 5;
+  const int lane = r & 63, wave = __builtin_amdgcn_readfirstlane(r >> 6), l31 = lane & 31, half = lane >> 5;
   const NetGeom g = make_geom(in_dim, HID, 1);
   const float* th = theta + ((long)s * N + i) * ldp;
   const long row0 = ((long)s * N + i) * HID;
@@ -455,53 +455,74 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   // The lane's ten layer-1 activations + target of a block are loaded ONE BLOCK AHEAD (round 4: a block is one dependent chain --
   // loads, split, matrix core, vector ALU, matrix core, ... -- and with three wavefronts per SIMD nothing else covered the ~2 us
   // an HBM load takes under load: the wavefronts sat 43 % of their cycles waiting).  Unconditional loads from a clamped row
-  // (ten in flight, no exec-mask branches); rows beyond B are zeroed when the values are used.
-  float nxa[LU], nxy;
-  auto fetch = [&](int bfirst) {
-    const int bc = min(bfirst + l31, B - 1);
+  // (ten in flight, no exec-mask branches).  Addresses: one wave-uniform base
+  // per local unit (scalar registers) + ONE 32-bit byte offset per lane and unit group -- no 64-bit vector address arithmetic.
+  const unsigned char* ubase[LU];
+#pragma unroll
+  for (int u = 0; u < LU; ++u) ubase[u] = reinterpret_cast<const unsigned char*>(a1t + (row0 + (u < 8 ? u : u + 8)) * ldb);
+  const unsigned hoff8 = (unsigned)(8 * half) * (unsigned)ldb, hoff2 = (unsigned)(2 * half) * (unsigned)ldb;   // v8_unit(half, u) - v8_unit(0, u) rows
+  float setA[LU], yA;                                  // the prefetched block
+  auto fetch = [&](float (&nxa)[LU], float& nxy, int bfirst) {
+    const unsigned bc = (unsigned)min(bfirst + l31, B - 1);
+    const unsigned o8 = (hoff8 + bc) * 4u, o2 = (hoff2 + bc) * 4u;
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
-      nxa[u] = a1t[(row0 + v8_unit(half, u)) * ldb + bc];
-      RC_SCHED_FENCE();                                  // the same issue order at both call sites: the wait at the top of a block then
-    }                                                    // counts only the loads, not the dz1 stores issued behind them (vmcnt is in order)
+      nxa[u] = *reinterpret_cast<const float*>(ubase[u] + (u < 8 ? o8 : o2));
+      RC_SCHED_FENCE();                                  // (the same issue order at both call sites)
+    }
     nxy = yrow[bc];
     RC_SCHED_FENCE();
   };
   // A block's packed dz1 chunks leave the staging planes at the TOP of the next block, behind that block's wait for its prefetched
   // loads: the memory counter is in order, so stores issued at the end of a block would be waited for -- a round trip to L2 -- at
   // the top of the next one; issued there, everything outstanding at a wait is one block old.
+  // Staging (over the B planes): [32 rows][48 columns] f16, a lane's row = its replay row, its 20 columns (24 * half ..) = the five
+  // (h pair, l pair) registers of its ten units as they come out of the split -- three 16-byte / 8-byte writes; the 16-byte chunks
+  // of the packed image (8 consecutive replay rows of one (unit, piece)) then come back through the TRANSPOSE read: pass p, the
+  // 16-lane group g of a wavefront reads columns 16p..16p+15 of rows 8g..8g+7, lane j of it receives column 16p + j.
+  constexpr int SC = 48;                               // staging columns per row (96 bytes)
+  static_assert(32 * SC * 2 <= 2 * PLANE * 2, "the dz1 staging fits the B planes");
+  const int st_wr = l31 * SC + 24 * half;              // the lane's 20 staging columns
+  const int st_rd = (8 * (lane >> 4) + ((lane & 15) >> 2)) * SC + 4 * (lane & 3);        // + 16 * pass (+ 4 * SC: rows 4..7 of the group)
+  unsigned st_off[3];                                   // byte offset of the lane's chunk inside the k-tile of the packed image, per pass
+  bool st_on[3];
+#pragma unroll
+  for (int ps = 0; ps < 3; ++ps) {
+    // (lanes j, j+16, j+32, j+48 -- not four neighbours -- write the four chunks of a 64-byte segment; a probe build with the
+    // neighbour mapping (and wrong placement) ran in the same time: 471 against 466 us, so the stores are left as the transpose delivers them)
+    const int c = 16 * ps + (lane & 15), hf = c >= 24, cc = c - 24 * hf;                // column -> (half, pair q, element e)
+    const int c4 = lane >> 4;                            // c4: the 8-row group
+    const int q = cc >> 2, e = cc & 3, piece = e >> 1;
+    const int unit = v8_unit(hf, min(2 * q + (e & 1), LU - 1));
+    const int R = i * HID + unit;
+    st_on[ps] = cc < 20 && c < 44;
+    st_off[ps] = (unsigned)(((R >> 7) * dzp_kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 + (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
+  }
+  unsigned char* dz_base = dzp + (long)s * dzp_rt * dzp_kt * (2 * RC_PK_BLOCK);
   int kt_staged = -1;
   auto store_staged = [&](int kt) {
-    const unsigned short* stg = pB;                    // [40 (unit, piece)][32 rows] f16 = 2560 B, written at the end of the block
-    unsigned char* base = dzp + (long)s * dzp_rt * dzp_kt * (2 * RC_PK_BLOCK);
+    const unsigned short* stg = pB;
+    if (kt < dzp_kt) {
 #pragma unroll
-    for (int it = 0; it < (HID * 2 * 4 + 63) / 64; ++it) {
-      const int c = it * 64 + lane;                    // chunk index: (unit, piece) = c >> 2, rows 8*(c&3) .. +7
-      if (c < HID * 2 * 4 && kt < dzp_kt) {
-        const int up = c >> 2, c4 = c & 3;
-        const int unit = up >> 1, piece = up & 1;
-        const int R = i * HID + unit;
-        const uint4 v4 = *reinterpret_cast<const uint4*>(stg + up * 32 + 8 * c4);
-        const unsigned off = (unsigned)(((R >> 7) * dzp_kt + kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 +
-                             (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
-        *reinterpret_cast<uint4*>(base + off) = v4;
+      for (int ps = 0; ps < 3; ++ps) {
+        const uint2 t0 = rc_lds_read_tr16(stg + st_rd + 16 * ps), t1 = rc_lds_read_tr16(stg + st_rd + 16 * ps + 4 * SC);
+        uint4 v4;
+        v4.x = t0.x; v4.y = t0.y; v4.z = t1.x; v4.w = t1.y;
+        if (st_on[ps]) *reinterpret_cast<uint4*>(dz_base + (st_off[ps] + (unsigned)kt * (2 * RC_PK_BLOCK))) = v4;
       }
     }
   };
-  fetch(c_begin * ROWS + wave * 64);
-  for (int chunk = c_begin; chunk < c_end; ++chunk) {
-#pragma unroll 1
-    for (int blk = 0; blk < 2; ++blk) {
-      const int b = chunk * ROWS + wave * 64 + 32 * blk + l31;
+  const float Bf = (float)B, rB = 1.0f / Bf;
+  const rc_f2 leak2 = rc_bcast2(RC_LEAK);
+  auto do_block = [&](float (&a1l)[LU], const float ycur, float (&nxa)[LU], float& nxy, const int chunk, const int blk) {
+      const int bfirst = chunk * ROWS + wave * 64 + 32 * blk;                 // wave-uniform
+      const int b = bfirst + l31;
       const bool valid = b < B;
-      float a1l[LU];
-#pragma unroll
-      for (int u = 0; u < LU; ++u) a1l[u] = valid ? nxa[u] : 0.f;
-      const float ycur = valid ? nxy : 0.f;
-      fetch(chunk * ROWS + wave * 64 + (blk ? ROWS : 32));  // the next block of this wavefront (past the workgroup's last: a clamped, unused read)
+      // (rows beyond B carry row B-1's activations, not zeros: their diff -- hence dz2, dz1 and every sum they enter -- is zero)
+      fetch(nxa, nxy, bfirst + (blk ? ROWS - 32 : 32));    // the next block of this wavefront (past the workgroup's last: a clamped, unused read)
       if (EMIT && kt_staged >= 0) store_staged(kt_staged);
 #pragma unroll
-      for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(a1l[u]), fabsf(a1l[u + 1])));
+      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1l[u], a1l[u + 1]);
       // ---- layer 2 forward on the f16 matrix core; the a1 pieces also go to the A planes (operand of the row reduction)
       V8Pieces pa0, pa1;
       {
@@ -522,26 +543,40 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
       zz = v8_mfma4(loadA(0, 1), pa1, zz);
       zz = v8_mfma4(loadA(0, 0), pa0, zz);
       RC_SCHED_FENCE();
-      float a2l[LU], vp = 0.f;
+      // a2 = lrelu(z2 + b2) two units at a time (max(z, leak z): bit for bit the select form), v = a2 . W3 + b3
+      rc_f2 a2p[LU / 2], w3p[LU / 2];
+      float vp = 0.f;
 #pragma unroll
-      for (int u = 0; u < LU; ++u) a2l[u] = rc_lrelu(fmaf(zz[u], RC_V8_US, sV[v8_unit(half, u)]));
+      for (int q = 0; q < LU / 2; ++q) {
+        const rc_f2 zq = {zz[2 * q], zz[2 * q + 1]};
+        const rc_f2 bq = {sV[v8_unit(half, 2 * q)], sV[v8_unit(half, 2 * q + 1)]};
+        w3p[q] = rc_f2{sV[HID + v8_unit(half, 2 * q)], sV[HID + v8_unit(half, 2 * q + 1)]};
+        a2p[q] = rc_lrelu2(rc_fma2(zq, rc_bcast2(RC_V8_US), bq));
+      }
 #pragma unroll
-      for (int u = 0; u < LU; ++u) vp = fmaf(a2l[u], sV[HID + v8_unit(half, u)], vp);
+      for (int q = 0; q < LU / 2; ++q) { vp = fmaf(a2p[q].x, w3p[q].x, vp); vp = fmaf(a2p[q].y, w3p[q].y, vp); }
       float va = vp, vb = vp;
       rc_swap32(va, vb);                                 // va: lanes 32-63 now hold the low half's partial; vb: lanes 0-31 the high half's
       const float v = (vp + (half ? va : vb)) + b3;
       const float diff = valid ? v - ycur : 0.f;
-      const float dv = (2.0f * diff) / (float)B;
+      // dv = (2 diff) / B, correctly rounded without the division sequence (q = x rB; r = x - q B exactly; q + r rB: Markstein --
+      // the rounded quotient whenever it is a normal number; B's significand is not all ones)
+      const float x2 = 2.0f * diff, q0 = x2 * rB;
+      const float dv = fmaf(fmaf(-q0, Bf, x2), rB, q0);
       const float dvs = dv * RC_V8_S;
       if (half == 0) { gb3a += dv; lossa = fmaf(diff, diff, lossa); }   // (both lanes of a row hold the same v: count it once)
+      // 2^10 dz2 = (dvs W3) * (a2 > 0 ? 1 : leak)  (power-of-two scale: same bits as scaling afterwards)
       float dz2l[LU];
 #pragma unroll
-      for (int u = 0; u < LU; ++u) {
-        gw3l[u] = fmaf(a2l[u], dv, gw3l[u]);
-        dz2l[u] = dvs * sV[HID + v8_unit(half, u)] * rc_lrelu_grad_from_act(a2l[u]);      // 2^10 dz2 (power-of-two scale: same bits as scaling afterwards)
+      for (int q = 0; q < LU / 2; ++q) {
+        const rc_f2 t = rc_mul2(rc_bcast2(dvs), w3p[q]), tl = rc_mul2(t, leak2);
+        const rc_f2 gw = rc_fma2(a2p[q], rc_bcast2(dv), rc_f2{gw3l[2 * q], gw3l[2 * q + 1]});
+        gw3l[2 * q] = gw.x; gw3l[2 * q + 1] = gw.y;
+        dz2l[2 * q] = a2p[q].x > 0.f ? t.x : tl.x;
+        dz2l[2 * q + 1] = a2p[q].y > 0.f ? t.y : tl.y;
       }
 #pragma unroll
-      for (int u = 0; u < LU; u += 2) amax = fmaxf(amax, fmaxf(fabsf(dz2l[u]), fabsf(dz2l[u + 1])));
+      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, dz2l[u], dz2l[u + 1]);
       // ---- layer 2 backward; the dz2 pieces also go to the B planes
       V8Pieces pd0, pd1;
       {
@@ -560,11 +595,16 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
       dd = v8_mfma4(loadA(1, 1), pd1, dd);
       dd = v8_mfma4(loadA(1, 0), pd0, dd);
       RC_SCHED_FENCE();
+      // dz1 = (dd * scale) * (a1 > 0 ? 1 : leak)   (EMIT: 2^8 dz1, what the packed operand carries)
       float dz1l[LU];
+      const rc_f2 sc2 = rc_bcast2(RC_V8_US * RC_V8_US * (EMIT ? RC_F16_DZ_SCALE : 1.f));
 #pragma unroll
-      for (int u = 0; u < LU; ++u) {
-        dz1l[u] = (dd[u] * (RC_V8_US * RC_V8_US * (EMIT ? RC_F16_DZ_SCALE : 1.f))) * rc_lrelu_grad_from_act(a1l[u]);   // EMIT: 2^8 dz1, what the packed operand carries
-        gb1l[u] += dz1l[u];
+      for (int q = 0; q < LU / 2; ++q) {
+        const rc_f2 t = rc_mul2(rc_f2{dd[2 * q], dd[2 * q + 1]}, sc2), tl = rc_mul2(t, leak2);
+        const rc_f2 dq = {a1l[2 * q] > 0.f ? t.x : tl.x, a1l[2 * q + 1] > 0.f ? t.y : tl.y};
+        const rc_f2 gb = rc_add2(rc_f2{gb1l[2 * q], gb1l[2 * q + 1]}, dq);
+        gb1l[2 * q] = gb.x; gb1l[2 * q + 1] = gb.y;
+        dz1l[2 * q] = dq.x; dz1l[2 * q + 1] = dq.y;
       }
       if (!EMIT) {
 #pragma unroll
@@ -591,24 +631,37 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
         RC_SCHED_FENCE();                              // (keeps the second k-step's eight reads from being hoisted: registers)
       }
       if (EMIT) {
-        // packed f16 pieces of 2^8 dz1 (rcmarl_lattice.h): row = i*HID + unit, k = replay row.  The block's 32 rows x 40 (unit, piece)
-        // values are transposed through the (now idle) B planes so that the stores are 16-byte chunks = 8 consecutive
-        // replay rows of one (unit, piece); a block is exactly one k-tile of the packed image.
-        unsigned short* stg = pB;                      // [40 (unit, piece)][32 rows] f16 = 2560 B
+        // the f16 pieces of 2^8 dz1 (rcmarl_lattice.h) go to the (now idle) B planes in staging order; a block is exactly one k-tile
+        // of the packed image
+        unsigned short* stg = pB;
         RC_WAVE_SYNC();                                // the reduction's transpose reads are done
-#pragma unroll
-        for (int q = 0; q < LU / 2; ++q) {
-          unsigned ph, pl;
-          rc_split2h_pair(dz1l[2 * q], dz1l[2 * q + 1], ph, pl);             // bits 0-15: local unit 2q, bits 16-31: 2q+1
-          const int u0 = v8_unit(half, 2 * q), u1 = v8_unit(half, 2 * q + 1);
-          stg[(u0 * 2 + 0) * 32 + l31] = (unsigned short)ph;
-          stg[(u0 * 2 + 1) * 32 + l31] = (unsigned short)pl;
-          stg[(u1 * 2 + 0) * 32 + l31] = (unsigned short)(ph >> 16);
-          stg[(u1 * 2 + 1) * 32 + l31] = (unsigned short)(pl >> 16);
+        uint4 ph, pl, w0, w1;                           // staging order: (h pair, l pair) of units (0,1), (2,3), ...
+        uint2 w2;
+        {
+          const float x0[8] = {dz1l[0], dz1l[1], dz1l[2], dz1l[3], dz1l[4], dz1l[5], dz1l[6], dz1l[7]};
+          rc_split2h_x8(x0, ph, pl);
+          rc_split2h_pair(dz1l[8], dz1l[9], w2.x, w2.y);
         }
+        w0.x = ph.x; w0.y = pl.x; w0.z = ph.y; w0.w = pl.y;
+        w1.x = ph.z; w1.y = pl.z; w1.z = ph.w; w1.w = pl.w;
+        *reinterpret_cast<uint4*>(stg + st_wr) = w0;
+        *reinterpret_cast<uint4*>(stg + st_wr + 8) = w1;
+        *reinterpret_cast<uint2*>(stg + st_wr + 16) = w2;
         RC_WAVE_SYNC();
-        kt_staged = (chunk * ROWS + wave * 64 + 32 * blk) >> 5;               // this block's k-tile: stored at the top of the next block
+        kt_staged = bfirst >> 5;                       // this block's k-tile: stored at the top of the next block
       }
+  };
+  fetch(setA, yA, c_begin * ROWS + wave * 64);
+  // (one register set + a copy per block; two sets used alternately by a twice-unrolled loop save the ten copies and measure 6 %
+  // SLOWER -- 498 against 468 us: profiles/r04q_mid_ab.txt)
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+      float cur[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) cur[u] = setA[u];
+      const float ycur = yA;
+      do_block(cur, ycur, setA, yA, chunk, blk);
     }
   }
   if (EMIT && kt_staged >= 0) store_staged(kt_staged);

@@ -133,16 +133,54 @@ __device__ __forceinline__ void rc_split2h_pair(float w0, float w1, unsigned& h,
   const unsigned l0 = rc_f16_rne(w0 - rc_f16_to_f32(h0)), l1 = rc_f16_rne(w1 - rc_f16_to_f32(h1));
   h = h0 | (h1 << 16); l = l0 | (l1 << 16);
 }
+__device__ __forceinline__ void rc_split2h_x8(const float (&x)[8], uint4& h, uint4& l) {
+  rc_split2h_pair(x[0], x[1], h.x, l.x);
+  rc_split2h_pair(x[2], x[3], h.y, l.y);
+  rc_split2h_pair(x[4], x[5], h.z, l.z);
+  rc_split2h_pair(x[6], x[7], h.w, l.w);
+}
 #else
 typedef _Float16 rc_h2 __attribute__((ext_vector_type(2)));
+// Three instructions per pair: one packed conversion for h, then l = rn_f16(v - h) as ONE mixed-precision FMA per value
+// (v_fma_mix{lo,hi}_f16: -h read as f16, times 1.0, plus v in fp32; v - h is exact in fp32, so the only rounding is the one to
+// f16) -- the plain form (convert h back, packed subtract, packed convert) is five, and hipcc folds any C++ spelling of the FMA
+// back into it.  Hence inline asm, which the compiler's hazard recognizer does not look into: a write to the HIGH half of a
+// register (v_fma_mixhi) must be one wait state away from a vector instruction that reads the register, and two from an MFMA
+// -- the s_nop closing each block (without it the fused kernels read stale pieces: fused_fit test, round 4).
+#ifndef RC_SPLIT_NOP
+#define RC_SPLIT_NOP "s_nop 1"
+#endif
+#define RC_MIXLO(d, h, v) "v_fma_mixlo_f16 " d ", -" h ", 1.0, " v " op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+#define RC_MIXHI(d, h, v) "v_fma_mixhi_f16 " d ", -" h ", 1.0, " v " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
 __device__ __forceinline__ void rc_split2h_pair(float w0, float w1, unsigned& h, unsigned& l) {
   const rc_f2 v = {w0, w1};
-  const rc_h2 hh = __builtin_convertvector(v, rc_h2);
-  const rc_f2 r = v - __builtin_convertvector(hh, rc_f2);
-  h = __builtin_bit_cast(unsigned, hh);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rc_h2));
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rc_h2));
+  asm(RC_MIXLO("%0", "%1", "%2") RC_MIXHI("%0", "%1", "%3") RC_SPLIT_NOP : "=&v"(l) : "v"(h), "v"(w0), "v"(w1));
 }
+// eight values: the pieces of (x0, x1), (x2, x3), ... in the four words of h and l; one closing s_nop for all
+__device__ __forceinline__ void rc_split2h_x8(const float (&x)[8], uint4& h, uint4& l) {
+  h.x = __builtin_bit_cast(unsigned, __builtin_convertvector((rc_f2{x[0], x[1]}), rc_h2));
+  h.y = __builtin_bit_cast(unsigned, __builtin_convertvector((rc_f2{x[2], x[3]}), rc_h2));
+  h.z = __builtin_bit_cast(unsigned, __builtin_convertvector((rc_f2{x[4], x[5]}), rc_h2));
+  h.w = __builtin_bit_cast(unsigned, __builtin_convertvector((rc_f2{x[6], x[7]}), rc_h2));
+  asm(RC_MIXLO("%0", "%4", "%8") RC_MIXHI("%0", "%4", "%9") RC_MIXLO("%1", "%5", "%10") RC_MIXHI("%1", "%5", "%11")
+      RC_MIXLO("%2", "%6", "%12") RC_MIXHI("%2", "%6", "%13") RC_MIXLO("%3", "%7", "%14") RC_MIXHI("%3", "%7", "%15") RC_SPLIT_NOP
+      : "=&v"(l.x), "=&v"(l.y), "=&v"(l.z), "=&v"(l.w)
+      : "v"(h.x), "v"(h.y), "v"(h.z), "v"(h.w), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+}
+#undef RC_MIXLO
+#undef RC_MIXHI
 #endif
+// acc = max(acc, |a|, |b|) in one instruction (hipcc spends three on fmaxf(acc, fmaxf(fabsf(a), fabsf(b))))
+__device__ __forceinline__ float rc_amax3(float acc, float a, float b) {
+#ifdef RCMARL_EMU
+  return fmaxf(acc, fmaxf(fabsf(a), fabsf(b)));
+#else
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+  return r;
+#endif
+}
 
 #ifdef RCMARL_EMU
 __device__ __forceinline__ rc_f32x16 rc_mfma_bf16(uint4 a, uint4 b, rc_f32x16 c) {
@@ -261,15 +299,10 @@ template <bool SCALED>
 __device__ __forceinline__ V8Pieces v8_split8(const float (&x)[8], float sc) {
   V8Pieces p;
   if (SCALED) {
-    rc_split2h_pair(x[0] * sc, x[1] * sc, p.h.x, p.l.x);
-    rc_split2h_pair(x[2] * sc, x[3] * sc, p.h.y, p.l.y);
-    rc_split2h_pair(x[4] * sc, x[5] * sc, p.h.z, p.l.z);
-    rc_split2h_pair(x[6] * sc, x[7] * sc, p.h.w, p.l.w);
+    const float xs[8] = {x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc, x[4] * sc, x[5] * sc, x[6] * sc, x[7] * sc};
+    rc_split2h_x8(xs, p.h, p.l);
   } else {
-    rc_split2h_pair(x[0], x[1], p.h.x, p.l.x);
-    rc_split2h_pair(x[2], x[3], p.h.y, p.l.y);
-    rc_split2h_pair(x[4], x[5], p.h.z, p.l.z);
-    rc_split2h_pair(x[6], x[7], p.h.w, p.l.w);
+    rc_split2h_x8(x, p.h, p.l);
   }
   return p;
 }
