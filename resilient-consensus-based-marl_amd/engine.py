@@ -1174,7 +1174,8 @@ class RPBCACEngine:
             if calls0 is not None:                                 # the capture advanced the host's shuffle-call counter by one epoch
                 g.rcmarl_draws = self.adv.calls[0] - calls0[0]     # ... without running anything: take it back, the replay below counts
                 self.adv.calls = calls0
-                self.adv.base_dev.fill_(int(calls0[0]))
+                if self.adv.base_dev is not None:                  # (None: no adversary of this instance fits -- only Faulty ones)
+                    self.adv.base_dev.fill_(int(calls0[0]))
             self._graphs[key] = g
             self.graph_captures += 1
         g.replay()
