@@ -539,7 +539,7 @@ def main(argv=None):
             out["kernels"] = {k.replace("rcmarl_", ""): {"launches": v[0], "total_ms": round(v[1], 3), "avg_us": round(v[2], 2),
                                                         "frac": round(v[1] / tot_ms, 4)} for k, v in
                               sorted(ksum.items(), key=lambda kv: -kv[1][1])}
-            out["roofline"], out["roofline_consensus"], out["roofline_gemm"] = roof
+            out["roofline"], out["roofline_consensus"], out["roofline_gemm"], out["roofline_mid"] = roof
         if world == 1 and not stub and not args.no_extra:
             del eng
             torch.cuda.empty_cache()
@@ -592,10 +592,12 @@ ROOFLINE_KIND = {
                                "dz1 pieces written = 160 B (RCMARL_LAT_F16=0: 20 x 3 bf16 pieces, 200 B); one API call = k_mid_fit_v8 (layers 2-3 "
                                "and the row reduction as v_mfma_f32_32x32x16_f16 on two-piece f16 operands, four exact products per fp32 "
                                "product) + a fix-up launch of the fp32 kernel k_mid_fit_v5 for agents whose operands left the f16 range "
-                               "(returns at once otherwise) + a one-thread generation bump.  Not HBM-bound: ~890 VALU + 48 MFMA + ~150 LDS "
-                               "instructions per 64 rows and wavefront, VALU ~57 % busy, wavefronts waiting 43 % of their cycles "
-                               "(profiles/r03u_sq_k_mid_fit_v8.json); the f32-input MFMA form it replaced (v5, RCMARL_MIDFIT=5) ran on the "
-                               "vector ALUs: 715-770 us (DESIGN.md section 5, Round 3)"),
+                               "(returns at once otherwise) + a one-thread generation bump.  Round 4: ~220 vector + 24 MFMA + ~45 LDS instructions "
+                               "per 32 rows and wavefront (was ~480 + 24 + ~75), the next block's loads issued a block ahead, one record "
+                               "reduction per workgroup: 600 -> 455-470 us; at 4.2 TB/s of its own bytes it is within ~20 % of what a "
+                               "half-read half-write stream sustains on this part (DESIGN.md section 5, Round 4; SQ counters of the "
+                               "intermediate build: profiles/r04r_sq_k_mid_fit_v8_prefetch_build.json).  The f32-input MFMA form it "
+                               "replaced (v5, RCMARL_MIDFIT=5) runs 720-770 us"),
     "rcmarl_minibatch_fit": ("mfma_f32", "the adversaries' fit(batch_size=32, epochs=10): 940 sequentially DEPENDENT SGD steps per "
                              "network, one wavefront per network (6 us per step): bound by the latency of one step, not by a pipe; "
                              "flops = 6 per weight per row"),
@@ -623,7 +625,7 @@ def _pmc_traffic(workload):
 
 
 def rooflines(tlib, ksum, workload=None):
-    """roofline objects for the time-dominant kernel, the consensus kernel (K1) and the layer-1 GEMM."""
+    """roofline objects for the time-dominant kernel, the consensus kernel (K1), the layer-1 GEMM and the mid (layers 2-3) step."""
     work = tlib.work
     dom = max(ksum.items(), key=lambda kv: kv[1][1])[0]
     pmc = _pmc_traffic(workload) if workload else {}
@@ -667,8 +669,9 @@ def rooflines(tlib, ksum, workload=None):
     gemm = next((k for k in ("rcmarl_layer1_forward_lattice", "rcmarl_layer1_forward")
                  if k in ksum), None)
     k1 = next((k for k in ("rcmarl_consensus_params_circulant", "rcmarl_consensus_params") if k in ksum), None)
+    mid = next((k for k in ("rcmarl_mid_fit_lattice", "rcmarl_mid_fit") if k in ksum), None)
     return (obj(dom), obj(k1) if k1 else None,
-            obj(gemm) if gemm else None)
+            obj(gemm) if gemm else None, obj(mid) if mid else None)
 
 
 if __name__ == "__main__":

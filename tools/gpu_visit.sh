@@ -20,7 +20,7 @@ import json
 d=json.loads([l for l in open('gpurun_out/${TAG}_bench_cfg4_shard.json') if l.startswith('{')][-1])
 print({k:d[k] for k in ('value','ms_per_step','n_gpus')}, d['phase_seconds_per_block'])
 for k,v in list(d['kernels'].items())[:8]: print('  ',k, v)
-for r in ('roofline','roofline_consensus','roofline_gemm','roofline_consensus_target'):
+for r in ('roofline','roofline_consensus','roofline_gemm','roofline_mid','roofline_consensus_target'):
     if d.get(r): print('  ',r, {k:d[r].get(k) for k in ('kernel','achieved','frac','avg_us')})
 for k,v in d.get('extra',{}).items(): print('  extra',k, {q:v.get(q) for q in ('ms_per_step','agent_steps_per_s','weights_finite','epochs_replayed_from_hipgraph','error')})
 print('  cpu', d.get('cpu_baseline',{}).get('value'), d.get('speedup_vs_cpu_port'))
