@@ -378,9 +378,20 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   static_assert(HID == 20, "unit sets and panel layout are written for 20 units");
   typedef FitPart<HID> PT;
   constexpr int LU = 10;                               // units per lane
-  constexpr int PC = 24;                               // columns of a plane row (48 bytes): 20 units | 1.0 | 3 spare; a transpose read of
-  //                                                      columns 16..31 runs 8 columns into the next row: those only feed elements of G nobody reads
-  constexpr int PLANE = 32 * PC;                       // bf16 elements of one piece plane: [32 rows][PC columns]
+  // A piece plane = two windows (columns 0-15 | 16-31) of [32 rows][16 columns] f16, 32 bytes per row: the 16-lane group of a
+  // transpose read then fetches 128 CONTIGUOUS bytes (four rows of one window) -- the one layout the LDS serves without bank
+  // conflicts (cdna guide, T10).  Rows 4-7 of every eight hold their two 16-byte halves swapped: the eight consecutive lanes a
+  // 16-byte write is served by then cover all 32 banks.
+  // Columns: 20 units | 1.0 (A planes) | unused; what the unused columns hold only feeds elements of G nobody reads.
+  constexpr int PLANE = 2 * 32 * 16;                   // f16 elements of one piece plane
+  // Window 1 stores rows 4-7 of every eight BEFORE rows 0-3 (the two 16-lane groups a transpose read serves together -- one per
+  // window -- then sit in opposite halves of the 256-byte bank row) and rotates its four 8-byte column groups by row >> 2
+  // (the 4-byte writes of units 16-19: 2-way instead of 4-way).
+  auto pl_addr = [](int row, int col) {
+    const int win = col >> 4, c = col & 15, x = (row >> 2) & 1;
+    if (win == 0) return row * 16 + (c ^ (8 * x));
+    return 512 + (row ^ 4) * 16 + ((((c >> 2) + (row >> 2)) & 3) << 2) + (c & 3);
+  };
   constexpr int PANEL_B = 2 * 2 * PLANE * 2;           // bytes per wavefront: A planes (a1 | 1) then B planes (dz2; later dz transpose, record)
   __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 2 * 2 * 32];   // [product][k-step][piece][k-group][row i]: 16-byte A fragments
   __shared__ __attribute__((aligned(16))) float sV[2 * HID + 4];           // b2 | W3 | b3
@@ -420,9 +431,9 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   // column 20 of the A planes is the constant 1 (-> gb2 = sum dz2): pieces (1.0, 0); written once, nothing else touches it.
   // The spare columns of the A planes are zeroed once; columns 20.. of the B planes (and what a transpose read picks up
   // beyond column 23) only feed elements of G nobody reads.
-  for (int e = lane; e < 2 * 32 * (PC - 20); e += 64) {
-    const int pc = e / (32 * (PC - 20)), rw = (e / (PC - 20)) & 31, cl = 20 + e % (PC - 20);
-    pA[pc * PLANE + rw * PC + cl] = (pc == 0 && cl == 20) ? (unsigned short)0x3C00 : (unsigned short)0;
+  for (int e = lane; e < 2 * 32 * 12; e += 64) {
+    const int pc = e / (32 * 12), rw = (e / 12) & 31, cl = 20 + e % 12;
+    pA[pc * PLANE + pl_addr(rw, cl)] = (pc == 0 && cl == 20) ? (unsigned short)0x3C00 : (unsigned short)0;
   }
   const float* yrow = y + ((long)s * N + i) * ldb;
   __syncthreads();
@@ -437,9 +448,11 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   // transpose-read address of this lane inside a plane (rcmarl_lattice.h: rc_lds_read_tr16): as MFMA operand lane (i = l31,
   // k-group = half) it wants rows 8*half .. 8*half+7 of column l31 -> two reads of four rows; its 16-lane group fetches the
   // [4 rows][16 columns] block of columns 16*((lane>>4)&1).., this lane row (lane&15)>>2 of it, columns 4*(lane&3)..
-  const int tr_off = (8 * half + ((lane & 15) >> 2)) * PC + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  int tr_off[2];                                        // rows 0-3 / 4-7 of the lane's eight (+ 16 rows per k-step)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) tr_off[t] = pl_addr(8 * half + 4 * t + ((lane & 15) >> 2), 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
   // this lane's own slots in a plane: row l31, columns 8*half..8*half+7 (local units 0..7) and 16+2*half, 17+2*half (8, 9)
-  const int wr8 = l31 * PC + 8 * half, wr2 = l31 * PC + 16 + 2 * half;
+  const int wr8 = pl_addr(l31, 8 * half), wr2 = pl_addr(l31, 16 + 2 * half);
   uint4 z4;
   z4.x = z4.y = z4.z = z4.w = 0u;
   float amax = 0.f;                                    // largest |operand| this lane split (a1, 2^10 dz2)
@@ -476,26 +489,32 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
   // A block's packed dz1 chunks leave the staging planes at the TOP of the next block, behind that block's wait for its prefetched
   // loads: the memory counter is in order, so stores issued at the end of a block would be waited for -- a round trip to L2 -- at
   // the top of the next one; issued there, everything outstanding at a wait is one block old.
-  // Staging (over the B planes): [32 rows][48 columns] f16, a lane's row = its replay row, its 20 columns (24 * half ..) = the five
-  // (h pair, l pair) registers of its ten units as they come out of the split -- three 16-byte / 8-byte writes; the 16-byte chunks
-  // of the packed image (8 consecutive replay rows of one (unit, piece)) then come back through the TRANSPOSE read: pass p, the
-  // 16-lane group g of a wavefront reads columns 16p..16p+15 of rows 8g..8g+7, lane j of it receives column 16p + j.
-  constexpr int SC = 48;                               // staging columns per row (96 bytes)
-  static_assert(32 * SC * 2 <= 2 * PLANE * 2, "the dz1 staging fits the B planes");
-  const int st_wr = l31 * SC + 24 * half;              // the lane's 20 staging columns
-  const int st_rd = (8 * (lane >> 4) + ((lane & 15) >> 2)) * SC + 4 * (lane & 3);        // + 16 * pass (+ 4 * SC: rows 4..7 of the group)
+  // The 16-byte chunks of the packed image (8 consecutive replay rows of one (unit, piece)) come back from the staging through the
+  // TRANSPOSE read: pass p, the 16-lane group g of a wavefront reads window p of rows 8g..8g+7, lane j of it receives column j.
+  // Staging = three windows of [32 rows][32 bytes], the layout of the piece planes (same swap of the 16-byte halves in rows 4-7
+  // of every eight): window m, row = replay row, bytes 0-15 = the lower half-wave's m-th piece register group, bytes 16-31 the
+  // upper's.  Piece groups of a lane: h of its local units 0-7 | l of units 0-7 | h, l of units 8, 9: 16, 16 and 8 bytes.
+  // (and rows 4-7 before rows 0-3 in every second group of eight: the two 16-lane groups a transpose read serves together)
+  auto st_addr = [&](int k, int m, int w) { return m * 1024 + 32 * (k ^ (4 * ((k >> 3) & 1))) + (w ^ (16 * ((k >> 2) & 1))); };
+  unsigned st_wr[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) st_wr[m] = (unsigned)st_addr(l31, m, 16 * half);
+  unsigned st_rd[2];                                       // transpose-read address of the lane for rows 0-3 / 4-7 of its group, window 0
+#pragma unroll
+  for (int t = 0; t < 2; ++t) st_rd[t] = (unsigned)st_addr(8 * (lane >> 4) + 4 * t + ((lane & 15) >> 2), 0, 8 * (lane & 3));
+  auto st_pass = [&](int ps, int t) { (void)t; return (unsigned)ps * 1024u; };
   unsigned st_off[3];                                   // byte offset of the lane's chunk inside the k-tile of the packed image, per pass
   bool st_on[3];
 #pragma unroll
   for (int ps = 0; ps < 3; ++ps) {
     // (lanes j, j+16, j+32, j+48 -- not four neighbours -- write the four chunks of a 64-byte segment; a probe build with the
     // neighbour mapping (and wrong placement) ran in the same time: 471 against 466 us, so the stores are left as the transpose delivers them)
-    const int c = 16 * ps + (lane & 15), hf = c >= 24, cc = c - 24 * hf;                // column -> (half, pair q, element e)
+    const int j = lane & 15, hf = j >> 3, cc = j & 7;    // column j of window ps -> (half, pair q, element e)
     const int c4 = lane >> 4;                            // c4: the 8-row group
-    const int q = cc >> 2, e = cc & 3, piece = e >> 1;
-    const int unit = v8_unit(hf, min(2 * q + (e & 1), LU - 1));
+    const int lu = ps < 2 ? cc : 8 + (cc & 1), piece = ps < 2 ? ps : (cc >> 1) & 1;      // local unit, piece of this column
+    const int unit = v8_unit(hf, lu);
     const int R = i * HID + unit;
-    st_on[ps] = cc < 20 && c < 44;
+    st_on[ps] = ps < 2 || cc < 4;
     st_off[ps] = (unsigned)(((R >> 7) * dzp_kt) * 2 + piece) * RC_PK_BLOCK + (unsigned)(R & 127) * 64 + (unsigned)((c4 ^ ((R >> 2) & 3)) << 4);
   }
   unsigned char* dz_base = dzp + (long)s * dzp_rt * dzp_kt * (2 * RC_PK_BLOCK);
@@ -505,7 +524,7 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
     if (kt < dzp_kt) {
 #pragma unroll
       for (int ps = 0; ps < 3; ++ps) {
-        const uint2 t0 = rc_lds_read_tr16(stg + st_rd + 16 * ps), t1 = rc_lds_read_tr16(stg + st_rd + 16 * ps + 4 * SC);
+        const uint2 t0 = rc_lds_read_tr16(stg + ((st_rd[0] + st_pass(ps, 0)) >> 1)), t1 = rc_lds_read_tr16(stg + ((st_rd[1] + st_pass(ps, 1)) >> 1));
         uint4 v4;
         v4.x = t0.x; v4.y = t0.y; v4.z = t1.x; v4.w = t1.y;
         if (st_on[ps]) *reinterpret_cast<uint4*>(dz_base + (st_off[ps] + (unsigned)kt * (2 * RC_PK_BLOCK))) = v4;
@@ -617,15 +636,15 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         V8Pieces ra, rb;
-        const int o = tr_off + 16 * PC * ks;
+        const int o = tr_off[0] + 16 * 16 * ks, o4 = tr_off[1] + 16 * 16 * ks;
         uint2 t0, t1;
-        t0 = rc_lds_read_tr16(pA + 0 * PLANE + o); t1 = rc_lds_read_tr16(pA + 0 * PLANE + o + 4 * PC);
+        t0 = rc_lds_read_tr16(pA + 0 * PLANE + o); t1 = rc_lds_read_tr16(pA + 0 * PLANE + o4);
         ra.h.x = t0.x; ra.h.y = t0.y; ra.h.z = t1.x; ra.h.w = t1.y;
-        t0 = rc_lds_read_tr16(pA + 1 * PLANE + o); t1 = rc_lds_read_tr16(pA + 1 * PLANE + o + 4 * PC);
+        t0 = rc_lds_read_tr16(pA + 1 * PLANE + o); t1 = rc_lds_read_tr16(pA + 1 * PLANE + o4);
         ra.l.x = t0.x; ra.l.y = t0.y; ra.l.z = t1.x; ra.l.w = t1.y;
-        t0 = rc_lds_read_tr16(pB + 0 * PLANE + o); t1 = rc_lds_read_tr16(pB + 0 * PLANE + o + 4 * PC);
+        t0 = rc_lds_read_tr16(pB + 0 * PLANE + o); t1 = rc_lds_read_tr16(pB + 0 * PLANE + o4);
         rb.h.x = t0.x; rb.h.y = t0.y; rb.h.z = t1.x; rb.h.w = t1.y;
-        t0 = rc_lds_read_tr16(pB + 1 * PLANE + o); t1 = rc_lds_read_tr16(pB + 1 * PLANE + o + 4 * PC);
+        t0 = rc_lds_read_tr16(pB + 1 * PLANE + o); t1 = rc_lds_read_tr16(pB + 1 * PLANE + o4);
         rb.l.x = t0.x; rb.l.y = t0.y; rb.l.z = t1.x; rb.l.w = t1.y;
         g1 = v8_mfma4(ra, rb, g1);
         RC_SCHED_FENCE();                              // (keeps the second k-step's eight reads from being hoisted: registers)
@@ -635,18 +654,18 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
         // of the packed image
         unsigned short* stg = pB;
         RC_WAVE_SYNC();                                // the reduction's transpose reads are done
-        uint4 ph, pl, w0, w1;                           // staging order: (h pair, l pair) of units (0,1), (2,3), ...
-        uint2 w2;
+        uint4 ph, pl;                                   // window 0: the h pieces of local units 0-7, window 1: their l pieces,
+        uint2 w2;                                       // window 2: h and l of units 8, 9 -- whole registers as the split delivers them
         {
           const float x0[8] = {dz1l[0], dz1l[1], dz1l[2], dz1l[3], dz1l[4], dz1l[5], dz1l[6], dz1l[7]};
           rc_split2h_x8(x0, ph, pl);
           rc_split2h_pair(dz1l[8], dz1l[9], w2.x, w2.y);
         }
-        w0.x = ph.x; w0.y = pl.x; w0.z = ph.y; w0.w = pl.y;
-        w1.x = ph.z; w1.y = pl.z; w1.z = ph.w; w1.w = pl.w;
-        *reinterpret_cast<uint4*>(stg + st_wr) = w0;
-        *reinterpret_cast<uint4*>(stg + st_wr + 8) = w1;
-        *reinterpret_cast<uint2*>(stg + st_wr + 16) = w2;
+        // (whole register groups: a 16-byte write assembled from registers of different groups is emitted as dword pairs,
+        // which conflict 4-way on these 32-byte rows -- knock-out counters in profiles/r04u_lds_conflict_knockouts.txt)
+        *reinterpret_cast<uint4*>(stg + (st_wr[0] >> 1)) = ph;
+        *reinterpret_cast<uint4*>(stg + (st_wr[1] >> 1)) = pl;
+        *reinterpret_cast<uint2*>(stg + (st_wr[2] >> 1)) = w2;
         RC_WAVE_SYNC();
         kt_staged = bfirst >> 5;                       // this block's k-tile: stored at the top of the next block
       }
