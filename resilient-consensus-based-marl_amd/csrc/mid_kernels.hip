@@ -1126,10 +1126,13 @@ __global__ __launch_bounds__(256) void k_td_error(const float* __restrict__ r_te
   if (t < n_total) delta[t] = r_team[t] + gamma * v_next[t] - v_cur[t];
 }
 
-// chunks of 256 rows one mid-fit workgroup walks (the agent's weights are staged once per workgroup): half the chunks of an
-// agent, at most 6, when S*N workgroup columns fill the chip anyway; fewer -- down to one -- when they do not (a single
-// instance of the reference's 5-agent scenario is 5 columns: 10 workgroups of 6 chunks each were 37 us of latency)
+// chunks of 256 rows one mid-fit workgroup walks (the agent's weights are staged once per workgroup -- ~4 us of mostly latency:
+// 3-, 4-, 6-, 12-chunk workgroups ran 517, 485, 458, 438 us at BASELINE configs[3], profiles/r04w_mid_cpw.txt): ALL of an agent's
+// chunks (at most 16) when the S*N workgroup columns alone fill the chip eight times over; else half of them, at most 6; fewer
+// -- down to one -- when even that leaves the chip short of workgroups (a single instance of the reference's 5-agent scenario is
+// 5 columns: 10 workgroups of 6 chunks each were 37 us of latency)
 int midfit_cpw(int nchunk, long columns) {
+  if (columns >= 2048) return nchunk < 16 ? nchunk : 16;
   int c = (nchunk + 1) / 2;
   if (c > 6) c = 6;
   while (c > 1 && columns * ((nchunk + c - 1) / c) < 512) --c;
