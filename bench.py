@@ -395,7 +395,7 @@ def extra_workloads(main_name, tlib, barrier, dev):
                 top = sorted(ksum.items(), key=lambda kv: -kv[1][1])[:4]
                 rec["top_kernels"] = {k.replace("rcmarl_", ""): {"avg_us": round(v[2], 2), "frac": round(v[1] / tot_ms, 4)}
                                       for k, v in top}
-                _, k1, _ = rooflines(tlib, ksum, name)
+                _, k1, _, _ = rooflines(tlib, ksum, name)
                 if k1:
                     rec["roofline_consensus"] = {k: k1[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_us",
                                                                     "launches", "algorithmic_bytes_per_launch",

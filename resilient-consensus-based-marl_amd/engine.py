@@ -13,13 +13,13 @@ raises if the HIP library or a GPU is missing (tests inject the hipemu build
 explicitly via ``lib=``/``device='cpu'``).
 """
 import contextlib
+import gc
 import math
+import os
 import time
 
 import numpy as np
 import torch
-
-import os
 
 from . import capi
 from . import lattice as LT
@@ -1169,8 +1169,17 @@ class RPBCACEngine:
                 self._graphs.pop(next(iter(self._graphs)))
             g = torch.cuda.CUDAGraph()
             calls0 = list(self.adv.calls) if hasattr(self, "adv") else None
-            with torch.cuda.graph(g):
-                self._epoch_body(B, t0)
+            # No cyclic garbage collection while the stream is capturing: a collected engine of an earlier run takes its hipGraphs
+            # (and pooled tensors) with it, and destroying those during a capture aborts the process (seen in the GPU suite, round 4).
+            gc_was_on = gc.isenabled()
+            gc.collect()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):
+                    self._epoch_body(B, t0)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             if calls0 is not None:                                 # the capture advanced the host's shuffle-call counter by one epoch
                 g.rcmarl_draws = self.adv.calls[0] - calls0[0]     # ... without running anything: take it back, the replay below counts
                 self.adv.calls = calls0
