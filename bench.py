@@ -293,25 +293,40 @@ def parse_args(argv=None):
     ap.add_argument("--seeds-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-timing-steps", type=int, default=2,
+                    help="timed steps whose launches carry HIP events (evenly spaced; 0 = all of them).  Two events per launch cost "
+                         "~10 us of queue time each: on all ~5000 launches of a 10-step run that is 5 %% of the step "
+                         "(204.4 against 194.4 ms per block at cfg4_shard, profiles/r04x_event_overhead.txt)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other workloads (`extra`)")
     ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY: CPU stub engine + gloo, exercises the launcher/"
                     "barrier/all-reduce control path without a GPU")
     return ap.parse_args(argv)
 
 
-def time_blocks(eng, steps, warmup, barrier, S, dev, tlib=None, want_kernels=True):
+def timed_steps(steps, k):
+    """the `k` evenly spaced steps of `steps` whose launches carry events (all of them for k <= 0 or k >= steps)"""
+    if k <= 0 or k >= steps:
+        return list(range(steps))
+    return sorted({(2 * i + 1) * steps // (2 * k) for i in range(k)})
+
+
+def time_blocks(eng, steps, warmup, barrier, S, dev, tlib=None, want_kernels=True, event_steps=0):
     """W untimed blocks, then exactly K timed blocks bracketed by barrier + synchronize; returns
-    (seconds on this rank, mean return curve over ALL ranks' seeds)."""
+    (seconds on this rank, mean return curve over ALL ranks' seeds).  Per-kernel HIP events ride on the launches of
+    timed_steps(steps, event_steps) -- inside the timed region, on the launch stream."""
     from rcmarl_amd.parallel import allreduce_curves
     for _ in range(warmup):
         eng.run_block()
     barrier()
+    ev = set(timed_steps(steps, event_steps)) if want_kernels else set()
     if tlib is not None:
-        tlib.enabled = want_kernels
+        tlib.enabled = False
         tlib.reset()
     curves = []
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
+        if tlib is not None:
+            tlib.enabled = k in ev
         team, adv, est = eng.run_block()
         curves.append(np.stack([team.sum(1), adv.sum(1), est.sum(1)], axis=1))   # per-episode sums over local seeds
     curve = allreduce_curves(np.concatenate(curves, 0), S, device=dev)            # C1: the path's only collective
@@ -379,7 +394,7 @@ def extra_workloads(main_name, tlib, barrier, dev):
             # single instances are launch-bound: timed WITHOUT the per-launch events, so the engine's captured epochs
             # (hipGraph, engine._epoch) run as they do for a user of the drop-in path
             single = name.endswith("_single")
-            dt, _ = time_blocks(eng, steps, 1, barrier, S, dev, tlib, want_kernels=not single)
+            dt, _ = time_blocks(eng, steps, 1, barrier, S, dev, tlib, want_kernels=not single, event_steps=1)
             ksum = {} if single else tlib.summary()
             finite = all(bool(torch.isfinite(eng.theta[k]).all().item()) for k in ("actor", "critic", "tr"))
             c = eng.cfg
@@ -478,7 +493,8 @@ def main(argv=None):
         if not stub:
             torch.cuda.synchronize()
 
-    dt, curve = time_blocks(eng, args.steps, args.warmup, barrier, S, dev, tlib, want_kernels=not args.no_kernel_timing)
+    dt, curve = time_blocks(eng, args.steps, args.warmup, barrier, S, dev, tlib, want_kernels=not args.no_kernel_timing,
+                            event_steps=args.kernel_timing_steps)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                # the slowest rank's clock
@@ -540,6 +556,9 @@ def main(argv=None):
                                                         "frac": round(v[1] / tot_ms, 4)} for k, v in
                               sorted(ksum.items(), key=lambda kv: -kv[1][1])}
             out["roofline"], out["roofline_consensus"], out["roofline_gemm"], out["roofline_mid"] = roof
+            out["kernel_timing"] = {"steps_with_events": timed_steps(args.steps, args.kernel_timing_steps), "of_timed_steps": args.steps,
+                                    "what": "HIP events around every C-ABI launch of these timed steps, on the launch stream; "
+                                            "launches / total_ms in `kernels` count those steps only"}
         if world == 1 and not stub and not args.no_extra:
             del eng
             torch.cuda.empty_cache()
