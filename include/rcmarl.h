@@ -330,6 +330,14 @@ int rcmarl_dense_backward_data(const float* dz_out, const float* theta, int w_of
 int rcmarl_dense_backward_sgd(const float* in, long in_seed_stride, long in_agent_stride, int in_row_major, int ld_in,
                               const float* dz, float* theta, int w_off, const int* mask, int S, int N, int B, int K,
                               int J, int ldp, int ldb, float lr, void* stream);
+/* The dense layers below run on the 16-bit matrix core (default; RCMARL_WIDE_F16=0: the fp32-input MFMA kernel): both fp32
+ * operands travel as two f16 pieces of the value times a fixed power of two (weights 2^10, dz 2^8, activations 1) -- each to one
+ * unit in its last place -- and a product is three matrix passes (l*h + h*l + h*h), fp32 accumulate; a workgroup whose operands
+ * leave the f16 range recomputes its tile in fp32 inside the same launch.  Read from the environment once;
+ * rcmarl_wide_set_f16_mode(0 / 1, or -1 = read the environment again) switches it.  Inputs given as replay rows (in_row_major)
+ * always take the fp32 kernel. */
+int rcmarl_wide_f16_mode(void);
+int rcmarl_wide_set_f16_mode(int mode);
 int rcmarl_wide_grad_size(int hid);      /* floats per (seed, agent) of `grads`: [gW3 (hid) | gb3 | gb2 (hid) | gb1 (hid)] */
 int rcmarl_wide_rows_per_chunk(void);    /* `losspart` holds ceil(B / this) floats per (seed, agent) */
 /* out[s][n][b] = a2[:,b] . W3 + b3, or r_applied + gamma * that (TD target, :114-115) */

@@ -161,6 +161,8 @@ SIGNATURES = {
     "rcmarl_dense_backward_sgd": [c_f32p, c_long, c_long, c_int, c_int, c_f32p, c_f32p, c_int, c_i32p, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     "rcmarl_wide_grad_size": [c_int],
+    "rcmarl_wide_f16_mode": [],
+    "rcmarl_wide_set_f16_mode": [c_int],
     "rcmarl_wide_rows_per_chunk": [],
     # a2, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_wide_head_value": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -183,7 +185,7 @@ SIGNATURES = {
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
-             "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk",
+             "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk", "rcmarl_wide_f16_mode", "rcmarl_wide_set_f16_mode",
              "rcmarl_consensus_params_circulant_supported"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",

@@ -22,6 +22,9 @@
 // come in either orientation (contiguous along k, or along m/n), which covers forward (W^T x), backward-data
 // (W dz) and backward-weights (x^T dz^T) without materialising a transpose.
 #include "rcmarl_common.h"
+#include "rcmarl_lattice.h"
+#include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "selnet_generated.inc"
 
@@ -37,6 +40,7 @@ struct WArgs {
   const float* aux; long aux_zs, aux_za; int ldaux;     // bias[m] (BIAS*) or activation(m, n) (LRELU_GRAD)
   const int* mask; float lr;                            // SGD
   int M, N, K, NA;
+  float sa, sb;                                         // k_wgemm16: power-of-two scales of A and B before the split into f16 pieces
 };
 
 // global -> registers: this thread's 8 floats of a [128 x 16] operand tile (zero-filled outside the matrix).
@@ -100,17 +104,11 @@ __device__ __forceinline__ void w_store(float* __restrict__ s, const float (&reg
   }
 }
 
-template <bool A_KC, bool B_KC, int EPI, bool VEC>
-__global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 workgroups per CU: <= 170 VGPRs
-  __shared__ __attribute__((aligned(16))) float sA[2][WBK * WLD];
-  __shared__ __attribute__((aligned(16))) float sB[2][WBK * WLD];
-  const int z = blockIdx.z, s = z / a.NA, ag = z - s * a.NA;
-  if (EPI == WEPI_SGD && a.mask && !a.mask[ag]) return;        // workgroup-uniform
-  const int m0 = blockIdx.y * WBM, n0 = blockIdx.x * WBN;
-  const float* __restrict__ A = a.A + s * a.A_zs + ag * a.A_za;
-  const float* __restrict__ Bp = a.B + s * a.B_zs + ag * a.B_za;
+// The fp32 k-loop: C tile (m0, n0) of one (seed, agent) accumulated with v_mfma_f32_32x32x2_f32; sA / sB: two stages of [WBK][WLD] floats each.
+template <bool A_KC, bool B_KC, bool VEC>
+__device__ __forceinline__ void w_loop_f32(const WArgs& a, const float* __restrict__ A, const float* __restrict__ Bp, int m0, int n0,
+                                           float* __restrict__ sA, float* __restrict__ sB, rc_f32x16 (&acc)[2][2]) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
-  rc_f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -121,8 +119,8 @@ __global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 wor
   const int nk = (a.K + WBK - 1) / WBK;
   w_load<A_KC, VEC>(A, a.lda, m0, 0, a.M, a.K, ra);
   w_load<B_KC, VEC>(Bp, a.ldb, n0, 0, a.N, a.K, rb);
-  w_store<A_KC, VEC>(sA[0], ra);
-  w_store<B_KC, VEC>(sB[0], rb);
+  w_store<A_KC, VEC>(sA, ra);
+  w_store<B_KC, VEC>(sB, rb);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -130,8 +128,8 @@ __global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 wor
       w_load<A_KC, VEC>(A, a.lda, m0, (kt + 1) * WBK, a.M, a.K, ra);
       w_load<B_KC, VEC>(Bp, a.ldb, n0, (kt + 1) * WBK, a.N, a.K, rb);
     }
-    const float* __restrict__ pa = sA[cur] + (l >> 5) * WLD + wm * 64 + (l & 31);
-    const float* __restrict__ pb = sB[cur] + (l >> 5) * WLD + wn * 64 + (l & 31);
+    const float* __restrict__ pa = sA + cur * (WBK * WLD) + (l >> 5) * WLD + wm * 64 + (l & 31);
+    const float* __restrict__ pb = sB + cur * (WBK * WLD) + (l >> 5) * WLD + wn * 64 + (l & 31);
 #pragma unroll
     for (int kk = 0; kk < WBK; kk += 2) {
       const float a0 = pa[kk * WLD], a1 = pa[kk * WLD + 32];
@@ -142,14 +140,20 @@ __global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 wor
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      w_store<A_KC, VEC>(sA[cur ^ 1], ra);
-      w_store<B_KC, VEC>(sB[cur ^ 1], rb);
+      w_store<A_KC, VEC>(sA + (cur ^ 1) * (WBK * WLD), ra);
+      w_store<B_KC, VEC>(sB + (cur ^ 1) * (WBK * WLD), rb);
     }
     __syncthreads();
   }
-  // epilogue: register r of tile (i, j) is C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][n0 + wn*64 + j*32 + (l&31)].
-  // Full tiles run straight-line (no per-element predicate, so the bias / activation / old-weight loads are all
-  // issued before the first dependent use); edge tiles keep the predicates.
+}
+
+// epilogue: register r of tile (i, j) is C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(l>>5)][n0 + wn*64 + j*32 + (l&31)] -- the layout of
+// v_mfma_f32_32x32x2_f32 and of v_mfma_f32_32x32x16_f16 alike.  Full tiles run straight-line (no per-element predicate, so the bias /
+// activation / old-weight loads are all issued before the first dependent use); edge tiles keep the predicates.  `unscale`: the
+// accumulators hold unscale^-1 times the product (1 for the fp32 loop).
+template <int EPI>
+__device__ __forceinline__ void w_epilogue(const WArgs& a, int s, int ag, int m0, int n0, const rc_f32x16 (&acc)[2][2], float unscale) {
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   float* __restrict__ C = a.C + s * a.C_zs + ag * a.C_za;
   const float* __restrict__ aux = a.aux ? a.aux + s * a.aux_zs + ag * a.aux_za : nullptr;
   const int mb = m0 + wm * 64 + 4 * (l >> 5), nb = n0 + wn * 64 + (l & 31);
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 wor
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2);
           if (!FULL && mb + i * 32 + dr >= a.M) continue;
-          const float v = acc[i][j][r];
+          const float v = acc[i][j][r] * unscale;              // (a power of two: exact; 1.0 after the fp32 loop)
           float o;
           if (EPI == WEPI_BIAS_LRELU) o = rc_lrelu(v + bias[i][r]);
           else if (EPI == WEPI_BIAS) o = v + bias[i][r];
@@ -199,7 +203,192 @@ __global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 wor
   if (m0 + WBM <= a.M && n0 + WBN <= a.N) tile_out(std::true_type{}); else tile_out(std::false_type{});
 }
 
+template <bool A_KC, bool B_KC, int EPI, bool VEC>
+__global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 workgroups per CU: <= 170 VGPRs
+  __shared__ __attribute__((aligned(16))) float sA[2 * WBK * WLD];
+  __shared__ __attribute__((aligned(16))) float sB[2 * WBK * WLD];
+  const int z = blockIdx.z, s = z / a.NA, ag = z - s * a.NA;
+  if (EPI == WEPI_SGD && a.mask && !a.mask[ag]) return;        // workgroup-uniform
+  const int m0 = blockIdx.y * WBM, n0 = blockIdx.x * WBN;
+  rc_f32x16 acc[2][2];
+  w_loop_f32<A_KC, B_KC, VEC>(a, a.A + s * a.A_zs + ag * a.A_za, a.B + s * a.B_zs + ag * a.B_za, m0, n0, sA, sB, acc);
+  w_epilogue<EPI>(a, s, ag, m0, n0, acc, 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same GEMM on the 16-bit matrix core: both fp32 operands as TWO f16 pieces of the value times a power of two (h = rn(v),
+// l = rn(v - h): v to one unit in its last place, rcmarl_lattice.h), three products per fp32 product -- l*h + h*l + h*h, the l*l term
+// (2^-22 of the product) dropped -- on v_mfma_f32_32x32x16_f16, fp32 accumulate.  16x the rate of the fp32-input MFMA at 3x the
+// instructions.  128 x 128 x 32 tiles, 4 wavefronts of 64 x 64; the loader splits while it stages (global fp32 -> registers -> pieces
+// -> LDS), two 32-KiB stages, one barrier per k-tile, two workgroups per CU.
+//   operand contiguous along k   -> LDS [row][32 k] f16, 64-byte rows, 16-byte chunks XORed with (row >> 2) & 3; an MFMA fragment
+//                                   (row, 8 k) is one ds_read_b128
+//   operand contiguous along m/n -> LDS [16-row window][32 k][16 rows] f16, 32-byte rows; a fragment is two TRANSPOSE reads
+//                                   (ds_read_b64_tr_b16: lane = row, 4 k each).  k-row placement inside a window: k ^ (w & 3) ^
+//                                   4 (w & 1) -- the four windows a 16-lane group of the 8-byte stores covers land on different banks,
+//                                   and the two windows a transpose read serves together on different halves of the bank row
+//                                   (the conflict rules measured on k_mid_fit_v8, profiles/r04u_lds_conflict_knockouts.txt).
+// A workgroup whose operands leave the f16 range (|scaled value| > 65000 anywhere in its row / column panels) recomputes its tile
+// with the fp32 loop above before the epilogue: same kernel, no flags, no second launch.
+constexpr int W16_BK = 32, W16_PIECE = 128 * W16_BK * 2, W16_STAGE = 4 * W16_PIECE;      // bytes: one piece of one operand, one stage
+#define RC_W16_RANGE 65000.f
+
+template <bool KC>
+__device__ __forceinline__ void w16_load(const float* __restrict__ P, int ld, int r0, int k0, int R, int K, float4 (&reg)[4]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int r = idx >> 3, k4 = (idx & 7) * 4;
+      if (r0 + r < R && k0 + k4 < K) v = *reinterpret_cast<const float4*>(P + (long)(r0 + r) * ld + k0 + k4);
+    } else {
+      const int k = idx >> 5, r4 = (idx & 31) * 4;
+      if (k0 + k < K && r0 + r4 < R) v = *reinterpret_cast<const float4*>(P + (long)(k0 + k) * ld + r0 + r4);
+    }
+    reg[i] = v;
+  }
+}
+
+__device__ __forceinline__ int w16_krow(int k, int w) { return k ^ (w & 3) ^ (4 * (w & 1)); }
+
+// registers -> the two piece planes of one operand (ph, pl: W16_PIECE bytes each); returns max |scaled value|
+template <bool KC>
+__device__ __forceinline__ float w16_store(unsigned char* __restrict__ ph, unsigned char* __restrict__ pl, const float4 (&reg)[4],
+                                           float scale, float amax) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    const float x0 = reg[i].x * scale, x1 = reg[i].y * scale, x2 = reg[i].z * scale, x3 = reg[i].w * scale;
+    amax = rc_amax3(rc_amax3(amax, x0, x1), x2, x3);
+    uint2 h, lo;
+    rc_split2h_pair(x0, x1, h.x, lo.x);
+    rc_split2h_pair(x2, x3, h.y, lo.y);
+    int off;
+    if (KC) {
+      const int r = idx >> 3, k4 = (idx & 7) * 4;
+      off = r * 64 + (((k4 >> 3) ^ ((r >> 2) & 3)) << 4) + (k4 & 4) * 2;
+    } else {
+      const int k = idx >> 5, r4 = (idx & 31) * 4, w = r4 >> 4;
+      off = w * 1024 + w16_krow(k, w) * 32 + (r4 & 15) * 2;
+    }
+    *reinterpret_cast<uint2*>(ph + off) = h;
+    *reinterpret_cast<uint2*>(pl + off) = lo;
+  }
+  return amax;
+}
+
+// the MFMA fragment (row tr0 + (lane & 31), k = 16 ks + 8 (lane >> 5) .. + 7) of one piece plane
+template <bool KC>
+__device__ __forceinline__ uint4 w16_frag(const unsigned char* __restrict__ pp, int tr0, int ks) {
+  const int l = threadIdx.x & 63, kg = l >> 5;
+  if (KC) {
+    const int r = tr0 + (l & 31);
+    return *reinterpret_cast<const uint4*>(pp + r * 64 + (((2 * ks + kg) ^ ((r >> 2) & 3)) << 4));
+  } else {
+    const int w = (tr0 >> 4) + ((l >> 4) & 1), j = l & 15, kb = 16 * ks + 8 * kg + (j >> 2);
+    const unsigned char* base = pp + w * 1024 + 8 * (j & 3);
+    const uint2 t0 = rc_lds_read_tr16(reinterpret_cast<const unsigned short*>(base + w16_krow(kb, w) * 32));
+    const uint2 t1 = rc_lds_read_tr16(reinterpret_cast<const unsigned short*>(base + w16_krow(kb + 4, w) * 32));
+    uint4 f;
+    f.x = t0.x; f.y = t0.y; f.z = t1.x; f.w = t1.y;
+    return f;
+  }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_wgemm16(const WArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * W16_STAGE];
+  __shared__ int s_ovf;
+  static_assert(2 * W16_STAGE >= (int)(4 * WBK * WLD * sizeof(float)), "the fp32 loop's stages fit the same memory");
+  const int z = blockIdx.z, s = z / a.NA, ag = z - s * a.NA;
+  if (EPI == WEPI_SGD && a.mask && !a.mask[ag]) return;        // workgroup-uniform
+  const int m0 = blockIdx.y * WBM, n0 = blockIdx.x * WBN;
+  const float* __restrict__ A = a.A + s * a.A_zs + ag * a.A_za;
+  const float* __restrict__ Bp = a.B + s * a.B_zs + ag * a.B_za;
+  const int t = threadIdx.x, w = t >> 6, wm = w >> 1, wn = w & 1;
+  rc_f16_saturate();
+  if (t == 0) s_ovf = 0;
+  rc_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 ra[4], rb[4];
+  float amax = 0.f;
+  const int nk = (a.K + W16_BK - 1) / W16_BK;
+  w16_load<A_KC>(A, a.lda, m0, 0, a.M, a.K, ra);
+  w16_load<B_KC>(Bp, a.ldb, n0, 0, a.N, a.K, rb);
+  amax = w16_store<A_KC>(sm, sm + W16_PIECE, ra, a.sa, amax);
+  amax = w16_store<B_KC>(sm + 2 * W16_PIECE, sm + 3 * W16_PIECE, rb, a.sb, amax);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* __restrict__ st = sm + (kt & 1) * W16_STAGE;
+    unsigned char* __restrict__ nx = sm + ((kt & 1) ^ 1) * W16_STAGE;
+    if (kt + 1 < nk) {
+      w16_load<A_KC>(A, a.lda, m0, (kt + 1) * W16_BK, a.M, a.K, ra);
+      w16_load<B_KC>(Bp, a.ldb, n0, (kt + 1) * W16_BK, a.N, a.K, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = w16_frag<A_KC>(st, wm * 64 + 32 * i, ks);
+        al[i] = w16_frag<A_KC>(st + W16_PIECE, wm * 64 + 32 * i, ks);
+        bh[i] = w16_frag<B_KC>(st + 2 * W16_PIECE, wn * 64 + 32 * i, ks);
+        bl[i] = w16_frag<B_KC>(st + 3 * W16_PIECE, wn * 64 + 32 * i, ks);
+      }
+      // smallest products first; consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = rc_mfma_f16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = rc_mfma_f16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = rc_mfma_f16(ah[i], bh[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      amax = w16_store<A_KC>(nx, nx + W16_PIECE, ra, a.sa, amax);
+      amax = w16_store<B_KC>(nx + 2 * W16_PIECE, nx + 3 * W16_PIECE, rb, a.sb, amax);
+    }
+    __syncthreads();
+  }
+  if (amax > RC_W16_RANGE) s_ovf = 1;                         // (NaN operands do not take this branch: they poison either loop alike)
+  __syncthreads();
+  float unscale = 1.f / (a.sa * a.sb);
+  if (s_ovf) {                                                // workgroup-uniform: out of the f16 range -> the fp32 loop, same tile
+    __syncthreads();
+    float* fa = reinterpret_cast<float*>(sm);
+    w_loop_f32<A_KC, B_KC, true>(a, A, Bp, m0, n0, fa, fa + 2 * WBK * WLD, acc);
+    unscale = 1.f;
+  }
+  w_epilogue<EPI>(a, s, ag, m0, n0, acc, unscale);
+}
+
 static inline bool w_al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// RCMARL_WIDE_F16 (default 1): the dense layers of wide networks on the 16-bit matrix core (k_wgemm16); 0 = the fp32-input MFMA
+// kernel.  Read once; rcmarl_wide_set_f16_mode() changes it (tests, bench.py's exact-form line).
+std::mutex g_w16_mu;
+int g_w16_mode = -1;
+int w16_mode() {
+  std::lock_guard<std::mutex> lk(g_w16_mu);
+  if (g_w16_mode < 0) {
+    const char* e = getenv("RCMARL_WIDE_F16");
+    g_w16_mode = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_w16_mode;
+}
 
 template <bool A_KC, bool B_KC, int EPI>
 static int w_launch(const WArgs& a, int S, void* stream) {
@@ -207,7 +396,8 @@ static int w_launch(const WArgs& a, int S, void* stream) {
   const bool vec = w_al4(a.A) && w_al4(a.B) && !(a.lda & 3) && !(a.ldb & 3) && !(a.A_zs & 3) && !(a.A_za & 3) &&
                    !(a.B_zs & 3) && !(a.B_za & 3) && !(a.K & 3) && (A_KC || !(a.M & 3)) && (B_KC || !(a.N & 3));
   const dim3 grid(rc_ceil_div(a.N, WBN), rc_ceil_div(a.M, WBM), S * a.NA), block(256);
-  if (vec) RCMARL_LAUNCH((k_wgemm<A_KC, B_KC, EPI, true>), grid, block, 0, stream, a);
+  if (vec && a.sa > 0.f && a.sb > 0.f && w16_mode()) RCMARL_LAUNCH((k_wgemm16<A_KC, B_KC, EPI>), grid, block, 0, stream, a);
+  else if (vec) RCMARL_LAUNCH((k_wgemm<A_KC, B_KC, EPI, true>), grid, block, 0, stream, a);
   else RCMARL_LAUNCH((k_wgemm<A_KC, B_KC, EPI, false>), grid, block, 0, stream, a);
   return rcmarl_check_launch();
 }
@@ -466,6 +656,12 @@ static inline bool w_dims_ok(int S, int N, int B, int K, int J, int ldp, int ldb
 }  // namespace
 
 RCMARL_EXPORT int rcmarl_wide_grad_size(int hid) { return w_grad_size(hid); }
+RCMARL_EXPORT int rcmarl_wide_f16_mode() { return w16_mode(); }
+RCMARL_EXPORT int rcmarl_wide_set_f16_mode(int mode) {           // 0 / 1; < 0: read RCMARL_WIDE_F16 again at the next call
+  std::lock_guard<std::mutex> lk(g_w16_mu);
+  g_w16_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  return RCMARL_OK;
+}
 RCMARL_EXPORT int rcmarl_wide_rows_per_chunk() { return WROWS; }
 
 // out[s][n][j][b] = lrelu(sum_k W[k][j] in(k, b) + bias[j]),  W = theta[s][n] + w_off (K x J, row-major),
@@ -482,6 +678,7 @@ RCMARL_EXPORT int rcmarl_dense_forward(const float* in, long in_seed_stride, lon
   a.C = out; a.C_zs = (long)N * J * ldb; a.C_za = (long)J * ldb; a.ldc = ldb;
   a.aux = theta + b_off; a.aux_zs = (long)N * ldp; a.aux_za = ldp; a.ldaux = 0;
   a.M = J; a.N = B; a.K = K; a.NA = N;
+  a.sa = RC_F16_W_SCALE; a.sb = in_row_major ? 0.f : 1.f;         // weights x activations (feature-major); raw inputs stay on the fp32 kernel
   return in_row_major ? w_launch<false, true, WEPI_BIAS_LRELU>(a, S, stream)
                       : w_launch<false, false, WEPI_BIAS_LRELU>(a, S, stream);
 }
@@ -497,6 +694,7 @@ RCMARL_EXPORT int rcmarl_dense_backward_data(const float* dz_out, const float* t
   a.C = dz_in; a.C_zs = (long)N * K * ldb; a.C_za = (long)K * ldb; a.ldc = ldb;
   a.aux = act_in; a.aux_zs = a.C_zs; a.aux_za = a.C_za; a.ldaux = ldb;
   a.M = K; a.N = B; a.K = J; a.NA = N;
+  a.sa = RC_F16_W_SCALE; a.sb = RC_F16_DZ_SCALE;                   // weights x dz
   return w_launch<true, false, WEPI_LRELU_GRAD>(a, S, stream);
 }
 
@@ -511,6 +709,7 @@ RCMARL_EXPORT int rcmarl_dense_backward_sgd(const float* in, long in_seed_stride
   a.C = theta + w_off; a.C_zs = (long)N * ldp; a.C_za = ldp; a.ldc = J;
   a.mask = mask; a.lr = lr;
   a.M = K; a.N = J; a.K = B; a.NA = N;
+  a.sa = in_row_major ? 0.f : 1.f; a.sb = RC_F16_DZ_SCALE;         // activations (feature-major) x dz
   return in_row_major ? w_launch<false, true, WEPI_SGD>(a, S, stream) : w_launch<true, true, WEPI_SGD>(a, S, stream);
 }
 

@@ -46,3 +46,17 @@ def lattice_form(monkeypatch):
     yield set_form
     for lib, prev in reversed(done):
         lib.rcmarl_lattice_set_f16_mode(prev)
+
+
+@pytest.fixture
+def wide_form():
+    """Switch the dense layers of the wide path between the 16-bit matrix core (1, the default) and the fp32-input MFMA kernel (0)
+    inside one process (rcmarl_wide_set_f16_mode: the library reads RCMARL_WIDE_F16 once).  Restored afterwards."""
+    done = []
+
+    def set_form(bk, mode):
+        done.append((bk.lib, bk.lib.rcmarl_wide_f16_mode()))
+        bk.lib.rcmarl_wide_set_f16_mode(int(mode))
+    yield set_form
+    for lib, prev in reversed(done):
+        lib.rcmarl_wide_set_f16_mode(prev)

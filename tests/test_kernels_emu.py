@@ -154,18 +154,28 @@ import wide_checks as WC
 @pytest.mark.parametrize("S,N,B,in_dim,hid", [(2, 3, 72, 12, 32),      # float4 staging
                                               (1, 2, 150, 10, 40),     # scalar staging (unaligned K / rows), 2 n-tiles
                                               (1, 2, 40, 136, 132)])   # > 1 m-tile, k tail
-def test_wide_forward(bk, S, N, B, in_dim, hid):
+@pytest.mark.parametrize("f16", [1, 0])
+def test_wide_forward(bk, S, N, B, in_dim, hid, f16, wide_form):
+    wide_form(bk, f16)
     WC.check_wide_forward(bk, S, N, B, in_dim, hid)
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,hid,masked", [(2, 3, 72, 12, 32, None), (1, 3, 70, 10, 24, 1), (1, 2, 260, 16, 64, None)])
-def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
+@pytest.mark.parametrize("f16", [1, 0])
+def test_wide_fit(bk, S, N, B, in_dim, hid, masked, f16, wide_form):
+    wide_form(bk, f16)
     WC.check_wide_fit(bk, S, N, B, in_dim, hid, steps=2, masked_agent=masked)
+
+
+def test_wide_dense_layer_out_of_f16_range_recomputes_in_fp32(bk):
+    WC.check_wide_out_of_range(bk, *(1, 3, 72, 12, 32))
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 72, 10, 32, 4, 1, "circ"), (1, 8, 140, 16, 24, 7, 2, "rand"),
                                                         (1, 24, 40, 8, 24, 23, 5, "rand")])     # no generated network: rank counting
-def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
+@pytest.mark.parametrize("f16", [1, 0])
+def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_form):
+    wide_form(bk, f16)
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 

@@ -190,19 +190,29 @@ import wide_checks as WC
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,hid", [(2, 5, 1000, 12, 64), (1, 3, 3000, 10, 40), (1, 4, 700, 256, 512), (1, 2, 333, 136, 132)])
-def test_wide_forward(bk, S, N, B, in_dim, hid):
+@pytest.mark.parametrize("f16", [1, 0])
+def test_wide_forward(bk, S, N, B, in_dim, hid, f16, wide_form):
+    wide_form(bk, f16)
     WC.check_wide_forward(bk, S, N, B, in_dim, hid)
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,hid,masked", [(2, 5, 1000, 12, 64, None), (1, 3, 701, 10, 24, 1), (1, 4, 3000, 128, 512, 2),
                                                      (1, 16, 1000, 32, 128, None)])
-def test_wide_fit(bk, S, N, B, in_dim, hid, masked):
+@pytest.mark.parametrize("f16", [1, 0])
+def test_wide_fit(bk, S, N, B, in_dim, hid, masked, f16, wide_form):
+    wide_form(bk, f16)
     WC.check_wide_fit(bk, S, N, B, in_dim, hid, steps=3, masked_agent=masked)
+
+
+def test_wide_dense_layer_out_of_f16_range_recomputes_in_fp32(bk):
+    WC.check_wide_out_of_range(bk, *(1, 3, 700, 64, 256))
 
 
 @pytest.mark.parametrize("S,N,B,in_dim,hid,d,H,graph", [(2, 5, 1000, 10, 64, 4, 1, "circ"), (1, 24, 700, 48, 128, 10, 4, "rand"),
                                                         (1, 70, 130, 140, 512, 66, 32, "circ"), (1, 30, 300, 60, 64, 23, 5, "rand")])
-def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph):
+@pytest.mark.parametrize("f16", [1, 0])
+def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_form):
+    wide_form(bk, f16)
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 

@@ -447,13 +447,17 @@ def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
                                                                         theta.data_ptr(), 0, mask.data_ptr(), S, N, B, in_dim, hid,
                                                                         ldp, ldb, 1e-9, st)),
     ]
-    tot = 0.0
-    for name, fl, fn in rows:
-        t = timeit(fn, iters=5, warm=2)
-        tot += t
-        print("%-22s %9.1f us  %s" % (name, t, ("%6.1f TF/s (%.0f%% of the 157 TF/s f32 MFMA peak)" % (fl / t / 1e6, fl / t / 1e6 / 1.573))
-                                         if fl else ""))
-    print("one SGD step, %d agents: %.2f ms  -> 1024 agents: %.1f ms" % (N, tot / 1e3, tot / 1e3 * 1024 / N))
+    for form in (1, 0):                                  # 16-bit matrix core (two f16 pieces per operand, three passes) | fp32-input MFMA
+        L.rcmarl_wide_set_f16_mode(form)
+        print("-- RCMARL_WIDE_F16=%d" % form)
+        tot = 0.0
+        for name, fl, fn in rows:
+            t = timeit(fn, iters=5, warm=2)
+            tot += t
+            print("%-22s %9.1f us  %s" % (name, t, ("%6.1f TF/s fp32-equivalent (%.0f%% of the 157 TF/s f32 MFMA peak)" % (fl / t / 1e6, fl / t / 1e6 / 1.573))
+                                             if fl else ""))
+        print("one SGD step, %d agents: %.2f ms  -> 1024 agents: %.1f ms" % (N, tot / 1e3, tot / 1e3 * 1024 / N))
+    L.rcmarl_wide_set_f16_mode(-1)
 
 
 if __name__ == "__main__":
