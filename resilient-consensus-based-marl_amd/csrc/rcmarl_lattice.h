@@ -147,15 +147,12 @@ typedef _Float16 rc_h2 __attribute__((ext_vector_type(2)));
 // back into it.  Hence inline asm, which the compiler's hazard recognizer does not look into: a write to the HIGH half of a
 // register (v_fma_mixhi) must be one wait state away from a vector instruction that reads the register, and two from an MFMA
 // -- the s_nop closing each block (without it the fused kernels read stale pieces: fused_fit test, round 4).
-#ifndef RC_SPLIT_NOP
-#define RC_SPLIT_NOP "s_nop 1"
-#endif
 #define RC_MIXLO(d, h, v) "v_fma_mixlo_f16 " d ", -" h ", 1.0, " v " op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
 #define RC_MIXHI(d, h, v) "v_fma_mixhi_f16 " d ", -" h ", 1.0, " v " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
 __device__ __forceinline__ void rc_split2h_pair(float w0, float w1, unsigned& h, unsigned& l) {
   const rc_f2 v = {w0, w1};
   h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rc_h2));
-  asm(RC_MIXLO("%0", "%1", "%2") RC_MIXHI("%0", "%1", "%3") RC_SPLIT_NOP : "=&v"(l) : "v"(h), "v"(w0), "v"(w1));
+  asm(RC_MIXLO("%0", "%1", "%2") RC_MIXHI("%0", "%1", "%3") "s_nop 1" : "=&v"(l) : "v"(h), "v"(w0), "v"(w1));
 }
 // eight values: the pieces of (x0, x1), (x2, x3), ... in the four words of h and l; one closing s_nop for all
 __device__ __forceinline__ void rc_split2h_x8(const float (&x)[8], uint4& h, uint4& l) {
@@ -164,7 +161,7 @@ __device__ __forceinline__ void rc_split2h_x8(const float (&x)[8], uint4& h, uin
   h.z = __builtin_bit_cast(unsigned, __builtin_convertvector((rc_f2{x[4], x[5]}), rc_h2));
   h.w = __builtin_bit_cast(unsigned, __builtin_convertvector((rc_f2{x[6], x[7]}), rc_h2));
   asm(RC_MIXLO("%0", "%4", "%8") RC_MIXHI("%0", "%4", "%9") RC_MIXLO("%1", "%5", "%10") RC_MIXHI("%1", "%5", "%11")
-      RC_MIXLO("%2", "%6", "%12") RC_MIXHI("%2", "%6", "%13") RC_MIXLO("%3", "%7", "%14") RC_MIXHI("%3", "%7", "%15") RC_SPLIT_NOP
+      RC_MIXLO("%2", "%6", "%12") RC_MIXHI("%2", "%6", "%13") RC_MIXLO("%3", "%7", "%14") RC_MIXHI("%3", "%7", "%15") "s_nop 1"
       : "=&v"(l.x), "=&v"(l.y), "=&v"(l.z), "=&v"(l.w)
       : "v"(h.x), "v"(h.y), "v"(h.z), "v"(h.w), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
 }
