@@ -303,9 +303,21 @@ __global__ __launch_bounds__(256, 2) void k_wgemm16(const WArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[2 * W16_STAGE];
   __shared__ int s_ovf;
   static_assert(2 * W16_STAGE >= (int)(4 * WBK * WLD * sizeof(float)), "the fp32 loop's stages fit the same memory");
-  const int z = blockIdx.z, s = z / a.NA, ag = z - s * a.NA;
+  // workgroup id -> ((seed, agent) z, m-tile, n-tile): all tiles of a (seed, agent) on ONE XCD (workgroups go round the eight XCDs by
+  // id), m-tile fastest -- the workgroups that share a B panel run side by side and the agent's A matrix stays in that XCD's L2
+  const int tm = (a.M + WBM - 1) / WBM, tn = (a.N + WBN - 1) / WBN, per = tm * tn, nz = (int)(gridDim.x / per);
+  int z, wq;
+  if ((nz & 7) == 0) {
+    const int g = blockIdx.x, q = g >> 3;
+    z = (g & 7) + 8 * (q / per);
+    wq = q % per;
+  } else {
+    z = blockIdx.x / per;
+    wq = blockIdx.x - z * per;
+  }
+  const int s = z / a.NA, ag = z - s * a.NA;
   if (EPI == WEPI_SGD && a.mask && !a.mask[ag]) return;        // workgroup-uniform
-  const int m0 = blockIdx.y * WBM, n0 = blockIdx.x * WBN;
+  const int m0 = (wq % tm) * WBM, n0 = (wq / tm) * WBN;
   const float* __restrict__ A = a.A + s * a.A_zs + ag * a.A_za;
   const float* __restrict__ Bp = a.B + s * a.B_zs + ag * a.B_za;
   const int t = threadIdx.x, w = t >> 6, wm = w >> 1, wn = w & 1;
@@ -396,7 +408,8 @@ static int w_launch(const WArgs& a, int S, void* stream) {
   const bool vec = w_al4(a.A) && w_al4(a.B) && !(a.lda & 3) && !(a.ldb & 3) && !(a.A_zs & 3) && !(a.A_za & 3) &&
                    !(a.B_zs & 3) && !(a.B_za & 3) && !(a.K & 3) && (A_KC || !(a.M & 3)) && (B_KC || !(a.N & 3));
   const dim3 grid(rc_ceil_div(a.N, WBN), rc_ceil_div(a.M, WBM), S * a.NA), block(256);
-  if (vec && a.sa > 0.f && a.sb > 0.f && w16_mode()) RCMARL_LAUNCH((k_wgemm16<A_KC, B_KC, EPI>), grid, block, 0, stream, a);
+  if (vec && a.sa > 0.f && a.sb > 0.f && w16_mode())
+    RCMARL_LAUNCH((k_wgemm16<A_KC, B_KC, EPI>), dim3(grid.x * grid.y * grid.z), block, 0, stream, a);
   else if (vec) RCMARL_LAUNCH((k_wgemm<A_KC, B_KC, EPI, true>), grid, block, 0, stream, a);
   else RCMARL_LAUNCH((k_wgemm<A_KC, B_KC, EPI, false>), grid, block, 0, stream, a);
   return rcmarl_check_launch();
