@@ -147,6 +147,10 @@ def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=2, masked_agent=masked)
 
 
+def test_mid_step_f16_kernel_vs_fp32_kernel(bk):
+    KC.check_mid_step_f16_vs_fp32_kernel(bk, 2, 6, 300, 12)
+
+
 # ---- wide networks (hid != 20): dense-GEMM path, csrc/wide_kernels.hip -------------------------------
 import wide_checks as WC
 

@@ -163,12 +163,16 @@ def test_lattice_forward(bk, S, N, B, width, nrow, ncol):
 
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol,masked", [(2, 5, 1000, 2, 5, 5, None), (2, 5, 3000, 3, 5, 5, 4),
                                                           (1, 64, 1000, 3, 16, 16, 5), (8, 32, 700, 2, 16, 16, 2),
-                                                          (1, 128, 333, 2, 32, 32, None),
-                                                          # 2048 (seed, agent) columns: the mid step's one-workgroup-per-agent
-                                                          # form (mid_kernels.hip: midfit_cpw), three chunks per workgroup
-                                                          (32, 64, 600, 2, 16, 16, 7)])
+                                                          (1, 128, 333, 2, 32, 32, None)])
 def test_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, masked):
     KC.check_lattice_sgd_fit(bk, S, N, B, width, nrow, ncol, steps=5, masked_agent=masked)
+
+
+@pytest.mark.parametrize("S,N,B,in_dim", [(2, 40, 700, 80),            # two workgroups per agent
+                                          (16, 128, 1500, 256),        # 2048 columns: one workgroup walks all six chunks of an agent
+                                          (16, 256, 3000, 512)])       # BASELINE configs[3]
+def test_mid_step_f16_kernel_vs_fp32_kernel(bk, S, N, B, in_dim):
+    KC.check_mid_step_f16_vs_fp32_kernel(bk, S, N, B, in_dim)
 
 
 @pytest.mark.parametrize("width", [2, 3])
