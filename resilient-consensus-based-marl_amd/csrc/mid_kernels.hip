@@ -69,18 +69,6 @@ __device__ __forceinline__ float head1(const float* __restrict__ w3, float b3, c
   return v + b3;
 }
 
-// the same head, two units per instruction (v_pk_fma_f32 on adjacent weight pairs -- scalar operands): even and odd units accumulate
-// separately and are added at the end, so the last bits differ from head1's chain.  k_consensus_head's d + 1 heads per row are
-// 40 % of its vector instructions in the chain form.
-template <int HID>
-__device__ __forceinline__ float head1_pk(const float* __restrict__ w3, float b3, const float (&a2)[HID]) {
-  static_assert(HID % 2 == 0, "units are processed in pairs");
-  rc_f2 acc = rc_bcast2(0.f);
-#pragma unroll
-  for (int k = 0; k < HID; k += 2) acc = rc_fma2(rc_f2{a2[k], a2[k + 1]}, rc_f2{w3[k], w3[k + 1]}, acc);
-  return (acc.x + acc.y) + b3;
-}
-
 // Sum K per-lane values over the 256 lanes (4 wavefronts) of the workgroup and store the K
 // totals to out[0..K).  red: >= 4*K floats of LDS.  Two barriers per call.
 template <int K>
@@ -828,10 +816,10 @@ __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     const float* mh = msg + ((long)s * N + nbr[i * D + k]) * ldp;
-    v[k] = head1_pk<HID>(mh + g.o_W3, mh[g.o_b3], phi);
+    v[k] = head1<HID>(mh + g.o_W3, mh[g.o_b3], phi);
   }
   const float agg = select_agg<HID, D, H>(v);
-  const float v_live = head1_pk<HID>(th + g.o_W3, th[g.o_b3], phi);
+  const float v_live = head1<HID>(th + g.o_W3, th[g.o_b3], phi);
   const float e = valid ? (agg - v_live) / nrm : 0.f;
   if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
   float* out = partials + (((long)s * N + i) * nchunk + chunk) * (HID + 1);
