@@ -117,6 +117,11 @@ int rcmarl_w1_split(const float* theta, const float* alpha, void* wp, int S, int
  * feature-major dz[S][N*hid][ldb]: the backward operand when dz1 was produced by rcmarl_dense_backward_data */
 int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int N, int B, int hid, int ldb, int dzp_rt, int dzp_kt,
                            void* stream);
+/* rcmarl_lattice_pack_dz and, in the same pass over dz, its row sums (= rcmarl_wide_bias_grad: gb1 of a wide net):
+ * sums[(s*N + n)*sums_ld + sums_off + j] = sum_b dz[s][n*hid + j][b].  One workgroup walks a row block's whole reduction length:
+ * a fixed summation order, no atomics. */
+int rcmarl_lattice_pack_dz_rowsum(const float* dz, void* dzp, float* sums, int sums_ld, int sums_off, int S, int N, int B, int hid,
+                                  int ldb, int dzp_rt, int dzp_kt, void* stream);
 /* = rcmarl_layer1_forward on (kp, wp); theta supplies b1 */
 int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt,
                                   const float* theta, float* a1t, int S, int N, int B, int in_dim, int hid, int ldp,

@@ -53,6 +53,8 @@ SIGNATURES = {
     "rcmarl_w1_split": [c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # dz, dzp, S, N, B, hid, ldb, dzp_rt, dzp_kt, stream
     "rcmarl_lattice_pack_dz": [c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # dz, dzp, sums, sums_ld, sums_off, S, N, B, hid, ldb, dzp_rt, dzp_kt, stream
+    "rcmarl_lattice_pack_dz_rowsum": [c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1t, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_layer1_forward_lattice": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_stream],

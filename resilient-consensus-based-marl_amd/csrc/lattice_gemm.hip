@@ -175,6 +175,51 @@ __global__ __launch_bounds__(256) void k_dz_pack(const float* __restrict__ dz, u
   }
 }
 
+// k_dz_pack + the row sums of dz (gb1 of a wide net = sum over replay rows of dz1, rcmarl_wide_bias_grad) in ONE pass over dz: one
+// workgroup = 128 rows x ALL k-tiles (so a row's sum is formed by one thread quad in a fixed order: deterministic, no atomics).
+// sums[((s * N + n) * sums_ld) + sums_off + j] for row n * hid + j.
+template <bool F16>
+__global__ __launch_bounds__(256) void k_dz_pack_rowsum(const float* __restrict__ dz, unsigned char* __restrict__ dzp,
+                                                        float* __restrict__ sums, int sums_ld, int sums_off, int hid, int nrows,
+                                                        int B, int ldb, int dzp_rt, int dzp_kt, int kts) {
+  const int s = blockIdx.y, rt = blockIdx.x;
+  const int t = threadIdx.x, c4 = t & 3;
+  constexpr int NP = F16 ? 2 : 3;
+  if (F16) rc_f16_saturate();
+  float acc[2] = {0.f, 0.f};
+  for (int kt = 0; kt < kts; ++kt) {
+    unsigned char* blk = dzp + (long)s * dzp_rt * dzp_kt * NP * RC_PK_BLOCK + ((long)rt * dzp_kt + kt) * NP * RC_PK_BLOCK;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = (t >> 2) + 64 * q;
+      const int row = rt * 128 + r;
+      const bool row_ok = row < nrows;
+      const float* src = dz + ((long)s * nrows + (row_ok ? row : 0)) * ldb + kt * 32 + 8 * c4;
+      float w[8];
+      if (row_ok && kt * 32 + 8 * c4 + 8 <= B) {         // ldb is a multiple of 64 floats: 16-B aligned
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = (row_ok && kt * 32 + 8 * c4 + e < B) ? src[e] : 0.f;
+      }
+      acc[q] += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      store_pieces<F16>(blk + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), w, RC_F16_DZ_SCALE);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    float v = acc[q];
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    const int row = rt * 128 + (t >> 2) + 64 * q;
+    if (c4 == 0 && row < nrows) {
+      const int n = row / hid, j = row - n * hid;
+      sums[((long)s * (nrows / hid) + n) * sums_ld + sums_off + j] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // WM x WN wavefronts per workgroup, each owning MT x NT accumulator blocks of 32 x 32
 template <int PA, int PB, int MT, int NT, int WM = 2, int WN = 2> struct LatCfg {
@@ -620,6 +665,24 @@ RCMARL_EXPORT int rcmarl_lattice_pack_dz(const float* dz, void* dzp, int S, int 
     RCMARL_LAUNCH(k_dz_pack<true>, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
   } else {
     RCMARL_LAUNCH(k_dz_pack<false>, dim3(kts, rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, N * hid, B, ldb, dzp_rt, dzp_kt);
+  }
+  return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_lattice_pack_dz_rowsum(const float* dz, void* dzp, float* sums, int sums_ld, int sums_off, int S, int N,
+                                                int B, int hid, int ldb, int dzp_rt, int dzp_kt, void* stream) {
+  if (!dz || !dzp || !sums || S <= 0 || N <= 0 || B <= 0 || hid <= 0 || ldb < B || (ldb & 3) || sums_ld < sums_off + hid ||
+      sums_off < 0 || (reinterpret_cast<uintptr_t>(dz) & 15))
+    return RCMARL_ERR_ARG;
+  const int rts = rc_ceil_div(N * hid, 128), kts = rc_ceil_div(B, 32);
+  if (dzp_rt < rts || dzp_kt < kts) return RCMARL_ERR_ARG;
+  rc_form_set(dzp, (rc_lat_f16_mode() >> 1) & 1);
+  if (rc_lat_f16_mode() & 2) {
+    RCMARL_LAUNCH(k_dz_pack_rowsum<true>, dim3(rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, sums, sums_ld, sums_off, hid,
+                  N * hid, B, ldb, dzp_rt, dzp_kt, kts);
+  } else {
+    RCMARL_LAUNCH(k_dz_pack_rowsum<false>, dim3(rts, S), dim3(256), 0, stream, dz, (unsigned char*)dzp, sums, sums_ld, sums_off, hid,
+                  N * hid, B, ldb, dzp_rt, dzp_kt, kts);
   }
   return rcmarl_check_launch();
 }

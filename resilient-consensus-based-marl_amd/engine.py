@@ -303,13 +303,15 @@ class RPBCACEngine:
                                    self.w_losspart.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)      # a2 now holds dz2
             L.rcmarl_dense_backward_data(a2.data_ptr(), msg.data_ptr(), o_W2, a1.data_ptr(), dz1.data_ptr(), S, N, B, hid, hid,
                                          ldp, ldb, st)
-            L.rcmarl_wide_bias_grad(dz1.data_ptr(), self.w_grads.data_ptr(), S, N, B, hid, ldb, st)
+            if not lat:                                            # (lattice path: the row sums ride on the pack pass below)
+                L.rcmarl_wide_bias_grad(dz1.data_ptr(), self.w_grads.data_ptr(), S, N, B, hid, ldb, st)
             # every gradient above came from the pre-step weights; now the updates
             L.rcmarl_dense_backward_sgd(a1.data_ptr(), N * hid * ldb, hid * ldb, 0, ldb, a2.data_ptr(), msg.data_ptr(), o_W2,
                                         mask.data_ptr(), S, N, B, hid, hid, ldp, ldb, lr, st)
             if lat:
                 dzp, wp = self.lat_dzp_f[xkey], self.lat_wp_f[xkey]
-                L.rcmarl_lattice_pack_dz(dz1.data_ptr(), dzp.data_ptr(), S, N, B, hid, ldb, g.dzp[0], g.dzp[1], st)
+                L.rcmarl_lattice_pack_dz_rowsum(dz1.data_ptr(), dzp.data_ptr(), self.w_grads.data_ptr(), 3 * hid + 1, 2 * hid + 1,
+                                                S, N, B, hid, ldb, g.dzp[0], g.dzp[1], st)       # dz1 pieces + gb1 = its row sums
                 L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(),
                                                      g.dzp[0], g.dzp[1], self.lat_alpha[xkey].data_ptr(), msg.data_ptr(),
                                                      mask.data_ptr(), S, N, B, in_dim, hid, ldp, lr,

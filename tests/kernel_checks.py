@@ -937,6 +937,38 @@ def check_lattice_f16_saturation(bk, S=1, N=5, B=70, width=2, nrow=5, ncol=5, lr
                 rel_close(got[k], pw[k], 1e-5, "fit param %d beside a saturated agent" % k)
 
 
+def check_pack_dz_rowsum(bk, S, N, B, hid):
+    """rcmarl_lattice_pack_dz_rowsum = rcmarl_lattice_pack_dz (the packed dz image, bit for bit) + the row sums of dz in the same
+    pass (gb1 of a wide net: rcmarl_wide_bias_grad), against float64 sums."""
+    rng = np.random.default_rng(S * 13 + N + B + hid)
+    ldb = pad64(B)
+    dz = np.zeros((S, N * hid, ldb), np.float32)
+    dz[:, :, :B] = (0.01 * rng.normal(size=(S, N * hid, B))).astype(np.float32)
+    dz[:, :, B:] = np.float32(7.0)                               # padding columns must be ignored
+    # (the dz image only depends on N * hid rows and B: a geometry for the 20-unit nets is too small for wide ones)
+    g = LT.Geometry(N * hid // HID + 1, 64, B)
+    z = lambda: bk.dev(np.full(S * LT.Geometry.nbytes(g.dzp, 3) // 2, 0x7fc0, np.uint16))
+    p1, p2 = z(), z()
+    d_dz = bk.dev(dz)
+    gsz = 3 * hid + 1
+    sums = bk.dev(np.full((S, N, gsz), np.float32(-5.0)))
+    L = bk.lib
+    L.rcmarl_lattice_pack_dz(bk.ptr(d_dz), bk.ptr(p1), S, N, B, hid, ldb, g.dzp[0], g.dzp[1], bk.stream)
+    L.rcmarl_lattice_pack_dz_rowsum(bk.ptr(d_dz), bk.ptr(p2), bk.ptr(sums), gsz, 2 * hid + 1, S, N, B, hid, ldb, g.dzp[0], g.dzp[1],
+                                    bk.stream)
+    npc = 2 if L.rcmarl_lattice_f16_mode() & 2 else 3
+    a, b = seed_views(bk.host(p1), S, g.dzp, npc), seed_views(bk.host(p2), S, g.dzp, npc)
+    for s_ in range(S):
+        for pc in range(npc):
+            idx = LT.pk_element_index(N * hid, ((B + 31) // 32) * 32, g.dzp[1], npc, pc)       # every k-tile in use, padding included
+            np.testing.assert_array_equal(a[s_][idx], b[s_][idx])
+    got = bk.host(sums)
+    want = dz[:, :, :B].astype(np.float64).sum(axis=2).reshape(S, N, hid)
+    scale = float(np.abs(dz[:, :, :B]).astype(np.float64).sum(axis=2).max())
+    assert np.abs(got[:, :, 2 * hid + 1:] - want).max() <= 2e-6 * scale
+    np.testing.assert_array_equal(got[:, :, :2 * hid + 1], np.float32(-5.0))      # the rest of the record untouched
+
+
 def check_mid_step_f16_vs_fp32_kernel(bk, S, N, B, in_dim, lr=0.01):
     """rcmarl_mid_fit_lattice + rcmarl_small_sgd on the f16 matrix-core kernel (k_mid_fit_v8, the default) against the same call on
     the fp32 kernel (RCMARL_MIDFIT=5, k_mid_fit_v5) on identical random inputs: the small arrays after the step agree to 2e-6 of

@@ -61,6 +61,7 @@ def test_argument_validation_needs_no_gpu():
         ("rcmarl_mid_fit", (None, None, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
         ("rcmarl_consensus_params_circulant", (None, None, None, 1, 5, 64, 40, 4, 1, None, None, None)),
         ("rcmarl_lattice_pack_dz", (None, None, 1, 5, 100, 20, 128, 1, 4, None)),
+        ("rcmarl_lattice_pack_dz_rowsum", (None, None, None, 61, 41, 1, 5, 100, 20, 128, 1, 4, None)),
         ("rcmarl_dense_forward", (None, 0, 0, 1, 10, None, 0, 200, None, 1, 5, 100, 10, 32, 1472, 128, None)),
         ("rcmarl_dense_backward_data", (None, None, 0, None, None, 1, 5, 100, 32, 32, 1472, 128, None)),
         ("rcmarl_dense_backward_sgd", (None, 0, 0, 1, 10, None, None, 0, None, 1, 5, 100, 10, 32, 1472, 128, 0.01, None)),

@@ -211,6 +211,11 @@ def test_wide_fit(bk, S, N, B, in_dim, hid, masked, f16, wide_form):
     WC.check_wide_fit(bk, S, N, B, in_dim, hid, steps=3, masked_agent=masked)
 
 
+@pytest.mark.parametrize("S,N,B,hid", [(2, 3, 70, 24), (1, 16, 3000, 512), (2, 37, 1000, 40)])
+def test_pack_dz_with_row_sums(bk, S, N, B, hid):
+    KC.check_pack_dz_rowsum(bk, S, N, B, hid)
+
+
 def test_wide_dense_layer_out_of_f16_range_recomputes_in_fp32(bk):
     WC.check_wide_out_of_range(bk, *(1, 3, 700, 64, 256))
 
