@@ -455,6 +455,14 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
   if (full_m) store_tile(std::true_type{}); else store_tile(std::false_type{});
 }
 
+#ifdef RC_LAT_PROTO   // measurement builds only: the round-5 forward shells that did not win (tools/prototypes/lattice_forward_shells.inc)
+#define RC_LAT_PROTO_KERNELS
+#include "../../tools/prototypes/lattice_forward_shells.inc"
+#undef RC_LAT_PROTO_KERNELS
+#else
+#define RC_TSB(slot) ((void)0)
+#endif
+
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
 // 256 x 128 block tile.  Default: four wavefronts of 128 x 64 with the spread LDS-DMA issue (875 -> 824 us in a block);
 // W8 (eight wavefronts of 64 x 64): 780 / 1103 against 756 / 1103 us -- the alternative.
@@ -479,11 +487,13 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
   op.a = ktp + (long)s * ktp_rt * ktp_kt * (PA * RC_PK_BLOCK); op.a_kt = ktp_kt; op.art0 = bm * C::ART;
   op.b = dzp + (long)s * dzp_rt * dzp_kt * (PB * RC_PK_BLOCK); op.b_kt = dzp_kt; op.brt0 = bn * C::BRT;
   rc_f32x16 acc[MT][NT];
+  RC_TSB(0);
 #if defined(RC_LAT_KNOCK) && RC_LAT_KNOCK == 2
   lat_mainloop<PA, PB, MT, NT, WM, WN, !W8, DZ16>(op, ldp == 12345 ? 1 : 0, lds, acc);
 #else
   lat_mainloop<PA, PB, MT, NT, WM, WN, !W8, DZ16>(op, (B + 31) >> 5, lds, acc);
 #endif
+  RC_TSB(1);
   // epilogue: W1[k][col] -= lr * alpha_k * acc; optionally the forward operand of the NEXT step is produced here
   // too (wp_out: bf16x3 pieces of alpha_k * W1_new, exactly what rcmarl_w1_split would write), so the local fit
   // needs no separate split pass.  A lane holds 4 consecutive k per (m-tile, register group) = half a 16-byte chunk.
@@ -579,7 +589,12 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
         }
       }
     }
+    RC_TSB(2 + nt);
   }
+#ifdef RC_LAT_TS
+  RC_WAIT_VMEM();
+  RC_TSB(4);
+#endif
 }
 
 // RCMARL_LAT_W8=0 / 1 forces the four- / eight-wavefront form of both kernels (read at every call: tests switch it);
@@ -598,6 +613,12 @@ int launch_forward(unsigned nblocks, void* stream, const unsigned char* wp, int 
   return rcmarl_check_launch();
 }
 
+#ifdef RC_LAT_PROTO
+#define RC_LAT_PROTO_LAUNCHERS
+#include "../../tools/prototypes/lattice_forward_shells.inc"
+#undef RC_LAT_PROTO_LAUNCHERS
+#endif
+
 template <bool W8, bool DZ16, bool WP16>
 int launch_backward(unsigned nblocks, void* stream, const unsigned char* ktp, int ktp_rt, int ktp_kt, const unsigned char* dzp,
                     int dzp_rt, int dzp_kt, const float* alpha, float* theta, const int* mask, int S, int N, int B, int in_dim,
@@ -613,6 +634,12 @@ int launch_backward(unsigned nblocks, void* stream, const unsigned char* ktp, in
 }
 
 }  // namespace
+
+#ifdef RC_LAT_PROTO
+#define RC_LAT_PROTO_DUMP
+#include "../../tools/prototypes/lattice_forward_shells.inc"
+#undef RC_LAT_PROTO_DUMP
+#endif
 
 // 0: exact bf16x3 everywhere; bit 0: forward operand (W', and K of the forward image) as f16x2; bit 1: backward operand (dz1, and
 // K^T) as f16x2.  Callers that decode packed buffers (tests) ask here; the buffers are always sized for three pieces.
@@ -699,6 +726,11 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
   const unsigned nb = (unsigned)(S * mtiles * ntiles);
   const bool w8 = lat_w8(true), f16 = rc_lat_f16_mode() & 1;
   if (!rc_form_ok(kp, f16) || !rc_form_ok(wp, f16)) return RCMARL_ERR_ARG;       // written in the other operand form
+#ifdef RC_LAT_PROTO
+#define RC_LAT_PROTO_DISPATCH
+#include "../../tools/prototypes/lattice_forward_shells.inc"
+#undef RC_LAT_PROTO_DISPATCH
+#endif
 #define RC_FWD(W8, F16)                                                                                                       \
   launch_forward<W8, F16>(nb, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp, kp_rt, kp_kt, theta, \
                           a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid)

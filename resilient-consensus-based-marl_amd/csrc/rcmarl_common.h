@@ -137,8 +137,14 @@ static inline int rc_ceil_div(int a, int b) { return (a + b - 1) / b; }
 // streaming store: data written once and not re-read by this kernel (keeps the operand panels in L2)
 #ifdef RCMARL_EMU
 #define RC_NT_STORE(ptr, val) (*(ptr) = (val))
+__device__ __forceinline__ void rc_nt_store4(float* p, float a, float b, float c, float d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 #else
 #define RC_NT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+// four consecutive floats at a 16-byte aligned address: one global_store_dwordx4 nt
+__device__ __forceinline__ void rc_nt_store4(float* p, float a, float b, float c, float d) {
+  typedef float rc_v4f __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((rc_v4f){a, b, c, d}, reinterpret_cast<rc_v4f*>(p));
+}
 #endif
 
 // Two fp32 lanes per register pair: v_pk_fma_f32 / v_pk_mul_f32 run 128 FMAs per wavefront instruction in the
@@ -204,6 +210,7 @@ __device__ __forceinline__ void rc_half_sum3_lane31(float& a, float& b, float& c
 #define RC_WAIT_VMEM() ((void)0)                      // (the emulated LDS-DMA is a synchronous copy)
 #define RC_WAIT_VMEM_N(n) ((void)0)
 __device__ __forceinline__ void rc_sleep(int) {}
+__device__ __forceinline__ void rc_sleep_short(int) {}
 __device__ __forceinline__ void rc_setprio1() {}
 #else
 // outstanding vector-memory operations of this wavefront (incl. LDS-DMA issued through inline asm, which hipcc does not see)
@@ -211,6 +218,9 @@ __device__ __forceinline__ void rc_setprio1() {}
 #define RC_WAIT_VMEM_N(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 __device__ __forceinline__ void rc_sleep(int n) {     // n x ~3.4 us (scheduling aid only)
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+__device__ __forceinline__ void rc_sleep_short(int n) {   // n x ~0.2 us (64 x 8 cycles)
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
 }
 __device__ __forceinline__ void rc_setprio1() { __builtin_amdgcn_s_setprio(1); }
 #endif
@@ -274,9 +284,12 @@ __device__ __forceinline__ bool rc_all(bool v) {
 #ifdef RCMARL_EMU
 __device__ __forceinline__ int rc_opaque_v(int v) { return v; }
 __device__ __forceinline__ int rc_opaque_s(int v) { return v; }
+__device__ __forceinline__ void rc_touch(float&) {}
 #else
 __device__ __forceinline__ int rc_opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int rc_opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+// a use of a loaded value that costs nothing: pins the compiler's s_waitcnt for it to this point of the program
+__device__ __forceinline__ void rc_touch(float& v) { asm volatile("" : "+v"(v)); }
 #endif
 
 // v_permlane32_swap on two floats: lanes 32-63 of `a` swap with lanes 0-31 of `b`
