@@ -80,7 +80,8 @@ WORKLOADS = {
     # BASELINE configs[4] as ONE instance on ONE GPU (the 8-GPU agent/column sharding of SURVEY.md 8e is not built):
     # only the critic is widened to 512 units (BASELINE: "wide (512-unit) critic"), team-reward net and actor keep 20
     "cfg5_1gpu": dict(N=1024, nrow=32, ncol=32, H=32, d=66, S=1, graph="circulant", fast_lr=0.0005, critic_hid=512,
-                      desc="BASELINE configs[4] on one GPU: 1024 agents, 512-unit critic (dense f32-MFMA GEMM path), 20-unit "
+                      desc="BASELINE configs[4] on one GPU: 1024 agents, 512-unit critic (dense per-agent GEMMs on the 16-bit matrix core: both "
+                           "fp32 operands as two f16 pieces, three passes, k_wgemm16; layer 1 on the lattice GEMMs), 20-unit "
                            "team-reward net and actor, 32x32 grid, H=32, circulant in-degree d=66 (=2H+2), one instance"),
     # the same instance sharded over ALL ranks of the job (strong scaling): agents for the per-agent phases, parameter
     # columns for the hidden-layer consensus, two all-to-all transposes per epoch (RPBCACEngine.shard_agents)
@@ -386,6 +387,7 @@ def extra_workloads(main_name, tlib, barrier, dev):
                 saved_env = {k: os.environ.get(k) for k in ("RCMARL_LAT_F16", "RCMARL_MIDFIT", "RCMARL_MB_MX")}
                 os.environ.update(RCMARL_LAT_F16="0", RCMARL_MIDFIT="5", RCMARL_MB_MX="0")
                 tlib.rcmarl_lattice_set_f16_mode(0)
+                tlib.rcmarl_wide_set_f16_mode(0)                 # a wide critic's dense layers on the f32-input matrix-core kernel
             S = w["S"]
             t_setup = time.perf_counter()
             eng = make_engine(w, S, [1000 + k for k in range(S)], tlib)
@@ -419,7 +421,8 @@ def extra_workloads(main_name, tlib, barrier, dev):
                         k1_target = k1
             if name == exact:
                 rec["operand_form"] = ("exact: RCMARL_LAT_F16=0 (three bf16 pieces whose sum is the fp32 operand, bit for bit), "
-                                       "RCMARL_MIDFIT=5 and RCMARL_MB_MX=0 (fp32-arithmetic mid / mini-batch kernels)")
+                                       "RCMARL_MIDFIT=5 and RCMARL_MB_MX=0 (fp32-arithmetic mid / mini-batch kernels), "
+                                       "rcmarl_wide_set_f16_mode(0) (a wide critic's dense layers on the f32-input MFMA kernel)")
             out[name] = rec
             del eng
             torch.cuda.empty_cache()
@@ -433,6 +436,7 @@ def extra_workloads(main_name, tlib, barrier, dev):
                     else:
                         os.environ[k] = v
                 tlib.rcmarl_lattice_set_f16_mode(-1)
+                tlib.rcmarl_wide_set_f16_mode(-1)
     return out, k1_target
 
 
@@ -585,11 +589,42 @@ def main(argv=None):
                 out["speedup_vs_cpu_port"] = _speedup(out)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        ex = (out.get("extra") or {}).get(args.workload + "_exact") or {}
+        if "ms_per_step" in ex:
+            # the headline workload with NO operand narrower than the reference's fp32 (three bf16 pieces whose sum is the fp32
+            # value, fp32-arithmetic mid kernels): the strict-fp32 form of `value` / `ms_per_step`, same process, same box
+            out["ms_per_step_exact"] = ex["ms_per_step"]
+            out["value_exact"] = ex["agent_steps_per_s"]
+            out["exact_steps"] = ex.get("steps")
+        # big objects first, the scalars a reader wants LAST (a truncated tail of this line still holds them)
+        big = ("dtype_note", "config", "kernels", "extra", "roofline_gemm", "roofline_mid", "roofline_consensus",
+               "roofline_consensus_target", "kernel_timing", "deviation", "phase_seconds_per_block", "phase_fraction", "comm")
+        line = {k: out[k] for k in big if k in out}
+        line.update({k: v for k, v in out.items() if k not in big and k not in ("roofline", "cpu_baseline")})
+        line["summary_ms_per_step"] = dict({args.workload: round(out["ms_per_step"], 2)},
+                                           **{k: (round(v["ms_per_step"], 2) if "ms_per_step" in v else "error")
+                                              for k, v in (out.get("extra") or {}).items()})
+        line["summary_hipgraph_epochs"] = {k: v.get("epochs_replayed_from_hipgraph") for k, v in (out.get("extra") or {}).items()
+                                           if "epochs_replayed_from_hipgraph" in v}
+        for k in ("roofline", "cpu_baseline"):
+            if k in out:
+                line[k] = _brief(out[k])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_exact", "value_exact"):
+            if k in line:
+                line[k] = line.pop(k)
+        print(json.dumps(line))
         sys.stdout.flush()
     if use_pg:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _brief(o):
+    """the object with its prose shortened (the full notes are in DESIGN.md section 3 / 5)"""
+    if not isinstance(o, dict):
+        return o
+    return {k: (_brief(v) if isinstance(v, dict) else
+                (v[:160] + " ..." if k in ("note", "what", "why") and isinstance(v, str) and len(v) > 164 else v)) for k, v in o.items()}
 
 
 BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
@@ -643,6 +678,29 @@ def _pmc_traffic(workload):
         return {}
 
 
+def _pmc_latbench(kernel_substr):
+    """Counters of the lattice GEMM kernels from the committed rocprofv3 passes of tools/micro/lat_bench on the same shapes
+    (tools/gpu_pmc_latbench.sh -> profiles/*_pmc_latbench.json): effective shader clock, matrix-pipe busy fraction, L2 hit rate."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_latbench.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        for k, v in d.items():
+            if k.startswith(kernel_substr + "<"):
+                clk = v.get("eff_clock_GHz")
+                return {"source": "profiles/" + os.path.basename(files[-1]), "kernel": k, "eff_clock_GHz": clk,
+                        "mfma_busy_frac_of_cycles": v.get("mfma_busy_frac"), "l2_hit_rate": v.get("l2_hit_rate"),
+                        "mfma_peak_at_that_clock_TFLOPs": None if clk is None else 1024 * 1024 * clk * 1e-3,
+                        "what": "GRBM_GUI_ACTIVE / 8 XCDs / duration; SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles; "
+                                "TCC_HIT / (TCC_HIT + TCC_MISS); 16-bit MFMA peak = 1024 SIMDs x 1024 flop/clk x clock"}
+    except Exception:
+        return None
+    return None
+
+
 def rooflines(tlib, ksum, workload=None):
     """roofline objects for the time-dominant kernel, the consensus kernel (K1), the layer-1 GEMM and the mid (layers 2-3) step."""
     work = tlib.work
@@ -672,6 +730,7 @@ def rooflines(tlib, ksum, workload=None):
             return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src, "launches": n, "avg_us": avg_us,
                     "algorithmic_flops_per_launch": flops / n,
+                    "counters": _pmc_latbench("k_lat_forward" if "forward" in name else "k_lat_backward_sgd"),
                     "executed": {"achieved": npc * ach, "frac": npc * ach / BF16_PEAK_TFLOPS,
                                  "frac_of_measured_sustained_peak": npc * ach / BF16_SUSTAINED_TFLOPS,
                                  "what": "16-bit MFMA flops actually issued = %d x algorithmic; sustained peak = %.0f TFLOP/s "

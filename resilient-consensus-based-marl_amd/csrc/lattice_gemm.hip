@@ -246,7 +246,8 @@ struct LatOperands {
 // (Round 2 built and measured, then round 3 removed: a 3-stage ring, a ring of four half-stages with counted vmcnt, the
 // three-piece operand's fragments loaded global -> registers, 256 x 256 and 512 x 128 tiles with eight wavefronts,
 // persistent workgroups, start staggers, static priorities, L2 prefetch touches -- all within -15..+0 % of this form;
-// DESIGN.md section 5 keeps the numbers.)
+// DESIGN.md section 5 keeps the numbers.  Round 5, on the forward (profiles/r05g_*): the second half of the wavefronts requesting
+// the next stage BEHIND its matrix work instead of in front of it +5..+9 %, static priority for that half +4..+6 %.)
 template <int PA, int PB, int MT, int NT, int WM, int WN, bool SPREAD, bool F16>
 __device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
                                              rc_f32x16 (&acc)[MT][NT]) {

@@ -15,10 +15,15 @@ def _gemm_flops(a, first):          # (..., S, N, B, in_dim, hid, ...) starting 
     return 2.0 * S * N * hid * B * in_dim, 0.0
 
 
-def lattice_pieces(bit):
-    """16-bit pieces per value of the forward (bit 1) / backward (bit 2) lattice operand under the library's current operand form
-    (RCMARL_LAT_F16, csrc/rcmarl_lattice.h: default 3 = two f16 pieces for both)."""
-    return 2 if int(capi.load().rcmarl_lattice_f16_mode()) & bit else 3
+_LIB = None          # the library the most recent TimedLib wraps (an injected / emulated one included)
+
+
+def lattice_pieces(bit, lib=None):
+    """16-bit pieces per value of the forward (bit 1) / backward (bit 2) lattice operand under the operand form of `lib` (default:
+    the library the current TimedLib wraps, else the product library; RCMARL_LAT_F16, csrc/rcmarl_lattice.h: default 3 = two
+    f16 pieces for both)."""
+    lib = lib or _LIB or capi.load()
+    return 2 if int(lib.rcmarl_lattice_f16_mode()) & bit else 3
 
 
 # algorithmic work per launch: name -> f(args) -> (flops, bytes)   (DESIGN.md "Kernels")
@@ -55,7 +60,8 @@ WORK = {
 
 class TimedLib:
     def __init__(self, lib):
-        self._lib = lib
+        global _LIB
+        self._lib = _LIB = lib
         self.enabled = False
         self._events = collections.defaultdict(list)
         self.work = {}

@@ -34,6 +34,59 @@ def make_inputs(args, nrow, seeds, weight_seed=3, critic_hid=20):
     return W, goals
 
 
+def _oracle_seed_job(payload):
+    """one seed of run_oracle in a worker process (spawned: nothing of the parent's GPU state travels)"""
+    import os
+    import sys
+    root, args, nrow, ncol, rng_mode, seed, W_s, goals_s, threads = payload
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(threads)
+    except Exception:
+        pass
+    logs, weights = run_oracle(args, nrow, ncol, rng_mode, (seed,), [W_s], [goals_s])
+    return logs[0], weights[0]
+
+
+def run_oracle_parallel(args, nrow, ncol, rng_mode, seeds, W, goals):
+    """run_oracle with one worker process per seed (the seeds are independent runs; the GPU boxes have hundreds of host cores and
+    the oracle's Python loops are serial).  Same results as run_oracle, in a fraction of the wall time."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(len(seeds), ncpu))
+    threads = max(1, min(16, ncpu // workers))
+    jobs = [(root, args, nrow, ncol, rng_mode, int(seeds[s]), W[s], goals[s], threads) for s in range(len(seeds))]
+    if workers == 1:
+        res = [_oracle_seed_job(j) for j in jobs]
+    else:
+        with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+            res = list(ex.map(_oracle_seed_job, jobs))
+    return [r[0] for r in res], [r[1] for r in res]
+
+
+def network_errors(eng, o_weights, nets=("critic", "tr")):
+    """per-network worst |w - w_oracle| / max(1, |w|max) -> {net: float array over (seed, agent)}"""
+    out = {}
+    for k, net in ((1, "critic"), (2, "tr")):
+        if net not in nets:
+            continue
+        errs = []
+        for s in range(eng.S):
+            for i in range(eng.N):
+                e = 0.0
+                for a, b in zip(eng.get_weights(s, i, net), o_weights[s][i][k]):
+                    e = max(e, float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max())))
+                errs.append(e)
+        out[net] = np.asarray(errs)
+    return out
+
+
 def run_oracle(args, nrow, ncol, rng_mode, seeds, W, goals, return_agents=False):
     """oracle.train, one run per seed -> (per-seed DataFrames, per-seed weight lists[, per-seed agent objects])."""
     n = args["n_agents"]
@@ -284,5 +337,9 @@ def check_actor_gradient(n, d, H, nrow, device, lib, fast_lr, n_ep_fixed=10, max
     # edge of the plain-SGD stability range amplify summation-order differences; the bars of this check are the gradient's)
     # the actor PARAMETERS after this single Adam step are +-lr wherever |g| >> eps: nothing to learn from them beyond the sign of
     # the gradient, which the bar above already holds (the statistical parameter bar sits at 1.2e-4 outliers on this 200-row run)
-    compare(eng, logs, o_logs, o_w, rtol_w=5e-4 if n >= 64 else 1e-4, actor="none" if n >= 64 else "strict")
+    # weights at hundreds of agents: SURVEY 8c's 1e-4 for at least 98 % of the networks, 3e-4 for all (round 4 held 5e-4 for all)
+    if n >= 64:
+        compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="none", outlier_frac=0.02, rtol_w_outlier=3e-4)
+    else:
+        compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="strict")
     return float(e.max())

@@ -44,7 +44,7 @@ def cfg4_oracle():
                         seed=1000, in_nodes=in_nodes, fast_lr=0.001, slow_lr=0.0)
     seeds = (1000, 1001)
     W, goals = EC.make_inputs(args, 32, seeds)
-    o_logs, o_w = EC.run_oracle(args, 32, 32, "device", seeds, W, goals)
+    o_logs, o_w = EC.run_oracle_parallel(args, 32, 32, "device", seeds, W, goals)
     return args, seeds, W, goals, o_logs, o_w
 
 
@@ -66,6 +66,62 @@ def test_engine_cfg4_shape_vs_oracle(cfg4_oracle, shortcut):
     # (three bf16 pieces + fp32 mid kernel): the tail is what full-batch SGD on 768 unscaled inputs makes of fp32 summation
     # order, not of the two-piece operands.
     EC.compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="stat", outlier_frac=0.01, rtol_w_outlier=3e-4)
+
+
+@pytest.fixture(scope="module")
+def cfg4_bench_oracle():
+    """BASELINE configs[3] at what bench.py TIMES: 10 consensus epochs, the actors LIVE (slow_lr 0.002), the
+    bench's fast_lr -- compared after ONE 50-episode block (B = 1000): inside the first block both sides draw identical actions
+    (the actors have not moved yet), so returns stay bit-comparable and the end-of-block weights are SURVEY 8c's "rtol 1e-4
+    after 10 epochs".  Two seeds (the diagnostic tools/diag_cfg4_parity.py bench runs four and writes the distribution to
+    profiles/); the oracle runs one process per seed, ~3.5 CPU-minutes."""
+    n, d = 256, 18
+    in_nodes = [[(i + k) % n for k in range(d)] for i in range(n)]
+    args = EC.make_args(["Cooperative"] * n, H=8, n_episodes=50, max_ep_len=20, n_ep_fixed=50, n_epochs=10, buffer_size=2000,
+                        seed=1000, in_nodes=in_nodes, fast_lr=0.001, slow_lr=0.002)
+    seeds = (1000, 1001)
+    W, goals = EC.make_inputs(args, 32, seeds)
+    o_logs, o_w = EC.run_oracle_parallel(args, 32, 32, "device", seeds, W, goals)
+    return args, seeds, W, goals, o_logs, o_w
+
+
+@pytest.mark.parametrize("form", ["f16x2", "exact"])
+def test_engine_cfg4_bench_config_one_block_vs_oracle(cfg4_bench_oracle, form, monkeypatch):
+    """The configuration the bench times, in BOTH operand forms of the matrix-core products (default: two f16 pieces + f16 mid kernel;
+    exact: three bf16 pieces + fp32 mid kernel).  MEASURED on four seeds (tools/diag_cfg4_parity.py bench,
+    profiles/r05h_cfg4_bench_config_parity.txt), per-network worst |w - w_oracle| / max(1, |w|max):
+      critic          median 1.1e-6, max 5.7e-6 in every form;
+      team-reward net median 2.0e-5, 90 % 6.9e-5, 99 % 2.4e-4, max 4.9e-4, 64 of 1024 beyond 1e-4 in the default form --
+                      median 1.9e-5, 90 % 6.4e-5, 99 % 2.2e-4, max 4.8e-4, 48 of 1024 beyond 1e-4 in the EXACT form.
+    SURVEY 8c's "1e-4 after 10 epochs" therefore does NOT hold for the team-reward net at 256 agents, and not because of the
+    two-piece operands: ten epochs of plain full-batch SGD on 768 unscaled inputs amplify fp32 summation-order differences to a
+    few 1e-4 whatever arithmetic produces them -- the oracle run twice with the rows of each local fit in another order (what
+    Keras' own shuffle does) differs from ITSELF by as much (tools/diag_oracle_selfnoise.py, profiles/r05i_oracle_selfnoise.txt).
+    Bars held here: critic 2e-5 for all; team-reward net 1e-4 for >= 90 %, 3e-4 for >= 98.5 %, 1e-3 for all; returns bit-identical;
+    the actor (ONE live Adam step per agent) to the statistical bar."""
+    from rcmarl_amd import capi
+    args, seeds, W, goals, o_logs, o_w = cfg4_bench_oracle
+    L = capi.load()
+    try:
+        if form == "exact":
+            monkeypatch.setenv("RCMARL_MIDFIT", "5")
+            L.rcmarl_lattice_set_f16_mode(0)
+        else:
+            L.rcmarl_lattice_set_f16_mode(3)
+        eng, logs = EC.run_engine(args, 32, 32, "device", "cuda", None, seeds, W, goals)
+    finally:
+        L.rcmarl_lattice_set_f16_mode(-1)
+    assert eng.lat_active and eng.k1_circulant and eng.adam_t == 1
+    errs = EC.network_errors(eng, o_w)
+    for net, e in errs.items():
+        print("[parity cfg4 bench config, %s] %-6s per-network worst: median %.2e  90%% %.2e  99%% %.2e  max %.2e | beyond 1e-4: %d of %d"
+              % (form, net, np.median(e), np.quantile(e, 0.9), np.quantile(e, 0.99), e.max(), int((e > 1e-4).sum()), e.size))
+        if net == "critic":
+            assert e.max() <= 2e-5, (net, float(e.max()))
+        else:
+            assert (e > 1e-4).mean() <= 0.10 and (e > 3e-4).mean() <= 0.015 and e.max() <= 1e-3, \
+                (net, float(e.max()), int((e > 1e-4).sum()), int((e > 3e-4).sum()))
+    EC.compare(eng, logs, o_logs, o_w, rtol_w=1e-3, actor="stat")      # returns bit-identical, values 1e-4, actor statistical
 
 
 def test_engine_wide_critic_d66_vs_oracle():
