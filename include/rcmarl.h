@@ -144,48 +144,8 @@ int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt, int ktp_kt, 
 int rcmarl_mid_fit_lattice(const float* a1t, const float* theta, const float* y, float* partials, void* dzp, int dzp_rt,
                            int dzp_kt, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, int* ovf_flags, void* stream);
 
-/* ---- the whole local fit in ONE launch ("fused fit", csrc/fused_fit.hip) --------------------------------------------
- * Replaces the per-agent Keras fit  self.critic.fit(s, TD_target, epochs=5, batch_size=B)  /  self.TR.fit(sa, r, ...)
- * (agents/resilient_CAC_agents.py:118,136) for ALL agents of all seeds: `nsteps` full-batch SGD steps on theta (the message
- * copy), every array of every network with mask[agent] != 0.  One workgroup owns three consecutive agents of a seed and runs
- * all steps by itself; layer-1 activations and dz1 stay in registers / LDS (the three-launch path above moves them through HBM
- * twice per step).  Arithmetic: that of the two-piece f16 operand form (rcmarl_lattice_f16_mode() == 3), element for element.
- * Operand images (device buffers owned by the caller, sizes from rcmarl_fit_fused_geometry, per seed, seeds contiguous):
- *   kf, ktf  the lattice integers of the replay rows as f16 MFMA fragments, rows x features and features x rows; written by
- *            rcmarl_fit_encode (same x / alpha contract as rcmarl_lattice_encode, whose flag tells whether x is on the lattice)
- *   wf       scratch for the f16 pieces of 2^10 alpha W1 (written and read by the fit itself)
- * rows_alloc: replay rows the images are laid out for (a multiple of 256, >= B).
- * flags[S][N] (int32, zeroed by the caller): set to 1 for an agent whose operands left the f16 range -- its row of theta is
- * then NOT the reference's result and must be recomputed from the pre-fit weights on the three-launch path (which redoes such
- * agents in fp32); all other agents are unaffected.  loss_out[S][N] (or NULL): the MSE before the first step.
- * Shapes: hid == 20, in_dim <= 768; otherwise RCMARL_ERR_UNSUPPORTED (use the three-launch path). */
-int rcmarl_fit_fused_geometry(int N, int in_dim, int hid, int rows_alloc, long* kf_bytes, long* ktf_bytes, long* wf_bytes);
-int rcmarl_fit_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, int rows_alloc,
-                      void* kf, void* ktf, void* stream);
-int rcmarl_fit_fused(const void* kf, const void* ktf, void* wf, const float* alpha, float* theta, const float* y,
-                     const int* mask, float* loss_out, int* flags, int S, int N, int B, int in_dim, int hid, int ldp,
-                     int ldb, int rows_alloc, int nsteps, float lr, void* stream);
-
-/* ---- forward + mid in ONE launch (csrc/fused_fit.hip, namespace fm): steps 2.. of the same Keras fit
- * (agents/resilient_CAC_agents.py:118,136) without the a1t round trip.  rcmarl_forward_mid = rcmarl_layer1_forward_lattice +
- * rcmarl_mid_fit_lattice: from Kf (rcmarl_fit_encode), Wf (the f16 pieces of 2^10 alpha W1 in fragment order: rcmarl_fit_wf_split
- * from theta, or left by rcmarl_layer1_backward_sgd_lattice_wf) and w2f (rcmarl_fit_w2_frags: the agents' 2^10 W2 as f16 MFMA
- * fragments, [S][N][8 KiB]) it writes dzp (the packed f16 pieces of 2^8 dz1, bit-identical to rcmarl_mid_fit_lattice's) and
- * partials[S][N][ceil(B/256)][rcmarl_fit_partial_size] -- one record per 256-row tile, to be applied with
- * rcmarl_small_sgd_records(nrec = ceil(B/256)).  flags[S][N] (int32, zeroed by the caller): 1 for an agent whose operands left
- * the f16 range (its outputs are then not to be used: redo the step through rcmarl_mid_fit_lattice, which has the fp32 fix-up).
- * Wf bytes per seed: rcmarl_fit_fused_geometry's wf_bytes.  f16 operand form only (rcmarl_lattice_f16_mode() == 3). */
-int rcmarl_fit_w2_frags(const float* theta, void* w2f, int* flags, int S, int N, int in_dim, int hid, int ldp, void* stream);
-int rcmarl_fit_wf_split(const float* theta, const float* alpha, void* wf, int* flags, int S, int N, int in_dim, int hid, int ldp,
-                        void* stream);
-int rcmarl_forward_mid(const void* kf, const void* wf, const void* w2f, const float* theta, const float* y, float* partials,
-                       void* dzp, int dzp_rt, int dzp_kt, int* flags, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
-                       int rows_alloc, void* stream);
-int rcmarl_small_sgd_records(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N, int B,
-                             int in_dim, int hid, int ldp, int nrec, float lr, void* stream);
-int rcmarl_layer1_backward_sgd_lattice_wf(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt, int dzp_kt,
-                                          const float* alpha, float* theta, const int* mask, int S, int N, int B, int in_dim,
-                                          int hid, int ldp, float lr, void* wf_out, void* stream);
+/* (ABI 3: the fused local-fit prototypes -- rcmarl_fit_fused, rcmarl_forward_mid and their six helpers, ABI 2 -- left the library:
+ * exact, measured not faster than the three launches above; tools/prototypes/fused_fit.hip keeps the source.) */
 
 /* Shuffle permutations of the adversaries' mini-batch fits (Keras fit(shuffle=True) inside
  * agents/adversarial_CAC_agents.py:38-41,131-135,163-165,237-253).  TensorFlow's shuffle RNG is not reproducible

@@ -65,27 +65,6 @@ SIGNATURES = {
     # a1t, theta, y, partials, dzp, dzp_rt, dzp_kt, S, N, B, in_dim, hid, ldp, ldb, ovf_flags, stream
     "rcmarl_mid_fit_lattice": [c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_i32p, c_stream],
-    # fused local fit, csrc/fused_fit.hip ---------------------------------------------------------------------
-    # N, in_dim, hid, rows_alloc, kf_bytes(long*, host), ktf_bytes, wf_bytes
-    "rcmarl_fit_fused_geometry": [c_int, c_int, c_int, c_int, C.c_void_p, C.c_void_p, C.c_void_p],
-    # x, x_seed_stride, alpha, S, B, in_dim, rows_alloc, kf, ktf, stream
-    "rcmarl_fit_encode": [c_f32p, c_long, c_f32p, c_int, c_int, c_int, c_int, c_u8p, c_u8p, c_stream],
-    # kf, ktf, wf, alpha, theta, y, mask, loss_out, flags, S, N, B, in_dim, hid, ldp, ldb, rows_alloc, nsteps, lr, stream
-    "rcmarl_fit_fused": [c_u8p, c_u8p, c_u8p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int,
-                         c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
-    # theta, w2f, flags, S, N, in_dim, hid, ldp, stream
-    "rcmarl_fit_w2_frags": [c_f32p, c_u8p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # theta, alpha, wf, flags, S, N, in_dim, hid, ldp, stream
-    "rcmarl_fit_wf_split": [c_f32p, c_f32p, c_u8p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # kf, wf, w2f, theta, y, partials, dzp, dzp_rt, dzp_kt, flags, S, N, B, in_dim, hid, ldp, ldb, rows_alloc, stream
-    "rcmarl_forward_mid": [c_u8p, c_u8p, c_u8p, c_f32p, c_f32p, c_f32p, c_u8p, c_int, c_int, c_i32p, c_int, c_int, c_int, c_int,
-                           c_int, c_int, c_int, c_int, c_stream],
-    # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, nrec, lr, stream
-    "rcmarl_small_sgd_records": [c_f32p, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                 c_stream],
-    # ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, wf_out, stream
-    "rcmarl_layer1_backward_sgd_lattice_wf": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_f32p, c_u8p, c_int, c_int,
-                                              c_int, c_int, c_int, c_int, c_float, c_u8p, c_stream],
     # seeds(u64[S]), calls(int[n]), n, epochs, B, perm(int[S][n][epochs][B]), S, stream
     "rcmarl_shuffle_perms": [C.c_void_p, c_i32p, c_int, c_int, c_int, c_i32p, c_int, c_stream],
     # partials, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, lr, stream

@@ -472,8 +472,7 @@ __global__ RC_LAT_OCC(W8 ? 512 : 256, W8 ? 4 : 2)
 void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt, const unsigned char* __restrict__ dzp,
                         int dzp_rt, int dzp_kt, const float* __restrict__ alpha, float* __restrict__ theta,
                         const int* __restrict__ mask, int S, int N, int B, int in_dim, int ldp, float lr, int mtiles, int ntiles,
-                        unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt, int hid, unsigned char* __restrict__ wf_out,
-                        int wf_ksp) {
+                        unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt, int hid) {
   constexpr int PA = 1, PB = DZ16 ? 2 : 3, MT = W8 ? 2 : 4, NT = 2, WM = W8 ? 4 : 2, WN = 2;
   constexpr int WNP = WP16 ? 2 : 3;                                 // pieces of the forward operand written by the epilogue
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
@@ -531,9 +530,6 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
       unsigned char* wrow = wp_out == nullptr ? nullptr
           : wp_out + (long)s * wp_rt * wp_kt * (WNP * RC_PK_BLOCK) + (long)(col >> 7) * wp_kt * (WNP * RC_PK_BLOCK) + (col & 127) * 64 + half * 8;
       const int sw = (col >> 2) & 3;
-      // ... or in the fused kernels' fragment order (rcmarl_lattice.h "Wf"; f16 pieces only): this lane's half of a 16-byte chunk
-      unsigned char* wfrow = (WP16 && wf_out != nullptr && hid == 20)
-          ? wf_out + (long)s * ((long)((N + 2) / 3) * wf_ksp * RC_WF_STEP) + rc_wf_row_offset(ag, j, wf_ksp) + half * 8 : nullptr;
       float wold[MT][16];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -559,16 +555,6 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
               th[(long)dk * hid] = w;
             }
             wn4[e] = w * av[e];
-          }
-          if constexpr (WP16) {
-            if (wfrow != nullptr && 2 * kt < wf_ksp) {   // features 32 kt + 8 gq + 4 half ..: k16 step 2 kt + (gq >> 1), k-group gq & 1
-              unsigned h0, l0, h1, l1;
-              rc_split2h_pair(wn4[0] * RC_F16_W_SCALE, wn4[1] * RC_F16_W_SCALE, h0, l0);
-              rc_split2h_pair(wn4[2] * RC_F16_W_SCALE, wn4[3] * RC_F16_W_SCALE, h1, l1);
-              unsigned char* qf = wfrow + (long)(2 * kt + (gq >> 1)) * RC_WF_STEP + (gq & 1) * 512;
-              *reinterpret_cast<uint2*>(qf) = make_uint2(h0, h1);
-              *reinterpret_cast<uint2*>(qf + RC_WF_UT * RC_WF_FRAG) = make_uint2(l0, l1);
-            }
           }
           if (wrow != nullptr && kt < wp_kt) {
             unsigned char* q = wrow + (long)kt * (WNP * RC_PK_BLOCK) + ((gq ^ sw) << 4);
@@ -623,14 +609,13 @@ int launch_forward(unsigned nblocks, void* stream, const unsigned char* wp, int 
 template <bool W8, bool DZ16, bool WP16>
 int launch_backward(unsigned nblocks, void* stream, const unsigned char* ktp, int ktp_rt, int ktp_kt, const unsigned char* dzp,
                     int dzp_rt, int dzp_kt, const float* alpha, float* theta, const int* mask, int S, int N, int B, int in_dim,
-                    int ldp, float lr, int mtiles, int ntiles, unsigned char* wp_out, int wp_rt, int wp_kt, int hid,
-                    unsigned char* wf_out = nullptr, int wf_ksp = 0) {
+                    int ldp, float lr, int mtiles, int ntiles, unsigned char* wp_out, int wp_rt, int wp_kt, int hid) {
   const size_t smem = (size_t)2 * LatCfg<1, DZ16 ? 2 : 3, 4, 2>::STAGE_BYTES;
   static const bool ok = rc_want_lds(k_lat_backward_sgd<W8, DZ16, WP16>, smem);
   if (!ok) return RCMARL_ERR_LAUNCH;
   RCMARL_LAUNCH((k_lat_backward_sgd<W8, DZ16, WP16>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, ktp, ktp_rt, ktp_kt, dzp,
                 dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, DZ16 ? lr * RC_F16_DZ_UNSCALE : lr, mtiles, ntiles,
-                wp_out, wp_rt, wp_kt, hid, wf_out, wf_ksp);
+                wp_out, wp_rt, wp_kt, hid);
   return rcmarl_check_launch();
 }
 
@@ -742,7 +727,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
 static int backward_sgd_lattice_impl(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
                                                      int dzp_kt, const float* alpha, float* theta, const int* mask,
                                                      int S, int N, int B, int in_dim, int hid, int ldp, float lr,
-                                                     void* wp_out, int wp_rt, int wp_kt, void* wf_out, void* stream) {
+                                                     void* wp_out, int wp_rt, int wp_kt, void* stream) {
   if (!ktp || !dzp || !alpha || !theta || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || (ldp & 63) ||
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
@@ -755,11 +740,10 @@ static int backward_sgd_lattice_impl(const void* ktp, int ktp_rt, int ktp_kt, co
   const bool w8 = lat_w8(false);
   if (!rc_form_ok(ktp, (mode >> 1) & 1) || !rc_form_ok(dzp, (mode >> 1) & 1)) return RCMARL_ERR_ARG;   // written in the other operand form
   rc_form_set(wp_out, mode & 1);
-  if (wf_out && (mode != 3 || hid != 20)) return RCMARL_ERR_UNSUPPORTED;      // the fragment-order output exists for f16 pieces only
 #define RC_BWD(W8, DZ16, WP16)                                                                                              \
   launch_backward<W8, DZ16, WP16>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, \
                                   dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,                     \
-                                  (unsigned char*)wp_out, wp_rt, wp_kt, hid, (unsigned char*)wf_out, rc_wf_ksp(in_dim))
+                                  (unsigned char*)wp_out, wp_rt, wp_kt, hid)
   switch (mode * 2 + (w8 ? 1 : 0)) {
     case 0: return RC_BWD(false, false, false);
     case 1: return RC_BWD(true, false, false);
@@ -778,16 +762,5 @@ RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice(const void* ktp, int ktp_rt
                                                      int S, int N, int B, int in_dim, int hid, int ldp, float lr,
                                                      void* wp_out, int wp_rt, int wp_kt, void* stream) {
   return backward_sgd_lattice_impl(ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, wp_out,
-                                   wp_rt, wp_kt, nullptr, stream);
-}
-
-// the same step; the forward operand of the NEXT step is left in the fused kernels' fragment order (wf_out, rcmarl_lattice.h "Wf":
-// what rcmarl_fit_wf_split would write from the updated theta) instead of / besides the packed form
-RCMARL_EXPORT int rcmarl_layer1_backward_sgd_lattice_wf(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,
-                                                        int dzp_kt, const float* alpha, float* theta, const int* mask,
-                                                        int S, int N, int B, int in_dim, int hid, int ldp, float lr,
-                                                        void* wf_out, void* stream) {
-  if (!wf_out) return RCMARL_ERR_ARG;
-  return backward_sgd_lattice_impl(ktp, ktp_rt, ktp_kt, dzp, dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, hid, ldp, lr, nullptr,
-                                   0, 0, wf_out, stream);
+                                   wp_rt, wp_kt, stream);
 }

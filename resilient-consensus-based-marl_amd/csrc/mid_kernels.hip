@@ -1225,16 +1225,6 @@ RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const in
   return rcmarl_check_launch();
 }
 
-// the same update from `nrec` records per (seed, agent) -- what rcmarl_forward_mid leaves: one per 256-row tile
-RCMARL_EXPORT int rcmarl_small_sgd_records(const float* partials, float* theta, const int* mask, float* loss_out, int S, int N,
-                                           int B, int in_dim, int hid, int ldp, int nrec, float lr, void* stream) {
-  if (!partials || !theta || S <= 0 || N <= 0 || B <= 0 || nrec <= 0) return RCMARL_ERR_ARG;
-  const dim3 grid(N, S), block(256);
-  RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_small_sgd<HID_>), grid, block, 0, stream, partials, theta, mask, loss_out, N, B,
-                                   in_dim, ldp, nrec, lr));
-  return rcmarl_check_launch();
-}
-
 RCMARL_EXPORT int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma,
                                    float* out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
                                    void* stream) {

@@ -146,7 +146,7 @@ typedef _Float16 rc_h2 __attribute__((ext_vector_type(2)));
 // f16) -- the plain form (convert h back, packed subtract, packed convert) is five, and hipcc folds any C++ spelling of the FMA
 // back into it.  Hence inline asm, which the compiler's hazard recognizer does not look into: a write to the HIGH half of a
 // register (v_fma_mixhi) must be one wait state away from a vector instruction that reads the register, and two from an MFMA
-// -- the s_nop closing each block (without it the fused kernels read stale pieces: fused_fit test, round 4).
+// -- the s_nop closing each block (without it the fused prototypes read stale pieces: tools/prototypes/fused_fit.hip, round 4).
 #define RC_MIXLO(d, h, v) "v_fma_mixlo_f16 " d ", -" h ", 1.0, " v " op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
 #define RC_MIXHI(d, h, v) "v_fma_mixhi_f16 " d ", -" h ", 1.0, " v " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
 __device__ __forceinline__ void rc_split2h_pair(float w0, float w1, unsigned& h, unsigned& l) {
@@ -242,28 +242,6 @@ __device__ __forceinline__ uint2 rc_lds_read_tr16(const unsigned short* p) {
   const rc_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) rc_s4*)(p));
   return __builtin_bit_cast(uint2, v);
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// "Wf": the forward operand of the fused kernels (fused_fit.hip) -- the two f16 pieces of 2^10 alpha_k W1 of THREE consecutive
-// agents (one group) as ready-made MFMA A fragments:  [group][k16 step][piece][slot tile 0/1][lane 64][8 x f16], lane =
-// (slot row i = lane & 31, k-group = lane >> 5).  Slot sigma = 10 * (agent % 3) + local unit u lives in tile sigma >> 4, row
-// acc_row(sigma & 15, h) = (q & 3) + 8 * (q >> 2) + 4 * h, where unit = v8_unit(h, u): the accumulator layout of the product then IS
-// k_mid_fit_v8's "ten units per lane" layout.  Four of the 64 slots are padding (zero).
-#define RC_WF_FRAG 1024
-#define RC_WF_UT 2
-#define RC_WF_STEP (2 * RC_WF_UT * RC_WF_FRAG)
-#define RC_WF_KC 8                     // the reduction is padded to a multiple of 2 * RC_WF_KC k16 steps (zeros)
-__host__ __device__ static inline int rc_wf_ksp(int in_dim) {
-  const int ks = 2 * ((in_dim + 31) / 32);
-  return (ks + 2 * RC_WF_KC - 1) / (2 * RC_WF_KC) * (2 * RC_WF_KC);
-}
-// byte offset, inside one seed's Wf, of the 16-byte chunk row of (agent, unit) at k16 step 0, piece 0, k-group 0
-__host__ __device__ static inline long rc_wf_row_offset(int agent, int unit, int ksp) {
-  const int g = agent / 3, a = agent - 3 * g;
-  const int h = unit < 16 ? (unit >> 3) : ((unit - 16) >> 1), u = unit < 16 ? (unit & 7) : 8 + ((unit - 16) & 1);
-  const int sg = 10 * a + u, t = sg >> 4, q = sg & 15, i = (q & 3) + 8 * (q >> 2) + 4 * h;
-  return (long)g * ksp * RC_WF_STEP + t * RC_WF_FRAG + i * 16;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -241,28 +241,6 @@ def test_mid_fit_fp32_form_behind_the_f16_operand(bk, monkeypatch):
 
 
 
-@pytest.mark.parametrize("S,n_agents,B,width", [(2, 5, 70, 2), (1, 12, 300, 3), (1, 40, 40, 3)])
-def test_fit_encode(bk, S, n_agents, B, width):
-    KC.check_fit_encode(bk, S, n_agents, B, width, 5, 5)
-
-
-@pytest.mark.parametrize("S,N,B,width,masked,steps", [(1, 5, 70, 2, None, 2), (2, 4, 300, 3, 1, 2), (1, 7, 40, 2, None, 3)])
-def test_fused_fit(bk, S, N, B, width, masked, steps):
-    KC.check_fused_fit(bk, S, N, B, width, 5, 5, steps=steps, masked_agent=masked)
-
-
-def test_fused_fit_reproduces_itself(bk):
-    """no atomics, fixed summation order: two runs give the same bits"""
-    a = KC.check_fused_fit(bk, 1, 5, 100, 2, 5, 5, steps=2, vs_unfused=False)
-    b = KC.check_fused_fit(bk, 1, 5, 100, 2, 5, 5, steps=2, vs_unfused=False)
-    np.testing.assert_array_equal(a, b)
-
-
-@pytest.mark.parametrize("S,N,B,width,masked,steps", [(1, 5, 70, 2, None, 2), (2, 4, 300, 3, 1, 2), (1, 7, 40, 2, None, 3)])
-def test_forward_mid_fit(bk, S, N, B, width, masked, steps):
-    KC.check_forward_mid_fit(bk, S, N, B, width, 5, 5, steps=steps, masked_agent=masked)
-
-
 def test_lattice_operand_form_mismatch_is_refused(bk, lattice_form):
     """A packed buffer remembers the operand form it was written in: switching the form between producer (rcmarl_w1_split,
     rcmarl_lattice_encode, rcmarl_mid_fit_lattice) and consumer (the two lattice GEMMs) is an RCMARL_ERR_ARG, not a garbage result."""

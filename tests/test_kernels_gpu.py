@@ -285,35 +285,6 @@ def test_mid_fit_fp32_form_behind_the_f16_operand(bk, S, N, B, width, nrow, ncol
 
 
 
-@pytest.mark.parametrize("S,n_agents,B,width", [(2, 5, 1000, 2), (1, 64, 700, 3), (2, 256, 300, 3)])
-def test_fit_encode(bk, S, n_agents, B, width):
-    KC.check_fit_encode(bk, S, n_agents, B, width, 16, 16)
-
-
-@pytest.mark.parametrize("S,N,B,width,masked,steps", [(2, 5, 1000, 2, None, 5), (1, 64, 700, 3, 7, 3), (1, 47, 270, 3, 5, 2),
-                                                      (2, 256, 600, 2, None, 2), (1, 256, 300, 3, 100, 2), (8, 20, 3000, 3, None, 5)])
-def test_fused_fit(bk, S, N, B, width, masked, steps):
-    """the whole local fit in one launch vs the oracle's fit_mse and vs the three-launch path (FTW = 1, 2, 4, 6 feature tiles
-    per wavefront; ragged last group; several tiles and W' stages; a masked agent)"""
-    KC.check_fused_fit(bk, S, N, B, width, 16 if N > 30 else 5, 16 if N > 30 else 5, steps=steps, masked_agent=masked,
-                       lr=0.01 if N < 100 else 0.002)
-
-
-def test_fused_fit_reproduces_itself(bk):
-    """no atomics, fixed summation order: two runs give the same bits"""
-    a = KC.check_fused_fit(bk, 2, 23, 800, 3, 5, 5, steps=3, vs_unfused=False)
-    b = KC.check_fused_fit(bk, 2, 23, 800, 3, 5, 5, steps=3, vs_unfused=False)
-    np.testing.assert_array_equal(a, b)
-
-
-@pytest.mark.parametrize("S,N,B,width,masked,steps", [(2, 5, 1000, 2, None, 5), (1, 64, 700, 3, 7, 3), (1, 47, 270, 3, 5, 2),
-                                                      (2, 256, 600, 2, None, 2), (1, 256, 300, 3, 100, 2), (8, 20, 3000, 3, None, 3)])
-def test_forward_mid_fit(bk, S, N, B, width, masked, steps):
-    """forward + mid in one launch: dz1 image bit-identical to the three-launch path, the same fit, the oracle's fit"""
-    KC.check_forward_mid_fit(bk, S, N, B, width, 16 if N > 30 else 5, 16 if N > 30 else 5, steps=steps, masked_agent=masked,
-                             lr=0.01 if N < 100 else 0.002)
-
-
 def test_lattice_operand_form_mismatch_is_refused(bk, lattice_form):
     """A packed buffer remembers the operand form it was written in: switching the form between producer (rcmarl_w1_split,
     rcmarl_lattice_encode, rcmarl_mid_fit_lattice) and consumer (the two lattice GEMMs) is an RCMARL_ERR_ARG, not a garbage result."""

@@ -4,8 +4,6 @@
     python tools/kbench.py gemm      # layer-1 GEMMs (variant via RCMARL_GEMM=0|1|2)
     python tools/kbench.py k1        # consensus_params at (d,H) = (4,1), (10,4), (18,8)
     python tools/kbench.py mid       # mid_fit / consensus_head / mid_value
-    python tools/kbench.py fused     # the whole local fit in one launch vs the three-launch path (csrc/fused_fit.hip)
-    python tools/kbench.py fwdmid    # forward + mid in one launch vs two
 """
 import os
 import sys
@@ -199,139 +197,6 @@ def lattice(L, S=16, N=256, B=3000):
                                                                                                    3 * flops / t / 1e6))
 
 
-def fused(L, S=16, N=256, B=3000, steps=5):
-    """the whole local fit as ONE launch (csrc/fused_fit.hip) against the three-launch path, same inputs; RCMARL_FUSED_NU=1|2"""
-    import ctypes
-    from rcmarl_amd import lattice as LT
-    st = torch.cuda.current_stream().cuda_stream
-    S, N, B = int(os.environ.get("KB_S", S)), int(os.environ.get("KB_N", N)), int(os.environ.get("KB_B", B))
-    for width in (2, 3):
-        in_dim = width * N
-        P = in_dim * HID + HID + HID * HID + HID + HID + 1
-        ldp, ldb = pad64(P), pad64(B)
-        g = LT.Geometry(N, in_dim, B)
-        std = float(np.std(np.arange(32)))
-        x = ((torch.randint(0, 32, (S, B, in_dim), device="cuda").float() - 15.5) / std).contiguous()
-        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
-        lim = float(np.sqrt(6.0 / (in_dim + HID)))
-        theta0 = (torch.rand(S, N, ldp, device="cuda") * 2 - 1) * lim
-        y = torch.randn(S, N, ldb, device="cuda")
-        mask = torch.ones(N, dtype=torch.int32, device="cuda")
-        lr = 1e-3
-        # ---- three launches per step
-        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
-        kp, ktp, wp, dzp = u8(g.kp, 1), u8(g.ktp, 1), u8(g.wp, 3), u8(g.dzp, 3)
-        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-        a1t = torch.zeros(S, N * HID, ldb, device="cuda")
-        part = torch.zeros(S * N * ((B + 255) // 256) * L.rcmarl_fit_partial_size(HID), device="cuda")
-        L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0], g.kp[1], ktp.data_ptr(),
-                                g.ktp[0], g.ktp[1], flag.data_ptr(), st)
-        th_a = theta0.clone()
-
-        def unfused():
-            th_a.copy_(theta0)
-            for k in range(steps):
-                if k == 0:
-                    L.rcmarl_w1_split(th_a.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], st)
-                L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], th_a.data_ptr(),
-                                                a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st)
-                L.rcmarl_mid_fit_lattice(a1t.data_ptr(), th_a.data_ptr(), y.data_ptr(), part.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1],
-                                         S, N, B, in_dim, HID, ldp, ldb, _flags(), st)
-                L.rcmarl_small_sgd(part.data_ptr(), th_a.data_ptr(), mask.data_ptr(), None, S, N, B, in_dim, HID, ldp, lr, st)
-                L.rcmarl_layer1_backward_sgd_lattice(ktp.data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0], g.dzp[1], alpha.data_ptr(),
-                                                     th_a.data_ptr(), mask.data_ptr(), S, N, B, in_dim, HID, ldp, lr,
-                                                     wp.data_ptr() if k + 1 < steps else None, g.wp[0], g.wp[1], st)
-        # ---- one launch
-        rows_alloc = (B + 255) // 256 * 256
-        nb = [ctypes.c_long() for _ in range(3)]
-        L.rcmarl_fit_fused_geometry(N, in_dim, HID, rows_alloc, *[ctypes.byref(v) for v in nb])
-        kf, ktf, wf = (torch.zeros(S * v.value, dtype=torch.uint8, device="cuda") for v in nb)
-        flags = torch.zeros(S, N, dtype=torch.int32, device="cuda")
-        loss = torch.zeros(S, N, device="cuda")
-        t_enc = timeit(lambda: L.rcmarl_fit_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, rows_alloc, kf.data_ptr(),
-                                                   ktf.data_ptr(), st))
-        th_b = theta0.clone()
-
-        def fusedfit():
-            th_b.copy_(theta0)
-            L.rcmarl_fit_fused(kf.data_ptr(), ktf.data_ptr(), wf.data_ptr(), alpha.data_ptr(), th_b.data_ptr(), y.data_ptr(),
-                               mask.data_ptr(), loss.data_ptr(), flags.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, rows_alloc, steps, lr, st)
-        for rnd in range(2):
-            tu = timeit(unfused, iters=3, warm=1)
-            tf = timeit(fusedfit, iters=3, warm=1)
-            print("in=%4d S=%d N=%d B=%d round %d: three-launch fit %9.1f us (%7.1f per step)   fused fit %9.1f us (%7.1f per step)   x%.2f"
-                  % (in_dim, S, N, B, rnd, tu, tu / steps, tf, tf / steps, tu / tf))
-        if os.environ.get("KB_FF_TIMING"):                 # a -DFF_TIMING build leaves 10-ns ticks per phase in loss_out
-            lo = loss.cpu().numpy().reshape(S, N)[:, :N // 3 * 3].reshape(S, -1, 3)
-            print("in=%4d phase time per workgroup over %d steps (us): F %.1f  M %.1f  B %.1f   (max F %.1f M %.1f B %.1f)"
-                  % ((in_dim, steps) + tuple(lo[:, 1:, k].mean() / 100 for k in range(3)) + tuple(lo[:, 1:, k].max() / 100 for k in range(3))))
-        d = float(((th_a - th_b).abs().max() / th_a.abs().max()).item())
-        print("in=%4d fit_encode %.1f us; max |fused - three-launch| / max|theta| = %.2e; flags %d; finite %s; moved %.3e"
-              % (in_dim, t_enc, d, int(flags.sum().item()), bool(torch.isfinite(th_b).all().item()),
-                 float((th_b - theta0).abs().max().item())))
-
-
-def fwdmid(L, S=16, N=256, B=3000):
-    """forward + mid in ONE launch (rcmarl_forward_mid) against rcmarl_layer1_forward_lattice + rcmarl_mid_fit_lattice, same inputs"""
-    import ctypes
-    from rcmarl_amd import lattice as LT
-    st = torch.cuda.current_stream().cuda_stream
-    S, N, B = int(os.environ.get("KB_S", S)), int(os.environ.get("KB_N", N)), int(os.environ.get("KB_B", B))
-    for width in [int(w) for w in os.environ.get("KB_WIDTHS", "2,3").split(",")]:
-        in_dim = width * N
-        P = in_dim * HID + HID + HID * HID + HID + HID + 1
-        ldp, ldb = pad64(P), pad64(B)
-        g = LT.Geometry(N, in_dim, B)
-        std = float(np.std(np.arange(32)))
-        x = ((torch.randint(0, 32, (S, B, in_dim), device="cuda").float() - 15.5) / std).contiguous()
-        alpha = torch.full((in_dim,), 0.5 / std, device="cuda")
-        lim = float(np.sqrt(6.0 / (in_dim + HID)))
-        theta = (torch.rand(S, N, ldp, device="cuda") * 2 - 1) * lim
-        y = torch.randn(S, N, ldb, device="cuda")
-        u8 = lambda rk, pc: torch.zeros(S * LT.Geometry.nbytes(rk, pc), dtype=torch.uint8, device="cuda")
-        kp, wp, dzp_a, dzp_b = u8(g.kp, 1), u8(g.wp, 3), u8(g.dzp, 3), u8(g.dzp, 3)
-        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-        a1t = torch.zeros(S, N * HID, ldb, device="cuda")
-        ntiles = (B + 255) // 256
-        psz = L.rcmarl_fit_partial_size(HID)
-        part_a, part_b = (torch.zeros(S * N * ntiles * psz * 4, device="cuda") for _ in range(2))     # (x4: variants with one record per wavefront)
-        L.rcmarl_lattice_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, kp.data_ptr(), g.kp[0], g.kp[1], None, 0, 0,
-                                flag.data_ptr(), st)
-        L.rcmarl_w1_split(theta.data_ptr(), alpha.data_ptr(), wp.data_ptr(), S, N, in_dim, HID, ldp, g.wp[0], g.wp[1], st)
-        rows_alloc = ntiles * 256
-        nb = [ctypes.c_long() for _ in range(3)]
-        L.rcmarl_fit_fused_geometry(N, in_dim, HID, rows_alloc, *[ctypes.byref(v) for v in nb])
-        kf, ktf, wf = (torch.zeros(S * v.value, dtype=torch.uint8, device="cuda") for v in nb)
-        w2f = torch.zeros(S * N * 8192, dtype=torch.uint8, device="cuda")
-        flags = torch.zeros(S, N, dtype=torch.int32, device="cuda")
-        L.rcmarl_fit_encode(x.data_ptr(), B * in_dim, alpha.data_ptr(), S, B, in_dim, rows_alloc, kf.data_ptr(), ktf.data_ptr(), st)
-        t_wf = timeit(lambda: L.rcmarl_fit_wf_split(theta.data_ptr(), alpha.data_ptr(), wf.data_ptr(), flags.data_ptr(), S, N, in_dim, HID, ldp, st))
-        t_w2 = timeit(lambda: L.rcmarl_fit_w2_frags(theta.data_ptr(), w2f.data_ptr(), flags.data_ptr(), S, N, in_dim, HID, ldp, st))
-
-        def two():
-            L.rcmarl_layer1_forward_lattice(kp.data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1], theta.data_ptr(),
-                                            a1t.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st)
-            L.rcmarl_mid_fit_lattice(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part_a.data_ptr(), dzp_a.data_ptr(), g.dzp[0],
-                                     g.dzp[1], S, N, B, in_dim, HID, ldp, ldb, _flags(), st)
-
-        def one():
-            L.rcmarl_forward_mid(kf.data_ptr(), wf.data_ptr(), w2f.data_ptr(), theta.data_ptr(), y.data_ptr(), part_b.data_ptr(),
-                                 dzp_b.data_ptr(), g.dzp[0], g.dzp[1], flags.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, rows_alloc, st)
-        libs = [("product", L)]
-        for pth in [q for q in os.environ.get("RCMARL_KBENCH_LIB_B", "").split(",") if q]:
-            libs.append((os.path.basename(pth).replace("lib", "").replace(".so", ""), capi.CLib(pth)))
-        for rnd in range(2):
-            ta = timeit(two, iters=10)
-            for name, lib in libs:
-                def one_v(lib=lib):
-                    lib.rcmarl_forward_mid(kf.data_ptr(), wf.data_ptr(), w2f.data_ptr(), theta.data_ptr(), y.data_ptr(), part_b.data_ptr(),
-                                           dzp_b.data_ptr(), g.dzp[0], g.dzp[1], flags.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, rows_alloc, st)
-                tb = timeit(one_v, iters=10)
-                print("in=%4d round %d: forward + mid (2 launches) %8.1f us   forward_mid [%s] %8.1f us   x%.2f" % (in_dim, rnd, ta, name, tb, ta / tb))
-        print("in=%4d wf_split %.1f us, w2_frags %.1f us; dz image identical: %s; flags %d" %
-              (in_dim, t_wf, t_w2, bool(torch.equal(dzp_a, dzp_b)), int(flags.sum().item())))
-
-
 def mid_ab(L, S=16, N=256, B=3000):
     """A/B of rcmarl_mid_fit_lattice: the product library (default kernel = v5, and RCMARL_MIDFIT=7 = the bf16 matrix-core form)
     against the variant builds named in RCMARL_KBENCH_LIB_B (comma-separated paths; tools/build_variant.py), interleaved."""
@@ -464,4 +329,4 @@ if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "fused": fused, "fwdmid": fwdmid, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "minibatch": minibatch, "wide": wide}[what](L)

@@ -1,3 +1,34 @@
+// PROTOTYPE (round 4; moved out of the product library in round 5, ABI 3): exact against the three-launch path, measured 0.8x / 1.0x of
+// its speed: NOT built, NOT exported.  To build it again: copy to csrc/, restore the "Wf" helpers
+// below into csrc/rcmarl_lattice.h, the wf_out epilogue of k_lat_backward_sgd (git show abb9a39:resilient-consensus-based-marl_amd/csrc/
+// lattice_gemm.hip), rcmarl_small_sgd_records (same commit, mid_kernels.hip) and the declarations (same commit, include/rcmarl.h);
+// its tests and kbench modes are in the same commit (tests/kernel_checks.py check_fit_encode / check_fused_fit / check_forward_mid_fit).
+//
+// ---- was in csrc/rcmarl_lattice.h:
+#if 0
+// ---------------------------------------------------------------------------------------------
+// "Wf": the forward operand of the fused kernels (fused_fit.hip) -- the two f16 pieces of 2^10 alpha_k W1 of THREE consecutive
+// agents (one group) as ready-made MFMA A fragments:  [group][k16 step][piece][slot tile 0/1][lane 64][8 x f16], lane =
+// (slot row i = lane & 31, k-group = lane >> 5).  Slot sigma = 10 * (agent % 3) + local unit u lives in tile sigma >> 4, row
+// acc_row(sigma & 15, h) = (q & 3) + 8 * (q >> 2) + 4 * h, where unit = v8_unit(h, u): the accumulator layout of the product then IS
+// k_mid_fit_v8's "ten units per lane" layout.  Four of the 64 slots are padding (zero).
+#define RC_WF_FRAG 1024
+#define RC_WF_UT 2
+#define RC_WF_STEP (2 * RC_WF_UT * RC_WF_FRAG)
+#define RC_WF_KC 8                     // the reduction is padded to a multiple of 2 * RC_WF_KC k16 steps (zeros)
+__host__ __device__ static inline int rc_wf_ksp(int in_dim) {
+  const int ks = 2 * ((in_dim + 31) / 32);
+  return (ks + 2 * RC_WF_KC - 1) / (2 * RC_WF_KC) * (2 * RC_WF_KC);
+}
+// byte offset, inside one seed's Wf, of the 16-byte chunk row of (agent, unit) at k16 step 0, piece 0, k-group 0
+__host__ __device__ static inline long rc_wf_row_offset(int agent, int unit, int ksp) {
+  const int g = agent / 3, a = agent - 3 * g;
+  const int h = unit < 16 ? (unit >> 3) : ((unit - 16) >> 1), u = unit < 16 ? (unit & 7) : 8 + ((unit - 16) & 1);
+  const int sg = 10 * a + u, t = sg >> 4, q = sg & 15, i = (q & 3) + 8 * (q >> 2) + 4 * h;
+  return (long)g * ksp * RC_WF_STEP + t * RC_WF_FRAG + i * 16;
+}
+
+#endif
 // The WHOLE local fit of the cooperative agents' critic / team-reward messages in ONE launch ("fused fit", round 4):
 // critic.fit / TR.fit of agents/resilient_CAC_agents.py:118,136 -- `nsteps` full-batch SGD steps on the message copy --
 // with the layer-1 activations and dz1 never leaving the compute unit.
