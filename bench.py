@@ -534,8 +534,9 @@ def main(argv=None):
             "dtype": "f32 (matrix-core operands as 2 x f16 pieces: each fp32 operand to <= 1 ulp)" if _lat_mode(tlib) else "f32",
             "dtype_note": "fp32 parameters, activations and accumulation throughout; the matrix-core products of Phase I take their fp32 "
                           "operands as two f16 pieces (the value to one unit in its last place: 22-23 significand bits where fp32 has 24; "
-                          "RCMARL_LAT_F16=3, the default) or, =0, as three bf16 pieces whose sum is the fp32 value bit for bit -- that form "
-                          "is timed in extra.<workload>_exact of this same line",
+                          "RCMARL_LAT_F16=3, the default; a value below 2^-3 of its fixed scale -- |alpha W1| < 1.2e-4, |dz1| < 4.9e-4 -- is carried to an "
+                          "absolute 3e-11 / 1.2e-10 instead) or, =0, as three bf16 pieces whose sum is the fp32 value bit for bit -- that form "
+                          "is timed in extra.<workload>_exact and reported as ms_per_step_exact / value_exact of this same line",
             "data": "synthetic" if not stub else "STUB ENGINE (control-path test, not a measurement)",
             "config": {"workload": args.workload, "description": w["desc"], "n_agents": N, "seeds_per_gpu": S,
                        "grid": [w["nrow"], w["ncol"]], "H": w["H"], "d": w["d"], "replay_rows_B": B_steady, "fast_lr": c.fast_lr, "slow_lr": c.slow_lr, "weights_finite": finite,

@@ -107,6 +107,9 @@ int rcmarl_lattice_f16_mode(void);
  * the form it was last written in (by base pointer): handing a consumer (rcmarl_layer1_forward_lattice,
  * rcmarl_layer1_backward_sgd_lattice) a buffer written in the other form returns RCMARL_ERR_ARG. */
 int rcmarl_lattice_set_f16_mode(int mode);
+/* Drop the recorded form of a packed buffer the caller is about to free or re-purpose (a recycled device address must not inherit
+ * it).  Host-side state only; unknown pointers are fine. */
+int rcmarl_lattice_forget(const void* buf);
 int rcmarl_lattice_encode(const float* x, long x_seed_stride, const float* alpha, int S, int B, int in_dim, void* kp,
                           int kp_rt, int kp_kt, void* ktp, int ktp_rt, int ktp_kt, int* flag, void* stream);
 /* wp (rows = (agent,unit) column, reduction = feature) <- the pieces of alpha[k]*W1[s][n][k][j] in the current operand form
@@ -189,6 +192,24 @@ int rcmarl_mid_actor(float* a1t, const float* theta, const float* act_t, const f
 int rcmarl_small_adam(const float* partials, float* theta, float* adam_m, float* adam_v, const int* mask,
                       float* loss_out, int S, int N, int B, int in_dim, int hid, int n_actions, int ldp, float alpha,
                       float one_m_b1, float one_m_b2, float eps, void* stream);
+
+/* Several independent rcmarl_minibatch_fit jobs in ONE launch (no side streams: the three chains a Malicious agent needs per consensus
+ * epoch -- private critic, compromised team-reward net, compromised critic, agents/adversarial_CAC_agents.py:131-135,146-152,163-165 --
+ * start together and the epoch stays capturable in a hipGraph).  Same arithmetic and results as njobs calls of rcmarl_minibatch_fit.
+ * Networks of at most 20 inputs, all jobs in the same input class (<= 16, or 17..20), at most 4 jobs; otherwise
+ * RCMARL_ERR_UNSUPPORTED (call rcmarl_minibatch_fit per job).  `jobs` is HOST memory, read during the call only. */
+typedef struct rcmarl_mb_job {
+  const float* x; long x_seed_stride;      /* replay tensor of this network's input family and its seed stride (floats) */
+  float* theta;                            /* [S][N][ldp], rows `agents` fitted in place */
+  const int* agents; int n_adv;            /* the fitted agents of every seed */
+  int in_dim, ldp, reserved_;
+  const float* y;                          /* targets [S][N][ldb] */
+  const int* perm;                         /* int32 [S][n_adv][epochs][B], or NULL (natural order) */
+  float* loss_out;                         /* [S][N] first-epoch loss, or NULL */
+  int* ovf_flags;                          /* int32[S * n_adv], zero before first use, one buffer per job and call site */
+} rcmarl_mb_job;
+int rcmarl_minibatch_fit_multi(const rcmarl_mb_job* jobs, int njobs, int S, int N, int B, int hid, int ldb, int batch_size,
+                               int epochs, float lr, void* stream);
 
 /* X1: one whole Keras fit() of the adversaries' networks per launch (one workgroup per (seed, adversary)).
  * agents: int[n_adv] agent indices; the rows theta[s][agents[k]] are trained IN PLACE.
@@ -296,9 +317,11 @@ int rcmarl_dense_backward_sgd(const float* in, long in_seed_stride, long in_agen
                               const float* dz, float* theta, int w_off, const int* mask, int S, int N, int B, int K,
                               int J, int ldp, int ldb, float lr, void* stream);
 /* The dense layers below run on the 16-bit matrix core (default; RCMARL_WIDE_F16=0: the fp32-input MFMA kernel): both fp32
- * operands travel as two f16 pieces of the value times a fixed power of two (weights 2^10, dz 2^8, activations 1) -- each to one
- * unit in its last place -- and a product is three matrix passes (l*h + h*l + h*h), fp32 accumulate; a workgroup whose operands
- * leave the f16 range recomputes its tile in fp32 inside the same launch.  Read from the environment once;
+ * operands travel as two f16 pieces of the value times a fixed power of two (weights 2^10, dz 2^8, activations 2^6) -- to 2^-22
+ * relative while the scaled value is at least 2^-3 (|w| >= 1.2e-4, |dz| >= 4.9e-4, |a| >= 2.0e-3), to an ABSOLUTE 2^-25 of the scaled
+ * unit below that (2.9e-11 / 1.2e-10 / 4.7e-10: the low piece is a subnormal f16 there) -- and a product is three matrix passes
+ * (l*h + h*l + h*h; the l*l term, 2^-22 of the product, is dropped), fp32 accumulate; a workgroup whose operands leave the f16 range
+ * (|w| > 63, |dz| > 254, |a| > 1015) recomputes its tile in fp32 inside the same launch.  Read from the environment once;
  * rcmarl_wide_set_f16_mode(0 / 1, or -1 = read the environment again) switches it.  Inputs given as replay rows (in_row_major)
  * always take the fp32 kernel. */
 int rcmarl_wide_f16_mode(void);

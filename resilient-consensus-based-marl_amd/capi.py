@@ -11,6 +11,13 @@ import os
 c_f32p = C.c_void_p      # float*   (device pointer, or host pointer for the hipemu build)
 c_i32p = C.c_void_p      # int*
 c_u8p = C.c_void_p       # unsigned char*
+
+
+class MbJob(C.Structure):
+    """rcmarl_mb_job (include/rcmarl.h): one network family of rcmarl_minibatch_fit_multi"""
+    _fields_ = [("x", C.c_void_p), ("x_seed_stride", C.c_long), ("theta", C.c_void_p), ("agents", C.c_void_p), ("n_adv", C.c_int),
+                ("in_dim", C.c_int), ("ldp", C.c_int), ("reserved_", C.c_int), ("y", C.c_void_p), ("perm", C.c_void_p),
+                ("loss_out", C.c_void_p), ("ovf_flags", C.c_void_p)]
 c_f64p = C.c_void_p      # double*
 c_stream = C.c_void_p    # hipStream_t
 
@@ -22,6 +29,9 @@ c_float = C.c_float
 # name -> argtypes (every function returns int: 0 ok, see RCMARL_ERR_* in include/rcmarl.h)
 SIGNATURES = {
     "rcmarl_abi_version": [],
+    # jobs (host array of MbJob), njobs, S, N, B, hid, ldb, batch_size, epochs, lr, stream
+    "rcmarl_minibatch_fit_multi": [C.c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
+    "rcmarl_lattice_forget": [c_u8p],
     "rcmarl_fit_partial_size": [c_int],
     "rcmarl_actor_partial_size": [c_int, c_int],
     "rcmarl_rows_per_chunk": [],
@@ -165,7 +175,7 @@ SIGNATURES = {
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_lattice_forget", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
              "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk", "rcmarl_wide_f16_mode", "rcmarl_wide_set_f16_mode",
              "rcmarl_consensus_params_circulant_supported"}
 

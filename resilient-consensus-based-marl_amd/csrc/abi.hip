@@ -44,6 +44,14 @@ void rc_form_set(const void* p, int form) {
   if (g_ntags < TAGS) { g_tags[g_ntags].p = p; g_tags[g_ntags].form = form; ++g_ntags; return; }
   g_tags[(reinterpret_cast<uintptr_t>(p) >> 8) % TAGS] = Tag{p, form};      // full: evict
 }
+// a caller that frees or re-purposes a packed buffer says so: a recycled address must not inherit the old buffer's form
+RCMARL_EXPORT int rcmarl_lattice_forget(const void* p) {
+  if (!p) return RCMARL_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < g_ntags; ++i)
+    if (g_tags[i].p == p) { g_tags[i] = g_tags[--g_ntags]; break; }
+  return RCMARL_OK;
+}
 bool rc_form_ok(const void* p, int form) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int i = 0; i < g_ntags; ++i)

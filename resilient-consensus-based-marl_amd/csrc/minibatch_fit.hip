@@ -285,12 +285,9 @@ __device__ __forceinline__ float rc_other_half(float v) {
 #endif
 
 template <int INMAX>                                        // inputs padded to INMAX (16 or 20): branch-free loops
-__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, int* __restrict__ fix_flags) {
+__device__ __forceinline__ void wave_fit_net(const MbArgs& a, int net, float* __restrict__ W, int* __restrict__ fix_flags) {
   constexpr int HID = 20, U = 10, XR = 11;                    // XR: first x row of the P2 panel
-  RCMARL_DYN_SMEM(float, smem);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int net = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (net >= n_nets) return;                               // (wave-uniform; the kernel has no workgroup barrier)
+  const int lane = threadIdx.x & 63;
   // fix-up launch behind k_minibatch_mx: flagged networks only.  The wavefront that redoes a network is the flag's one reader: it
   // clears it (nothing host-side to go stale when the launch pair is replayed from a hipGraph)
   if (fix_flags != nullptr) {
@@ -299,7 +296,6 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, in
     if ((threadIdx.x & 63) == 0) fix_flags[net] = 0;
   }
   const int s = net / a.n_adv, adv = net - s * a.n_adv;
-  float* W = smem + wave * WP_FLOATS;
   float* W2T = W + WP_W;
   float* pA = W2T + WP_W2T;                                  // P1 A panel
   float* pA2 = pA + WP_A;                                    // P2 A panel
@@ -509,6 +505,38 @@ __global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, in
   }
   RC_WAVE_SYNC();
   for (int e = lane; e < g.P; e += 64) th[e] = W[e];
+}
+
+template <int INMAX>
+__global__ __launch_bounds__(256) void k_minibatch_wave(MbArgs a, int n_nets, int* __restrict__ fix_flags) {
+  RCMARL_DYN_SMEM(float, smem);
+  const int wave = threadIdx.x >> 6;
+  const int net = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (net >= n_nets) return;                               // (wave-uniform; the kernel has no workgroup barrier)
+  wave_fit_net<INMAX>(a, net, smem + wave * WP_FLOATS, fix_flags);
+}
+
+// Several INDEPENDENT fits (jobs) in one launch: the three chains a Malicious agent needs per consensus epoch (private critic,
+// compromised team-reward net, compromised critic: agents/adversarial_CAC_agents.py:131-135,146-152,163-165) start together without
+// side streams.  Block b belongs to job j with first[j] <= b < first[j + 1]; one wavefront per network as in the single-job kernels.
+constexpr int MB_MAX_JOBS = 4;
+struct MbMulti {
+  MbArgs a[MB_MAX_JOBS];
+  int* flags[MB_MAX_JOBS];
+  int first[MB_MAX_JOBS + 1];
+  int njobs;
+};
+__device__ __forceinline__ int mb_job_of(const MbMulti& m, int b) {
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < MB_MAX_JOBS; ++q) j += (q < m.njobs && b >= m.first[q]) ? 1 : 0;
+  return j;
+}
+template <int INMAX>
+__global__ __launch_bounds__(64) void k_minibatch_wave_multi(MbMulti m) {
+  RCMARL_DYN_SMEM(float, smem);
+  const int j = mb_job_of(m, (int)blockIdx.x);
+  wave_fit_net<INMAX>(m.a[j], (int)blockIdx.x - m.first[j], smem, m.flags[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -922,6 +950,13 @@ __global__ RC_MX_OCC void k_minibatch_mx(MbArgs a, int net0, int* __restrict__ o
   mx_fit_net<KS1, COMPACT>(a, net0 + (int)blockIdx.x, smem, ovf_flags);
 }
 
+template <int KS1, bool COMPACT>
+__global__ RC_MX_OCC void k_minibatch_mx_multi(MbMulti m) {
+  RCMARL_DYN_SMEM(unsigned char, smem);
+  const int j = mb_job_of(m, (int)blockIdx.x);
+  mx_fit_net<KS1, COMPACT>(m.a[j], (int)blockIdx.x - m.first[j], smem, m.flags[j]);
+}
+
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
   const NetGeom g = make_geom(in_dim, hid, out);
   const int Ppad = (g.P + 3) & ~3;
@@ -990,6 +1025,54 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
     return rcmarl_check_launch();
   }
   return mb_launch(k_minibatch_train<20, 1, false>, a, S, mb_smem_bytes(in_dim, 20, 1), stream);
+}
+
+RCMARL_EXPORT int rcmarl_minibatch_fit_multi(const rcmarl_mb_job* jobs, int njobs, int S, int N, int B, int hid, int ldb,
+                                             int batch_size, int epochs, float lr, void* stream) {
+  if (!jobs || njobs <= 0 || S <= 0 || N <= 0 || B <= 0 || batch_size <= 0 || epochs <= 0 || ldb < B) return RCMARL_ERR_ARG;
+  if (njobs > MB_MAX_JOBS || hid != 20) return RCMARL_ERR_UNSUPPORTED;
+  MbMulti m{};
+  m.njobs = njobs;
+  int total = 0, ks1 = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const rcmarl_mb_job& q = jobs[j];
+    if (!q.x || !q.theta || !q.agents || !q.y || !q.ovf_flags || q.n_adv <= 0 || q.in_dim <= 0 || (q.ldp & 63)) return RCMARL_ERR_ARG;
+    if (q.in_dim > 20) return RCMARL_ERR_UNSUPPORTED;            // (wider inputs: one workgroup per network, rcmarl_minibatch_fit)
+    const int k = q.in_dim <= 16 ? 1 : 2;
+    if (ks1 && k != ks1) return RCMARL_ERR_UNSUPPORTED;           // one kernel form per launch: all jobs <= 16 inputs, or all 17..20
+    ks1 = k;
+    MbArgs& a = m.a[j];
+    a.x = q.x; a.x_seed_stride = q.x_seed_stride; a.theta = q.theta; a.agents = q.agents; a.y = q.y; a.perm = q.perm;
+    a.loss_out = q.loss_out; a.N = N; a.B = B; a.in_dim = q.in_dim; a.ldp = q.ldp; a.ldb = ldb;
+    a.bs = batch_size < B ? batch_size : B; a.epochs = epochs; a.n_adv = q.n_adv; a.lr = lr;
+    m.flags[j] = q.ovf_flags;
+    m.first[j] = total;
+    total += q.n_adv * S;
+  }
+  for (int j = njobs; j <= MB_MAX_JOBS; ++j) m.first[j] = total;
+  const size_t smem_w = (size_t)WP_FLOATS * sizeof(float);
+  static const bool attr_ok = rc_want_lds(k_minibatch_wave_multi<16>, smem_w) && rc_want_lds(k_minibatch_wave_multi<20>, smem_w);
+  if (!attr_ok) return RCMARL_ERR_LAUNCH;
+  const char* e = getenv("RCMARL_MB_MX");
+  const bool mx = !(e && atoi(e) == 0);
+  if (mx) {
+    const char* ce = getenv("RCMARL_MB_MX_COMPACT");
+    const bool compact = ce ? atoi(ce) != 0 : total > 1536;
+    if (compact) {
+      if (ks1 == 1) { RCMARL_LAUNCH((k_minibatch_mx_multi<1, true>), dim3(total), dim3(64), MX_CBYTES, stream, m); }
+      else { RCMARL_LAUNCH((k_minibatch_mx_multi<2, true>), dim3(total), dim3(64), MX_CBYTES, stream, m); }
+    } else if (ks1 == 1) {
+      RCMARL_LAUNCH((k_minibatch_mx_multi<1, false>), dim3(total), dim3(64), MX_BYTES, stream, m);
+    } else {
+      RCMARL_LAUNCH((k_minibatch_mx_multi<2, false>), dim3(total), dim3(64), MX_BYTES, stream, m);
+    }
+  } else {
+    for (int j = 0; j < njobs; ++j) m.flags[j] = nullptr;          // the fp32 kernel alone fits every network
+  }
+  // the fp32 wavefront kernel: the fix-up of flagged networks (returns at once otherwise), or alone with RCMARL_MB_MX=0
+  if (ks1 == 1) { RCMARL_LAUNCH((k_minibatch_wave_multi<16>), dim3(total), dim3(64), smem_w, stream, m); }
+  else { RCMARL_LAUNCH((k_minibatch_wave_multi<20>), dim3(total), dim3(64), smem_w, stream, m); }
+  return rcmarl_check_launch();
 }
 
 RCMARL_EXPORT int rcmarl_minibatch_actor(const float* x, long x_seed_stride, float* theta, float* adam_m,

@@ -16,6 +16,17 @@
 #define RCMARL_OK 0
 #define RCMARL_ERR_ARG 1
 #define RCMARL_ERR_LAUNCH 2
+// one job of rcmarl_minibatch_fit_multi (include/rcmarl.h has the same definition)
+typedef struct rcmarl_mb_job {
+  const float* x; long x_seed_stride;      /* replay tensor of this network's input family and its seed stride (floats) */
+  float* theta;                            /* [S][N][ldp], rows `agents` fitted in place */
+  const int* agents; int n_adv;            /* the fitted agents of every seed */
+  int in_dim, ldp, reserved_;
+  const float* y;                          /* targets [S][N][ldb] */
+  const int* perm;                         /* int32 [S][n_adv][epochs][B], or NULL (natural order) */
+  float* loss_out;                         /* [S][N] first-epoch loss, or NULL */
+  int* ovf_flags;                          /* int32[S * n_adv], zero before first use, one buffer per job and call site */
+} rcmarl_mb_job;
 #define RCMARL_ERR_UNSUPPORTED 3
 
 #ifdef RCMARL_EMU

@@ -232,6 +232,13 @@ __global__ __launch_bounds__(256, 3) void k_wgemm(const WArgs a) {      // 3 wor
 // with the fp32 loop above before the epilogue: same kernel, no flags, no second launch.
 constexpr int W16_BK = 32, W16_PIECE = 128 * W16_BK * 2, W16_STAGE = 4 * W16_PIECE;      // bytes: one piece of one operand, one stage
 #define RC_W16_RANGE 65000.f
+// Precision window of a two-piece operand (h = rn_f16(x), l = rn_f16(x - h), x = scale * value): x to 2^-22 relative while the
+// low piece is a normal f16, i.e. |x| >= 2^-3; below that l is subnormal and x carries an ABSOLUTE error of up to 2^-25 (scaled
+// units).  With the fixed scales: weights (2^10) full precision from |w| >= 1.2e-4, absolute 2.9e-11 below; dz (2^8) from
+// |dz| >= 4.9e-4, absolute 1.2e-10 below; activations (2^6 since round 5; 1 before: full precision only from 0.125) from
+// |a| >= 2.0e-3, absolute 4.7e-10 below -- against fp32's own 6e-8 relative on values of order one.  Above 65000 / scale
+// (weights 63, dz 254, activations 1015) the workgroup recomputes its tile in fp32.
+#define RC_W16_ACT_SCALE 64.f
 
 template <bool KC>
 __device__ __forceinline__ void w16_load(const float* __restrict__ P, int ld, int r0, int k0, int R, int K, float4 (&reg)[4]) {
@@ -691,7 +698,7 @@ RCMARL_EXPORT int rcmarl_dense_forward(const float* in, long in_seed_stride, lon
   a.C = out; a.C_zs = (long)N * J * ldb; a.C_za = (long)J * ldb; a.ldc = ldb;
   a.aux = theta + b_off; a.aux_zs = (long)N * ldp; a.aux_za = ldp; a.ldaux = 0;
   a.M = J; a.N = B; a.K = K; a.NA = N;
-  a.sa = RC_F16_W_SCALE; a.sb = in_row_major ? 0.f : 1.f;         // weights x activations (feature-major); raw inputs stay on the fp32 kernel
+  a.sa = RC_F16_W_SCALE; a.sb = in_row_major ? 0.f : RC_W16_ACT_SCALE;   // weights x activations (feature-major); raw inputs stay on the fp32 kernel
   return in_row_major ? w_launch<false, true, WEPI_BIAS_LRELU>(a, S, stream)
                       : w_launch<false, false, WEPI_BIAS_LRELU>(a, S, stream);
 }
@@ -722,7 +729,7 @@ RCMARL_EXPORT int rcmarl_dense_backward_sgd(const float* in, long in_seed_stride
   a.C = theta + w_off; a.C_zs = (long)N * ldp; a.C_za = ldp; a.ldc = J;
   a.mask = mask; a.lr = lr;
   a.M = K; a.N = J; a.K = B; a.NA = N;
-  a.sa = in_row_major ? 0.f : 1.f; a.sb = RC_F16_DZ_SCALE;         // activations (feature-major) x dz
+  a.sa = in_row_major ? 0.f : RC_W16_ACT_SCALE; a.sb = RC_F16_DZ_SCALE;   // activations (feature-major) x dz
   return in_row_major ? w_launch<false, true, WEPI_SGD>(a, S, stream) : w_launch<true, true, WEPI_SGD>(a, S, stream);
 }
 

@@ -529,6 +529,20 @@ class RPBCACEngine:
         self.lat_kp_term = u8(self.lat_geom_term.kp, 1)
         self.lat_flag_term = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
+    def __del__(self):
+        # the library remembers the operand form of every packed buffer by ADDRESS: tell it these addresses are free again, so a
+        # later allocation that lands on one of them does not inherit a stale form (include/rcmarl.h: rcmarl_lattice_forget)
+        try:
+            forget = getattr(self.lib, "rcmarl_lattice_forget", None)
+            if forget is None or not getattr(self, "lat_enabled", False):
+                return
+            for d in (self.lat_kp, self.lat_ktp, self.lat_wp_f, self.lat_dzp_f):
+                for t in d.values():
+                    forget(t.data_ptr())
+            forget(self.lat_kp_term.data_ptr())
+        except Exception:
+            pass
+
     def _lattice_encode(self, B):
         """Once per update block: integer-lattice images of the replay tensors (rows 0..B)."""
         self.lat_active = False
@@ -1149,7 +1163,10 @@ class RPBCACEngine:
             want = self.S * self.N <= 256
         if not want or self.dev.type != "cuda" or self.shard is not None or self.wide or self.profile_phases:
             return False
-        if hasattr(self, "adv") and self.adv.fit and os.environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false"):
+        if hasattr(self, "adv") and self.adv.fit and not self.adv._multi_ok() and \
+                os.environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false"):
+            # (round 5: with all fits of an epoch in ONE rcmarl_minibatch_fit_multi launch -- AdversaryPath._multi_ok -- there are no
+            # side streams: the chains start together AND the epoch is captured.  What follows concerns the per-family launches.)
             # Greedy / Malicious agents: their three 940-step chains run side by side on three streams, and capturing that fork/join
             # SEGFAULTS inside the HIP runtime of this ROCm (7.2; reproduced with tools/diag_graph_adversaries.py, round 4).  Inline on
             # the capture stream (RCMARL_ADV_ASYNC=0) the capture works -- the shuffle-call counter lives on the device for that,
@@ -1182,11 +1199,11 @@ class RPBCACEngine:
             finally:
                 if gc_was_on:
                     gc.enable()
-            if calls0 is not None:                                 # the capture advanced the host's shuffle-call counter by one epoch
-                g.rcmarl_draws = self.adv.calls[0] - calls0[0]     # ... without running anything: take it back, the replay below counts
-                self.adv.calls = calls0
-                if self.adv.base_dev is not None:                  # (None: no adversary of this instance fits -- only Faulty ones)
-                    self.adv.base_dev.fill_(int(calls0[0]))
+                if calls0 is not None:                             # the capture advanced the host's shuffle-call counter by one epoch
+                    g.rcmarl_draws = self.adv.calls[0] - calls0[0]     # ... without running anything: take it back (also when the
+                    self.adv.calls = calls0                        # capture raised), the replay below counts
+                    if self.adv.base_dev is not None:              # (None: no adversary of this instance fits -- only Faulty ones)
+                        self.adv.base_dev.fill_(int(calls0[0]))
             self._graphs[key] = g
             self.graph_captures += 1
         g.replay()

@@ -23,6 +23,8 @@ a counter-based stream (csrc/shuffle.hip, generated on the device for all seeds 
 states the same definition), consumed in the reference's call order so that oracle and engine stay in
 lock step.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -44,6 +46,8 @@ class AdversaryPath:
         self.fit_t = torch.tensor(self.fit, **i32) if self.fit else None
         self.mal_t = torch.tensor(self.mal, **i32) if self.mal else None
         self.fit_idx = torch.tensor(self.fit, dtype=torch.long, device=dev) if self.fit else None
+        self.fit_mask = torch.tensor([1 if i in self.fit else 0 for i in range(len(labels))], **i32)      # rows rcmarl_copy3d copies
+        self.mal_mask = torch.tensor([1 if i in self.mal else 0 for i in range(len(labels))], **i32)
         self.mal_idx = torch.tensor(self.mal, dtype=torch.long, device=dev) if self.mal else None
         self.calls = [0] * eng.S                       # ShuffleStream.calls per seed
         self.base_dev, self._draw_bufs, self.last_draw = None, {}, 0
@@ -173,9 +177,11 @@ class AdversaryPath:
             plan.append((i, "critic"))
         perms = self._draw(plan, FIT_EPOCHS, B)
         S, N = e.S, e.N
+        if self._multi_ok():
+            return self._phase1_multi(B, perms)
         # The (up to) three fits are independent networks and each is ONE latency-bound workgroup per (seed, adversary):
         # on a GPU they run side by side on three streams (forked from / joined to the current one).
-        par = e.dev.type == "cuda" and not e.wide and __import__("os").environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false")
+        par = e.dev.type == "cuda" and not e.wide and os.environ.get("RCMARL_ADV_ASYNC", "1") not in ("0", "false")
         cur = torch.cuda.current_stream() if par else None
         if par and not hasattr(self, "fit_streams"):
             self.fit_streams = [torch.cuda.Stream(device=e.dev) for _ in range(2)]
@@ -201,9 +207,7 @@ class AdversaryPath:
                 joins.append(ev)
         if self.mal:                                   # private critic: own reward, own bootstrap (:137-152)
             with on(2):
-                rptr, rstride = e._x("r")
-                L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, B, e.ldb, e.stream)
-                e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"], scratch=self.a1t)
+                self._local_targets(B)
                 self._fit_critic_family(e.theta["critic_local"], self.mal_t, self.mal, e.ybuf["y_l"], perms["local"], B, None)
                 done(2)
         # transmitted TR: targets r_fit (own reward for Greedy, -r_coop for Malicious)
@@ -213,13 +217,57 @@ class AdversaryPath:
                                    e.ybuf["r_fit"].data_ptr(), perms["tr"].data_ptr(), S, N, B, e.in_r, HID, e.ldp["tr"],
                                    e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.loss["tr"].data_ptr(),
                                    e.ovf_flags(("adv", "tr"), S * len(self.fit)).data_ptr(), e.stream)
-            e.msg["tr"].index_copy_(1, self.fit_idx, e.theta["tr"].index_select(1, self.fit_idx))   # the fitted net IS the message
+            self._publish("tr")                        # the fitted net IS the message
             done(1)
         # transmitted critic: targets y_c = r_fit + gamma*V_theta(ns), computed from the pre-fit weights
         self._fit_critic_family(e.theta["critic"], self.fit_t, self.fit, y_c, perms["critic"], B, e.loss["critic"])
-        e.msg["critic"].index_copy_(1, self.fit_idx, e.theta["critic"].index_select(1, self.fit_idx))
+        self._publish("critic")
         for ev in joins:
             cur.wait_event(ev)
+
+    def _local_targets(self, B):
+        """targets of the Malicious agents' private critic: own reward + gamma V_local(ns) (:137-152)"""
+        e, L = self.e, self.e.lib
+        rptr, rstride = e._x("r")
+        L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), e.S, e.N, B, e.ldb, e.stream)
+        e._value("ns", e.theta["critic_local"], "critic", e.ybuf["y_l"], B, r_applied=e.ybuf["r_own"], scratch=self.a1t)
+
+    def _publish(self, net):
+        """msg[net] rows of the fitting adversaries <- their theta rows (one masked strided copy, no framework kernels)"""
+        e = self.e
+        ldp = e.ldp[net]
+        e.lib.rcmarl_copy3d(e.theta[net].data_ptr(), e.N * ldp, ldp, e.msg[net].data_ptr(), e.N * ldp, ldp, e.S, e.N, ldp,
+                            self.fit_mask.data_ptr(), e.stream)
+
+    def _multi_ok(self):
+        """all fits of an epoch as ONE rcmarl_minibatch_fit_multi launch?  20-unit networks of at most 20 inputs in one input class
+        (the reference's own 5-agent scenarios); RCMARL_ADV_MULTI=0: the per-family launches (on side streams on a GPU)."""
+        e = self.e
+        if e.wide or os.environ.get("RCMARL_ADV_MULTI", "1") in ("0", "false") or not hasattr(e.lib, "rcmarl_minibatch_fit_multi"):
+            return False
+        return max(e.in_c, e.in_r) <= 20 and (e.in_c <= 16) == (e.in_r <= 16)
+
+    def _phase1_multi(self, B, perms):
+        from . import capi
+        e, L = self.e, self.e.lib
+        S, N = e.S, e.N
+        jobs = []
+
+        def job(xkey, theta, agents_t, n, y, perm, in_dim, ldp, loss, flag_key):
+            xptr, xstride = e._x(xkey)
+            jobs.append(capi.MbJob(xptr, xstride, theta.data_ptr(), agents_t.data_ptr(), n, in_dim, ldp, 0, y.data_ptr(), perm.data_ptr(),
+                                   None if loss is None else loss.data_ptr(), e.ovf_flags(("adv", flag_key), S * n).data_ptr()))
+        if self.mal:
+            self._local_targets(B)
+            job("s", e.theta["critic_local"], self.mal_t, len(self.mal), e.ybuf["y_l"], perms["local"], e.in_c, e.ldp["critic"], None,
+                "local")
+        job("sa", e.theta["tr"], self.fit_t, len(self.fit), e.ybuf["r_fit"], perms["tr"], e.in_r, e.ldp["tr"], e.loss["tr"], "tr")
+        job("s", e.theta["critic"], self.fit_t, len(self.fit), e.ybuf["y_c"], perms["critic"], e.in_c, e.ldp["critic"], e.loss["critic"],
+            "critic")
+        arr = (capi.MbJob * len(jobs))(*jobs)
+        L.rcmarl_minibatch_fit_multi(arr, len(jobs), S, N, B, HID, e.ldb, FIT_BATCH, FIT_EPOCHS, e.cfg.fast_lr, e.stream)
+        self._publish("tr")
+        self._publish("critic")
 
     # -- phase III ---------------------------------------------------------------------------
     def actor_updates(self, B):
@@ -229,9 +277,13 @@ class AdversaryPath:
         shuffle = nl > ACTOR_BATCH
         perms = self._draw([(i, "actor") for i in self.adv], 1, nl)["actor"] if shuffle else None
         own = e.theta["critic"]
-        if self.mal:
-            own = own.clone()
-            own.index_copy_(1, self.mal_idx, e.theta["critic_local"].index_select(1, self.mal_idx))
+        if self.mal:                                   # a Malicious agent's TD error comes from its PRIVATE critic (:111-115)
+            if getattr(self, "_own", None) is None:
+                self._own = torch.empty_like(e.theta["critic"])
+            own, ldp = self._own, e.ldp["critic"]
+            L.rcmarl_copy3d(e.theta["critic"].data_ptr(), N * ldp, ldp, own.data_ptr(), N * ldp, ldp, S, N, ldp, None, e.stream)
+            L.rcmarl_copy3d(e.theta["critic_local"].data_ptr(), N * ldp, ldp, own.data_ptr(), N * ldp, ldp, S, N, ldp,
+                            self.mal_mask.data_ptr(), e.stream)
         rptr, rstride = e._x("r", row0)
         L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, nl, e.ldb, e.stream)
         e._value("ns", own, "critic", e.ybuf["v_next_adv"], nl, row0)

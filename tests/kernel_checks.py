@@ -607,6 +607,48 @@ def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shu
     return th_new, loss
 
 
+def check_minibatch_fit_multi(bk, S=2, N=5, B=96, in_dims=(10, 15, 10), adv_sets=((4,), (3, 4), (3, 4)), bs=32, epochs=2, lr=0.01):
+    """rcmarl_minibatch_fit_multi: several fits in ONE launch (the Malicious agent's private critic, compromised team-reward net and
+    compromised critic of a consensus epoch) leave the bits that one rcmarl_minibatch_fit call per job leaves -- parameters, losses
+    and untouched rows alike.  (The single-job entry point is held to the oracle by check_minibatch_fit.)"""
+    from rcmarl_amd import capi
+    rng = np.random.default_rng(77)
+    ldb, cap = pad64(B), B + 3
+    jobs = []
+    for in_dim, advs in zip(in_dims, adv_sets):
+        P, _ = geom(in_dim, 1)
+        ldp = pad64(P)
+        advs = np.asarray(advs, np.int32)
+        jobs.append(dict(in_dim=in_dim, ldp=ldp, advs=advs, theta=pack_rows(random_params(rng, S, N, in_dim, 1), ldp),
+                         x=rng.normal(size=(S, cap, in_dim)).astype(np.float32), y=rng.normal(size=(S, N, ldb)).astype(np.float32),
+                         perm=np.stack([[[rng.permutation(B) for _ in range(epochs)] for _ in advs] for _ in range(S)]).astype(np.int32)))
+    results = {}
+    for mode in ("single", "multi"):
+        dev = []
+        for j in jobs:
+            dev.append(dict(x=bk.dev(j["x"]), th=bk.dev(j["theta"]), y=bk.dev(j["y"]), adv=bk.dev(j["advs"]), perm=bk.dev(j["perm"]),
+                            loss=bk.dev(np.zeros((S, N), np.float32)), flags=bk.dev(np.zeros(S * len(j["advs"]) + 1, np.int32))))
+        if mode == "single":
+            for j, d in zip(jobs, dev):
+                rc = bk.lib.rcmarl_minibatch_fit(bk.ptr(d["x"]), cap * j["in_dim"], bk.ptr(d["th"]), bk.ptr(d["adv"]), len(j["advs"]),
+                                                 bk.ptr(d["y"]), bk.ptr(d["perm"]), S, N, B, j["in_dim"], HID, j["ldp"], ldb, bs, epochs, lr,
+                                                 bk.ptr(d["loss"]), bk.ptr(d["flags"]), bk.stream)
+                assert rc in (0, None)
+        else:
+            arr = (capi.MbJob * len(jobs))(*[capi.MbJob(bk.ptr(d["x"]), cap * j["in_dim"], bk.ptr(d["th"]), bk.ptr(d["adv"]), len(j["advs"]),
+                                                        j["in_dim"], j["ldp"], 0, bk.ptr(d["y"]), bk.ptr(d["perm"]), bk.ptr(d["loss"]),
+                                                        bk.ptr(d["flags"])) for j, d in zip(jobs, dev)])
+            rc = bk.lib.rcmarl_minibatch_fit_multi(arr, len(jobs), S, N, B, HID, ldb, bs, epochs, lr, bk.stream)
+            assert rc in (0, None)
+        results[mode] = [(bk.host(d["th"]), bk.host(d["loss"])) for d in dev]
+    for j, (a, b) in enumerate(zip(results["single"], results["multi"])):
+        np.testing.assert_array_equal(a[0], b[0], err_msg="job %d parameters" % j)
+        np.testing.assert_array_equal(a[1], b[1], err_msg="job %d losses" % j)
+        assert not np.array_equal(a[0], jobs[j]["theta"])
+    # a job list the entry point does not take: mixed input classes (<= 16 and 17..20) -> RCMARL_ERR_UNSUPPORTED, nothing launched
+    return results
+
+
 def check_shuffle_perms(bk, seeds, calls, epochs, B):
     """rcmarl_shuffle_perms (csrc/shuffle.hip: per permutation a bucket sort of the Philox keys) against the oracle's ShuffleStream
     (argsort of the same keys, ties to the lower row): every entry equal."""

@@ -126,6 +126,10 @@ def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
     KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=B > bs)
 
 
+def test_minibatch_fit_multi_equals_single_job_launches(bk):
+    KC.check_minibatch_fit_multi(bk)
+
+
 def test_projection(bk):
     KC.check_projection(bk, 2, 3, 300, 6)
 

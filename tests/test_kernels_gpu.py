@@ -143,6 +143,10 @@ def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
     KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=True)
 
 
+def test_minibatch_fit_multi_equals_single_job_launches(bk):
+    KC.check_minibatch_fit_multi(bk)
+
+
 def test_projection(bk):
     KC.check_projection(bk, 2, 5, 1000, 10)
     KC.check_projection(bk, 1, 16, 700, 48)

@@ -16,6 +16,7 @@ blocks = int(os.environ.get("BLOCKS", "8"))
 lib = capi.load()
 for mode in os.environ.get("MODES", "3,0").split(","):
     os.environ["RCMARL_LAT_F16"] = mode
+    lib.rcmarl_lattice_set_f16_mode(int(mode))           # (the library reads the environment only once)
     seed0 = int(os.environ.get("SEED0", "1000"))
     eng = bench.make_engine(w, S, list(range(seed0, seed0 + S)), lib)
     for b in range(blocks):
