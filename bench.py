@@ -597,6 +597,9 @@ def main(argv=None):
             out["ms_per_step_exact"] = ex["ms_per_step"]
             out["value_exact"] = ex["agent_steps_per_s"]
             out["exact_steps"] = ex.get("steps")
+            out["config"] = dict(out["config"], ms_per_step_exact=ex["ms_per_step"], value_exact=ex["agent_steps_per_s"],
+                                 exact_form="three bf16 pieces whose sum is the fp32 operand + fp32-arithmetic mid kernels "
+                                            "(extra.%s_exact)" % args.workload)
         # big objects first, the scalars a reader wants LAST (a truncated tail of this line still holds them)
         big = ("dtype_note", "config", "kernels", "extra", "roofline_gemm", "roofline_mid", "roofline_consensus",
                "roofline_consensus_target", "kernel_timing", "deviation", "phase_seconds_per_block", "phase_fraction", "comm")

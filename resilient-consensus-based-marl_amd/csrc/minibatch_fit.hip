@@ -957,6 +957,22 @@ __global__ RC_MX_OCC void k_minibatch_mx_multi(MbMulti m) {
   mx_fit_net<KS1, COMPACT>(m.a[j], (int)blockIdx.x - m.first[j], smem, m.flags[j]);
 }
 
+// wavefronts of the 27-KB form the GPU holds at once: FIVE per CU, not the six its LDS arithmetic promises (measured, round 5,
+// tools/kbench.py multi, profiles/r05k_*: 1026 networks 4.1 ms, 1536 networks 7.2 ms -- two rounds -- against 5.6 ms in the compact
+// form); beyond that the compact form (eight per CU) takes over
+int mx_slots() {
+  static const int n = [] {
+#ifdef RCMARL_EMU
+    return 1280;
+#else
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return 5 * cus;
+#endif
+  }();
+  return n;
+}
+
 size_t mb_smem_bytes(int in_dim, int hid, int out) {
   const NetGeom g = make_geom(in_dim, hid, out);
   const int Ppad = (g.P + 3) & ~3;
@@ -1001,7 +1017,7 @@ RCMARL_EXPORT int rcmarl_minibatch_fit(const float* x, long x_seed_stride, float
       flags = fl;
       // more networks than wavefront slots at six per CU: the compact form (eight per CU)
       const char* ce = getenv("RCMARL_MB_MX_COMPACT");
-      const bool compact = ce ? atoi(ce) != 0 : n_nets > 1536;
+      const bool compact = ce ? atoi(ce) != 0 : n_nets > mx_slots();
       if (compact) {
         if (in_dim <= 16) {
           RCMARL_LAUNCH((k_minibatch_mx<1, true>), dim3(n_nets), dim3(64), MX_CBYTES, stream, a, 0, fl);
@@ -1057,7 +1073,7 @@ RCMARL_EXPORT int rcmarl_minibatch_fit_multi(const rcmarl_mb_job* jobs, int njob
   const bool mx = !(e && atoi(e) == 0);
   if (mx) {
     const char* ce = getenv("RCMARL_MB_MX_COMPACT");
-    const bool compact = ce ? atoi(ce) != 0 : total > 1536;
+    const bool compact = ce ? atoi(ce) != 0 : total > mx_slots();
     if (compact) {
       if (ks1 == 1) { RCMARL_LAUNCH((k_minibatch_mx_multi<1, true>), dim3(total), dim3(64), MX_CBYTES, stream, m); }
       else { RCMARL_LAUNCH((k_minibatch_mx_multi<2, true>), dim3(total), dim3(64), MX_CBYTES, stream, m); }

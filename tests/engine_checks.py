@@ -143,7 +143,7 @@ def run_pair(args, nrow, ncol, rng_mode, device, lib, seeds=(11,), weight_seed=3
     return eng, logs, o_logs, o_weights
 
 
-def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict", outlier_frac=0.0, rtol_w_outlier=None):
+def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict", outlier_frac=0.0, rtol_w_outlier=None, actor_outlier_frac=1e-4):
     """rtol_w: end-of-run critic / team-reward weights vs the oracle, |err| <= rtol_w * max(1, |w|max) per array -- SURVEY.md 8c's
     1e-4 (measured worst cases on the MI355X, profiles/r03f_parity_worst_cases.txt: <= 2.9e-5 everywhere except the 256-agent
     BASELINE configs[3] run, 9.3e-5, which therefore passes 2e-4 explicitly).  Prints the measured worst case.
@@ -153,8 +153,8 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict", outlier_f
     actor="none": the caller judges the actor itself.  actor="strict": every actor parameter within 5 % of an Adam step per update.  actor="stat" (hundreds of agents):
     Adam turns a gradient of magnitude ~eps into anything in [-lr, lr] and a pre-activation within rounding of 0 flips its
     LeakyReLU slope, so among millions of parameters a few legitimately differ by more between any two fp32 summation
-    orders: bulk within 5 % of a step, at most 1e-4 of the entries beyond, none beyond two full steps (the bar of
-    kernel_checks.check_actor_step)."""
+    orders: bulk within 5 % of a step, at most actor_outlier_frac (1e-4) of the entries beyond, none beyond two full steps (the bar
+    of kernel_checks.check_actor_step)."""
     S, n = eng.S, eng.N
     steps = max(1, eng.adam_t)
     worst = {"critic": 0.0, "tr": 0.0, "critic_local": 0.0}        # measured max |err| / max(1, |w|max) per family
@@ -197,7 +197,9 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict", outlier_f
             lr = eng.cfg.slow_lr
             assert e.max() <= 2.0 * lr * steps + 1e-6, ("actor", float(e.max()))
             frac = float(np.mean(e > 0.05 * lr * steps + 1e-5))
-            assert frac <= 1e-4, ("actor outliers", frac, float(e.max()))
+            assert frac <= actor_outlier_frac, ("actor outliers", frac, float(e.max()))
+            print("[parity] actor (statistical bar): %.2e of the parameters beyond 5 %% of an Adam step (bar %.0e), max |err| %.2e = %.2f steps"
+                  % (frac, actor_outlier_frac, float(e.max()), float(e.max()) / (lr * steps)))
     n_out = len({(s_, i_, net_) for s_, i_, net_, _ in outliers})
     assert n_out <= outlier_frac * n_nets, ("networks beyond rtol_w", n_out, n_nets, outliers[:5])
     print("[parity] N=%d S=%d worst |w - w_oracle| / max(1,|w|max): critic %.2e  tr %.2e%s  (bar %.0e%s)"

@@ -163,32 +163,37 @@ def test_engine_epochs_replayed_from_a_hipgraph_are_bit_identical(n, S, nrow, mo
 @pytest.mark.parametrize("labels,S", [(["Cooperative"] * 4 + ["Malicious"], 1), (["Greedy", "Cooperative", "Cooperative", "Malicious", "Faulty"], 2),
                                       (["Cooperative", "Faulty", "Cooperative", "Cooperative", "Faulty"], 1)])
 def test_engine_epochs_with_adversaries_replayed_from_a_hipgraph_are_bit_identical(labels, S, monkeypatch):
-    """The reference's own headline scenario (main.py:88-104 with a Malicious agent) as captured epochs, the adversaries' mini-batch
-    fits INLINE on the capture stream (RCMARL_ADV_ASYNC=0; on their side streams the capture crashes this ROCm's runtime, so the
-    engine's default keeps such instances eager -- asserted below): the shuffle stream's call counter lives on the device
-    (engine_adversaries._draw), the out-of-range flags are consumed by the fix-up launch.  Weights, logs and the number of shuffle
-    draws equal the eager run's bit for bit, and epochs really are replayed."""
+    """The reference's own headline scenario (main.py:88-104 with a Malicious agent) as captured epochs.  Round 5: all fits of an
+    epoch are ONE rcmarl_minibatch_fit_multi launch on the capture stream (no side streams), so the DEFAULT engine captures such
+    instances too.  The per-family launches stay behind RCMARL_ADV_MULTI=0: inline on the capture stream (RCMARL_ADV_ASYNC=0) they
+    capture as well; on their side streams the capture crashes this ROCm's runtime, so that combination keeps the instance eager
+    (asserted).  The shuffle stream's call counter lives on the device (engine_adversaries._draw), the out-of-range flags are consumed
+    by the fix-up launch.  Weights, logs and the number of shuffle draws equal the eager per-family run's bit for bit in every
+    mode, and epochs really are replayed."""
     import numpy as np
     from rcmarl_amd.engine import EngineConfig, RPBCACEngine
     n = len(labels)
     fits = any(l in ("Greedy", "Malicious") for l in labels)
     res = {}
-    for mode, asyn in (("0", "1"), ("1", "0"), ("1", "1")):
-        monkeypatch.setenv("RCMARL_GRAPH", mode)
+    for graph, asyn, multi in (("0", "1", "0"), ("1", "0", "0"), ("1", "1", "0"), ("0", "1", "1"), ("1", "1", "1")):
+        monkeypatch.setenv("RCMARL_GRAPH", graph)
         monkeypatch.setenv("RCMARL_ADV_ASYNC", asyn)
+        monkeypatch.setenv("RCMARL_ADV_MULTI", multi)
         cfg = EngineConfig(n, labels, EC.CIRC5, H=1, n_seeds=S, rng_mode="device", max_ep_len=20, n_ep_fixed=10, n_epochs=4,
                            buffer_size=400, nrow=5, ncol=5)
         eng = RPBCACEngine(cfg, seeds=list(range(200, 200 + S)))
         eng.init_glorot(base_seed=2)
         eng.set_goals(np.stack([np.random.RandomState(s).randint(0, 5, size=(n, 2)) for s in range(S)]))
         logs = eng.train(50)                       # 5 blocks: B = 200, 400, 600, 600, 600
-        res[(mode, asyn)] = (logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}, eng.graph_captures,
-                             eng.graph_replays, list(eng.adv.calls))
-    eager, inline, dflt = res[("0", "1")], res[("1", "0")], res[("1", "1")]
-    assert eager[2:4] == (0, 0)
+        res[(graph, asyn, multi)] = (logs, {k: eng.theta[k].detach().cpu().numpy().copy() for k in eng.theta}, eng.graph_captures,
+                                     eng.graph_replays, list(eng.adv.calls))
+    eager, inline, side = res[("0", "1", "0")], res[("1", "0", "0")], res[("1", "1", "0")]
+    eager_multi, dflt = res[("0", "1", "1")], res[("1", "1", "1")]
+    assert eager[2:4] == (0, 0) and eager_multi[2:4] == (0, 0)
     assert inline[2] == 3 and inline[3] == 5 * 3, inline[2:4]
-    assert dflt[2:4] == ((0, 0) if fits else (3, 15))                         # side-stream fits: the engine stays eager
-    for other in (inline, dflt):
+    assert side[2:4] == ((0, 0) if fits else (3, 15))                         # per-family fits on side streams: the engine stays eager
+    assert dflt[2:4] == (3, 15), dflt[2:4]                                    # the default (one multi launch): captured and replayed
+    for other in (inline, side, eager_multi, dflt):
         assert eager[4] == other[4]                                           # the same number of shuffle draws was consumed
         for k in eager[0]:
             np.testing.assert_array_equal(eager[0][k], other[0][k])

@@ -129,6 +129,54 @@ def minibatch(L, S=512, N=5, B=3000):
         print("minibatch_fit in=%3d S=%d: %9.1f us per launch, %.2f us per SGD step" % (in_dim, S, t, t / (10 * ((B + 31) // 32))))
 
 
+def multi(L, S=None, N=5, B=3000):
+    S = int(os.environ.get("KB_S", "512")) if S is None else S
+    """the Malicious agent's three chains of a consensus epoch: three rcmarl_minibatch_fit launches (one after the other / on three
+    streams, as the engine did until round 4) against ONE rcmarl_minibatch_fit_multi launch"""
+    st = torch.cuda.current_stream().cuda_stream
+    jobs = []
+    for in_dim, n_adv in ((2 * N, 1), (3 * N, 1), (2 * N, 1)):
+        P = in_dim * HID + HID + HID * HID + HID + HID + 1
+        ldp, ldb = pad64(P), pad64(B)
+        jobs.append(dict(in_dim=in_dim, ldp=ldp, x=torch.randn(S, B, in_dim, device="cuda"), theta=torch.randn(S, N, ldp, device="cuda") * 0.05,
+                         y=torch.randn(S, N, ldb, device="cuda"), agents=torch.tensor([N - 1], dtype=torch.int32, device="cuda"),
+                         perm=torch.stack([torch.stack([torch.randperm(B, device="cuda") for _ in range(10)]) for _ in range(S)]).to(torch.int32).reshape(S, 1, 10, B).contiguous(),
+                         flags=torch.zeros(S + 1, dtype=torch.int32, device="cuda")))
+    ldb = pad64(B)
+
+    def single(j, stream):
+        L.rcmarl_minibatch_fit(j["x"].data_ptr(), B * j["in_dim"], j["theta"].data_ptr(), j["agents"].data_ptr(), 1, j["y"].data_ptr(),
+                               j["perm"].data_ptr(), S, N, B, j["in_dim"], HID, j["ldp"], ldb, 32, 10, 1e-4, None, j["flags"].data_ptr(), stream)
+
+    def seq():
+        for j in jobs:
+            single(j, st)
+    side = [torch.cuda.Stream() for _ in range(2)]
+
+    def par():
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(cur)
+        for j, s_ in zip(jobs[1:], side):
+            s_.wait_event(ev)
+            single(j, s_.cuda_stream)
+        single(jobs[0], st)
+        for s_ in side:
+            e2 = torch.cuda.Event(); e2.record(s_); cur.wait_event(e2)
+    arr = (capi.MbJob * 3)(*[capi.MbJob(j["x"].data_ptr(), B * j["in_dim"], j["theta"].data_ptr(), j["agents"].data_ptr(), 1, j["in_dim"], j["ldp"], 0,
+                                       j["y"].data_ptr(), j["perm"].data_ptr(), None, j["flags"].data_ptr()) for j in jobs])
+
+    def one():
+        L.rcmarl_minibatch_fit_multi(arr, 3, S, N, B, HID, ldb, 32, 10, 1e-4, st)
+    for name, fn in (("three launches, one stream", seq), ("three launches, three streams", par), ("ONE multi launch", one)):
+        t = timeit(fn, iters=3, warm=1)
+        print("%-32s %9.1f us  (%.2f us per SGD step of a chain)" % (name, t, t / 940))
+    for c in ("0", "1"):
+        os.environ["RCMARL_MB_MX_COMPACT"] = c
+        t = timeit(one, iters=3, warm=1)
+        print("ONE multi launch, compact=%s      %9.1f us" % (c, t))
+    os.environ.pop("RCMARL_MB_MX_COMPACT")
+
+
 def mid(L, S=16, N=256, B=3000):
     st = torch.cuda.current_stream().cuda_stream
     in_dim = 2 * N
@@ -329,4 +377,4 @@ if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "minibatch": minibatch, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "minibatch": minibatch, "multi": multi, "wide": wide}[what](L)
