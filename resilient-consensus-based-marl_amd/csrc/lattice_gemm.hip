@@ -518,31 +518,40 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
     const int cl = wn * 32 * NT + 32 * nt + (lane & 31);                 // column within the 128-wide tile
     const int col = bn * C::BN + cl;
 #if defined(RC_LAT_KNOCK) && RC_LAT_KNOCK == 1
-    if (col < ncols && ldp == 12345) {
+    const bool act = col < ncols && ldp == 12345;
 #else
-    if (col < ncols) {
+    const bool act = col < ncols;                                        // (the same for both lanes of a column: lane ^ 32)
 #endif
-      const int ag = col / hid, j = col - ag * hid;
-      const bool upd = mask == nullptr || mask[ag];
-      // the lane's first row: k = bm*BM + wm*32*MT + 4*half; rows of (mt, gq, e) follow at uniform distances
-      const int k0 = bm * C::BM + wm * 32 * MT + 4 * half;
-      float* th = theta + ((long)s * N + ag) * ldp + j + (long)k0 * hid;
-      unsigned char* wrow = wp_out == nullptr ? nullptr
-          : wp_out + (long)s * wp_rt * wp_kt * (WNP * RC_PK_BLOCK) + (long)(col >> 7) * wp_kt * (WNP * RC_PK_BLOCK) + (col & 127) * 64 + half * 8;
-      const int sw = (col >> 2) & 3;
-      float wold[MT][16];
+    const int colc = act ? col : 0;
+    const int ag = colc / hid, j = colc - ag * hid;
+    const bool upd = act && (mask == nullptr || mask[ag]);
+    // the lane's first row: k = bm*BM + wm*32*MT + 4*half; rows of (mt, gq, e) follow at uniform distances
+    const int k0 = bm * C::BM + wm * 32 * MT + 4 * half;
+    float* th = theta + ((long)s * N + ag) * ldp + j + (long)k0 * hid;
+    // The forward operand of the next step: a lane's four consecutive k of one (mt, gq) are HALF a 16-byte chunk of the packed row
+    // (the other half sits in lane ^ 32).  Round 5: the two lanes exchange halves (one v_permlane32_swap per dword) so that each
+    // stores WHOLE chunks -- lane half 0 the even gq, half 1 the odd ones -- as 16-byte stores: half the store instructions and half
+    // the cache lines touched per byte (the store path is paced by lines touched per instruction, profiles/r05d_*, r05f_*).
+    unsigned char* wrow = wp_out == nullptr ? nullptr
+        : wp_out + (long)s * wp_rt * wp_kt * (WNP * RC_PK_BLOCK) + (long)(colc >> 7) * wp_kt * (WNP * RC_PK_BLOCK) + (colc & 127) * 64;
+    const int sw = (colc >> 2) & 3;
+    float wold[MT][16];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int dk = 32 * mt + 8 * (q >> 2) + (q & 3);               // uniform
-          wold[mt][q] = (full_k || k0 + dk < in_dim) ? th[(long)dk * hid] : 0.f;
-        }
+      for (int q = 0; q < 16; ++q) {
+        const int dk = 32 * mt + 8 * (q >> 2) + (q & 3);               // uniform
+        wold[mt][q] = (act && (full_k || k0 + dk < in_dim)) ? th[(long)dk * hid] : 0.f;
+      }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int kt = bm * (C::BM / 32) + wm * MT + mt;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int kt = bm * (C::BM / 32) + wm * MT + mt;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
+      for (int gp = 0; gp < 2; ++gp) {                                   // gq = 2 gp, 2 gp + 1
+        unsigned pc[2][WNP][2];                                          // [gq & 1][piece][dword]
+#pragma unroll
+        for (int g1 = 0; g1 < 2; ++g1) {
+          const int gq = 2 * gp + g1;
           const float4 a4 = *reinterpret_cast<const float4*>(al + wm * 32 * MT + 32 * mt + 8 * gq + 4 * half);
           const float av[4] = {a4.x, a4.y, a4.z, a4.w};
           float wn4[4];
@@ -556,21 +565,29 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
             }
             wn4[e] = w * av[e];
           }
-          if (wrow != nullptr && kt < wp_kt) {
-            unsigned char* q = wrow + (long)kt * (WNP * RC_PK_BLOCK) + ((gq ^ sw) << 4);
-            if constexpr (WP16) {
-              unsigned h0, l0, h1, l1;
-              rc_split2h_pair(wn4[0] * RC_F16_W_SCALE, wn4[1] * RC_F16_W_SCALE, h0, l0);
-              rc_split2h_pair(wn4[2] * RC_F16_W_SCALE, wn4[3] * RC_F16_W_SCALE, h1, l1);
-              *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
-              *reinterpret_cast<uint2*>(q + RC_PK_BLOCK) = make_uint2(l0, l1);
-            } else {
-              unsigned h0, m0, l0, h1, m1, l1;
-              rc_split3_pair(wn4[0], wn4[1], h0, m0, l0);
-              rc_split3_pair(wn4[2], wn4[3], h1, m1, l1);
-              *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
-              *reinterpret_cast<uint2*>(q + RC_PK_BLOCK) = make_uint2(m0, m1);
-              *reinterpret_cast<uint2*>(q + 2 * RC_PK_BLOCK) = make_uint2(l0, l1);
+          if constexpr (WP16) {
+            rc_split2h_pair(wn4[0] * RC_F16_W_SCALE, wn4[1] * RC_F16_W_SCALE, pc[g1][0][0], pc[g1][1][0]);
+            rc_split2h_pair(wn4[2] * RC_F16_W_SCALE, wn4[3] * RC_F16_W_SCALE, pc[g1][0][1], pc[g1][1][1]);
+          } else {
+            rc_split3_pair(wn4[0], wn4[1], pc[g1][0][0], pc[g1][1][0], pc[g1][2][0]);
+            rc_split3_pair(wn4[2], wn4[3], pc[g1][0][1], pc[g1][1][1], pc[g1][2][1]);
+          }
+        }
+        if (wp_out != nullptr && kt < wp_kt) {                            // (workgroup-uniform)
+#pragma unroll
+          for (int p = 0; p < WNP; ++p)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) rc_swap_halves(pc[0][p][dw], pc[1][p][dw]);
+          // now: half 0 holds chunk gq = 2 gp (own k 0..3 in pc[0], the partner's k 4..7 in pc[1]); half 1 chunk 2 gp + 1 (the
+          // partner's k 0..3 in pc[0], own k 4..7 in pc[1])
+          if (act) {
+            unsigned char* q = wrow + (long)kt * (WNP * RC_PK_BLOCK) + (((2 * gp + half) ^ sw) << 4);
+#pragma unroll
+            for (int p = 0; p < WNP; ++p)
+            {
+              uint4 v;
+              v.x = pc[0][p][0]; v.y = pc[0][p][1]; v.z = pc[1][p][0]; v.w = pc[1][p][1];
+              st_u4(q + p * RC_PK_BLOCK, v);
             }
           }
         }

@@ -296,9 +296,20 @@ __device__ __forceinline__ bool rc_all(bool v) {
 __device__ __forceinline__ int rc_opaque_v(int v) { return v; }
 __device__ __forceinline__ int rc_opaque_s(int v) { return v; }
 __device__ __forceinline__ void rc_touch(float&) {}
+__device__ __forceinline__ void rc_swap_halves(unsigned& a, unsigned& b) {      // (every lane of the wavefront must call it)
+  const unsigned pa = __shfl_xor(a, 32, 64), pb = __shfl_xor(b, 32, 64);
+  if (threadIdx.x & 32) a = pb; else b = pa;
+}
 #else
 __device__ __forceinline__ int rc_opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int rc_opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+// Exchange between the two lanes of a pair (lane, lane ^ 32): lanes 0-31 receive the partner's `a` in `b`, lanes 32-63 the partner's
+// `b` in `a` (v_permlane32_swap: lanes 32-63 of its first operand <-> lanes 0-31 of its second; one instruction, no LDS).
+__device__ __forceinline__ void rc_swap_halves(unsigned& a, unsigned& b) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = sw[0];
+  b = sw[1];
+}
 // a use of a loaded value that costs nothing: pins the compiler's s_waitcnt for it to this point of the program
 __device__ __forceinline__ void rc_touch(float& v) { asm volatile("" : "+v"(v)); }
 #endif
