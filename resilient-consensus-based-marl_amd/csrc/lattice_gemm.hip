@@ -531,7 +531,10 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
     // The forward operand of the next step: a lane's four consecutive k of one (mt, gq) are HALF a 16-byte chunk of the packed row
     // (the other half sits in lane ^ 32).  Round 5: the two lanes exchange halves (one v_permlane32_swap per dword) so that each
     // stores WHOLE chunks -- lane half 0 the even gq, half 1 the odd ones -- as 16-byte stores: half the store instructions and half
-    // the cache lines touched per byte (the store path is paced by lines touched per instruction, profiles/r05d_*, r05f_*).
+    // the cache lines touched per byte (the store path is paced by lines touched per instruction, profiles/r05d_*, r05f_*): 550 -> 500
+    // and 802 -> 733 us at the cfg-4 shapes, bit-identical (profiles/r05m_*).  (Also built: theta itself as float4 accesses -- the
+    // four lanes of a quad transpose their 4 x 4 old / new weights in registers by two DPP exchanges so that a lane holds one k and
+    // four consecutive columns: bit-identical, 515-523 / 754 us, i.e. SLOWER than the dword accesses; profiles/r05n_*.)
     unsigned char* wrow = wp_out == nullptr ? nullptr
         : wp_out + (long)s * wp_rt * wp_kt * (WNP * RC_PK_BLOCK) + (long)(colc >> 7) * wp_kt * (WNP * RC_PK_BLOCK) + (colc & 127) * 64;
     const int sw = (colc >> 2) & 3;
