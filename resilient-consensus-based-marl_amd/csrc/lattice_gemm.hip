@@ -123,17 +123,18 @@ __global__ __launch_bounds__(256) void k_w1_split(const float* __restrict__ thet
                                                   unsigned char* __restrict__ wp, int N, int in_dim, int ldp,
                                                   int wp_rt, int wp_kt, int hid) {
   const int s = blockIdx.z, rt = blockIdx.y, kt = blockIdx.x;
-  const int t = threadIdx.x, r = t & 127;
-  const int col = rt * 128 + r, ncols = N * hid;
-  const bool col_ok = col < ncols;
-  const int ag = col_ok ? col / hid : 0, j = col - ag * hid;
-  const float* th = theta + ((long)s * N + ag) * ldp + j;
-  constexpr int NP = F16 ? 2 : 3;
+  const int t = threadIdx.x, c4 = t & 3;               // four adjacent lanes = the four 16-byte chunks of one 64-byte packed row: a store
+  const int ncols = N * hid;                          // instruction touches 16 rows x 64 B instead of 64 rows x 16 B (a quarter of the
+  constexpr int NP = F16 ? 2 : 3;                      // cache lines; the store path is paced by lines touched)
   if (F16) rc_f16_saturate();
   unsigned char* blk = wp + (long)s * wp_rt * wp_kt * NP * RC_PK_BLOCK + ((long)rt * wp_kt + kt) * NP * RC_PK_BLOCK;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int c4 = (t >> 7) + 2 * q;
+    const int r = (t >> 2) + 64 * q;
+    const int col = rt * 128 + r;
+    const bool col_ok = col < ncols;
+    const int ag = col_ok ? col / hid : 0, j = col - ag * hid;
+    const float* th = theta + ((long)s * N + ag) * ldp + j;
     float w[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -534,7 +535,9 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
     // the cache lines touched per byte (the store path is paced by lines touched per instruction, profiles/r05d_*, r05f_*): 550 -> 500
     // and 802 -> 733 us at the cfg-4 shapes, bit-identical (profiles/r05m_*).  (Also built: theta itself as float4 accesses -- the
     // four lanes of a quad transpose their 4 x 4 old / new weights in registers by two DPP exchanges so that a lane holds one k and
-    // four consecutive columns: bit-identical, 515-523 / 754 us, i.e. SLOWER than the dword accesses; profiles/r05n_*.)
+    // four consecutive columns: bit-identical, 515-523 / 754 us, i.e. SLOWER than the dword accesses; profiles/r05n_*.  And a second
+    // exchange, lane ^ 16 (v_permlane16_swap), after which a store covers 16 rows x 64 B instead of 32 rows x 32 B: bit-identical,
+    // no further gain, 497 / 733 us; profiles/r05r_*.  What the operand still costs: 22 / 41 us of the launch, profiles/r05q_*.)
     unsigned char* wrow = wp_out == nullptr ? nullptr
         : wp_out + (long)s * wp_rt * wp_kt * (WNP * RC_PK_BLOCK) + (long)(colc >> 7) * wp_kt * (WNP * RC_PK_BLOCK) + (colc & 127) * 64;
     const int sw = (colc >> 2) & 3;
