@@ -415,6 +415,10 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
   // ds_read_b32 per element), row bases are wave-uniform (SGPR) and the lane part of the address is ONE 32-bit
   // offset, full tiles take no per-element predicate.  (The first version of this epilogue -- a branch, an LDS round
   // trip and a 64-bit multiply per element -- cost as much as the k-loop of a 512-deep GEMM: 176 of 832 us.)
+  // (Round 5, built and measured, bit-identical, NOT faster: the four lanes of a quad transposing each 4 x 4 block in registers
+  // (two DPP exchanges) so that a lane stores four consecutive replay rows of one column as one global_store_dwordx4 -- 16 stores of
+  // eight full cache lines per wavefront tile instead of 64 of two: 496 / 696 us against 473 / 683, profiles/r05s_*; and the
+  // operand-swapped kernel whose accumulators are born that way but whose 16-byte stores cover 32 rows: 876 us, profiles/r05d_*.)
   const int lane = threadIdx.x & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave / WN, wn = wave % WN;
   float bv[MT][16];
