@@ -199,7 +199,7 @@ def compare(eng, logs, o_logs, o_weights, rtol_w=1e-4, actor="strict", outlier_f
             frac = float(np.mean(e > 0.05 * lr * steps + 1e-5))
             assert frac <= actor_outlier_frac, ("actor outliers", frac, float(e.max()))
             print("[parity] actor (statistical bar): %.2e of the parameters beyond 5 %% of an Adam step (bar %.0e), max |err| %.2e = %.2f steps"
-                  % (frac, actor_outlier_frac, float(e.max()), float(e.max()) / (lr * steps)))
+                  % (frac, actor_outlier_frac, float(e.max()), float(e.max()) / max(lr * steps, 1e-30)))
     n_out = len({(s_, i_, net_) for s_, i_, net_, _ in outliers})
     assert n_out <= outlier_frac * n_nets, ("networks beyond rtol_w", n_out, n_nets, outliers[:5])
     print("[parity] N=%d S=%d worst |w - w_oracle| / max(1,|w|max): critic %.2e  tr %.2e%s  (bar %.0e%s)"
