@@ -633,7 +633,10 @@ def _brief(o):
 
 BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA, MI355X_MICROARCH.md
 BF16_SUSTAINED_TFLOPS = 1780.0  # measured on this pool: pure v_mfma_f32_32x32x16_bf16 loops on all SIMDs with operands that
-#                                 change every instruction (tools/micro/mfma_peak.hip; 2100 with constant operands)
+#                                 change every instruction (tools/micro/mfma_peak.hip; 2100 with constant operands).  It is a POWER
+#                                 limit: that stream runs at an effective 1.79 GHz with the matrix pipe 97 % busy (2.09 GHz with
+#                                 constant operands; GRBM_GUI_ACTIVE / duration, profiles/r05_mfma_peak_clock.txt); the lattice GEMMs
+#                                 themselves clock at 1.45-1.6 GHz (roofline*.counters)
 
 # kernel -> (bound, note).  "mfma_pieces": fp32-equivalent flops 2MNK against the 16-bit dense peak (f16 = bf16 rate); the kernel
 # EXECUTES as many times those flops as the fp32 operand has 16-bit pieces (2 f16, or 3 bf16), so its ceiling is peak / pieces.
@@ -738,7 +741,8 @@ def rooflines(tlib, ksum, workload=None):
                     "executed": {"achieved": npc * ach, "frac": npc * ach / BF16_PEAK_TFLOPS,
                                  "frac_of_measured_sustained_peak": npc * ach / BF16_SUSTAINED_TFLOPS,
                                  "what": "16-bit MFMA flops actually issued = %d x algorithmic; sustained peak = %.0f TFLOP/s "
-                                         "measured with tools/micro/mfma_peak.hip (f16 and bf16 MFMA issue at the same rate)"
+                                         "measured with tools/micro/mfma_peak.hip at an effective 1.79 GHz (a power limit: "
+                                         "profiles/r05_mfma_peak_clock.txt); `counters` has this kernel's own clock and pipe-busy fraction"
                                          % (npc, BF16_SUSTAINED_TFLOPS)},
                     "note": "fp32 GEMM as %d passes of v_mfma_f32_32x32x16_%s (integer-lattice operand x %s, fp32 accumulate): "
                             "achieved = fp32-equivalent 2MNK flops; ceiling of the method = 16-bit dense peak / %d = %.0f TFLOP/s; "

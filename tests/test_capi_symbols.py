@@ -43,6 +43,7 @@ def test_argument_validation_needs_no_gpu():
     from rcmarl_amd import build, capi
     lib = capi.CLib(build.build_hip())
     bad = [
+        ("rcmarl_minibatch_fit_multi", (None, 3, 1, 5, 100, 20, 128, 32, 10, 0.01, None)),
         ("rcmarl_consensus_params", (None, None, None, None, 1, 5, 64, 40, 4, 1, None, None, None)),
         ("rcmarl_layer1_forward", (None, 0, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
         ("rcmarl_lattice_encode", (None, 0, None, 1, 100, 10, None, 0, 0, None, 0, 0, None, None)),
