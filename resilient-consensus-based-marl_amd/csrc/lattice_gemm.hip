@@ -472,13 +472,16 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
 // ---- backward: A = K^T (rows = features), B = dz1 pieces (rows = (agent,unit) columns) ----------
 // 256 x 128 block tile.  Default: four wavefronts of 128 x 64 with the spread LDS-DMA issue (875 -> 824 us in a block);
 // W8 (eight wavefronts of 64 x 64): 780 / 1103 against 756 / 1103 us -- the alternative.
-template <bool W8, bool DZ16, bool WP16>
+// M128 (four-wavefront form only): 128 x 128 block tiles for networks of at most 128 inputs (BASELINE configs[2]'s critic: 64 agents,
+// 128 inputs) -- the 256-row tile would spend half its matrix work on rows beyond the input width.
+template <bool W8, bool DZ16, bool WP16, bool M128 = false>
 __global__ RC_LAT_OCC(W8 ? 512 : 256, W8 ? 4 : 2)
 void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int ktp_kt, const unsigned char* __restrict__ dzp,
                         int dzp_rt, int dzp_kt, const float* __restrict__ alpha, float* __restrict__ theta,
                         const int* __restrict__ mask, int S, int N, int B, int in_dim, int ldp, float lr, int mtiles, int ntiles,
                         unsigned char* __restrict__ wp_out, int wp_rt, int wp_kt, int hid) {
-  constexpr int PA = 1, PB = DZ16 ? 2 : 3, MT = W8 ? 2 : 4, NT = 2, WM = W8 ? 4 : 2, WN = 2;
+  static_assert(!(W8 && M128), "the 128-row tile exists in the four-wavefront form");
+  constexpr int PA = 1, PB = DZ16 ? 2 : 3, MT = W8 ? 2 : (M128 ? 2 : 4), NT = 2, WM = W8 ? 4 : 2, WN = 2;
   constexpr int WNP = WP16 ? 2 : 3;                                 // pieces of the forward operand written by the epilogue
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
@@ -613,6 +616,7 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
 
 // RCMARL_LAT_W8=0 / 1 forces the four- / eight-wavefront form of both kernels (read at every call: tests switch it);
 // default: forward eight, backward four (see the kernels' comments).
+int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 bool lat_w8(bool forward) { const char* e = getenv("RCMARL_LAT_W8"); return e ? atoi(e) != 0 : forward; }
 
 template <bool W8, bool F16>
@@ -633,14 +637,14 @@ int launch_forward(unsigned nblocks, void* stream, const unsigned char* wp, int 
 #undef RC_LAT_PROTO_LAUNCHERS
 #endif
 
-template <bool W8, bool DZ16, bool WP16>
+template <bool W8, bool DZ16, bool WP16, bool M128 = false>
 int launch_backward(unsigned nblocks, void* stream, const unsigned char* ktp, int ktp_rt, int ktp_kt, const unsigned char* dzp,
                     int dzp_rt, int dzp_kt, const float* alpha, float* theta, const int* mask, int S, int N, int B, int in_dim,
                     int ldp, float lr, int mtiles, int ntiles, unsigned char* wp_out, int wp_rt, int wp_kt, int hid) {
   const size_t smem = (size_t)2 * LatCfg<1, DZ16 ? 2 : 3, 4, 2>::STAGE_BYTES;
-  static const bool ok = rc_want_lds(k_lat_backward_sgd<W8, DZ16, WP16>, smem);
+  static const bool ok = rc_want_lds(k_lat_backward_sgd<W8, DZ16, WP16, M128>, smem);
   if (!ok) return RCMARL_ERR_LAUNCH;
-  RCMARL_LAUNCH((k_lat_backward_sgd<W8, DZ16, WP16>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, ktp, ktp_rt, ktp_kt, dzp,
+  RCMARL_LAUNCH((k_lat_backward_sgd<W8, DZ16, WP16, M128>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, ktp, ktp_rt, ktp_kt, dzp,
                 dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, DZ16 ? lr * RC_F16_DZ_UNSCALE : lr, mtiles, ntiles,
                 wp_out, wp_rt, wp_kt, hid);
   return rcmarl_check_launch();
@@ -771,6 +775,20 @@ static int backward_sgd_lattice_impl(const void* ktp, int ktp_rt, int ktp_kt, co
   launch_backward<W8, DZ16, WP16>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, \
                                   dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,                     \
                                   (unsigned char*)wp_out, wp_rt, wp_kt, hid)
+  // at most 128 inputs: 128-row tiles (mtiles is 1 either way; RCMARL_LAT_M128=0 keeps the 256-row tile)
+  if (!w8 && in_dim <= 128 && lat_env_int("RCMARL_LAT_M128", 1) != 0) {
+#define RC_BWD128(DZ16, WP16)                                                                                                  \
+  launch_backward<false, DZ16, WP16, true>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp,  \
+                                           dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,       \
+                                           (unsigned char*)wp_out, wp_rt, wp_kt, hid)
+    switch (mode) {
+      case 0: return RC_BWD128(false, false);
+      case 1: return RC_BWD128(false, true);
+      case 2: return RC_BWD128(true, false);
+      default: return RC_BWD128(true, true);
+    }
+#undef RC_BWD128
+  }
   switch (mode * 2 + (w8 ? 1 : 0)) {
     case 0: return RC_BWD(false, false, false);
     case 1: return RC_BWD(true, false, false);

@@ -192,6 +192,14 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_fo
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 
+@pytest.mark.parametrize("m128", ["0", "1"])
+def test_lattice_backward_both_tile_heights(bk, m128, monkeypatch):
+    """Networks of at most 128 inputs take 128-row tiles in the backward GEMM (RCMARL_LAT_M128=0: the 256-row tile of the wide
+    inputs): the same products in the same k order, the same oracle fit either way."""
+    monkeypatch.setenv("RCMARL_LAT_M128", m128)
+    KC.check_lattice_sgd_fit(bk, 1, 7, 130, 2, 5, 5, steps=2, masked_agent=2)
+
+
 @pytest.mark.parametrize("w8", ["0", "1"])
 def test_lattice_gemms_both_wavefront_shapes(bk, w8, monkeypatch):
     monkeypatch.setenv("RCMARL_LAT_W8", w8)
