@@ -763,20 +763,23 @@ static int backward_sgd_lattice_impl(const void* ktp, int ktp_rt, int ktp_kt, co
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
   if (hid <= 0) return RCMARL_ERR_ARG;
-  const int mtiles = rc_ceil_div(in_dim, 256), ntiles = rc_ceil_div(N * hid, 128), ktiles = rc_ceil_div(B, 32);
-  if (ktp_rt < 2 * mtiles || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
+  const bool w8 = lat_w8(false);
+  const int m128_env = lat_env_int("RCMARL_LAT_M128", 1);           // 1: 128-row tiles up to 128 inputs; 0: never; 2: always (measurement)
+  const bool m128 = !w8 && ((in_dim <= 128 && m128_env != 0) || m128_env == 2);
+  const int mtiles = m128 ? rc_ceil_div(in_dim, 128) : rc_ceil_div(in_dim, 256);
+  const int ntiles = rc_ceil_div(N * hid, 128), ktiles = rc_ceil_div(B, 32);
+  if (ktp_rt < (m128 ? mtiles : 2 * mtiles) || dzp_rt < ntiles || ktp_kt < ktiles || dzp_kt < ktiles) return RCMARL_ERR_ARG;
   if (wp_out && ((long)wp_rt * 128 < (long)ntiles * 128 || wp_kt < rc_ceil_div(in_dim, 32))) return RCMARL_ERR_ARG;
   const unsigned nb = (unsigned)(S * mtiles * ntiles);
   const int mode = rc_lat_f16_mode();
-  const bool w8 = lat_w8(false);
   if (!rc_form_ok(ktp, (mode >> 1) & 1) || !rc_form_ok(dzp, (mode >> 1) & 1)) return RCMARL_ERR_ARG;   // written in the other operand form
   rc_form_set(wp_out, mode & 1);
 #define RC_BWD(W8, DZ16, WP16)                                                                                              \
   launch_backward<W8, DZ16, WP16>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp, dzp_rt, \
                                   dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,                     \
                                   (unsigned char*)wp_out, wp_rt, wp_kt, hid)
-  // at most 128 inputs: 128-row tiles (mtiles is 1 either way; RCMARL_LAT_M128=0 keeps the 256-row tile)
-  if (!w8 && in_dim <= 128 && lat_env_int("RCMARL_LAT_M128", 1) != 0) {
+  // at most 128 inputs: 128-row tiles (RCMARL_LAT_M128=0 keeps the 256-row tile)
+  if (m128) {
 #define RC_BWD128(DZ16, WP16)                                                                                                  \
   launch_backward<false, DZ16, WP16, true>(nb, stream, (const unsigned char*)ktp, ktp_rt, ktp_kt, (const unsigned char*)dzp,  \
                                            dzp_rt, dzp_kt, alpha, theta, mask, S, N, B, in_dim, ldp, lr, mtiles, ntiles,       \
