@@ -418,7 +418,10 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
   // (Round 5, built and measured, bit-identical, NOT faster: the four lanes of a quad transposing each 4 x 4 block in registers
   // (two DPP exchanges) so that a lane stores four consecutive replay rows of one column as one global_store_dwordx4 -- 16 stores of
   // eight full cache lines per wavefront tile instead of 64 of two: 496 / 696 us against 473 / 683, profiles/r05s_*; and the
-  // operand-swapped kernel whose accumulators are born that way but whose 16-byte stores cover 32 rows: 876 us, profiles/r05d_*.)
+  // operand-swapped kernel whose accumulators are born that way but whose 16-byte stores cover 32 rows: 876 us, profiles/r05d_*.
+  // The NON-TEMPORAL hint of these stores is worth 16 %: plain stores 535 / 716 us against 460 / 675 -- they push the operand panels
+  // out of the L2 (profiles/r05w_*).  The backward is the other way round: its theta / Wp stores as non-temporal ones cost +5..10 %
+  // (profiles/r05x_*).)
   const int lane = threadIdx.x & 63, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave / WN, wn = wave % WN;
   float bv[MT][16];
