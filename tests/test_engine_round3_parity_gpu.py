@@ -55,6 +55,8 @@ def test_engine_cfg3_steady_state_B3000_vs_oracle():
 
 
 def test_actor_gradient_at_256_agents_vs_oracle():
-    worst = EC.check_actor_gradient(256, 18, 8, 32, "cuda", None, fast_lr=0.0025)
-    print("[parity] actor gradient end to end (Adam m after one step) at 256 agents: worst max|dm| / max|m| = %.2e (bar 2e-3; "
-          "identical-input kernel bar 1e-4: test_actor_step)" % worst)
+    # round 5: measured median 1.2e-6, worst 4.95e-6 (profiles/r05_parity_worst_cases.txt; round 3's build: 8.3e-4, hence its 2e-3):
+    # the bar is the identical-input kernel bar now, 1e-4 (a LeakyReLU knife edge may still move one gradient column: <= 2 % of the agents)
+    worst = EC.check_actor_gradient(256, 18, 8, 32, "cuda", None, fast_lr=0.0025, rtol=1e-4)
+    print("[parity] actor gradient end to end (Adam m after one step) at 256 agents: worst max|dm| / max|m| = %.2e (bar 1e-4 = the "
+          "identical-input kernel bar of test_actor_step)" % worst)
