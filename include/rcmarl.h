@@ -33,7 +33,8 @@ extern "C" {
 #define RCMARL_ERR_LAUNCH 2       /* hipGetLastError() != hipSuccess after the launch */
 #define RCMARL_ERR_UNSUPPORTED 3  /* shape outside the compiled kernels (hid != 20, n_actions != 5, ...) */
 
-int rcmarl_abi_version(void);
+int rcmarl_abi_version(void);                          /* 3 (round 5): ABI 2 minus the fused local-fit prototypes, plus
+                                                        * rcmarl_minibatch_fit_multi and rcmarl_lattice_forget */
 int rcmarl_fit_partial_size(int hid);                  /* floats per partial record of rcmarl_mid_fit */
 int rcmarl_actor_partial_size(int hid, int n_actions); /* floats per partial record of rcmarl_mid_actor */
 int rcmarl_rows_per_chunk(void);                       /* replay rows per workgroup (256); nchunk = ceil(B/256) */
