@@ -5,6 +5,8 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
 TAG=${1:-r05}
+[ -x tools/micro/lat_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/micro/lat_bench.hip -o tools/micro/lat_bench -ldl 2> /dev/null
+[ -x tools/micro/mfma_peak ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/micro/mfma_peak.hip -o tools/micro/mfma_peak 2> /dev/null
 echo "== lattice GEMM counters (both shapes, final build)"
 bash tools/gpu_pmc_latbench.sh ${TAG} both X=1 > gpurun_out/${TAG}_pmc_latbench.txt 2>&1
 grep -E "^k_lat|eff_clock|mfma_busy|l2_hit|avg_us" gpurun_out/${TAG}_pmc_latbench.txt

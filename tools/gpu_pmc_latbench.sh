@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 L=$R/resilient-consensus-based-marl_amd/lib/librcmarl_hip.so
 mkdir -p $R/gpurun_out/pmclb
+[ -x $R/tools/micro/lat_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $R/tools/micro/lat_bench.hip -o $R/tools/micro/lat_bench -ldl 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 export LB_ITERS=${LB_ITERS:-5}
 i=0
