@@ -33,8 +33,9 @@ extern "C" {
 #define RCMARL_ERR_LAUNCH 2       /* hipGetLastError() != hipSuccess after the launch */
 #define RCMARL_ERR_UNSUPPORTED 3  /* shape outside the compiled kernels (hid != 20, n_actions != 5, ...) */
 
-int rcmarl_abi_version(void);                          /* 3 (round 5): ABI 2 minus the fused local-fit prototypes, plus
-                                                        * rcmarl_minibatch_fit_multi and rcmarl_lattice_forget */
+int rcmarl_abi_version(void);                          /* 4 (round 6): ABI 3 (= ABI 2 minus the fused local-fit prototypes, plus
+                                                        * rcmarl_minibatch_fit_multi and rcmarl_lattice_forget) plus the packed-operand
+                                                        * dense layers of wide networks, rcmarl_pk_* */
 int rcmarl_fit_partial_size(int hid);                  /* floats per partial record of rcmarl_mid_fit */
 int rcmarl_actor_partial_size(int hid, int n_actions); /* floats per partial record of rcmarl_mid_actor */
 int rcmarl_rows_per_chunk(void);                       /* replay rows per workgroup (256); nchunk = ceil(B/256) */
@@ -353,6 +354,50 @@ int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float
 int rcmarl_wide_head_apply(const float* grads, float* theta, const int* coop, int S, int N, int B, int in_dim, int hid,
                            int ldp, void* stream);
 
+
+/* ---- wide networks on PRE-SPLIT packed operands (ABI 4, round 6) -- csrc/dense_pk.hip ------------------------------------------
+ * The same reference functions as the block above (one full-batch SGD step of fit(), agents/resilient_CAC_agents.py:103-122, and
+ * model(x), :95-97,114) for a hidden width that is a multiple of 128 in the two-piece f16 operand form: every GEMM operand reaches
+ * its kernel as packed f16 pieces written by the epilogue of the kernel that produced it ("PK" blocks of 8 KiB:
+ * [rows/128][k/32][pieces][128 rows][32 k], 16-byte chunks XOR-swizzled; csrc/rcmarl_lattice.h), and the GEMMs run the LDS-DMA main
+ * loop of the layer-1 lattice kernels.  Neither a2 nor dz2 is ever stored: LeakyReLU' takes two values, so the layer-2 masks travel as
+ * ONE 16-bit piece and dz2 = W3 dz3 lrelu'(z2) is re-formed inside the consumers (csrc/dense_pk.hip has the algebra).
+ * Z = S*N below; Bp = B rounded up to 256; JT = hid/128; JK = hid/32.
+ *   a1_bk [Z][bk_rt >= Bp/128][JK][2][8 KiB]   rows = replay row, reduction = unit: two f16 pieces of 2^6 a1
+ *   a1_kb [Z][JT][kb_kt >= Bp/32][2][8 KiB]    rows = unit, reduction = replay row
+ *   s1    [Z*hid][s1_ld >= Bp/32] uint32       sign bits of a1 (bit b & 31 of word b >> 5)
+ *   w2t, w2w3 [Z][JT][JK][2][8 KiB]            2^10 W2 (rows = j, reduction = k) / 2^10 W2[k][j] W3[j] (rows = k, reduction = j)
+ *   mask_bj [Z][mbj_rt >= Bp/128][JK][8 KiB]   [z2 > 0] as f16 1.0 / 0;  mask_jb [Z][JT][mjb_kt >= Bp/32][8 KiB] as 0xffff / 0
+ *   vpart [Z][JT][ldb], dzv [Z][4][Bp] uint16, gw3part [Z][JT][hid], q [Z][hid], rs [Z][hid], gb1part [Z][ceil(B/128)][hid]
+ * Every buffer must be readable over its whole extent (allocate zero-filled). */
+int rcmarl_pk_supported(int hid);        /* 1: hid % 128 == 0 and the lattice path is in its two-piece f16 form (RCMARL_LAT_F16 = 3) */
+/* the layer-1 lattice forward GEMM (rcmarl_layer1_forward_lattice) whose epilogue writes a1_bk / a1_kb / s1 (each optional)
+ * INSTEAD of the fp32 activations */
+int rcmarl_layer1_forward_lattice_pk(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt, const float* theta,
+                                     void* a1_bk, int bk_rt, void* a1_kb, int kb_kt, unsigned* s1, int s1_ld, int S, int N, int B,
+                                     int in_dim, int hid, int ldp, void* stream);
+/* W2, W3 of theta[s][n] -> w2t, w2w3, rs[k] = sum_j W2[k][j] W3[j] */
+int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, float* rs, int S, int N, int in_dim, int hid, int ldp, void* stream);
+/* layer 2 forward; outputs, each optional: a2 (fp32 feature-major [S][N*hid][ldb]: phi of rcmarl_wide_consensus_head), mask_bj,
+ * mask_jb, vpart (per 128-unit tile: sum_j a2[j][b] W3[j]) */
+int rcmarl_pk_forward2(const void* w2t, const void* a1_bk, int bk_rt, const float* theta, float* a2, void* mask_bj, int mbj_rt,
+                       void* mask_jb, int mjb_kt, float* vpart, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+/* V = sum_t vpart[t] + b3.  mode 0: out = V; 1: out = aux + gamma V (TD target, :114-115); 2: MSE head of fit() with aux = y:
+ * out = dz3 = 2 (V - y) / B, dzv = f16 pieces of 2^8 dz3 and 2^8 (0.1 dz3), losspart [Z][ceil(B/256)] */
+int rcmarl_pk_head(const float* vpart, const float* theta, const float* aux, float gamma, int mode, float* out, void* dzv,
+                   float* losspart, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+/* dz1 = lrelu'(a1) W2 dz2 straight into the lattice backward GEMM's operand dzp ([S][dzp_rt][dzp_kt][2][8 KiB], rows = n*hid + unit)
+ * + gb1part (sums of dz1 over each tile of 128 replay rows) */
+int rcmarl_pk_backward_data(const void* mask_bj, int mbj_rt, const void* w2w3, const float* rs, const unsigned* s1, int s1_ld,
+                            const float* dz3, void* dzp, int dzp_rt, int dzp_kt, float* gb1part, int S, int N, int B, int hid, int ldb,
+                            void* stream);
+/* W2 -= lr a1^T dz2 (agents with mask[n] != 0; NULL: all); gw3part and q carry the head's and b2's gradients to rcmarl_pk_small_sgd */
+int rcmarl_pk_backward_w2(const void* a1_kb, int kb_kt, const void* mask_jb, int mjb_kt, const void* dzv, float* theta, const int* mask,
+                          float* gw3part, float* q, int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream);
+/* b1, b2, W3, b3 -= lr grad (masked agents); loss_out [S][N] = sum(losspart) / B if not NULL */
+int rcmarl_pk_small_sgd(const float* gw3part, const float* q, const float* gb1part, const float* dz3, const float* losspart, float* theta,
+                        const int* mask, float* loss_out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, float lr,
+                        void* stream);
 
 /* C2 (one instance over several GPUs): the pack / unpack pass of the two all-to-all transposes of the message
  * matrix, which replace the reference's in-process gather `[critic_weights[i] for i in in_nodes[node]]`

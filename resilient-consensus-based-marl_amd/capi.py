@@ -171,13 +171,35 @@ SIGNATURES = {
                                    c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # grads, theta, coop, S, N, B, in_dim, hid, ldp, stream
     "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # ---- wide networks on pre-split packed operands (csrc/dense_pk.hip) -----------------------------------
+    "rcmarl_pk_supported": [c_int],
+    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1_bk, bk_rt, a1_kb, kb_kt, s1, s1_ld, S, N, B, in_dim, hid, ldp, stream
+    "rcmarl_layer1_forward_lattice_pk": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_u8p, c_int, c_u8p, c_int, c_i32p, c_int,
+                                         c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # theta, w2t, w2w3, rs, S, N, in_dim, hid, ldp, stream
+    "rcmarl_pk_pack_w2": [c_f32p, c_u8p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # w2t, a1_bk, bk_rt, theta, a2, mask_bj, mbj_rt, mask_jb, mjb_kt, vpart, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_pk_forward2": [c_u8p, c_u8p, c_int, c_f32p, c_f32p, c_u8p, c_int, c_u8p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_int,
+                           c_int, c_int, c_stream],
+    # vpart, theta, aux, gamma, mode, out, dzv, losspart, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_pk_head": [c_f32p, c_f32p, c_f32p, c_float, c_int, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                       c_stream],
+    # mask_bj, mbj_rt, w2w3, rs, s1, s1_ld, dz3, dzp, dzp_rt, dzp_kt, gb1part, S, N, B, hid, ldb, stream
+    "rcmarl_pk_backward_data": [c_u8p, c_int, c_u8p, c_f32p, c_i32p, c_int, c_f32p, c_u8p, c_int, c_int, c_f32p, c_int, c_int, c_int,
+                                c_int, c_int, c_stream],
+    # a1_kb, kb_kt, mask_jb, mjb_kt, dzv, theta, mask, gw3part, q, S, N, B, in_dim, hid, ldp, lr, stream
+    "rcmarl_pk_backward_w2": [c_u8p, c_int, c_u8p, c_int, c_u8p, c_f32p, c_i32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_float, c_stream],
+    # gw3part, q, gb1part, dz3, losspart, theta, mask, loss_out, S, N, B, in_dim, hid, ldp, ldb, lr, stream
+    "rcmarl_pk_small_sgd": [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_float, c_stream],
     # ---- sharded instance (csrc/shard_pack.hip) ----------------------------------------------------------
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_lattice_forget", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
              "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk", "rcmarl_wide_f16_mode", "rcmarl_wide_set_f16_mode",
-             "rcmarl_consensus_params_circulant_supported"}
+             "rcmarl_consensus_params_circulant_supported", "rcmarl_pk_supported"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",
           3: "RCMARL_ERR_UNSUPPORTED (shape outside the compiled kernels)"}

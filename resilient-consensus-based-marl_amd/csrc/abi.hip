@@ -4,7 +4,7 @@
 #include <stdlib.h>
 #include <mutex>
 
-RCMARL_EXPORT int rcmarl_abi_version(void) { return 3; }
+RCMARL_EXPORT int rcmarl_abi_version(void) { return 4; }
 
 namespace {
 std::mutex g_mu;

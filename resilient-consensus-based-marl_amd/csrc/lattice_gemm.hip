@@ -19,13 +19,12 @@
 // Workgroups are numbered so that all tiles of one seed run on ONE XCD (block b -> XCD b%8): the
 // seed's small operand (K, 3 MB) stays in that XCD's L2 and the big one streams through once.
 #include "rcmarl_lattice.h"
+#include "rcmarl_lat_mainloop.h"
 #include <type_traits>
 #include <stdlib.h>
 
 namespace {
 
-__device__ __forceinline__ uint4 ld_u4(const unsigned char* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ void st_u4(unsigned char* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 __device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) { return (lo & 0xffffu) | (hi << 16); }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,166 +220,24 @@ __global__ __launch_bounds__(256) void k_dz_pack_rowsum(const float* __restrict_
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// WM x WN wavefronts per workgroup, each owning MT x NT accumulator blocks of 32 x 32
-template <int PA, int PB, int MT, int NT, int WM = 2, int WN = 2> struct LatCfg {
-  static constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NWV = WM * WN;
-  static_assert(BM % 128 == 0 && BN % 128 == 0, "block tile sides are multiples of 128");
-  static constexpr int ART = BM / 128, BRT = BN / 128;              // 128-row tiles per block side
-  static constexpr int A_KB = ART * PA * 8, B_KB = BRT * PB * 8;    // KiB per k-tile stage
-  static constexpr int STAGE_KB = A_KB + B_KB, STAGE_BYTES = STAGE_KB * 1024;
-  static constexpr int GLDS = STAGE_KB / NWV;                       // 1-KiB bursts per wavefront per stage
-  static_assert(STAGE_KB % NWV == 0, "stage splits evenly over the wavefronts");
-};
-
-struct LatOperands {
-  const unsigned char* a; const unsigned char* b;   // seed base of each packed operand
-  int a_kt, b_kt;                                   // allocated k-tiles (block stride along the row-tile axis)
-  int art0, brt0;                                   // first 128-row tile of this workgroup on each side
-};
-
-// The k-loop: two LDS stages filled by LDS-DMA, one barrier per k-tile.
-// SPREAD: the LDS-DMA bursts of the next k-tile are issued one at a time BETWEEN the matrix-core instructions of the first
-// half of this k-tile instead of back to back right after the barrier (an LDS-DMA instruction blocks the wavefront's issue
-// for 60-180 cycles; in a burst those add up while no MFMA of this wavefront is in flight).  Measured: -2..-4 % on the
-// backward, +1..+8 % on the forward; bit-identical either way.
-// (Round 2 built and measured, then round 3 removed: a 3-stage ring, a ring of four half-stages with counted vmcnt, the
-// three-piece operand's fragments loaded global -> registers, 256 x 256 and 512 x 128 tiles with eight wavefronts,
-// persistent workgroups, start staggers, static priorities, L2 prefetch touches -- all within -15..+0 % of this form;
-// DESIGN.md section 5 keeps the numbers.  Round 5, on the forward (profiles/r05g_*): the second half of the wavefronts requesting
-// the next stage BEHIND its matrix work instead of in front of it +5..+9 %, static priority for that half +4..+6 %.)
-template <int PA, int PB, int MT, int NT, int WM, int WN, bool SPREAD, bool F16>
-__device__ __forceinline__ void lat_mainloop(const LatOperands& op, int n_ktiles, unsigned char* lds,
-                                             rc_f32x16 (&acc)[MT][NT]) {
-  typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wm = wave / WN, wn = wave % WN;
-  const int l31 = lane & 31, half = lane >> 5;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-
-  // wave-uniform source of each of this wavefront's bursts at k-tile 0, and its per-k-tile advance
-  const unsigned char* gsrc[C::GLDS];
-  int gstep[C::GLDS];
-#pragma unroll
-  for (int i = 0; i < C::GLDS; ++i) {
-    const int q = wave + C::NWV * i;
-    if (q < C::A_KB) {
-      const int seg = q / (PA * 8), off = q - seg * (PA * 8);
-      gsrc[i] = op.a + ((long)(op.art0 + seg) * op.a_kt) * (PA * RC_PK_BLOCK) + off * 1024;
-      gstep[i] = PA * RC_PK_BLOCK;
-    } else {
-      const int q2 = q - C::A_KB;
-      const int seg = q2 / (PB * 8), off = q2 - seg * (PB * 8);
-      gsrc[i] = op.b + ((long)(op.brt0 + seg) * op.b_kt) * (PB * RC_PK_BLOCK) + off * 1024;
-      gstep[i] = PB * RC_PK_BLOCK;
-    }
-  }
-  const unsigned lane16 = lane * 16;
-  const rc_lds_t lds0 = rc_lds_addr(lds) + wave * 1024;
-  auto stage = [&](int buf, int t) {
-    const rc_lds_t dst = lds0 + buf * C::STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < C::GLDS; ++i) RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, dst + i * (C::NWV * 1024));
-  };
-  auto stage_one = [&](int buf, int t, int i) {
-    RC_GLDS16S(gsrc[i] + (long)t * gstep[i], lane16, lds0 + buf * C::STAGE_BYTES + i * (C::NWV * 1024));
-  };
-  constexpr int N_MFMA = 2 * PA * PB * MT * NT;                 // matrix-core instructions of a wavefront per k-tile
-  constexpr int EVERY = (N_MFMA / 2) / C::GLDS > 0 ? (N_MFMA / 2) / C::GLDS : 1;     // all bursts within the first half
-  static_assert(!SPREAD || EVERY * C::GLDS <= N_MFMA, "spread issue: every burst has a slot");
-
-  // fragment addresses: row = lane&31 (+ tile offsets), chunk = 2*kstep + lane>>5, XOR (row>>2)&3
-  const int sw = (l31 >> 2) & 3;
-  const int co0 = ((0 + half) ^ sw) << 4, co1 = ((2 + half) ^ sw) << 4;
-  int offA[MT], offB[NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = wm * 32 * MT + 32 * mt + l31;
-    offA[mt] = (row >> 7) * PA * RC_PK_BLOCK + (row & 127) * 64;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int row = wn * 32 * NT + 32 * nt + l31;
-    offB[nt] = C::A_KB * 1024 + (row >> 7) * PB * RC_PK_BLOCK + (row & 127) * 64;
-  }
-
-  stage(0, 0);
-  for (int t = 0; t < n_ktiles; ++t) {
-    const int cur = t & 1;
-    RC_WAIT_VMEM();                 // this wavefront's bursts of tile t have landed ...
-    __syncthreads();                // ... and everybody's; all reads of the buffer refilled next are done
-    const bool more = t + 1 < n_ktiles;
-    if (more && !SPREAD) stage(cur ^ 1, t + 1);
-    const unsigned char* st = lds + cur * C::STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int co = ks == 0 ? co0 : co1;
-      uint4 af[MT][PA], bf[NT][PB];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int p = 0; p < PA; ++p) af[mt][p] = ld_u4(st + offA[mt] + p * RC_PK_BLOCK + co);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int p = 0; p < PB; ++p) bf[nt][p] = ld_u4(st + offB[nt] + p * RC_PK_BLOCK + co);
-      // smallest pieces first; consecutive MFMAs hit different accumulators
-#pragma unroll
-      for (int pa = PA - 1; pa >= 0; --pa)
-#pragma unroll
-        for (int pb = PB - 1; pb >= 0; --pb)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[mt][nt] = F16 ? rc_mfma_f16(af[mt][pa], bf[nt][pb], acc[mt][nt]) : rc_mfma_bf16(af[mt][pa], bf[nt][pb], acc[mt][nt]);
-              if constexpr (SPREAD) {
-                const int o = ks * (PA * PB * MT * NT) + (((PA - 1 - pa) * PB + (PB - 1 - pb)) * MT + mt) * NT + nt;
-                if (o % EVERY == EVERY - 1 && o / EVERY < C::GLDS) {
-                  RC_SCHED_FENCE();
-                  if (more) stage_one(cur ^ 1, t + 1, o / EVERY);
-                  RC_SCHED_FENCE();
-                }
-              }
-            }
-    }
-  }
-}
-
-// workgroup id -> (seed, tile w within the seed); all tiles of a seed on one XCD when S % 8 == 0
-__device__ __forceinline__ void lat_decode(int g, int per_seed, int S, int& seed, int& w) {
-  if ((S & 7) == 0) {
-    const int xcd = g & 7, q = g >> 3;
-    seed = xcd + 8 * (q / per_seed);
-    w = q % per_seed;
-  } else {
-    seed = g / per_seed;
-    w = g - seed * per_seed;
-  }
-}
-
-// explicit work-group size + waves per SIMD (with __launch_bounds__(512, 2) hipcc allots 129 registers to an eight-wavefront
-// form, one too many for the four wavefronts per SIMD that two such workgroups per CU need)
-#ifdef RCMARL_EMU
-#define RC_LAT_OCC(threads, waves)
-#else
-#define RC_LAT_OCC(threads, waves) __attribute__((amdgpu_flat_work_group_size(threads, threads), amdgpu_waves_per_eu(waves)))
-#endif
-
 // ---- forward: A = W' pieces (rows = (agent,unit) columns), B = K (rows = replay rows) ----------
 // 128 x 256 block tile, two 40-KiB stages, two workgroups per CU.  W8: eight wavefronts of 64 x 64 (four per SIMD) instead
 // of four of 64 x 128: measured 749 / 988 us against 776 / 1037 at the two cfg-4 shapes -> the forward's default.
-template <bool W8, bool F16>
+// PK (wide networks, hid a multiple of 128, two-piece f16 form; dense_pk.hip consumes them): instead of the fp32 activations the
+// epilogue writes what the NEXT GEMMs read -- the activations as two f16 pieces of 2^6 a1 in packed form in BOTH orientations
+// (a1_bk: rows = replay row, reduction = unit, for layer 2's forward; a1_kb: rows = unit, reduction = replay row, for layer 2's weight
+// gradient) and the sign bits of a1 (s1: one 32-bit word per (unit, 32 replay rows), for LeakyReLU' in the backward pass).
+struct LatPkOut {
+  unsigned char* a1_bk; int bk_rt;      // [S][N][bk_rt][hid/32][2][8 KiB]
+  unsigned char* a1_kb; int kb_kt;      // [S][N][hid/128][kb_kt][2][8 KiB]
+  unsigned* s1; int s1_ld;              // [S][N*hid][s1_ld]
+};
+
+template <bool W8, bool F16, bool PK = false>
 __global__ RC_LAT_OCC(W8 ? 512 : 256, W8 ? 4 : 2)
 void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, const unsigned char* __restrict__ kp, int kp_rt,
                    int kp_kt, const float* __restrict__ theta, float* __restrict__ a1t, int S, int N, int B, int in_dim, int ldp,
-                   int ldb, int mtiles, int ntiles, int hid) {
+                   int ldb, int mtiles, int ntiles, int hid, const LatPkOut pk) {
   constexpr int PA = F16 ? 2 : 3, PB = 1, MT = 2, NT = W8 ? 2 : 4, WM = 2, WN = W8 ? 4 : 2;
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
@@ -432,6 +289,68 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
       const float4 b4 = *reinterpret_cast<const float4*>(bias + wm * 32 * MT + 32 * mt + 8 * q + 4 * half);
       bv[mt][4 * q] = b4.x; bv[mt][4 * q + 1] = b4.y; bv[mt][4 * q + 2] = b4.z; bv[mt][4 * q + 3] = b4.w;
     }
+  if constexpr (PK) {
+    // one 128-column tile = 128 units of ONE agent (hid % 128 == 0); all of it is written, replay rows beyond B included
+    // (finite values nobody weighs: the consumers' other operand is zero there)
+    static_assert(F16, "packed activations exist in the two-piece f16 form");
+    rc_f16_saturate();
+    const int l31 = lane & 31;
+    const int agent = (bm * C::BM) / hid, u0 = bm * C::BM - agent * hid, JK = hid >> 5, JT = hid >> 7;
+    const long ag_lin = (long)s * N + agent;
+    unsigned char* scratch = lds + 1024 + wave * 4096;              // (the bias values sit in the first 512 bytes)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n0 = bn * C::BN + wn * 32 * NT + 32 * nt, n = n0 + l31;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int ublk = u0 + wm * 32 * MT + 32 * mt;               // first unit of this 32 x 32 block inside the agent
+        unsigned ph[8], pl[8];
+        unsigned myw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float o[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 2 * j + e;
+            const float z = fmaf(acc[mt][nt][r], RC_F16_W_UNSCALE, bv[mt][r]);
+            o[e] = fmaxf(z, RC_LEAK * z);
+            if (pk.s1 != nullptr) {
+              const unsigned long long bal = rc_ballot(o[e] > 0.f);
+              const unsigned wsel = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+              if (l31 == r) myw = wsel;
+            }
+          }
+          rc_split2h_pair(o[0] * RC_F16_ACT_SCALE, o[1] * RC_F16_ACT_SCALE, ph[j], pl[j]);
+        }
+        if (pk.s1 != nullptr && l31 < 16) {
+          const int col = bm * C::BM + wm * 32 * MT + 32 * mt + 8 * (l31 >> 2) + (l31 & 3) + 4 * half;
+          pk.s1[((long)s * ncols + col) * pk.s1_ld + (n0 >> 5)] = myw;
+        }
+        if (pk.a1_bk != nullptr) {
+          unsigned pc[2][4][2];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) { pc[0][q][dw] = ph[2 * q + dw]; pc[1][q][dw] = pl[2 * q + dw]; }
+          unsigned char* rowp = pk.a1_bk + ((ag_lin * pk.bk_rt + (n >> 7)) * JK + (ublk >> 5)) * (2 * RC_PK_BLOCK) + (n & 127) * 64;
+          pk_emit_rows_from_lanes<2>(pc, rowp, (n >> 2) & 3, (n >> 7) < pk.bk_rt);
+        }
+        if (pk.a1_kb != nullptr) {
+          unsigned short h16[2][16];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            h16[0][2 * j] = (unsigned short)(ph[j] & 0xffffu); h16[0][2 * j + 1] = (unsigned short)(ph[j] >> 16);
+            h16[1][2 * j] = (unsigned short)(pl[j] & 0xffffu); h16[1][2 * j + 1] = (unsigned short)(pl[j] >> 16);
+          }
+          if ((n0 >> 5) < pk.kb_kt) {                               // (wave-uniform)
+            unsigned char* blk = pk.a1_kb + ((ag_lin * JT + (ublk >> 7)) * pk.kb_kt + (n0 >> 5)) * (2 * RC_PK_BLOCK);
+            pk_emit_rows_from_regs<2>(h16, scratch, blk, ublk & 127);
+          }
+        }
+      }
+    }
+    return;
+  }
   const bool full_m = (bm + 1) * C::BM <= ncols;                   // workgroup-uniform
   auto store_tile = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -622,15 +541,15 @@ void k_lat_backward_sgd(const unsigned char* __restrict__ ktp, int ktp_rt, int k
 int lat_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 bool lat_w8(bool forward) { const char* e = getenv("RCMARL_LAT_W8"); return e ? atoi(e) != 0 : forward; }
 
-template <bool W8, bool F16>
+template <bool W8, bool F16, bool PK = false>
 int launch_forward(unsigned nblocks, void* stream, const unsigned char* wp, int wp_rt, int wp_kt, const unsigned char* kp, int kp_rt,
                    int kp_kt, const float* theta, float* a1t, int S, int N, int B, int in_dim, int ldp, int ldb, int mtiles,
-                   int ntiles, int hid) {
+                   int ntiles, int hid, const LatPkOut pk = LatPkOut{}) {
   const size_t smem = (size_t)2 * LatCfg<F16 ? 2 : 3, 1, 2, 4>::STAGE_BYTES;
-  static const bool ok = rc_want_lds(k_lat_forward<W8, F16>, smem);
+  static const bool ok = rc_want_lds(k_lat_forward<W8, F16, PK>, smem);
   if (!ok) return RCMARL_ERR_LAUNCH;
-  RCMARL_LAUNCH((k_lat_forward<W8, F16>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, wp, wp_rt, wp_kt, kp, kp_rt, kp_kt,
-                theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid);
+  RCMARL_LAUNCH((k_lat_forward<W8, F16, PK>), dim3(nblocks), dim3(W8 ? 512 : 256), smem, stream, wp, wp_rt, wp_kt, kp, kp_rt, kp_kt,
+                theta, a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid, pk);
   return rcmarl_check_launch();
 }
 
@@ -756,6 +675,31 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
                           a1t, S, N, B, in_dim, ldp, ldb, mtiles, ntiles, hid)
   return f16 ? (w8 ? RC_FWD(true, true) : RC_FWD(false, true)) : (w8 ? RC_FWD(true, false) : RC_FWD(false, false));
 #undef RC_FWD
+}
+
+// The same GEMM for a WIDE network (hid a multiple of 128) whose next layers run on packed operands (dense_pk.hip): the epilogue
+// writes the activations as two f16 pieces of 2^6 a1 in packed form -- a1_bk [S][N][bk_rt][hid/32][2][8 KiB] (rows = replay row,
+// reduction = unit), a1_kb [S][N][hid/128][kb_kt][2][8 KiB] (rows = unit, reduction = replay row) -- and their sign bits
+// s1 [S][N*hid][s1_ld] (bit b & 31 of word b >> 5), each optional, INSTEAD of the fp32 activations.  Two-piece f16 form only
+// (RCMARL_ERR_UNSUPPORTED otherwise).  Replaces model(x) of the first Dense layer, agents/resilient_CAC_agents.py:95-97,114,118.
+RCMARL_EXPORT int rcmarl_layer1_forward_lattice_pk(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt,
+                                                   const float* theta, void* a1_bk, int bk_rt, void* a1_kb, int kb_kt,
+                                                   unsigned* s1, int s1_ld, int S, int N, int B, int in_dim, int hid, int ldp,
+                                                   void* stream) {
+  if (!kp || !wp || !theta || (!a1_bk && !a1_kb && !s1) || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) ||
+      ldp < in_dim * hid + hid)
+    return RCMARL_ERR_ARG;
+  if (hid & 127) return RCMARL_ERR_UNSUPPORTED;
+  const int mtiles = N * hid / 128, ntiles = rc_ceil_div(B, 256), ktiles = rc_ceil_div(in_dim, 32);
+  if (wp_rt < mtiles || kp_rt < 2 * ntiles || wp_kt < ktiles || kp_kt < ktiles) return RCMARL_ERR_ARG;
+  if ((a1_bk && bk_rt < 2 * ntiles) || (a1_kb && kb_kt < 8 * ntiles) || (s1 && s1_ld < 8 * ntiles)) return RCMARL_ERR_ARG;
+  if (!(rc_lat_f16_mode() & 1)) return RCMARL_ERR_UNSUPPORTED;
+  if (!rc_form_ok(kp, true) || !rc_form_ok(wp, true)) return RCMARL_ERR_ARG;
+  const unsigned nb = (unsigned)(S * mtiles * ntiles);
+  LatPkOut pk;
+  pk.a1_bk = (unsigned char*)a1_bk; pk.bk_rt = bk_rt; pk.a1_kb = (unsigned char*)a1_kb; pk.kb_kt = kb_kt; pk.s1 = s1; pk.s1_ld = s1_ld;
+  return launch_forward<true, true, true>(nb, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp, kp_rt, kp_kt, theta,
+                                          nullptr, S, N, B, in_dim, ldp, 64, mtiles, ntiles, hid, pk);
 }
 
 static int backward_sgd_lattice_impl(const void* ktp, int ktp_rt, int ktp_kt, const void* dzp, int dzp_rt,

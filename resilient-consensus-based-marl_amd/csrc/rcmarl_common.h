@@ -264,6 +264,19 @@ __device__ __forceinline__ bool rc_any(bool v) {
 #endif
 }
 
+// 64-bit mask of `v` over the lanes of the wavefront (bit l = lane l; every lane must call it)
+__device__ __forceinline__ unsigned long long rc_ballot(bool v) {
+#ifdef RCMARL_EMU
+  float all[64];
+  __hipemu_gather64(v ? 1.f : 0.f, all);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) if (all[l] != 0.f) m |= 1ull << l;
+  return m;
+#else
+  return __builtin_amdgcn_ballot_w64(v);
+#endif
+}
+
 // True if `v` holds for every active lane (for a fast path without per-lane predicates; the other path must be correct
 // for any lane, and the host emulation decides per lane)
 __device__ __forceinline__ bool rc_all(bool v) {

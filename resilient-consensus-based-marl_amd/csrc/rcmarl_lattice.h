@@ -86,6 +86,9 @@ __device__ __forceinline__ void rc_split3_pair(float w0, float w1, unsigned& h, 
 #define RC_F16_W_UNSCALE 0.0009765625f
 #define RC_F16_DZ_SCALE 256.f
 #define RC_F16_DZ_UNSCALE 0.00390625f
+// activations of a wide network as two f16 pieces (wide_kernels.hip, dense_pk.hip): full precision from |a| >= 2.0e-3, finite to 1015
+#define RC_F16_ACT_SCALE 64.f
+#define RC_F16_ACT_UNSCALE 0.015625f
 #ifndef RC_LAT_F16_DEFAULT
 #define RC_LAT_F16_DEFAULT 3
 #endif

@@ -192,6 +192,17 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_fo
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 
+# ---- the same layers on pre-split packed operands (hid % 128 == 0): csrc/dense_pk.hip ---------------------------------
+def test_pk_forward(bk):
+    WC.check_pk_forward(bk, 1, 2, 150, 2, 5, 5, 128)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,hid,steps,masked", [(1, 2, 300, 2, 5, 5, 256, 3, None),      # two unit tiles, three row tiles
+                                                                    (2, 3, 150, 3, 7, 9, 128, 2, 1)])
+def test_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps, masked):
+    WC.check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=steps, lr=0.05, masked_agent=masked, tol=1e-6)
+
+
 @pytest.mark.parametrize("m128", ["0", "1"])
 def test_lattice_backward_both_tile_heights(bk, m128, monkeypatch):
     """Networks of at most 128 inputs take 128-row tiles in the backward GEMM (RCMARL_LAT_M128=0: the 256-row tile of the wide

@@ -232,6 +232,19 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_fo
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
 
 
+# ---- the same layers on pre-split packed operands (hid % 128 == 0): csrc/dense_pk.hip ---------------------------------
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,hid", [(1, 8, 1000, 2, 16, 16, 512), (2, 5, 333, 3, 7, 9, 128), (1, 3, 3000, 3, 32, 32, 256)])
+def test_pk_forward(bk, S, N, B, width, nrow, ncol, hid):
+    WC.check_pk_forward(bk, S, N, B, width, nrow, ncol, hid)
+
+
+@pytest.mark.parametrize("S,N,B,width,nrow,ncol,hid,steps,masked", [(1, 8, 1000, 2, 16, 16, 512, 3, None), (2, 16, 777, 3, 7, 9, 128, 3, 4),
+                                                                    (1, 3, 3000, 3, 32, 32, 256, 5, 1), (3, 8, 130, 2, 5, 5, 128, 2, None)])
+def test_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps, masked):
+    worst = WC.check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=steps, lr=0.02, masked_agent=masked, tol=1e-5)
+    print("packed-operand fit: worst |w - w_oracle| / max(1, |w|max) = %.2e" % worst)
+
+
 @pytest.mark.parametrize("m128", ["0", "1"])
 def test_lattice_backward_both_tile_heights(bk, m128, monkeypatch):
     """Networks of at most 128 inputs take 128-row tiles in the backward GEMM (RCMARL_LAT_M128=0: the 256-row tile of the wide

@@ -210,3 +210,155 @@ def check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph="circ"):
             rel_close(got[4], ag.critic[4], 3e-5 if hid <= 128 else 1e-4, "W3 after projection")
             rel_close(got[5], ag.critic[5], 3e-5 if hid <= 128 else 1e-4, "b3 after projection")
             rel_close(th_proj[s, i, :P], th_new[s, i, :P], 2e-6, "projection toward a given aggregate")
+
+
+# ---- dense layers on pre-split packed operands (csrc/dense_pk.hip) ----------------------------------------------------
+class PkBuffers:
+    """Packed operands + scratch of the rcmarl_pk_* path for S seeds x N agents of an (in_dim -> hid -> hid -> 1) net, B rows."""
+
+    def __init__(self, bk, S, N, B, in_dim, hid):
+        from rcmarl_amd import lattice as LT
+        Z, Bp, JT, JK, ldb = S * N, (B + 255) // 256 * 256, hid // 128, hid // 32, pad64(B)
+        self.g = g = LT.Geometry(N, in_dim, B, hid)
+        self.Bp, self.JT, self.JK = Bp, JT, JK
+        u8 = lambda n: bk.dev(np.zeros(int(n), np.uint8))
+        f32 = lambda *sh: bk.dev(np.zeros(sh, np.float32))
+        nb = LT.Geometry.nbytes
+        self.kp, self.ktp = u8(S * nb(g.kp, 1)), u8(S * nb(g.ktp, 1))
+        self.wp, self.dzp = u8(S * nb(g.wp, 3)), u8(S * nb(g.dzp, 3))
+        self.flag = bk.dev(np.zeros(1, np.int32))
+        self.bk_rt, self.kb_kt = Bp // 128, Bp // 32
+        self.a1_bk, self.a1_kb = u8(Z * self.bk_rt * JK * 2 * 8192), u8(Z * JT * self.kb_kt * 2 * 8192)
+        self.s1 = bk.dev(np.zeros((Z * hid, Bp // 32), np.int32))
+        self.w2t, self.w2w3, self.rs = u8(Z * JT * JK * 2 * 8192), u8(Z * JT * JK * 2 * 8192), f32(Z, hid)
+        self.mask_bj, self.mask_jb = u8(Z * self.bk_rt * JK * 8192), u8(Z * JT * self.kb_kt * 8192)
+        self.vpart, self.dz3 = f32(Z, JT, ldb), f32(Z, ldb)
+        self.dzv = bk.dev(np.zeros((Z, 4, Bp), np.int16))
+        self.losspart = f32(Z, (B + 255) // 256)
+        self.gw3part, self.q, self.gb1part = f32(Z, JT, hid), f32(Z, hid), f32(Z, (B + 127) // 128, hid)
+        self.a2 = f32(S, N * hid, ldb)
+
+
+def pk_encode(bk, pb, d_x, x_stride, d_alpha, S, B, in_dim):
+    g = pb.g
+    bk.lib.rcmarl_lattice_encode(bk.ptr(d_x), x_stride, bk.ptr(d_alpha), S, B, in_dim, bk.ptr(pb.kp), g.kp[0], g.kp[1], bk.ptr(pb.ktp),
+                                 g.ktp[0], g.ktp[1], bk.ptr(pb.flag), bk.stream)
+
+
+def pk_forward(bk, pb, d_alpha, d_theta, S, N, B, in_dim, hid, ldp, ldb, split=True, fit=True, want_a2=False):
+    """layer 1 (lattice GEMM, packed outputs) + pack of W2 + layer 2 (masks / value parts / fp32 a2)"""
+    g, L = pb.g, bk.lib
+    if split:
+        L.rcmarl_w1_split(bk.ptr(d_theta), bk.ptr(d_alpha), bk.ptr(pb.wp), S, N, in_dim, hid, ldp, g.wp[0], g.wp[1], bk.stream)
+    L.rcmarl_layer1_forward_lattice_pk(bk.ptr(pb.kp), g.kp[0], g.kp[1], bk.ptr(pb.wp), g.wp[0], g.wp[1], bk.ptr(d_theta),
+                                       bk.ptr(pb.a1_bk), pb.bk_rt, bk.ptr(pb.a1_kb) if fit else None, pb.kb_kt,
+                                       bk.ptr(pb.s1) if fit else None, pb.Bp // 32, S, N, B, in_dim, hid, ldp, bk.stream)
+    L.rcmarl_pk_pack_w2(bk.ptr(d_theta), bk.ptr(pb.w2t), bk.ptr(pb.w2w3), bk.ptr(pb.rs), S, N, in_dim, hid, ldp, bk.stream)
+    L.rcmarl_pk_forward2(bk.ptr(pb.w2t), bk.ptr(pb.a1_bk), pb.bk_rt, bk.ptr(d_theta), bk.ptr(pb.a2) if want_a2 else None,
+                         bk.ptr(pb.mask_bj) if fit else None, pb.bk_rt, bk.ptr(pb.mask_jb) if fit else None, pb.kb_kt,
+                         bk.ptr(pb.vpart), S, N, B, in_dim, hid, ldp, ldb, bk.stream)
+
+
+def pk_fit_step(bk, pb, d_alpha, d_msg, d_y, d_mask, d_loss, S, N, B, in_dim, hid, ldp, ldb, lr, split, emit_wp=True):
+    """one full-batch SGD step of fit() on the packed-operand path (the sequence engine._local_fit_wide_pk runs)"""
+    g, L = pb.g, bk.lib
+    pk_forward(bk, pb, d_alpha, d_msg, S, N, B, in_dim, hid, ldp, ldb, split=split)
+    L.rcmarl_pk_head(bk.ptr(pb.vpart), bk.ptr(d_msg), bk.ptr(d_y), 0.0, 2, bk.ptr(pb.dz3), bk.ptr(pb.dzv), bk.ptr(pb.losspart), S, N, B,
+                     in_dim, hid, ldp, ldb, bk.stream)
+    L.rcmarl_pk_backward_data(bk.ptr(pb.mask_bj), pb.bk_rt, bk.ptr(pb.w2w3), bk.ptr(pb.rs), bk.ptr(pb.s1), pb.Bp // 32, bk.ptr(pb.dz3),
+                              bk.ptr(pb.dzp), g.dzp[0], g.dzp[1], bk.ptr(pb.gb1part), S, N, B, hid, ldb, bk.stream)
+    L.rcmarl_pk_backward_w2(bk.ptr(pb.a1_kb), pb.kb_kt, bk.ptr(pb.mask_jb), pb.kb_kt, bk.ptr(pb.dzv), bk.ptr(d_msg), bk.ptr(d_mask),
+                            bk.ptr(pb.gw3part), bk.ptr(pb.q), S, N, B, in_dim, hid, ldp, lr, bk.stream)
+    L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(pb.ktp), g.ktp[0], g.ktp[1], bk.ptr(pb.dzp), g.dzp[0], g.dzp[1], bk.ptr(d_alpha),
+                                         bk.ptr(d_msg), bk.ptr(d_mask), S, N, B, in_dim, hid, ldp, lr,
+                                         bk.ptr(pb.wp) if emit_wp else None, g.wp[0], g.wp[1], bk.stream)
+    L.rcmarl_pk_small_sgd(bk.ptr(pb.gw3part), bk.ptr(pb.q), bk.ptr(pb.gb1part), bk.ptr(pb.dz3), bk.ptr(pb.losspart), bk.ptr(d_msg),
+                          bk.ptr(d_mask), bk.ptr(d_loss), S, N, B, in_dim, hid, ldp, ldb, lr, bk.stream)
+
+
+def _wide_lattice_case(S, N, B, width, nrow, ncol, hid, seed_off=0):
+    from kernel_checks import lattice_rows
+    rng = np.random.default_rng(S * 1000 + N * 100 + B + width + hid + seed_off)
+    in_dim = N * width
+    g = wgeom(in_dim, hid)
+    ldp, ldb = pad64(g["P"]), pad64(B)
+    params = wide_params(rng, S, N, in_dim, hid)
+    x, alpha = lattice_rows(rng, S, B, N, width, nrow, ncol)
+    return rng, in_dim, g, ldp, ldb, params, x, alpha
+
+
+def check_pk_forward(bk, S, N, B, width, nrow, ncol, hid):
+    """values, TD targets and the fp32 layer-2 activations of the packed-operand path vs the oracle's forward pass; the packed
+    activations decode to a1 (two f16 pieces of 2^6 a1) in both orientations and the sign words to [a1 > 0]."""
+    from rcmarl_amd import lattice as LT
+    assert bk.lib.rcmarl_pk_supported(hid) == 1
+    rng, in_dim, g, ldp, ldb, params, x, alpha = _wide_lattice_case(S, N, B, width, nrow, ncol, hid)
+    theta = pack_rows(params, ldp)
+    r = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    d_x, d_al, d_th, d_r = bk.dev(x), bk.dev(alpha), bk.dev(theta), bk.dev(r)
+    pb = PkBuffers(bk, S, N, B, in_dim, hid)
+    pk_encode(bk, pb, d_x, B * in_dim, d_al, S, B, in_dim)
+    pk_forward(bk, pb, d_al, d_th, S, N, B, in_dim, hid, ldp, ldb, want_a2=True)
+    d_v, d_y = bk.dev(np.zeros((S, N, ldb), np.float32)), bk.dev(np.zeros((S, N, ldb), np.float32))
+    L = bk.lib
+    L.rcmarl_pk_head(bk.ptr(pb.vpart), bk.ptr(d_th), None, 0.0, 0, bk.ptr(d_v), None, None, S, N, B, in_dim, hid, ldp, ldb, bk.stream)
+    L.rcmarl_pk_head(bk.ptr(pb.vpart), bk.ptr(d_th), bk.ptr(d_r), 0.9, 1, bk.ptr(d_y), None, None, S, N, B, in_dim, hid, ldp, ldb,
+                     bk.stream)
+    assert bk.host(pb.flag)[0] == 0
+    a2, v, y = bk.host(pb.a2), bk.host(d_v), bk.host(d_y)
+    Bp, JT, JK = pb.Bp, pb.JT, pb.JK
+    bk16 = np.asarray(bk.host(pb.a1_bk)).view(np.uint16).reshape(S * N, -1)
+    kb16 = np.asarray(bk.host(pb.a1_kb)).view(np.uint16).reshape(S * N, -1)
+    s1 = np.asarray(bk.host(pb.s1)).view(np.uint32).reshape(S * N, hid, Bp // 32)
+    for s in range(S):
+        for n in range(N):
+            p = params[s][n]
+            z1 = x[s] @ p[0] + p[1]
+            w1 = np.where(z1 > 0, z1, np.float32(0.1) * z1)
+            z2 = w1 @ p[2] + p[3]
+            w2 = np.where(z2 > 0, z2, np.float32(0.1) * z2)
+            zi = s * N + n
+            dec = LT.pk_unpack(bk16[zi], B, hid, JK, 2, f16=True)                   # [2][B][hid]
+            rel_close((dec[0] + dec[1]) / 64.0, w1, 3e-6, "a1_bk (rows = replay row)")
+            dect = LT.pk_unpack(kb16[zi], hid, B, pb.kb_kt, 2, f16=True)            # [2][hid][B]
+            np.testing.assert_array_equal(dect[0], dec[0].T)
+            np.testing.assert_array_equal(dect[1], dec[1].T)
+            bits = (s1[zi][:, np.arange(B) >> 5] >> (np.arange(B) & 31).astype(np.uint32)) & 1
+            np.testing.assert_array_equal(bits.astype(bool), (dec[0] + dec[1]).T > 0)
+            rel_close(a2[s, n * hid:(n + 1) * hid, :B].T, w2, 6e-6, "layer-2 activations")
+            want = M.forward(p, x[s])[:, 0]
+            rel_close(v[s, n, :B], want, 8e-6, "value")
+            rel_close(y[s, n, :B], r[s, n, :B] + np.float32(0.9) * want, 8e-6, "td target")
+
+
+def check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=2, lr=0.01, masked_agent=None, tol=2e-5):
+    """`steps` full-batch SGD steps on the packed-operand path vs the oracle's fit (M.fit_mse)."""
+    assert bk.lib.rcmarl_pk_supported(hid) == 1
+    rng, in_dim, g, ldp, ldb, params, x, alpha = _wide_lattice_case(S, N, B, width, nrow, ncol, hid, 1)
+    theta = pack_rows(params, ldp)
+    yv = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    mask = np.ones(N, np.int32)
+    if masked_agent is not None:
+        mask[masked_agent] = 0
+    d_x, d_al, d_y, d_mask, d_msg = bk.dev(x), bk.dev(alpha), bk.dev(yv), bk.dev(mask), bk.dev(theta.copy())
+    d_loss = bk.dev(np.zeros((S, N), np.float32))
+    pb = PkBuffers(bk, S, N, B, in_dim, hid)
+    pk_encode(bk, pb, d_x, B * in_dim, d_al, S, B, in_dim)
+    for st in range(steps):
+        pk_fit_step(bk, pb, d_al, d_msg, d_y, d_mask, d_loss if st == 0 else None, S, N, B, in_dim, hid, ldp, ldb, lr, split=(st == 0))
+    assert bk.host(pb.flag)[0] == 0
+    msg, loss = bk.host(d_msg), bk.host(d_loss)
+    worst = 0.0
+    for s in range(S):
+        for n in range(N):
+            if not mask[n]:
+                np.testing.assert_array_equal(msg[s, n], theta[s, n])
+                continue
+            pw = M.copy_params(params[s][n])
+            hist = M.fit_mse(pw, x[s], yv[s, n, :B, None], lr, epochs=steps)
+            got = unpack_row(msg[s, n], in_dim, 1, hid)
+            for k in range(6):
+                rel_close(got[k], pw[k], tol, "packed-operand fit param %d" % k)
+                worst = max(worst, float(np.max(np.abs(got[k] - pw[k])) / max(1.0, float(np.max(np.abs(pw[k]))))))
+            assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
+    return worst
