@@ -217,6 +217,7 @@ class RPBCACEngine:
             for k in self.rp:
                 self.rp[k][:, :old_B] = old_rp[k][:, :old_B]
         self._init_lattice()
+        self._init_wide_pk()
         self._ns_term = None                  # scratch: the last next-state row of every episode, gathered (rcmarl_gather_rows)
         self._graphs = {}                     # captured epochs point into the buffers replaced here
         if hasattr(self, "adv"):
@@ -256,6 +257,93 @@ class RPBCACEngine:
     def EP_pad(self):
         return pad64(self.cfg.n_ep_fixed)
 
+    # ---- wide critic on PRE-SPLIT packed operands (hid % 128 == 0, two-piece f16 form, lattice layer 1): csrc/dense_pk.hip ----
+    def _init_wide_pk(self):
+        """Packed operands of the rcmarl_pk_* path (include/rcmarl.h has the layouts): the layer-1 activations of the network a fit /
+        the consensus step works on in both orientations + their sign bits (`net`: what step 0 of the next local fit re-uses), a
+        second replay-row-major image for value passes, the two packed forms of W2, the layer-2 masks, and the small reduction parts.
+        RCMARL_WIDE_PK=0 keeps the round-4 path (fp32 operands split while they are staged, wide_kernels.hip)."""
+        self.pk = None
+        if not (self.wide and getattr(self, "lat_enabled", False)) or self.hid["critic"] % 128:
+            return
+        if os.environ.get("RCMARL_WIDE_PK", "1") in ("0", "false"):
+            return
+        S, N, hid = self.S, self.N, self.hid["critic"]
+        Z, Bp, JT, JK = S * N, (self.cap + 255) // 256 * 256, hid // 128, hid // 32
+
+        class _Pk:
+            pass
+        pk = _Pk()
+        u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=self.dev)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        pk.Bp, pk.bk_rt, pk.kb_kt = Bp, Bp // 128, Bp // 32
+        pk.a1_bk = {"net": u8(Z * pk.bk_rt * JK * 2 * LT.PK_BLOCK), "scratch": u8(Z * pk.bk_rt * JK * 2 * LT.PK_BLOCK)}
+        pk.a1_kb = u8(Z * JT * pk.kb_kt * 2 * LT.PK_BLOCK)
+        pk.s1 = torch.zeros(Z * hid, Bp // 32, dtype=torch.int32, device=self.dev)
+        pk.w2t, pk.w2w3 = u8(Z * JT * JK * 2 * LT.PK_BLOCK), u8(Z * JT * JK * 2 * LT.PK_BLOCK)
+        pk.rs = torch.zeros(Z, hid, **f32)
+        pk.mask_bj, pk.mask_jb = u8(Z * pk.bk_rt * JK * LT.PK_BLOCK), u8(Z * JT * pk.kb_kt * LT.PK_BLOCK)
+        pk.vpart = torch.zeros(Z, JT, self.ldb, **f32)
+        pk.dzv = torch.zeros(Z, 4, Bp, dtype=torch.int16, device=self.dev)
+        pk.gw3part, pk.q = torch.zeros(Z, JT, hid, **f32), torch.zeros(Z, hid, **f32)
+        pk.gb1part = torch.zeros(Z, (self.cap + 127) // 128, hid, **f32)
+        self.pk = pk
+
+    def _pk_ok(self, net, xkey, B, row0=0):
+        """does this pass of a wide net run on the packed-operand path?  (lattice layer 1 on these rows, both operand forms f16)"""
+        return (self.pk is not None and self.hid[net] != HID and self._lattice_ok(xkey, B, row0)
+                and self.lib.rcmarl_pk_supported(self.hid[net]) == 1 and self.lib.rcmarl_wide_f16_mode() == 1)
+
+    def _wide_forward_pk(self, xkey, theta, net, B, which, fit=False, want_a2=False, skip_layer1=False, wp_fresh=False):
+        """layers 1 and 2 of a wide net on packed operands.  which: 'net' (the image a fit / the consensus step leaves behind) or
+        'scratch' (value passes).  fit: also a1_kb, s1, the layer-2 masks.  Always leaves the head's value parts in pk.vpart;
+        want_a2: the fp32 layer-2 activations in self.w_a2 (phi of the estimate consensus)."""
+        L, S, N, hid, pk, st = self.lib, self.S, self.N, self.hid[net], self.pk, self.stream
+        in_dim, ldp = self.in_dim[net], self.ldp[net]
+        g, wp = self.lat_geom[xkey], self.lat_wp_f[xkey]
+        a1_bk = pk.a1_bk[which]
+        full = which == "net"                  # the cached image always carries both orientations and the sign bits
+        if not skip_layer1:
+            if not wp_fresh:
+                L.rcmarl_w1_split(theta.data_ptr(), self.lat_alpha[xkey].data_ptr(), wp.data_ptr(), S, N, in_dim, hid, ldp, g.wp[0],
+                                  g.wp[1], st)
+            L.rcmarl_layer1_forward_lattice_pk(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1],
+                                               theta.data_ptr(), a1_bk.data_ptr(), pk.bk_rt, pk.a1_kb.data_ptr() if full else None,
+                                               pk.kb_kt, pk.s1.data_ptr() if full else None, pk.Bp // 32, S, N, B, in_dim, hid, ldp,
+                                               st)
+        L.rcmarl_pk_pack_w2(theta.data_ptr(), pk.w2t.data_ptr(), pk.w2w3.data_ptr(), pk.rs.data_ptr(), S, N, in_dim, hid, ldp, st)
+        L.rcmarl_pk_forward2(pk.w2t.data_ptr(), a1_bk.data_ptr(), pk.bk_rt, theta.data_ptr(), self.w_a2.data_ptr() if want_a2 else None,
+                             pk.mask_bj.data_ptr() if fit else None, pk.bk_rt, pk.mask_jb.data_ptr() if fit else None, pk.kb_kt,
+                             pk.vpart.data_ptr(), S, N, B, in_dim, hid, ldp, self.ldb, st)
+
+    def _local_fit_wide_pk(self, net, xkey, y, B, mask):
+        """_local_fit_wide with every GEMM operand pre-split and packed by its producer (csrc/dense_pk.hip): per step
+        layer 1 -> [pack W2] -> layer 2 -> head -> dz1 -> W2 step -> W1 step -> small parameters."""
+        L, S, N, hid, in_dim, pk = self.lib, self.S, self.N, self.hid[net], self.in_dim[net], self.pk
+        msg, ldp, ldb, st, lr = self.msg[net], self.ldp[net], self.ldb, self.stream, self.cfg.fast_lr
+        g, dzp, wp = self.lat_geom[xkey], self.lat_dzp_f[xkey], self.lat_wp_f[xkey]
+        wp_fresh = False
+        for step in range(self.cfg.local_fit_steps):
+            last = step == self.cfg.local_fit_steps - 1
+            self._wide_forward_pk(xkey, msg, net, B, "net", fit=True, skip_layer1=(step == 0 and self.a1_cached[net] == "pk"),
+                                  wp_fresh=wp_fresh)
+            L.rcmarl_pk_head(pk.vpart.data_ptr(), msg.data_ptr(), y.data_ptr(), 0.0, 2, self.w_dz3.data_ptr(), pk.dzv.data_ptr(),
+                             self.w_losspart.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)
+            L.rcmarl_pk_backward_data(pk.mask_bj.data_ptr(), pk.bk_rt, pk.w2w3.data_ptr(), pk.rs.data_ptr(), pk.s1.data_ptr(),
+                                      pk.Bp // 32, self.w_dz3.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], pk.gb1part.data_ptr(),
+                                      S, N, B, hid, ldb, st)
+            # every gradient comes from the pre-step weights: the W2 step reads W3, the small step updates it afterwards
+            L.rcmarl_pk_backward_w2(pk.a1_kb.data_ptr(), pk.kb_kt, pk.mask_jb.data_ptr(), pk.kb_kt, pk.dzv.data_ptr(), msg.data_ptr(),
+                                    mask.data_ptr(), pk.gw3part.data_ptr(), pk.q.data_ptr(), S, N, B, in_dim, hid, ldp, lr, st)
+            L.rcmarl_layer1_backward_sgd_lattice(self.lat_ktp[xkey].data_ptr(), g.ktp[0], g.ktp[1], dzp.data_ptr(), g.dzp[0], g.dzp[1],
+                                                 self.lat_alpha[xkey].data_ptr(), msg.data_ptr(), mask.data_ptr(), S, N, B, in_dim,
+                                                 hid, ldp, lr, None if last else wp.data_ptr(), g.wp[0], g.wp[1], st)
+            wp_fresh = True
+            L.rcmarl_pk_small_sgd(pk.gw3part.data_ptr(), pk.q.data_ptr(), pk.gb1part.data_ptr(), self.w_dz3.data_ptr(),
+                                  self.w_losspart.data_ptr(), msg.data_ptr(), mask.data_ptr(),
+                                  self.loss[net].data_ptr() if step == 0 else None, S, N, B, in_dim, hid, ldp, ldb, lr, st)
+        self.a1_cached[net] = False
+
     def _wide_offsets(self, net):
         in_dim, hid = self.in_dim[net], self.hid[net]
         o_b1 = in_dim * hid
@@ -289,6 +377,8 @@ class RPBCACEngine:
 
     def _local_fit_wide(self, net, xkey, y, B, mask):
         """_local_fit for a wide net: every layer of every step is a dense GEMM per agent (f32 MFMA)."""
+        if self._pk_ok(net, xkey, B) and xkey in self.lat_ktp:
+            return self._local_fit_wide_pk(net, xkey, y, B, mask)
         L, S, N, hid, in_dim = self.lib, self.S, self.N, self.hid[net], self.in_dim[net]
         msg, a1, a2, dz1 = self.msg[net], self.a1net[net], self.w_a2, self.w_dz1
         ldp, ldb, st, lr = self.ldp[net], self.ldb, self.stream, self.cfg.fast_lr
@@ -298,7 +388,7 @@ class RPBCACEngine:
         g = self.lat_geom[xkey] if lat else None
         wp_fresh = False
         for step in range(self.cfg.local_fit_steps):
-            self._wide_forward(xkey, msg, net, B, a1=a1, skip_layer1=(step == 0 and self.a1_cached[net]), wp_fresh=wp_fresh)
+            self._wide_forward(xkey, msg, net, B, a1=a1, skip_layer1=(step == 0 and self.a1_cached[net] is True), wp_fresh=wp_fresh)
             L.rcmarl_wide_head_fit(a2.data_ptr(), msg.data_ptr(), y.data_ptr(), self.w_dz3.data_ptr(), self.w_grads.data_ptr(),
                                    self.w_losspart.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)      # a2 now holds dz2
             L.rcmarl_dense_backward_data(a2.data_ptr(), msg.data_ptr(), o_W2, a1.data_ptr(), dz1.data_ptr(), S, N, B, hid, hid,
@@ -329,17 +419,27 @@ class RPBCACEngine:
         L, S, N, c, hid = self.lib, self.S, self.N, self.cfg, self.hid[net]
         msg_all = self.msg[net] if msg_all is None else msg_all      # rows indexed by GLOBAL agent (in_nodes)
         self._k1(net, self.P[net] - (hid + 1))
-        self._wide_forward(xkey, self.theta[net], net, B, a1=self.a1net[net])
+        pk = self._pk_ok(net, xkey, B) and xkey in self.lat_ktp
+        if pk:      # the packed layer-1 image stays behind for step 0 of the next local fit; phi = fp32 layer-2 activations
+            self._wide_forward_pk(xkey, self.theta[net], net, B, "net", want_a2=True)
+        else:
+            self._wide_forward(xkey, self.theta[net], net, B, a1=self.a1net[net])
         L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), msg_all.data_ptr(),
                                      self.nbr.data_ptr(), self.coop.data_ptr(), None, self.w_hmat.data_ptr(),
                                      self.w_hb.data_ptr(), self.w_est.data_ptr(), self.w_ebuf.data_ptr(),
                                      self.w_grads.data_ptr(), None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb,
                                      c.d, c.H, self.stream)
-        self.a1_cached[net] = self.reuse_activations
+        self.a1_cached[net] = ("pk" if pk else True) if self.reuse_activations else False
         L.rcmarl_wide_head_apply(self.w_grads.data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(), S, N, B,
                                  self.in_dim[net], hid, self.ldp[net], self.stream)
 
     def _value_wide(self, xkey, theta, net, out, B, row0=0, r_applied=None, x=None):
+        if x is None and self._pk_ok(net, xkey, B, row0):
+            self._wide_forward_pk(xkey, theta, net, B, "scratch")
+            self.lib.rcmarl_pk_head(self.pk.vpart.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma,
+                                    0 if r_applied is None else 1, out.data_ptr(), None, None, self.S, self.N, B, self.in_dim[net],
+                                    self.hid[net], self.ldp[net], self.ldb, self.stream)
+            return
         self._wide_forward(xkey, theta, net, B, row0, x=x)
         self.lib.rcmarl_wide_head_value(self.w_a2.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma,
                                         out.data_ptr(), self.S, self.N, B, self.in_dim[net], self.hid[net], self.ldp[net],

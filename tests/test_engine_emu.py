@@ -59,6 +59,15 @@ def test_engine_wide_critic_matches_oracle(rng_mode, critic_hid, H, lattice):
     EC.compare(eng, logs, o_logs, o_w)
 
 
+def test_engine_wide_critic_on_packed_operands_matches_oracle():
+    """A critic width that is a multiple of 128 beside the lattice layer 1: every dense layer of its local fits, TD targets and
+    the estimate consensus runs on pre-split packed operands (csrc/dense_pk.hip; RPBCACEngine._local_fit_wide_pk)."""
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=4, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=9, seed=41)
+    eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(41,), critic_hid=128, lattice=True)
+    assert eng.wide and eng.lat_active and eng.pk is not None and eng._pk_ok("critic", "s", eng.lat_B)
+    EC.compare(eng, logs, o_logs, o_w)
+
+
 def test_engine_wide_critic_with_faulty_agent_matches_oracle():
     """A Faulty agent (frozen critic / team-reward net, learning actor: adversarial_CAC_agents.py:5-55) beside a wide critic:
     its frozen wide message enters every neighbour's aggregation, its actor takes the mini-batch Adam steps from TD errors

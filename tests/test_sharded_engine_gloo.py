@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # (agents, d, H, graph, critic width, lattice path, rng mode)
 CASES = [(4, 4, 1, "circ", 64, True, "device"),        # packed bf16x3 layer 1: 2 agents x 64 units = one 128-row tile per rank
-         (6, 3, 1, "rand", 24, False, "numpy")]        # dense f32 path, general K1 kernel
+         (6, 3, 1, "rand", 24, False, "numpy"),        # dense f32 path, general K1 kernel
+         (4, 4, 1, "circ", 128, True, "device")]       # dense layers on pre-split packed operands (csrc/dense_pk.hip)
 
 
 def _free_port():

@@ -373,8 +373,82 @@ def wide(L, S=1, N=64, B=3000, in_dim=2048, hid=512):
     L.rcmarl_wide_set_f16_mode(-1)
 
 
+def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2, hid=512):
+    """the wide critic's SGD step on pre-split packed operands (csrc/dense_pk.hip) at the cfg-5 shape (1024 agents x 512 units;
+    here RCMARL_KBENCH_N agents of the same 2048-input network), kernel by kernel, beside the round-4 path (`wide`)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import wide_checks as WC
+    from kernel_checks import lattice_rows
+    from rcmarl_amd import lattice as LT
+
+    class Bk:
+        lib = L
+        stream = torch.cuda.current_stream().cuda_stream
+        dev = staticmethod(lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda())
+        ptr = staticmethod(lambda h: None if h is None else h.data_ptr())
+    bk = Bk()
+    NA = 1024                                          # the network's input width is that of the 1024-agent instance
+    in_dim = NA * width
+    g = WC.wgeom(in_dim, hid)
+    ldp, ldb = pad64(g["P"]), pad64(B)
+    rng = np.random.default_rng(0)
+    x, alpha = lattice_rows(rng, S, B, NA, width, 32, 32)
+    theta = (torch.randn(S, N, ldp, device="cuda") * 0.02)
+    y = torch.randn(S, N, ldb, device="cuda")
+    mask = torch.ones(N, dtype=torch.int32, device="cuda")
+    loss = torch.zeros(S, N, device="cuda")
+    pb = WC.PkBuffers(bk, S, N, B, in_dim, hid)
+    d_x, d_al = bk.dev(x), bk.dev(alpha)
+    WC.pk_encode(bk, pb, d_x, B * in_dim, d_al, S, B, in_dim)
+    gg, st = pb.g, bk.stream
+    p = lambda t: t.data_ptr()
+    f1, f2 = 2.0 * S * N * hid * B * in_dim, 2.0 * S * N * hid * B * hid
+    lr = 1e-9
+    rows = [
+        ("W1 split", 0, lambda: L.rcmarl_w1_split(p(theta), p(d_al), p(pb.wp), S, N, in_dim, hid, ldp, gg.wp[0], gg.wp[1], st)),
+        ("fwd L1 lattice -> packed a1 x2 + signs", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
+            p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, p(pb.a1_kb), pb.kb_kt, p(pb.s1),
+            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+        ("fwd L1 lattice -> packed a1 (values)", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
+            p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, None, pb.kb_kt, None,
+            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+        ("pack W2", 0, lambda: L.rcmarl_pk_pack_w2(p(theta), p(pb.w2t), p(pb.w2w3), p(pb.rs), S, N, in_dim, hid, ldp, st)),
+        ("fwd L2 -> masks + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, p(pb.mask_bj),
+                                                                            pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), S, N, B,
+                                                                            in_dim, hid, ldp, ldb, st)),
+        ("fwd L2 -> value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, None, pb.bk_rt, None,
+                                                                    pb.kb_kt, p(pb.vpart), S, N, B, in_dim, hid, ldp, ldb, st)),
+        ("fwd L2 -> fp32 a2 (consensus)", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), p(pb.a2), None,
+                                                                            pb.bk_rt, None, pb.kb_kt, p(pb.vpart), S, N, B, in_dim, hid,
+                                                                            ldp, ldb, st)),
+        ("head", 0, lambda: L.rcmarl_pk_head(p(pb.vpart), p(theta), p(y), 0.0, 2, p(pb.dz3), p(pb.dzv), p(pb.losspart), S, N, B, in_dim,
+                                             hid, ldp, ldb, st)),
+        ("bwd data L2 -> packed dz1", f2, lambda: L.rcmarl_pk_backward_data(p(pb.mask_bj), pb.bk_rt, p(pb.w2w3), p(pb.rs), p(pb.s1),
+                                                                             pb.Bp // 32, p(pb.dz3), p(pb.dzp), gg.dzp[0], gg.dzp[1],
+                                                                             p(pb.gb1part), S, N, B, hid, ldb, st)),
+        ("bwd W2", f2, lambda: L.rcmarl_pk_backward_w2(p(pb.a1_kb), pb.kb_kt, p(pb.mask_jb), pb.kb_kt, p(pb.dzv), p(theta), p(mask),
+                                                        p(pb.gw3part), p(pb.q), S, N, B, in_dim, hid, ldp, lr, st)),
+        ("bwd W1 lattice", f1, lambda: L.rcmarl_layer1_backward_sgd_lattice(p(pb.ktp), gg.ktp[0], gg.ktp[1], p(pb.dzp), gg.dzp[0],
+                                                                             gg.dzp[1], p(d_al), p(theta), p(mask), S, N, B, in_dim, hid,
+                                                                             ldp, lr, p(pb.wp), gg.wp[0], gg.wp[1], st)),
+        ("small sgd", 0, lambda: L.rcmarl_pk_small_sgd(p(pb.gw3part), p(pb.q), p(pb.gb1part), p(pb.dz3), p(pb.losspart), p(theta), p(mask),
+                                                       p(loss), S, N, B, in_dim, hid, ldp, ldb, lr, st)),
+    ]
+    only = os.environ.get("RCMARL_KBENCH_ONLY")
+    tot = 0.0
+    for name, fl, fn in rows:
+        if only and only not in name:
+            fn()                                       # (later kernels still need their inputs)
+            continue
+        t = timeit(fn, iters=5, warm=2)
+        step = name not in ("W1 split", "fwd L1 lattice -> packed a1 (values)", "fwd L2 -> value parts", "fwd L2 -> fp32 a2 (consensus)")
+        tot += t if step else 0.0
+        print("%-40s %9.1f us  %s" % (name, t, ("%7.1f TF/s fp32-equivalent (%.3f of 2.5 PF)" % (fl / t / 1e6, fl / t / 1e6 / 2500)) if fl else ""))
+    print("one SGD step, %d agents: %.2f ms  -> 1024 agents: %.1f ms" % (N, tot / 1e3, tot / 1e3 * 1024 / N))
+
+
 if __name__ == "__main__":
     L = capi.CLib(os.environ["RCMARL_KBENCH_LIB"]) if os.environ.get("RCMARL_KBENCH_LIB") else capi.load()     # (variant builds)
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
     print("== %s  RCMARL_GEMM=%s RCMARL_K1=%s" % (what, os.environ.get("RCMARL_GEMM"), os.environ.get("RCMARL_K1")))
-    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "minibatch": minibatch, "multi": multi, "wide": wide}[what](L)
+    {"gemm": gemm, "k1": k1, "k1_cfg5": k1_cfg5, "mid": mid, "lattice": lattice, "lattice_ab": lattice_ab, "mid_ab": mid_ab, "minibatch": minibatch, "multi": multi, "wide": wide, "pk": pk}[what](L)
