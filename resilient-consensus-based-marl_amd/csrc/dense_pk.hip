@@ -38,7 +38,12 @@
 
 namespace {
 
-constexpr int PK_T = 128;                                 // block tile side of all three GEMMs
+// Block tiles of the three GEMMs: 256 x 256 with eight wavefronts of 128 x 64 when hid is a multiple of 256 (one workgroup per CU;
+// half the operand bytes per matrix instruction of the 128 x 128 form: at 128 x 128 the launches ran at 7-11 TB/s of LDS-DMA
+// traffic out of the L2 with the matrix pipe half idle, profiles/r06a_kbench_pk.txt), else 128 x 128 with four of 64 x 64.
+struct PkSmall { static constexpr int MT = 2, NT = 2, WM = 2, WN = 2, BM = 128, BN = 128, THREADS = 256; };
+struct PkBig { static constexpr int MT = 4, NT = 2, WM = 2, WN = 4, BM = 256, BN = 256, THREADS = 512; };
+__host__ __device__ static inline int pk_tile(int hid) { return (hid & 255) == 0 ? 256 : 128; }
 constexpr float PK_LEAK_COMP = 0.9f;                      // g = RC_LEAK + PK_LEAK_COMP * [z > 0]
 
 // workgroup id -> (z = seed * N + agent, tile q): all tiles of an agent on ONE XCD (workgroups go round the eight XCDs by id)
@@ -116,39 +121,40 @@ struct PkFwdArgs {
   int Z, B, hid, ntb;                       // ntb = ceil(B / 128)
 };
 
-__global__ RC_LAT_OCC(256, 2) void k_pk_forward2(const PkFwdArgs a) {
-  constexpr int MT = 2, NT = 2, WM = 2, WN = 2;
+template <class T>
+__global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_forward2(const PkFwdArgs a) {
+  constexpr int MT = T::MT, NT = T::NT, WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN;
   RCMARL_DYN_SMEM(unsigned char, lds);
-  const int JT = a.hid >> 7, JK = a.hid >> 5;
+  const int JT = a.hid >> 7, JK = a.hid >> 5, MTL = a.hid / BM;
   int z, q;
-  pk_decode(blockIdx.x, JT * a.ntb, a.Z, z, q);
-  const int bm = q % JT, bn = q / JT;                     // m fastest: the workgroups that share an a1 panel run side by side
+  pk_decode(blockIdx.x, MTL * a.ntb, a.Z, z, q);
+  const int bm = q % MTL, bn = q / MTL;                   // m fastest: the workgroups that share an a1 panel run side by side
   LatOperands op;
-  op.a = a.w2t + (long)z * JT * JK * (2 * RC_PK_BLOCK); op.a_kt = JK; op.art0 = bm;
-  op.b = a.a1bk + (long)z * a.bk_rt * JK * (2 * RC_PK_BLOCK); op.b_kt = JK; op.brt0 = bn;
+  op.a = a.w2t + (long)z * JT * JK * (2 * RC_PK_BLOCK); op.a_kt = JK; op.art0 = bm * (BM / 128);
+  op.b = a.a1bk + (long)z * a.bk_rt * JK * (2 * RC_PK_BLOCK); op.b_kt = JK; op.brt0 = bn * (BN / 128);
   rc_f32x16 acc[MT][NT];
   lat_mainloop<2, 2, MT, NT, WM, WN, false, true, true>(op, JK, lds, acc);
   __syncthreads();
-  float* sb = reinterpret_cast<float*>(lds);              // b2, W3 of the tile's 128 units; the two row halves' parts of v
-  float* sw3 = sb + PK_T;
-  float* sv = sw3 + PK_T;
+  float* sb = reinterpret_cast<float*>(lds);              // b2, W3 of the tile's units; the row halves' parts of v
+  float* sw3 = sb + BM;
+  float* sv = sw3 + BM;
   const float* __restrict__ th = a.theta + (long)z * a.ldp;
-  if (threadIdx.x < PK_T) {
-    sb[threadIdx.x] = th[a.o_b2 + bm * PK_T + threadIdx.x];
-    sw3[threadIdx.x] = th[a.o_W3 + bm * PK_T + threadIdx.x];
+  if (threadIdx.x < BM) {
+    sb[threadIdx.x] = th[a.o_b2 + bm * BM + threadIdx.x];
+    sw3[threadIdx.x] = th[a.o_W3 + bm * BM + threadIdx.x];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave / WN, wn = wave % WN;
-  unsigned char* scratch = lds + 4096 + wave * 2048;
+  unsigned char* scratch = lds + 8192 + wave * 2048;
   constexpr float UNSCALE = RC_F16_W_UNSCALE * RC_F16_ACT_UNSCALE;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n0 = bn * PK_T + wn * 64 + 32 * nt, n = n0 + l31;
+    const int n0 = bn * BN + wn * 32 * NT + 32 * nt, n = n0 + l31;
     float vp = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int j0 = wm * 64 + 32 * mt;                   // first unit of this 32 x 32 block inside the tile
+      const int j0 = wm * 32 * MT + 32 * mt;              // first unit of this 32 x 32 block inside the tile
       unsigned pc[1][4][2];
       unsigned short m16[1][16];
 #pragma unroll
@@ -165,31 +171,35 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_forward2(const PkFwdArgs a) {
           pos[e] = o > 0.f;
           vp = fmaf(o, wq[e], vp);
           if (a.a2 != nullptr && n < a.B)
-            RC_NT_STORE(a.a2 + ((long)z * a.hid + bm * PK_T + j0 + 8 * qq + 4 * half + e) * a.ldb + n, o);
+            RC_NT_STORE(a.a2 + ((long)z * a.hid + bm * BM + j0 + 8 * qq + 4 * half + e) * a.ldb + n, o);
           m16[0][r] = pos[e] ? (unsigned short)0xffffu : (unsigned short)0u;
         }
         pc[0][qq][0] = (pos[0] ? 0x3c00u : 0u) | (pos[1] ? 0x3c000000u : 0u);
         pc[0][qq][1] = (pos[2] ? 0x3c00u : 0u) | (pos[3] ? 0x3c000000u : 0u);
       }
       if (a.mask_bj != nullptr) {
-        unsigned char* rowp = a.mask_bj + (((long)z * a.mbj_rt + (n >> 7)) * JK + ((bm * PK_T + j0) >> 5)) * RC_PK_BLOCK + (n & 127) * 64;
+        unsigned char* rowp = a.mask_bj + (((long)z * a.mbj_rt + (n >> 7)) * JK + ((bm * BM + j0) >> 5)) * RC_PK_BLOCK + (n & 127) * 64;
         pk_emit_rows_from_lanes<1>(pc, rowp, (n >> 2) & 3, (n >> 7) < a.mbj_rt);
       }
       if (a.mask_jb != nullptr && (n0 >> 5) < a.mjb_kt) {
-        unsigned char* blk = a.mask_jb + (((long)z * JT + bm) * a.mjb_kt + (n0 >> 5)) * RC_PK_BLOCK;
-        pk_emit_rows_from_regs<1>(m16, scratch, blk, j0);
+        const int jg = bm * BM + j0;                       // the block's first unit inside the agent
+        unsigned char* blk = a.mask_jb + (((long)z * JT + (jg >> 7)) * a.mjb_kt + (n0 >> 5)) * RC_PK_BLOCK;
+        pk_emit_rows_from_regs<1>(m16, scratch, blk, jg & 127);
       }
     }
     if (a.vpart != nullptr) {
       vp += __shfl_xor(vp, 32);
-      if (half == 0) sv[wm * PK_T + wn * 64 + 32 * nt + l31] = vp;
+      if (half == 0) sv[wm * BN + wn * 32 * NT + 32 * nt + l31] = vp;
     }
   }
   if (a.vpart != nullptr) {
     __syncthreads();
-    if (threadIdx.x < PK_T) {
-      const int n = bn * PK_T + threadIdx.x;
-      if (n < a.ldb) a.vpart[((long)z * JT + bm) * a.ldb + n] = sv[threadIdx.x] + sv[PK_T + threadIdx.x];
+    if (threadIdx.x < BN) {
+      const int n = bn * BN + threadIdx.x;
+      float v = sv[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < WM; ++w) v += sv[w * BN + threadIdx.x];
+      if (n < a.ldb) a.vpart[((long)z * MTL + bm) * a.ldb + n] = v;
     }
   }
 }
@@ -248,23 +258,24 @@ struct PkBdArgs {
   int Z, N, B, hid, ntb;
 };
 
-__global__ RC_LAT_OCC(256, 2) void k_pk_backward_data(const PkBdArgs a) {
-  constexpr int MT = 2, NT = 2, WM = 2, WN = 2;
+template <class T>
+__global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_backward_data(const PkBdArgs a) {
+  constexpr int MT = T::MT, NT = T::NT, WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN;
   RCMARL_DYN_SMEM(unsigned char, lds);
-  const int JT = a.hid >> 7, JK = a.hid >> 5;
+  const int JT = a.hid >> 7, JK = a.hid >> 5, NTL = a.hid / BN;
   int z, q;
-  pk_decode(blockIdx.x, JT * a.ntb, a.Z, z, q);
-  const int bn = q % JT, bm = q / JT;                     // n (unit tile) fastest: neighbours share the mask panel
+  pk_decode(blockIdx.x, NTL * a.ntb, a.Z, z, q);
+  const int bn = q % NTL, bm = q / NTL;                   // n (unit tile) fastest: neighbours share the mask panel
   LatOperands op;
-  op.a = a.mask_bj + (long)z * a.mbj_rt * JK * RC_PK_BLOCK; op.a_kt = JK; op.art0 = bm;
-  op.b = a.w2w3 + (long)z * JT * JK * (2 * RC_PK_BLOCK); op.b_kt = JK; op.brt0 = bn;
+  op.a = a.mask_bj + (long)z * a.mbj_rt * JK * RC_PK_BLOCK; op.a_kt = JK; op.art0 = bm * (BM / 128);
+  op.b = a.w2w3 + (long)z * JT * JK * (2 * RC_PK_BLOCK); op.b_kt = JK; op.brt0 = bn * (BN / 128);
   rc_f32x16 acc[MT][NT];
   lat_mainloop<1, 2, MT, NT, WM, WN, false, true>(op, JK, lds, acc);
   __syncthreads();
-  float* sdz = reinterpret_cast<float*>(lds);             // dz3 of the tile's 128 replay rows; the two row halves' parts of gb1
-  float* sg = sdz + PK_T;
-  if (threadIdx.x < PK_T) {
-    const int b = bm * PK_T + threadIdx.x;
+  float* sdz = reinterpret_cast<float*>(lds);             // dz3 of the tile's replay rows; the row halves' parts of gb1
+  float* sg = sdz + BM;
+  if (threadIdx.x < BM) {
+    const int b = bm * BM + threadIdx.x;
     sdz[threadIdx.x] = b < a.B ? a.dz3[(long)z * a.ldb + b] : 0.f;
   }
   __syncthreads();
@@ -275,13 +286,13 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_backward_data(const PkBdArgs a) {
   unsigned char* dzp_s = a.dzp + (long)s * a.dzp_rt * a.dzp_kt * (2 * RC_PK_BLOCK);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int kc = bn * PK_T + wn * 64 + 32 * nt + l31;   // the lane's unit
+    const int kc = bn * BN + wn * 32 * NT + 32 * nt + l31; // the lane's unit
     const float t01 = RC_LEAK * a.rs[(long)z * a.hid + kc];
     const int prow = agent * a.hid + kc;                  // its row in the packed dz operand
     float gsum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int bl = wm * 64 + 32 * mt, b0 = bm * PK_T + bl;     // first replay row of this 32 x 32 block (a multiple of 32)
+      const int bl = wm * 32 * MT + 32 * mt, b0 = bm * BM + bl;  // first replay row of this 32 x 32 block (a multiple of 32)
       const unsigned word = a.s1[((long)z * a.hid + kc) * a.s1_ld + (b0 >> 5)];
       unsigned pc[2][4][2];
 #pragma unroll
@@ -305,11 +316,15 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_backward_data(const PkBdArgs a) {
       pk_emit_rows_from_lanes<2>(pc, rowp, (prow >> 2) & 3, (b0 >> 5) < a.dzp_kt);
     }
     gsum += __shfl_xor(gsum, 32);
-    if (half == 0) sg[wm * PK_T + wn * 64 + 32 * nt + l31] = gsum;
+    if (half == 0) sg[wm * BN + wn * 32 * NT + 32 * nt + l31] = gsum;
   }
   __syncthreads();
-  if (threadIdx.x < PK_T)
-    a.gb1part[((long)z * a.ntb + bm) * a.hid + bn * PK_T + threadIdx.x] = sg[threadIdx.x] + sg[PK_T + threadIdx.x];
+  if (threadIdx.x < BN) {
+    float v = sg[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < WM; ++w) v += sg[w * BN + threadIdx.x];
+    a.gb1part[((long)z * a.ntb + bm) * a.hid + bn * BN + threadIdx.x] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -351,16 +366,17 @@ __device__ __forceinline__ float pk_sum8(const uint4& f, float acc) {
 #endif
 }
 
-__global__ RC_LAT_OCC(256, 2) void k_pk_backward_w2(const PkBwArgs a) {
-  constexpr int PA = 2, PB = 1, MT = 2, NT = 2, WM = 2, WN = 2;
+template <class T>
+__global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_backward_w2(const PkBwArgs a) {
+  constexpr int PA = 2, PB = 1, MT = T::MT, NT = T::NT, WM = T::WM, WN = T::WN, BM = T::BM, BN = T::BN;
   typedef LatCfg<PA, PB, MT, NT, WM, WN> C;
   RCMARL_DYN_SMEM(unsigned char, lds);
-  const int JT = a.hid >> 7;
+  const int JT = a.hid >> 7, MTL = a.hid / BM, NTL = a.hid / BN;
   int z, q;
-  pk_decode(blockIdx.x, JT * JT, a.Z, z, q);
+  pk_decode(blockIdx.x, MTL * NTL, a.Z, z, q);
   const int agent = z % a.N;
   if (a.mask != nullptr && !a.mask[agent]) return;        // workgroup-uniform
-  const int bm = q % JT, bn = q / JT;
+  const int bm = q % MTL, bn = q / MTL;
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wm = wave / WN, wn = wave % WN;
   const bool do_q = bm == 0 && wm == 0;                   // wave-uniform
@@ -371,17 +387,24 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_backward_w2(const PkBwArgs a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-  float qs[NT] = {0.f, 0.f};
+  float qs[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) qs[nt] = 0.f;
   {
-    const unsigned char* pa = a.a1kb + ((long)z * JT + bm) * a.kb_kt * (PA * RC_PK_BLOCK);
-    const unsigned char* pb = a.mask_jb + ((long)z * JT + bn) * a.mjb_kt * (PB * RC_PK_BLOCK);
+    const unsigned char* pa = a.a1kb + ((long)z * JT + bm * (BM / 128)) * a.kb_kt * (PA * RC_PK_BLOCK);
+    const unsigned char* pb = a.mask_jb + ((long)z * JT + bn * (BN / 128)) * a.mjb_kt * (PB * RC_PK_BLOCK);
     const unsigned char* gsrc[C::GLDS];
     int gstep[C::GLDS];
 #pragma unroll
     for (int i = 0; i < C::GLDS; ++i) {
       const int qi = wave + C::NWV * i;
-      if (qi < C::A_KB) { gsrc[i] = pa + qi * 1024; gstep[i] = PA * RC_PK_BLOCK; }
-      else { gsrc[i] = pb + (qi - C::A_KB) * 1024; gstep[i] = PB * RC_PK_BLOCK; }
+      if (qi < C::A_KB) {
+        const int seg = qi / (PA * 8), off = qi - seg * (PA * 8);
+        gsrc[i] = pa + (long)seg * a.kb_kt * (PA * RC_PK_BLOCK) + off * 1024; gstep[i] = PA * RC_PK_BLOCK;
+      } else {
+        const int q2 = qi - C::A_KB, seg = q2 / (PB * 8), off = q2 - seg * (PB * 8);
+        gsrc[i] = pb + (long)seg * a.mjb_kt * (PB * RC_PK_BLOCK) + off * 1024; gstep[i] = PB * RC_PK_BLOCK;
+      }
     }
     const unsigned lane16 = lane * 16;
     const rc_lds_t lds0 = rc_lds_addr(lds) + wave * 1024;
@@ -402,9 +425,15 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_backward_w2(const PkBwArgs a) {
     const int co0 = ((0 + half) ^ sw) << 4, co1 = ((2 + half) ^ sw) << 4;
     int offA[MT], offB[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) offA[mt] = (wm * 32 * MT + 32 * mt + l31) * 64;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = wm * 32 * MT + 32 * mt + l31;
+      offA[mt] = (row >> 7) * PA * RC_PK_BLOCK + (row & 127) * 64;
+    }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) offB[nt] = C::A_KB * 1024 + (wn * 32 * NT + 32 * nt + l31) * 64;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = wn * 32 * NT + 32 * nt + l31;
+      offB[nt] = C::A_KB * 1024 + (row >> 7) * PB * RC_PK_BLOCK + (row & 127) * 64;
+    }
     const int n_ktiles = (a.B + 31) >> 5;
     stage(0, 0);
     load_dz(0);
@@ -453,20 +482,20 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_backward_w2(const PkBwArgs a) {
     }
   }
   __syncthreads();
-  float* sw3 = reinterpret_cast<float*>(lds);             // W3 of the tile's 128 columns; the two row halves' parts of gW3
-  float* sgw = sw3 + PK_T;
+  float* sw3 = reinterpret_cast<float*>(lds);             // W3 of the tile's columns; the row halves' parts of gW3
+  float* sgw = sw3 + BN;
   float* __restrict__ th = a.theta + (long)z * a.ldp;
-  if (threadIdx.x < PK_T) sw3[threadIdx.x] = th[a.o_W3 + bn * PK_T + threadIdx.x];
+  if (threadIdx.x < BN) sw3[threadIdx.x] = th[a.o_W3 + bn * BN + threadIdx.x];
   __syncthreads();
   constexpr float UNSCALE = RC_F16_ACT_UNSCALE * RC_F16_DZ_UNSCALE;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int jl = wn * 64 + 32 * nt + l31, j = bn * PK_T + jl;
+    const int jl = wn * 32 * NT + 32 * nt + l31, j = bn * BN + jl;
     const float w3 = sw3[jl];
     float gsum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      float* __restrict__ wp = th + a.o_W2 + (long)(bm * PK_T + wm * 64 + 32 * mt + 4 * half) * a.hid + j;
+      float* __restrict__ wp = th + a.o_W2 + (long)(bm * BM + wm * 32 * MT + 32 * mt + 4 * half) * a.hid + j;
       float wold[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) wold[r] = wp[(long)(8 * (r >> 2) + (r & 3)) * a.hid];
@@ -478,27 +507,31 @@ __global__ RC_LAT_OCC(256, 2) void k_pk_backward_w2(const PkBwArgs a) {
       }
     }
     gsum += __shfl_xor(gsum, 32);
-    if (half == 0) sgw[wm * PK_T + jl] = gsum;
+    if (half == 0) sgw[wm * BN + jl] = gsum;
     if (do_q) {
       const float qv = qs[nt] + __shfl_xor(qs[nt], 32);
       if (half == 0) a.qout[(long)z * a.hid + j] = qv * RC_F16_DZ_UNSCALE;
     }
   }
   __syncthreads();
-  if (threadIdx.x < PK_T)
-    a.gw3part[((long)z * JT + bm) * a.hid + bn * PK_T + threadIdx.x] = sgw[threadIdx.x] + sgw[PK_T + threadIdx.x];
+  if (threadIdx.x < BN) {
+    float v = sgw[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < WM; ++w) v += sgw[w * BN + threadIdx.x];
+    a.gw3part[((long)z * MTL + bm) * a.hid + bn * BN + threadIdx.x] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // b1, b2, W3, b3 -= lr * grad (masked agents only); loss_out[z] = sum(diff^2) / B
-__global__ __launch_bounds__(256) void k_pk_small_sgd(const float* __restrict__ gw3part, const float* __restrict__ qv,
+__global__ __launch_bounds__(256) void k_pk_small_sgd(const float* __restrict__ gw3part, int JT, const float* __restrict__ qv,
                                                       const float* __restrict__ gb1part, int ntb, const float* __restrict__ dz3,
                                                       int ldb, const float* __restrict__ losspart, int nchunk,
                                                       float* __restrict__ theta, int ldp, int o_b1, int o_b2, int o_W3, int o_b3,
                                                       const int* __restrict__ mask, float* __restrict__ loss_out, int N, int B, int hid,
                                                       float lr) {
   __shared__ float red[256];
-  const int z = blockIdx.x, t = threadIdx.x, JT = hid >> 7;
+  const int z = blockIdx.x, t = threadIdx.x;
   if (loss_out != nullptr && t == 0) {
     float sum = 0.f;
     for (int c = 0; c < nchunk; ++c) sum += losspart[(long)z * nchunk + c];
@@ -528,7 +561,29 @@ __global__ __launch_bounds__(256) void k_pk_small_sgd(const float* __restrict__ 
 }
 
 static inline bool pk_dims_ok(int S, int N, int B, int hid, int ldp) { return S > 0 && N > 0 && B > 0 && hid > 0 && ldp > 0; }
-static inline size_t pk_smem(int pa, int pb) { return (size_t)2 * (pa + pb) * RC_PK_BLOCK; }
+template <class T> static inline size_t pk_smem(int pa, int pb) { return (size_t)2 * (pa * (T::BM / 128) + pb * (T::BN / 128)) * RC_PK_BLOCK; }
+
+template <class T> static int pk_launch_forward2(const PkFwdArgs& a, void* stream) {
+  const size_t smem = pk_smem<T>(2, 2);
+  static const bool ok = rc_want_lds(k_pk_forward2<T>, smem);
+  if (!ok) return RCMARL_ERR_LAUNCH;
+  RCMARL_LAUNCH((k_pk_forward2<T>), dim3((unsigned)(a.Z * (a.hid / T::BM) * a.ntb)), dim3(T::THREADS), smem, stream, a);
+  return rcmarl_check_launch();
+}
+template <class T> static int pk_launch_backward_data(const PkBdArgs& a, void* stream) {
+  const size_t smem = pk_smem<T>(1, 2);
+  static const bool ok = rc_want_lds(k_pk_backward_data<T>, smem);
+  if (!ok) return RCMARL_ERR_LAUNCH;
+  RCMARL_LAUNCH((k_pk_backward_data<T>), dim3((unsigned)(a.Z * (a.hid / T::BN) * a.ntb)), dim3(T::THREADS), smem, stream, a);
+  return rcmarl_check_launch();
+}
+template <class T> static int pk_launch_backward_w2(const PkBwArgs& a, void* stream) {
+  const size_t smem = pk_smem<T>(2, 1);
+  static const bool ok = rc_want_lds(k_pk_backward_w2<T>, smem);
+  if (!ok) return RCMARL_ERR_LAUNCH;
+  RCMARL_LAUNCH((k_pk_backward_w2<T>), dim3((unsigned)(a.Z * (a.hid / T::BM) * (a.hid / T::BN))), dim3(T::THREADS), smem, stream, a);
+  return rcmarl_check_launch();
+}
 
 }  // namespace
 
@@ -536,6 +591,7 @@ static inline size_t pk_smem(int pa, int pb) { return (size_t)2 * (pa + pb) * RC
 //   a1_bk, a1_kb: S*N * (Bp/128) * (hid/32) * 2 * 8192 bytes each       mask_bj, mask_jb: half of that
 //   w2t, w2w3:    S*N * (hid/128) * (hid/32) * 2 * 8192 bytes each       s1: S*N*hid * (Bp/32) uint32
 //   dzv: S*N * 4 * Bp uint16     vpart: S*N * (hid/128) * ldb fp32      gw3part: S*N * (hid/128) * hid    gb1part: S*N * ceil(B/128) * hid
+// (the part buffers are used up to hid/T resp. ceil(B/T) entries, T = the block tile side: 256 when hid % 256 == 0, else 128)
 RCMARL_EXPORT int rcmarl_pk_supported(int hid) { return hid > 0 && (hid & 127) == 0 && (rc_lat_f16_mode() & 3) == 3; }
 
 // theta[s][n] -> w2t, w2w3, rs   (o_W2 = in_dim*hid + hid, o_W3 = o_W2 + hid*hid + hid: the Keras row of rcmarl_common.h)
@@ -558,19 +614,15 @@ RCMARL_EXPORT int rcmarl_pk_forward2(const void* w2t, const void* a1_bk, int bk_
   if (!w2t || !a1_bk || !theta || (!a2 && !mask_bj && !mask_jb && !vpart) || !pk_dims_ok(S, N, B, hid, ldp) || in_dim <= 0 || ldb < B)
     return RCMARL_ERR_ARG;
   if (hid & 127) return RCMARL_ERR_UNSUPPORTED;
-  const int ntb = rc_ceil_div(B, PK_T);
-  if (bk_rt < ntb || (mask_bj && mbj_rt < ntb) || (mask_jb && mjb_kt < 4 * ntb)) return RCMARL_ERR_ARG;
+  const int T = pk_tile(hid), ntb = rc_ceil_div(B, T), rts = ntb * (T / 128);
+  if (bk_rt < rts || (mask_bj && mbj_rt < rts) || (mask_jb && mjb_kt < 4 * rts)) return RCMARL_ERR_ARG;
   const NetGeom g = make_geom(in_dim, hid, 1);
   PkFwdArgs a{};
   a.w2t = (const unsigned char*)w2t; a.a1bk = (const unsigned char*)a1_bk; a.bk_rt = bk_rt;
   a.theta = theta; a.ldp = ldp; a.o_b2 = g.o_b2; a.o_W3 = g.o_W3;
   a.a2 = a2; a.ldb = ldb; a.mask_bj = (unsigned char*)mask_bj; a.mbj_rt = mbj_rt; a.mask_jb = (unsigned char*)mask_jb; a.mjb_kt = mjb_kt;
   a.vpart = vpart; a.Z = S * N; a.B = B; a.hid = hid; a.ntb = ntb;
-  const size_t smem = pk_smem(2, 2);
-  static const bool ok = rc_want_lds(k_pk_forward2, smem);
-  if (!ok) return RCMARL_ERR_LAUNCH;
-  RCMARL_LAUNCH(k_pk_forward2, dim3((unsigned)(a.Z * (hid >> 7) * ntb)), dim3(256), smem, stream, a);
-  return rcmarl_check_launch();
+  return T == 256 ? pk_launch_forward2<PkBig>(a, stream) : pk_launch_forward2<PkSmall>(a, stream);
 }
 
 // mode 0: out = V; 1: out = aux + gamma V (aux = applied reward: the TD target, :114-115); 2: the MSE head of fit() (aux = y):
@@ -583,7 +635,7 @@ RCMARL_EXPORT int rcmarl_pk_head(const float* vpart, const float* theta, const f
   if (hid & 127) return RCMARL_ERR_UNSUPPORTED;
   const int Bp = rc_ceil_div(B, 256) * 256;
   const NetGeom g = make_geom(in_dim, hid, 1);
-  RCMARL_LAUNCH(k_pk_head, dim3(Bp / 256, S * N), dim3(256), 0, stream, vpart, theta, ldp, g.o_b3, hid >> 7, aux, gamma, mode, out,
+  RCMARL_LAUNCH(k_pk_head, dim3(Bp / 256, S * N), dim3(256), 0, stream, vpart, theta, ldp, g.o_b3, hid / pk_tile(hid), aux, gamma, mode, out,
                 (unsigned short*)dzv, Bp, losspart, rc_ceil_div(B, 256), B, ldb);
   return rcmarl_check_launch();
 }
@@ -595,18 +647,14 @@ RCMARL_EXPORT int rcmarl_pk_backward_data(const void* mask_bj, int mbj_rt, const
                                           int B, int hid, int ldb, void* stream) {
   if (!mask_bj || !w2w3 || !rs || !s1 || !dz3 || !dzp || !gb1part || !pk_dims_ok(S, N, B, hid, 1) || ldb < B) return RCMARL_ERR_ARG;
   if ((hid & 127) || !(rc_lat_f16_mode() & 2)) return RCMARL_ERR_UNSUPPORTED;
-  const int ntb = rc_ceil_div(B, PK_T);
-  if (mbj_rt < ntb || s1_ld < 4 * ntb || dzp_rt < N * (hid >> 7) || dzp_kt < rc_ceil_div(B, 32)) return RCMARL_ERR_ARG;
+  const int T = pk_tile(hid), ntb = rc_ceil_div(B, T), rts = ntb * (T / 128);
+  if (mbj_rt < rts || s1_ld < 4 * rts || dzp_rt < N * (hid >> 7) || dzp_kt < 4 * rts) return RCMARL_ERR_ARG;
   PkBdArgs a{};
   a.mask_bj = (const unsigned char*)mask_bj; a.mbj_rt = mbj_rt; a.w2w3 = (const unsigned char*)w2w3; a.rs = rs; a.s1 = s1; a.s1_ld = s1_ld;
   a.dz3 = dz3; a.ldb = ldb; a.dzp = (unsigned char*)dzp; a.dzp_rt = dzp_rt; a.dzp_kt = dzp_kt; a.gb1part = gb1part;
   a.Z = S * N; a.N = N; a.B = B; a.hid = hid; a.ntb = ntb;
   rc_form_set(dzp, 1);
-  const size_t smem = pk_smem(1, 2);
-  static const bool ok = rc_want_lds(k_pk_backward_data, smem);
-  if (!ok) return RCMARL_ERR_LAUNCH;
-  RCMARL_LAUNCH(k_pk_backward_data, dim3((unsigned)(a.Z * (hid >> 7) * ntb)), dim3(256), smem, stream, a);
-  return rcmarl_check_launch();
+  return T == 256 ? pk_launch_backward_data<PkBig>(a, stream) : pk_launch_backward_data<PkSmall>(a, stream);
 }
 
 // W2 -= lr * gW2 for the agents with mask[n] != 0 (NULL: all); gw3part [S][N][hid/128][hid], q [S][N][hid] for rcmarl_pk_small_sgd
@@ -622,12 +670,7 @@ RCMARL_EXPORT int rcmarl_pk_backward_w2(const void* a1_kb, int kb_kt, const void
   a.a1kb = (const unsigned char*)a1_kb; a.kb_kt = kb_kt; a.mask_jb = (const unsigned char*)mask_jb; a.mjb_kt = mjb_kt;
   a.dzv = (const unsigned short*)dzv; a.Bp = rc_ceil_div(B, 256) * 256; a.theta = theta; a.ldp = ldp; a.o_W2 = g.o_W2; a.o_W3 = g.o_W3;
   a.mask = mask; a.lr = lr; a.gw3part = gw3part; a.qout = q; a.Z = S * N; a.N = N; a.B = B; a.hid = hid;
-  const size_t smem = pk_smem(2, 1);
-  static const bool ok = rc_want_lds(k_pk_backward_w2, smem);
-  if (!ok) return RCMARL_ERR_LAUNCH;
-  const int JT = hid >> 7;
-  RCMARL_LAUNCH(k_pk_backward_w2, dim3((unsigned)(a.Z * JT * JT)), dim3(256), smem, stream, a);
-  return rcmarl_check_launch();
+  return pk_tile(hid) == 256 ? pk_launch_backward_w2<PkBig>(a, stream) : pk_launch_backward_w2<PkSmall>(a, stream);
 }
 
 // b1, b2, W3, b3 -= lr * grad from the parts the two backward GEMMs and the head left; loss_out [S][N] (optional)
@@ -638,7 +681,7 @@ RCMARL_EXPORT int rcmarl_pk_small_sgd(const float* gw3part, const float* q, cons
     return RCMARL_ERR_ARG;
   if (hid & 127) return RCMARL_ERR_UNSUPPORTED;
   const NetGeom g = make_geom(in_dim, hid, 1);
-  RCMARL_LAUNCH(k_pk_small_sgd, dim3(S * N), dim3(256), 0, stream, gw3part, q, gb1part, rc_ceil_div(B, PK_T), dz3, ldb, losspart,
+  RCMARL_LAUNCH(k_pk_small_sgd, dim3(S * N), dim3(256), 0, stream, gw3part, hid / pk_tile(hid), q, gb1part, rc_ceil_div(B, pk_tile(hid)), dz3, ldb, losspart,
                 rc_ceil_div(B, 256), theta, ldp, g.o_b1, g.o_b2, g.o_W3, g.o_b3, mask, loss_out, N, B, hid, lr);
   return rcmarl_check_launch();
 }

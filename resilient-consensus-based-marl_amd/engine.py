@@ -132,6 +132,7 @@ class RPBCACEngine:
         self.adam_v = torch.zeros(S, N, self.ldp["actor"], **f32)
         self.adam_t = 0
         self.a1_cached = {"critic": False, "tr": False}
+        self.a2_cached = False                # wide critic: self.w_a2 holds the fp32 layer-2 activations of the LIVE critic on the s rows
         self._graphs, self.graph_captures, self.graph_replays = {}, 0, 0       # captured update epochs (see _epoch)
         self.loss = {k: torch.zeros(S, N, **f32) for k in ("actor", "critic", "tr")}
         self.rp, self.ybuf = None, {k: None for k in ("r_fit", "y_c", "v_tr", "v_next", "v_cur", "delta", "act_t")}
@@ -204,7 +205,7 @@ class RPBCACEngine:
         # fit inputs there, which are exactly what step 0 of the next epoch's local fit needs (the fit starts
         # from a copy of the live net and only W3,b3 moved since) -> one forward GEMM per net per epoch saved
         self.a1net = {k: torch.zeros(S, N * self.hid[k], self.ldb, **f32) for k in ("critic", "tr")}
-        self.a1_cached["critic"] = self.a1_cached["tr"] = False
+        self.a1_cached["critic"] = self.a1_cached["tr"] = self.a2_cached = False
         self._init_wide()
         self.ybuf = {k: torch.zeros(S, N, self.ldb, **f32) for k in self.ybuf}
         self.rcoop = torch.zeros(S, self.ldb, **f32)
@@ -302,6 +303,8 @@ class RPBCACEngine:
         in_dim, ldp = self.in_dim[net], self.ldp[net]
         g, wp = self.lat_geom[xkey], self.lat_wp_f[xkey]
         a1_bk = pk.a1_bk[which]
+        if want_a2:
+            self.a2_cached = False
         full = which == "net"                  # the cached image always carries both orientations and the sign bits
         if not skip_layer1:
             if not wp_fresh:
@@ -355,6 +358,7 @@ class RPBCACEngine:
         x: (ptr, seed_stride, row_major, ld) of an input other than a replay tensor (rollout start states)."""
         L, S, N, hid = self.lib, self.S, self.N, self.hid[net]
         o_b1, o_W2, o_b2 = self._wide_offsets(net)
+        self.a2_cached = False
         a1 = self.w_a1 if a1 is None else a1
         if not skip_layer1:
             if x is None and self._lattice_ok(xkey, B, row0):
@@ -430,6 +434,7 @@ class RPBCACEngine:
                                      self.w_grads.data_ptr(), None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb,
                                      c.d, c.H, self.stream)
         self.a1_cached[net] = ("pk" if pk else True) if self.reuse_activations else False
+        self.a2_cached = bool(pk and net == "critic" and xkey == "s" and self.reuse_activations)
         L.rcmarl_wide_head_apply(self.w_grads.data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(), S, N, B,
                                  self.in_dim[net], hid, self.ldp[net], self.stream)
 
@@ -844,7 +849,7 @@ class RPBCACEngine:
                 r.set_state((st["name"], st["keys"].numpy().astype(np.uint32), int(st["pos"]), int(st["has_gauss"]),
                              float(st["cached"])))
                 self.np_rngs.append(r)
-        self.a1_cached["critic"] = self.a1_cached["tr"] = False
+        self.a1_cached["critic"] = self.a1_cached["tr"] = self.a2_cached = False
         self.lat_active = False
         self.rows_episode_aligned = bool(sd.get("rows_episode_aligned", False))
 
@@ -1159,6 +1164,32 @@ class RPBCACEngine:
         L.rcmarl_scatter_values(scratch.data_ptr(), self._p(r_applied), c.gamma, out.data_ptr(), ep - 1, ep, nt, S, N, self.ldb,
                                 self.stream)
 
+    def _a2_rows_ok(self, row0, nrows):
+        """wide critic: may the values of the next states come from the fp32 layer-2 activations the consensus step's forward pass
+        left in w_a2?  (live hidden layers unchanged since, rows are whole episodes of ours, not an agent-sharded instance)"""
+        ep = self.cfg.max_ep_len
+        return (self.td_shortcut and self.a2_cached and self.wide and self.shard is None and self.rows_episode_aligned and ep >= 2
+                and row0 % ep == 0 and nrows % ep == 0)
+
+    def _value_next_cached_wide(self, out, row0, nrows, r_applied, scratch):
+        """_value_next_cached for a wide critic: inside an episode V(ns[b]) = V(s[b+1]) is the live head on the cached layer-2
+        activations of row b+1 (the head moved since they were computed, the hidden layers did not); the last step of every episode
+        gets a forward pass of its own on the gathered ns rows."""
+        c, L, S, N = self.cfg, self.lib, self.S, self.N
+        ep, th, hid = c.max_ep_len, self.theta["critic"], self.hid["critic"]
+        L.rcmarl_wide_head_value(self.w_a2.data_ptr() + 4 * (row0 + 1), th.data_ptr(), self._p(r_applied), c.gamma, out.data_ptr(),
+                                 S, N, nrows - 1, self.in_c, hid, self.ldp["critic"], self.ldb, self.stream)
+        nt = nrows // ep
+        ns_w = self.rp["ns"].shape[2]
+        if self._ns_term is None or self._ns_term.numel() < S * nt * ns_w:
+            self._ns_term = torch.empty(S * nt * ns_w, dtype=torch.float32, device=self.dev)
+        ns_term = self._ns_term
+        nptr, nstride = self._x("ns", row0)
+        L.rcmarl_gather_rows(nptr, nstride, ep - 1, ep, nt, ns_w, ns_term.data_ptr(), S, self.stream)
+        self._value_wide(None, th, "critic", scratch, nt, x=(ns_term.data_ptr(), nt * self.in_c, 1, self.in_c))     # (overwrites w_a2)
+        L.rcmarl_scatter_values(scratch.data_ptr(), self._p(r_applied), c.gamma, out.data_ptr(), ep - 1, ep, nt, S, N, self.ldb,
+                                self.stream)
+
     def _td_target(self, B):
         """y = r_applied + gamma * V_critic(ns)   (agents/resilient_CAC_agents.py:114-115), all agents, all rows: from the
         activations the previous epoch's consensus step left behind where possible (one forward GEMM and one W1 split
@@ -1166,6 +1197,8 @@ class RPBCACEngine:
         y, r = self.ybuf["y_c"], self.ybuf["r_fit"]
         if self._cached_rows_ok("critic", 0, B):
             self._value_next_cached(y, 0, B, r, self.ybuf["v_next"])
+        elif self._a2_rows_ok(0, B):
+            self._value_next_cached_wide(y, 0, B, r, self.ybuf["v_next"])
         else:
             self._value("ns", self.theta["critic"], "critic", y, B, r_applied=r)
 
@@ -1323,7 +1356,7 @@ class RPBCACEngine:
         if self.profile_phases:
             self.sync()
             t0 = time.perf_counter()
-        self.a1_cached["critic"] = self.a1_cached["tr"] = False       # new replay rows
+        self.a1_cached["critic"] = self.a1_cached["tr"] = self.a2_cached = False       # new replay rows
         self._lattice_encode(B)
         rptr, rstride = self._x("r")
         L.rcmarl_team_reward(rptr, rstride, self.coop.data_ptr(), max(self.n_coop, 1), self.rcoop.data_ptr(), S, N, B,

@@ -193,8 +193,9 @@ def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_fo
 
 
 # ---- the same layers on pre-split packed operands (hid % 128 == 0): csrc/dense_pk.hip ---------------------------------
-def test_pk_forward(bk):
-    WC.check_pk_forward(bk, 1, 2, 150, 2, 5, 5, 128)
+@pytest.mark.parametrize("S,N,B,width,hid", [(1, 2, 150, 2, 128), (1, 1, 300, 3, 256)])      # 128 x 128 tiles / 256 x 256 tiles
+def test_pk_forward(bk, S, N, B, width, hid):
+    WC.check_pk_forward(bk, S, N, B, width, 5, 5, hid)
 
 
 @pytest.mark.parametrize("S,N,B,width,nrow,ncol,hid,steps,masked", [(1, 2, 300, 2, 5, 5, 256, 3, None),      # two unit tiles, three row tiles

@@ -6,6 +6,7 @@ TAG=${1:-r06a}
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py tests/test_engine_baseline_shapes_gpu.py tests/test_sharded_engine_gpu.py -m gpu -q -k "pk or wide or packed or sharded or d66 or 66" --maxfail=20 -p no:cacheprovider -rP > gpurun_out/${TAG}_tests.log 2>&1
 grep -E "^(FAILED|ERROR)|passed|failed|packed-operand fit|parity\]" gpurun_out/${TAG}_tests.log | tail -40
 grep -E "^E  " gpurun_out/${TAG}_tests.log | head -30
+echo "== knife"; timeout 300 python tools/diag_pk_knife.py 2 16 777 3 7 9 128 3 0.02 4 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_knife.txt | grep -B1 -A6 "<--" | head -40
 echo "== kbench pk"; timeout 600 python tools/kbench.py pk 2>&1 | tail -16 | tee gpurun_out/${TAG}_kbench_pk.txt
 echo "== kbench wide"; timeout 300 python tools/kbench.py wide 2>&1 | tail -20 | tee gpurun_out/${TAG}_kbench_wide.txt
 echo "== bench cfg5_1gpu"
