@@ -1166,15 +1166,19 @@ class RPBCACEngine:
 
     def _a2_rows_ok(self, row0, nrows):
         """wide critic: may the values of the next states come from the fp32 layer-2 activations the consensus step's forward pass
-        left in w_a2?  (live hidden layers unchanged since, rows are whole episodes of ours, not an agent-sharded instance)"""
+        left in w_a2?  (live hidden layers unchanged since, rows are whole episodes of ours)"""
         ep = self.cfg.max_ep_len
-        return (self.td_shortcut and self.a2_cached and self.wide and self.shard is None and self.rows_episode_aligned and ep >= 2
+        return (self.td_shortcut and self.a2_cached and self.wide and self.rows_episode_aligned and ep >= 2
                 and row0 % ep == 0 and nrows % ep == 0)
 
     def _value_next_cached_wide(self, out, row0, nrows, r_applied, scratch):
         """_value_next_cached for a wide critic: inside an episode V(ns[b]) = V(s[b+1]) is the live head on the cached layer-2
         activations of row b+1 (the head moved since they were computed, the hidden layers did not); the last step of every episode
         gets a forward pass of its own on the gathered ns rows."""
+        if self._sharded("critic"):             # this rank's agents only: the targets feed their own local fits
+            o, r, sc = self._wv(out), self._wv(r_applied), self._wv(scratch)
+            with self._agent_window():
+                return self._value_next_cached_wide(o, row0, nrows, r, sc)
         c, L, S, N = self.cfg, self.lib, self.S, self.N
         ep, th, hid = c.max_ep_len, self.theta["critic"], self.hid["critic"]
         L.rcmarl_wide_head_value(self.w_a2.data_ptr() + 4 * (row0 + 1), th.data_ptr(), self._p(r_applied), c.gamma, out.data_ptr(),

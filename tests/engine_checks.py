@@ -70,6 +70,90 @@ def run_oracle_parallel(args, nrow, ncol, rng_mode, seeds, W, goals):
     return [r[0] for r in res], [r[1] for r in res]
 
 
+def snapshot_for_oracle(eng, seed_idx):
+    """Everything oracle.update_block needs to repeat the engine's NEXT update block of one seed from identical state: every
+    network of every agent, the actors' Adam slots and step count, the replay rows (fp32, as the reference casts them at
+    training/train_agents.py:89-92)."""
+    from rcmarl_amd.engine import unflatten_params
+    N, B = eng.N, eng.B
+    W = [{net: [a.copy() for a in eng.get_weights(seed_idx, i, net)] for net in ("actor", "critic", "tr")} for i in range(N)]
+    adam = []
+    for i in range(N):
+        m, v, t = eng.dump_adam(seed_idx, i)
+        adam.append((unflatten_params(m, eng.in_dim["actor"], eng.out_dim["actor"]), unflatten_params(v, eng.in_dim["actor"], eng.out_dim["actor"]), t))
+    g = lambda k: eng.rp[k][seed_idx, :B].detach().cpu().numpy().copy()
+    return {"W": W, "adam": adam, "s": g("s").reshape(B, N, 2), "ns": g("ns").reshape(B, N, 2), "r": g("r").reshape(B, N, 1),
+            "a": g("a").reshape(B, N, 1)}
+
+
+def _oracle_block_job(payload):
+    """oracle.update_block (training/train_agents.py:100-153) on one snapshot, in a worker process"""
+    import os
+    import sys
+    root, args, snap, threads = payload[:4]
+    mode = payload[4] if len(payload) > 4 else "f32"
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(threads)
+    except Exception:
+        pass
+    from oracle import mlp_np as M_
+    from oracle import rpbcac_oracle as O_
+    # (a pool worker may serve several jobs: start from the pristine module state every time)
+    if not hasattr(M_, "_pristine_fit_mse"):
+        M_._pristine_fit_mse = M_.fit_mse
+    M_.fit_mse = M_._pristine_fit_mse
+    M_.F32 = O_.F32 = np.float32
+    M_.LEAK = np.float32(0.1)
+    if mode == "f64":
+        # the ARBITER: the same loop nest in float64 (this worker process only).  Every array and every scalar the restatement
+        # forms through its F32 alias becomes a double; the inputs are the fp32 snapshot widened.  (Constants such as lr and the
+        # LeakyReLU slope are then the doubles 0.001 / 0.1 rather than their fp32 roundings: a relative 5e-8 on the update.)
+        M_.F32 = O_.F32 = np.float64
+        M_.LEAK = np.float64(0.1)
+    elif mode == "f32_shuffled":
+        # the CONTROL: fp32, the rows of every full-batch local fit in another order per epoch -- what Keras' fit(shuffle=True)
+        # does to the single batch (SURVEY.md 8a): the same sums, taken in another order
+        orig, rng = M_.fit_mse, np.random.default_rng(12345 + int(args.get("random_seed", 0)))
+
+        def fit_shuffled(params, x, y, lr, epochs, batch_size=None, perms=None, sample_weight=None):
+            if batch_size is None and perms is None:
+                B = np.asarray(x).shape[0]
+                perms = np.stack([rng.permutation(B) for _ in range(epochs)])
+            return orig(params, x, y, lr, epochs, batch_size=batch_size, perms=perms, sample_weight=sample_weight)
+        M_.fit_mse = fit_shuffled
+    agents = []
+    for i, lab in enumerate(args["agent_label"]):
+        w = snap["W"][i]
+        ag = O_.make_agent(lab, w["actor"], w["critic"], w["tr"], args["slow_lr"], args["fast_lr"], args["gamma"], args["H"])
+        m, v, t = snap["adam"][i]
+        ag.adam.m, ag.adam.v, ag.adam.t = [x.astype(M_.F32).copy() for x in m], [x.astype(M_.F32).copy() for x in v], int(t)
+        agents.append(ag)
+    O_.update_block(agents, args["agent_label"], args["in_nodes"], snap["s"], snap["ns"], snap["r"], snap["a"], args["n_epochs"],
+                    args["common_reward"], args["max_ep_len"], args["n_ep_fixed"], O_.ShuffleStream(args.get("random_seed", 0)))
+    return [ag.parameters() for ag in agents]
+
+
+def run_oracle_blocks_parallel(args, snaps, modes=None):
+    """one oracle.update_block per snapshot, one worker process each -> per-snapshot weight lists [agent][actor, critic, tr].
+    modes (per snapshot): "f32" (the oracle), "f64" (the same loop nest in float64), "f32_shuffled" (fp32, local-fit rows reordered)"""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(len(snaps), ncpu))
+    threads = max(1, min(16, ncpu // workers))
+    jobs = [(root, args, sn, threads, "f32" if modes is None else modes[k]) for k, sn in enumerate(snaps)]
+    if workers == 1:
+        return [_oracle_block_job(j) for j in jobs]
+    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_oracle_block_job, jobs))
+
+
 def network_errors(eng, o_weights, nets=("critic", "tr")):
     """per-network worst |w - w_oracle| / max(1, |w|max) -> {net: float array over (seed, agent)}"""
     out = {}
@@ -345,3 +429,45 @@ def check_actor_gradient(n, d, H, nrow, device, lib, fast_lr, n_ep_fixed=10, max
     else:
         compare(eng, logs, o_logs, o_w, rtol_w=1e-4, actor="strict")
     return float(e.max())
+
+
+def actor_stat(eng, o_weights, lr, steps=1):
+    """(fraction of the actor parameters further than 5 % of `steps` Adam steps from the oracle's, largest |difference|)"""
+    errs = []
+    for s in range(eng.S):
+        for i in range(eng.N):
+            for a, b in zip(eng.get_weights(s, i, "actor"), o_weights[s][i][0]):
+                errs.append(np.abs(a - b).ravel())
+    e = np.concatenate(errs)
+    return float(np.mean(e > 0.05 * lr * steps + 1e-5)), float(e.max())
+
+
+def check_block_from_injected_state(args, nrow, ncol, device, lib, seeds, blocks_before=2, lattice="auto", tweak=None, oracle_later=False):
+    """ONE update block against the oracle from IDENTICAL state: the engine runs `blocks_before` whole blocks and the rollout of the
+    next one, its state (every network, the Adam slots, the replay rows) is handed to oracle.update_block, then both sides run the
+    update.  Unlike a run from the initial weights this comparison does not need the two rollouts to stay in step, so it reaches the
+    steady-state batch (B = buffer_size + one block of rows) with live actors.  Returns (engine, per-network errors)."""
+    n, S = args["n_agents"], len(seeds)
+    W, goals = make_inputs(args, nrow, seeds)
+    cfg = EngineConfig(n, args["agent_label"], args["in_nodes"], H=args["H"], gamma=args["gamma"], slow_lr=args["slow_lr"],
+                       fast_lr=args["fast_lr"], max_ep_len=args["max_ep_len"], n_ep_fixed=args["n_ep_fixed"],
+                       n_epochs=args["n_epochs"], buffer_size=args["buffer_size"], common_reward=args["common_reward"],
+                       nrow=nrow, ncol=ncol, n_seeds=S, rng_mode="device", lattice=lattice)
+    eng = RPBCACEngine(cfg, seeds=list(seeds), device=device, lib=lib)
+    for s in range(S):
+        for i in range(n):
+            for net in ("actor", "critic", "tr"):
+                eng.set_weights(s, i, net, W[s][i][net])
+    eng.set_goals(np.stack(goals))
+    if tweak is not None:
+        tweak(eng)
+    for _ in range(blocks_before):
+        eng.run_block()
+    eng.rollout_block(cfg.n_ep_fixed)
+    snaps = [snapshot_for_oracle(eng, s) for s in range(S)]
+    if oracle_later:                                   # the caller batches the oracle jobs of several engines (one process each)
+        return eng, snaps
+    o_w = run_oracle_blocks_parallel(dict(args), snaps)
+    eng.update_block()
+    eng.sync()
+    return eng, network_errors(eng, o_w), o_w

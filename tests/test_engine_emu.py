@@ -1,5 +1,6 @@
 """End-to-end engine (host logic + every kernel, hipemu build) vs the oracle's
 train() on tiny cooperative scenarios, both RNG modes.  CPU-only."""
+import numpy as np
 import pytest
 
 import engine_checks as EC
@@ -66,6 +67,18 @@ def test_engine_wide_critic_on_packed_operands_matches_oracle():
     eng, logs, o_logs, o_w = EC.run_pair(args, 5, 5, "device", "cpu", emu_lib(), seeds=(41,), critic_hid=128, lattice=True)
     assert eng.wide and eng.lat_active and eng.pk is not None and eng._pk_ok("critic", "s", eng.lat_B)
     EC.compare(eng, logs, o_logs, o_w)
+
+
+def test_update_block_from_injected_state_matches_oracle():
+    """One update block from IDENTICAL state (tests/engine_checks.check_block_from_injected_state): after two blocks and the rollout
+    of the third the engine's weights, Adam slots and replay rows go into oracle.update_block (training/train_agents.py:100-153);
+    the third block then runs on both sides at the steady-state batch B = buffer_size + n_ep_fixed * max_ep_len with live actors."""
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=0, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=12, seed=71)
+    eng, errs, o_w = EC.check_block_from_injected_state(args, 5, 5, "cpu", emu_lib(), (71, 72))
+    assert eng.B == 12 and eng.adam_t == 3                       # (the trim after the update brought the 18 rows back to buffer_size)
+    assert max(float(e.max()) for e in errs.values()) <= 1e-5, errs
+    worst = max(float(np.abs(a - b).max()) for s in range(2) for i in range(5) for a, b in zip(eng.get_weights(s, i, "actor"), o_w[s][i][0]))
+    assert worst <= 1e-5, worst
 
 
 def test_engine_wide_critic_with_faulty_agent_matches_oracle():

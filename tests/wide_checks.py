@@ -331,8 +331,29 @@ def check_pk_forward(bk, S, N, B, width, nrow, ncol, hid):
             rel_close(y[s, n, :B], r[s, n, :B] + np.float32(0.9) * want, 8e-6, "td target")
 
 
-def check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=2, lr=0.01, masked_agent=None, tol=2e-5):
-    """`steps` full-batch SGD steps on the packed-operand path vs the oracle's fit (M.fit_mse)."""
+def knife_edge_ratio(p0, x, y, lr, steps):
+    """fp64 replay of the oracle's full-batch fit from p0: the smallest |pre-activation| / sum |terms| over both hidden layers, all rows
+    and all `steps` steps.  A LeakyReLU input within rounding of zero (ratio ~1e-7 or less) takes the other slope in one of two fp32
+    chains that differ in rounding order: that unit's weights then move by about lr * 0.9 * |dz| * |x| / B -- a "knife edge"."""
+    pw = M.copy_params(p0)
+    worst = np.inf
+    for _ in range(steps):
+        p64 = [q.astype(np.float64) for q in pw]
+        x64 = x.astype(np.float64)
+        z1 = x64 @ p64[0] + p64[1]
+        a1 = np.where(z1 > 0, z1, 0.1 * z1)
+        z2 = a1 @ p64[2] + p64[3]
+        s1 = np.abs(x64) @ np.abs(p64[0]) + np.abs(p64[1])
+        s2 = np.abs(a1) @ np.abs(p64[2]) + np.abs(p64[3])
+        worst = min(worst, float((np.abs(z1) / s1).min()), float((np.abs(z2) / s2).min()))
+        M.fit_mse(pw, x, y, lr, epochs=1)
+    return worst
+
+
+def check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=2, lr=0.01, masked_agent=None, tol=2e-5, knife_tol=1e-3):
+    """`steps` full-batch SGD steps on the packed-operand path vs the oracle's fit (M.fit_mse).  A network beyond `tol` must be a
+    PROVEN knife edge (knife_edge_ratio below 2e-7: one of its ~B * hid * steps LeakyReLU inputs sits within fp32 rounding of zero)
+    and stay within knife_tol."""
     assert bk.lib.rcmarl_pk_supported(hid) == 1
     rng, in_dim, g, ldp, ldb, params, x, alpha = _wide_lattice_case(S, N, B, width, nrow, ncol, hid, 1)
     theta = pack_rows(params, ldp)
@@ -357,8 +378,13 @@ def check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=2, lr=0.01, masked_a
             pw = M.copy_params(params[s][n])
             hist = M.fit_mse(pw, x[s], yv[s, n, :B, None], lr, epochs=steps)
             got = unpack_row(msg[s, n], in_dim, 1, hid)
-            for k in range(6):
-                rel_close(got[k], pw[k], tol, "packed-operand fit param %d" % k)
-                worst = max(worst, float(np.max(np.abs(got[k] - pw[k])) / max(1.0, float(np.max(np.abs(pw[k]))))))
+            err = max(float(np.max(np.abs(got[k] - pw[k])) / max(1.0, float(np.max(np.abs(pw[k]))))) for k in range(6))
+            if err > tol:
+                ratio = knife_edge_ratio(params[s][n], x[s], yv[s, n, :B, None], lr, steps)
+                assert ratio < 2e-7 and err <= knife_tol, "packed-operand fit, seed %d agent %d: error %.2e beyond %.1e without a knife " \
+                    "edge to explain it (smallest |z| / sum|terms| %.1e)" % (s, n, err, tol, ratio)
+                print("packed-operand fit: seed %d agent %d is a knife edge (|z| / sum|terms| = %.1e): error %.2e" % (s, n, ratio, err))
+            else:
+                worst = max(worst, err)
             assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
     return worst
