@@ -36,6 +36,8 @@ extern "C" {
 int rcmarl_abi_version(void);                          /* 4 (round 6): ABI 3 (= ABI 2 minus the fused local-fit prototypes, plus
                                                         * rcmarl_minibatch_fit_multi and rcmarl_lattice_forget) plus the packed-operand
                                                         * dense layers of wide networks, rcmarl_pk_* */
+int rcmarl_mb_job_layout(int what);                    /* sizeof(rcmarl_mb_job) (what = 0) / offset of its field number `what` (1 = x_seed_stride
+                                                        * ... 10 = ovf_flags), -1 otherwise: a binding checks its own declaration against it */
 int rcmarl_fit_partial_size(int hid);                  /* floats per partial record of rcmarl_mid_fit */
 int rcmarl_actor_partial_size(int hid, int n_actions); /* floats per partial record of rcmarl_mid_actor */
 int rcmarl_rows_per_chunk(void);                       /* replay rows per workgroup (256); nchunk = ceil(B/256) */

@@ -29,6 +29,7 @@ c_float = C.c_float
 # name -> argtypes (every function returns int: 0 ok, see RCMARL_ERR_* in include/rcmarl.h)
 SIGNATURES = {
     "rcmarl_abi_version": [],
+    "rcmarl_mb_job_layout": [c_int],
     # jobs (host array of MbJob), njobs, S, N, B, hid, ldb, batch_size, epochs, lr, stream
     "rcmarl_minibatch_fit_multi": [C.c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_stream],
     "rcmarl_lattice_forget": [c_u8p],
@@ -197,7 +198,7 @@ SIGNATURES = {
     # src, src_batch, ld_src, dst, dst_batch, ld_dst, batches, rows, cols, row_mask, stream
     "rcmarl_copy3d": [c_f32p, c_long, c_long, c_f32p, c_long, c_long, c_int, c_int, c_int, c_i32p, c_stream],
 }
-UNCHECKED = {"rcmarl_abi_version", "rcmarl_lattice_forget", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
+UNCHECKED = {"rcmarl_abi_version", "rcmarl_mb_job_layout", "rcmarl_lattice_forget", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
              "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk", "rcmarl_wide_f16_mode", "rcmarl_wide_set_f16_mode",
              "rcmarl_consensus_params_circulant_supported", "rcmarl_pk_supported"}
 

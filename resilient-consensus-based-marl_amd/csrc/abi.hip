@@ -6,6 +6,25 @@
 
 RCMARL_EXPORT int rcmarl_abi_version(void) { return 4; }
 
+// sizeof(rcmarl_mb_job) (what = 0) or the offset of its field number `what` (1 x_seed_stride, 2 theta, 3 agents, 4 n_adv, 5 in_dim, 6 ldp,
+// 7 y, 8 perm, 9 loss_out, 10 ovf_flags), -1 otherwise: lets a binding check its own declaration of the structure against the library's
+RCMARL_EXPORT int rcmarl_mb_job_layout(int what) {
+  switch (what) {
+    case 0: return (int)sizeof(rcmarl_mb_job);
+    case 1: return (int)offsetof(rcmarl_mb_job, x_seed_stride);
+    case 2: return (int)offsetof(rcmarl_mb_job, theta);
+    case 3: return (int)offsetof(rcmarl_mb_job, agents);
+    case 4: return (int)offsetof(rcmarl_mb_job, n_adv);
+    case 5: return (int)offsetof(rcmarl_mb_job, in_dim);
+    case 6: return (int)offsetof(rcmarl_mb_job, ldp);
+    case 7: return (int)offsetof(rcmarl_mb_job, y);
+    case 8: return (int)offsetof(rcmarl_mb_job, perm);
+    case 9: return (int)offsetof(rcmarl_mb_job, loss_out);
+    case 10: return (int)offsetof(rcmarl_mb_job, ovf_flags);
+    default: return -1;
+  }
+}
+
 namespace {
 std::mutex g_mu;
 int g_mode = -1;                                         // -1: not read yet

@@ -16,7 +16,10 @@
 #define RCMARL_OK 0
 #define RCMARL_ERR_ARG 1
 #define RCMARL_ERR_LAUNCH 2
-// one job of rcmarl_minibatch_fit_multi (include/rcmarl.h has the same definition)
+#define RCMARL_ERR_UNSUPPORTED 3
+// one job of rcmarl_minibatch_fit_multi.  THREE definitions must agree: this one, include/rcmarl.h and capi.MbJob (ctypes); the
+// static_asserts below pin this one, rcmarl_mb_job_layout() (abi.hip) hands the numbers to tests/test_capi_symbols.py, which holds
+// the ctypes structure and the public header to them.
 typedef struct rcmarl_mb_job {
   const float* x; long x_seed_stride;      /* replay tensor of this network's input family and its seed stride (floats) */
   float* theta;                            /* [S][N][ldp], rows `agents` fitted in place */
@@ -27,7 +30,12 @@ typedef struct rcmarl_mb_job {
   float* loss_out;                         /* [S][N] first-epoch loss, or NULL */
   int* ovf_flags;                          /* int32[S * n_adv], zero before first use, one buffer per job and call site */
 } rcmarl_mb_job;
-#define RCMARL_ERR_UNSUPPORTED 3
+#include <stddef.h>
+static_assert(sizeof(rcmarl_mb_job) == 80 && offsetof(rcmarl_mb_job, x_seed_stride) == 8 && offsetof(rcmarl_mb_job, theta) == 16 &&
+              offsetof(rcmarl_mb_job, agents) == 24 && offsetof(rcmarl_mb_job, n_adv) == 32 && offsetof(rcmarl_mb_job, in_dim) == 36 &&
+              offsetof(rcmarl_mb_job, ldp) == 40 && offsetof(rcmarl_mb_job, y) == 48 && offsetof(rcmarl_mb_job, perm) == 56 &&
+              offsetof(rcmarl_mb_job, loss_out) == 64 && offsetof(rcmarl_mb_job, ovf_flags) == 72,
+              "rcmarl_mb_job: the layout include/rcmarl.h and capi.MbJob declare");
 
 #ifdef RCMARL_EMU
 #define RCMARL_LAUNCH(kernel, grid, block, smem, stream, ...) \

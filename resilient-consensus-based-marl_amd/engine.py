@@ -1318,7 +1318,9 @@ class RPBCACEngine:
             return self._epoch_body(B, t0)
         key = (B, self.lat_active, bool(self.td_shortcut), bool(self.rows_episode_aligned), bool(self.k1_circulant),
                bool(self.reuse_activations), self.cap, self.lib.rcmarl_lattice_f16_mode(), os.environ.get("RCMARL_LAT_W8"),
-               os.environ.get("RCMARL_MIDFIT"))
+               os.environ.get("RCMARL_MIDFIT"),
+               # the adversaries' launch form is re-read every epoch (AdversaryPath._multi_ok, phase1): a captured epoch belongs to one form
+               bool(hasattr(self, "adv") and self.adv._multi_ok()), os.environ.get("RCMARL_ADV_ASYNC", "1"))
         g = self._graphs.get(key)
         if g is None:
             if len(self._graphs) >= 8:                             # growing replay buffer: B changes every block until steady state
@@ -1330,9 +1332,11 @@ class RPBCACEngine:
             gc_was_on = gc.isenabled()
             gc.collect()
             gc.disable()
+            captured = False
             try:
                 with torch.cuda.graph(g):
                     self._epoch_body(B, t0)
+                captured = True
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -1340,7 +1344,11 @@ class RPBCACEngine:
                     g.rcmarl_draws = self.adv.calls[0] - calls0[0]     # ... without running anything: take it back (also when the
                     self.adv.calls = calls0                        # capture raised), the replay below counts
                     if self.adv.base_dev is not None:              # (None: no adversary of this instance fits -- only Faulty ones)
-                        self.adv.base_dev.fill_(int(calls0[0]))
+                        try:                                       # the device-side counter: a stream whose capture just failed may
+                            self.adv.base_dev.fill_(int(calls0[0]))    # refuse the launch -- that must not mask the capture's own error
+                        except Exception:
+                            if captured:
+                                raise
             self._graphs[key] = g
             self.graph_captures += 1
         g.replay()

@@ -278,8 +278,8 @@ class AdversaryPath:
         perms = self._draw([(i, "actor") for i in self.adv], 1, nl)["actor"] if shuffle else None
         own = e.theta["critic"]
         if self.mal:                                   # a Malicious agent's TD error comes from its PRIVATE critic (:111-115)
-            if getattr(self, "_own", None) is None:
-                self._own = torch.empty_like(e.theta["critic"])
+            if getattr(self, "_own", None) is None or self._own.shape != e.theta["critic"].shape or self._own.device != e.theta["critic"].device:
+                self._own = torch.empty_like(e.theta["critic"])      # (re-made if the parameter matrix was re-allocated in another shape)
             own, ldp = self._own, e.ldp["critic"]
             L.rcmarl_copy3d(e.theta["critic"].data_ptr(), N * ldp, ldp, own.data_ptr(), N * ldp, ldp, S, N, ldp, None, e.stream)
             L.rcmarl_copy3d(e.theta["critic_local"].data_ptr(), N * ldp, ldp, own.data_ptr(), N * ldp, ldp, S, N, ldp,

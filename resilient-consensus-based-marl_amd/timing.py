@@ -48,6 +48,9 @@ WORK = {
     # x, x_seed_stride, theta, agents, n_adv, y, perm, S, N, B, in_dim, hid, ..., batch_size, epochs: whole Keras fit() of
     # n_adv networks per seed: epochs x B rows x (forward + backward ~ 6 flops per weight)
     "rcmarl_minibatch_fit": lambda a: (6.0 * a[7] * a[4] * a[15] * a[9] * (a[10] * a[11] + a[11] * a[11] + a[11]), 0.0),
+    # jobs (host array of capi.MbJob), njobs, S, N, B, hid, ldb, batch_size, epochs: the same count summed over the jobs
+    "rcmarl_minibatch_fit_multi": lambda a: (sum(6.0 * a[2] * j.n_adv * a[8] * a[4] * (j.in_dim * a[5] + a[5] * a[5] + a[5])
+                                                 for j in list(a[0])[:a[1]]) if hasattr(a[0], "__len__") else 0.0, 0.0),
     # wide path (csrc/wide_kernels.hip): dense per-agent GEMMs, 2*S*N*B*K*J flops
     # in, zs, za, rm, ld, theta, w_off, b_off, out, S, N, B, K, J
     "rcmarl_dense_forward": lambda a: (2.0 * a[9] * a[10] * a[11] * a[12] * a[13], 0.0),

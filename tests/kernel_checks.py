@@ -607,19 +607,27 @@ def check_minibatch_fit(bk, S, N, B, in_dim, advs, bs=32, epochs=3, lr=0.01, shu
     return th_new, loss
 
 
-def check_minibatch_fit_multi(bk, S=2, N=5, B=96, in_dims=(10, 15, 10), adv_sets=((4,), (3, 4), (3, 4)), bs=32, epochs=2, lr=0.01):
+def check_minibatch_fit_multi(bk, S=2, N=5, B=96, in_dims=(10, 15, 10), adv_sets=((4,), (3, 4), (3, 4)), bs=32, epochs=2, lr=0.01, blow=None):
     """rcmarl_minibatch_fit_multi: several fits in ONE launch (the Malicious agent's private critic, compromised team-reward net and
     compromised critic of a consensus epoch) leave the bits that one rcmarl_minibatch_fit call per job leaves -- parameters, losses
-    and untouched rows alike.  (The single-job entry point is held to the oracle by check_minibatch_fit.)"""
+    and untouched rows alike.  (The single-job entry point is held to the oracle by check_minibatch_fit.)
+    blow = (job, position in its adversary list): that network's layer-2 weights are +-100 (2^10 W beyond the f16 range), so the f16
+    kernel flags it through THAT job's ovf_flags and the fp32 fix-up launch redoes it -- in both launch forms."""
     from rcmarl_amd import capi
+    import pytest
     rng = np.random.default_rng(77)
     ldb, cap = pad64(B), B + 3
     jobs = []
-    for in_dim, advs in zip(in_dims, adv_sets):
+    for jn, (in_dim, advs) in enumerate(zip(in_dims, adv_sets)):
         P, _ = geom(in_dim, 1)
         ldp = pad64(P)
         advs = np.asarray(advs, np.int32)
-        jobs.append(dict(in_dim=in_dim, ldp=ldp, advs=advs, theta=pack_rows(random_params(rng, S, N, in_dim, 1), ldp),
+        params = random_params(rng, S, N, in_dim, 1)
+        if blow is not None and blow[0] == jn:
+            for s_ in range(S):
+                w2 = params[s_][int(advs[blow[1]])][2]
+                w2[...] = np.float32(100.0) * rng.choice([-1.0, 1.0], size=w2.shape).astype(np.float32)
+        jobs.append(dict(in_dim=in_dim, ldp=ldp, advs=advs, theta=pack_rows(params, ldp),
                          x=rng.normal(size=(S, cap, in_dim)).astype(np.float32), y=rng.normal(size=(S, N, ldb)).astype(np.float32),
                          perm=np.stack([[[rng.permutation(B) for _ in range(epochs)] for _ in advs] for _ in range(S)]).astype(np.int32)))
     results = {}
@@ -645,7 +653,18 @@ def check_minibatch_fit_multi(bk, S=2, N=5, B=96, in_dims=(10, 15, 10), adv_sets
         np.testing.assert_array_equal(a[0], b[0], err_msg="job %d parameters" % j)
         np.testing.assert_array_equal(a[1], b[1], err_msg="job %d losses" % j)
         assert not np.array_equal(a[0], jobs[j]["theta"])
-    # a job list the entry point does not take: mixed input classes (<= 16 and 17..20) -> RCMARL_ERR_UNSUPPORTED, nothing launched
+    # job lists the entry point does not take -> RCMARL_ERR_UNSUPPORTED before anything is launched: mixed input classes (<= 16 and
+    # 17..20 inputs need different kernel forms) and more jobs than one launch carries
+    d, j = dev[0], jobs[0]
+    other = 18 if j["in_dim"] <= 16 else 10
+    mk = lambda in_dim: capi.MbJob(bk.ptr(d["x"]), cap * j["in_dim"], bk.ptr(d["th"]), bk.ptr(d["adv"]), len(j["advs"]), in_dim, j["ldp"], 0,
+                                   bk.ptr(d["y"]), bk.ptr(d["perm"]), bk.ptr(d["loss"]), bk.ptr(d["flags"]))
+    before = bk.host(d["th"]).copy()
+    for bad in ([mk(j["in_dim"]), mk(other)], [mk(j["in_dim"])] * 5):
+        arr = (capi.MbJob * len(bad))(*bad)
+        with pytest.raises(capi.RcmarlError, match="RCMARL_ERR_UNSUPPORTED"):
+            bk.lib.rcmarl_minibatch_fit_multi(arr, len(bad), S, N, B, HID, ldb, bs, epochs, lr, bk.stream)
+    np.testing.assert_array_equal(bk.host(d["th"]), before)
     return results
 
 

@@ -31,6 +31,24 @@ def test_hip_library_builds_loads_and_exports_all_symbols():
     assert set(header_functions()) <= exported
 
 
+def test_mb_job_structure_is_the_same_in_the_header_the_library_and_the_binding():
+    """rcmarl_mb_job is declared three times (include/rcmarl.h, csrc/rcmarl_common.h, capi.MbJob): the library reports its own layout,
+    the ctypes structure must match it field by field, and the public header must declare the same fields in the same order."""
+    import ctypes
+    from rcmarl_amd import build, capi
+    lib = capi.CLib(build.build_hip())
+    fields = [f[0] for f in capi.MbJob._fields_]
+    assert lib.rcmarl_mb_job_layout(0) == ctypes.sizeof(capi.MbJob)
+    for k, name in enumerate(("x_seed_stride", "theta", "agents", "n_adv", "in_dim", "ldp", "y", "perm", "loss_out", "ovf_flags"), 1):
+        assert lib.rcmarl_mb_job_layout(k) == getattr(capi.MbJob, name).offset, name
+    assert lib.rcmarl_mb_job_layout(11) == -1
+    txt = open(os.path.join(ROOT, "include", "rcmarl.h")).read()
+    body = re.search(r"typedef struct rcmarl_mb_job \{(.*?)\} rcmarl_mb_job;", txt, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = re.findall(r"(\w+)\s*[;,]", body)
+    assert decl == fields, (decl, fields)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from rcmarl_amd import capi
     with pytest.raises(capi.RcmarlError, match="no CPU fallback|not found"):

@@ -126,8 +126,12 @@ def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
     KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=B > bs)
 
 
-def test_minibatch_fit_multi_equals_single_job_launches(bk):
-    KC.check_minibatch_fit_multi(bk)
+@pytest.mark.parametrize("in_dims,blow,compact", [((10, 15, 10), None, None), ((18, 20, 18), None, None),      # both input classes
+                                                  ((10, 15, 10), (1, 0), None), ((18, 20, 18), (2, 1), "1")])    # a flag set by job j > 0
+def test_minibatch_fit_multi_equals_single_job_launches(bk, in_dims, blow, compact, monkeypatch):
+    if compact is not None:
+        monkeypatch.setenv("RCMARL_MB_MX_COMPACT", compact)
+    KC.check_minibatch_fit_multi(bk, in_dims=in_dims, blow=blow)
 
 
 def test_projection(bk):

@@ -143,8 +143,12 @@ def test_minibatch_actor(bk, S, N, B, in_dim, advs, bs, t0):
     KC.check_minibatch_actor(bk, S, N, B, in_dim, advs, bs=bs, t0=t0, shuffle=True)
 
 
-def test_minibatch_fit_multi_equals_single_job_launches(bk):
-    KC.check_minibatch_fit_multi(bk)
+@pytest.mark.parametrize("in_dims,blow,compact", [((10, 15, 10), None, None), ((18, 20, 18), None, None),      # both input classes
+                                                  ((10, 15, 10), (1, 0), None), ((18, 20, 18), (2, 1), "1")])    # a flag set by job j > 0
+def test_minibatch_fit_multi_equals_single_job_launches(bk, in_dims, blow, compact, monkeypatch):
+    if compact is not None:
+        monkeypatch.setenv("RCMARL_MB_MX_COMPACT", compact)
+    KC.check_minibatch_fit_multi(bk, in_dims=in_dims, blow=blow)
 
 
 def test_projection(bk):
@@ -230,6 +234,22 @@ def test_wide_dense_layer_out_of_f16_range_recomputes_in_fp32(bk):
 def test_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph, f16, wide_form):
     wide_form(bk, f16)
     WC.check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph)
+
+
+def test_copy3d_more_batches_than_a_grid_dimension(bk):
+    """rcmarl_copy3d with more than 65535 batches (AdversaryPath publishes message rows with batches = seeds): the grid's z extent is
+    capped and the kernel strides over the rest; masked rows stay untouched."""
+    rng = np.random.default_rng(9)
+    batches, rows, cols, ld = 70001, 3, 8, 12
+    src = rng.normal(size=(batches, rows, ld)).astype(np.float32)
+    dst0 = rng.normal(size=(batches, rows, ld)).astype(np.float32)
+    mask = np.array([1, 0, 1], np.int32)
+    d_src, d_dst, d_mask = bk.dev(src), bk.dev(dst0), bk.dev(mask)
+    bk.lib.rcmarl_copy3d(bk.ptr(d_src), rows * ld, ld, bk.ptr(d_dst), rows * ld, ld, batches, rows, cols, bk.ptr(d_mask), bk.stream)
+    got = bk.host(d_dst)
+    want = dst0.copy()
+    want[:, [0, 2], :cols] = src[:, [0, 2], :cols]
+    np.testing.assert_array_equal(got, want)
 
 
 # ---- the same layers on pre-split packed operands (hid % 128 == 0): csrc/dense_pk.hip ---------------------------------

@@ -412,10 +412,22 @@ def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2,
         ("fwd L1 lattice -> packed a1 (values)", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
             p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, None, pb.kb_kt, None,
             pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+        ("fwd L1 lattice -> a1_bk + a1_kb", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
+            p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, p(pb.a1_kb), pb.kb_kt, None,
+            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+        ("fwd L1 lattice -> a1_bk + signs", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
+            p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, None, pb.kb_kt, p(pb.s1),
+            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
         ("pack W2", 0, lambda: L.rcmarl_pk_pack_w2(p(theta), p(pb.w2t), p(pb.w2w3), p(pb.rs), S, N, in_dim, hid, ldp, st)),
         ("fwd L2 -> masks + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, p(pb.mask_bj),
                                                                             pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), S, N, B,
                                                                             in_dim, hid, ldp, ldb, st)),
+        ("fwd L2 -> mask_bj + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, p(pb.mask_bj),
+                                                                              pb.bk_rt, None, pb.kb_kt, p(pb.vpart), S, N, B,
+                                                                              in_dim, hid, ldp, ldb, st)),
+        ("fwd L2 -> mask_jb + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, None,
+                                                                              pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), S, N, B,
+                                                                              in_dim, hid, ldp, ldb, st)),
         ("fwd L2 -> value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, None, pb.bk_rt, None,
                                                                     pb.kb_kt, p(pb.vpart), S, N, B, in_dim, hid, ldp, ldb, st)),
         ("fwd L2 -> fp32 a2 (consensus)", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), p(pb.a2), None,
@@ -441,7 +453,8 @@ def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2,
             fn()                                       # (later kernels still need their inputs)
             continue
         t = timeit(fn, iters=5, warm=2)
-        step = name not in ("W1 split", "fwd L1 lattice -> packed a1 (values)", "fwd L2 -> value parts", "fwd L2 -> fp32 a2 (consensus)")
+        step = name in ("fwd L1 lattice -> packed a1 x2 + signs", "pack W2", "fwd L2 -> masks + value parts", "head", "bwd data L2 -> packed dz1",
+                        "bwd W2", "bwd W1 lattice", "small sgd")
         tot += t if step else 0.0
         print("%-40s %9.1f us  %s" % (name, t, ("%7.1f TF/s fp32-equivalent (%.3f of 2.5 PF)" % (fl / t / 1e6, fl / t / 1e6 / 2500)) if fl else ""))
     print("one SGD step, %d agents: %.2f ms  -> 1024 agents: %.1f ms" % (N, tot / 1e3, tot / 1e3 * 1024 / N))
