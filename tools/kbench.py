@@ -447,14 +447,17 @@ def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2,
                                                        p(loss), S, N, B, in_dim, hid, ldp, ldb, lr, st)),
     ]
     only = os.environ.get("RCMARL_KBENCH_ONLY")
+    step_names = ("fwd L1 lattice -> packed a1 x2 + signs", "pack W2", "fwd L2 -> masks + value parts", "head", "bwd data L2 -> packed dz1",
+                  "bwd W2", "bwd W1 lattice", "small sgd")
+    if os.environ.get("RCMARL_KBENCH_STEP_ONLY"):          # counter runs: only the launches of a real fit step (no variant rows)
+        rows = [r for r in rows if r[0] in step_names or r[0] == "W1 split"]
     tot = 0.0
     for name, fl, fn in rows:
         if only and only not in name:
             fn()                                       # (later kernels still need their inputs)
             continue
         t = timeit(fn, iters=5, warm=2)
-        step = name in ("fwd L1 lattice -> packed a1 x2 + signs", "pack W2", "fwd L2 -> masks + value parts", "head", "bwd data L2 -> packed dz1",
-                        "bwd W2", "bwd W1 lattice", "small sgd")
+        step = name in step_names
         tot += t if step else 0.0
         print("%-40s %9.1f us  %s" % (name, t, ("%7.1f TF/s fp32-equivalent (%.3f of 2.5 PF)" % (fl / t / 1e6, fl / t / 1e6 / 2500)) if fl else ""))
     print("one SGD step, %d agents: %.2f ms  -> 1024 agents: %.1f ms" % (N, tot / 1e3, tot / 1e3 * 1024 / N))
