@@ -352,6 +352,11 @@ int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float
                                const float* agg_in, float* hmat, float* hb, float* est, float* ebuf, float* grads,
                                float* agg_out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, int d, int H,
                                void* stream);
+/* rcmarl_wide_consensus_head (estimate consensus, no agg_in) with |phi|^2 per replay row given as n_parts parts
+ * nparts[s][n][n_parts][ldb] (rcmarl_pk_forward2's npart): the selection pass reads d + 1 estimates per row instead of d + 1 + hid values */
+int rcmarl_wide_consensus_head_nrm(const float* phi, const float* nparts, int n_parts, const float* theta, const float* msg,
+                                   const int* nbr, const int* coop, float* hmat, float* hb, float* est, float* ebuf, float* grads,
+                                   float* agg_out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, int d, int H, void* stream);
 /* W3 += grads[0..hid)/B, b3 += grads[hid]/B (cooperative agents) */
 int rcmarl_wide_head_apply(const float* grads, float* theta, const int* coop, int S, int N, int B, int in_dim, int hid,
                            int ldp, void* stream);
@@ -381,9 +386,11 @@ int rcmarl_layer1_forward_lattice_pk(const void* kp, int kp_rt, int kp_kt, const
 /* W2, W3 of theta[s][n] -> w2t, w2w3, rs[k] = sum_j W2[k][j] W3[j] */
 int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, float* rs, int S, int N, int in_dim, int hid, int ldp, void* stream);
 /* layer 2 forward; outputs, each optional: a2 (fp32 feature-major [S][N*hid][ldb]: phi of rcmarl_wide_consensus_head), mask_bj,
- * mask_jb, vpart (per 128-unit tile: sum_j a2[j][b] W3[j]) */
+ * mask_jb, vpart (per tile of units: sum_j a2[j][b] W3[j]), npart (same shape: sum_j a2[j][b]^2, |phi|^2 of the projection step) */
 int rcmarl_pk_forward2(const void* w2t, const void* a1_bk, int bk_rt, const float* theta, float* a2, void* mask_bj, int mbj_rt,
-                       void* mask_jb, int mjb_kt, float* vpart, int S, int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+                       void* mask_jb, int mjb_kt, float* vpart, float* npart, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                       void* stream);
+int rcmarl_pk_parts(int hid);            /* tiles of units per agent = parts per row in vpart / npart / gw3part (hid / 256, or hid / 128) */
 /* V = sum_t vpart[t] + b3.  mode 0: out = V; 1: out = aux + gamma V (TD target, :114-115); 2: MSE head of fit() with aux = y:
  * out = dz3 = 2 (V - y) / B, dzv = f16 pieces of 2^8 dz3 and 2^8 (0.1 dz3), losspart [Z][ceil(B/256)] */
 int rcmarl_pk_head(const float* vpart, const float* theta, const float* aux, float gamma, int mode, float* out, void* dzv,

@@ -179,9 +179,13 @@ SIGNATURES = {
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # theta, w2t, w2w3, rs, S, N, in_dim, hid, ldp, stream
     "rcmarl_pk_pack_w2": [c_f32p, c_u8p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # w2t, a1_bk, bk_rt, theta, a2, mask_bj, mbj_rt, mask_jb, mjb_kt, vpart, S, N, B, in_dim, hid, ldp, ldb, stream
-    "rcmarl_pk_forward2": [c_u8p, c_u8p, c_int, c_f32p, c_f32p, c_u8p, c_int, c_u8p, c_int, c_f32p, c_int, c_int, c_int, c_int, c_int,
-                           c_int, c_int, c_stream],
+    # w2t, a1_bk, bk_rt, theta, a2, mask_bj, mbj_rt, mask_jb, mjb_kt, vpart, npart, S, N, B, in_dim, hid, ldp, ldb, stream
+    "rcmarl_pk_forward2": [c_u8p, c_u8p, c_int, c_f32p, c_f32p, c_u8p, c_int, c_u8p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
+                           c_int, c_int, c_int, c_stream],
+    "rcmarl_pk_parts": [c_int],
+    # phi, nparts, n_parts, theta, msg, nbr, coop, hmat, hb, est, ebuf, grads, agg_out, S, N, B, in_dim, hid, ldp, ldb, d, H, stream
+    "rcmarl_wide_consensus_head_nrm": [c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                       c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # vpart, theta, aux, gamma, mode, out, dzv, losspart, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_pk_head": [c_f32p, c_f32p, c_f32p, c_float, c_int, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                        c_stream],
@@ -200,7 +204,7 @@ SIGNATURES = {
 }
 UNCHECKED = {"rcmarl_abi_version", "rcmarl_mb_job_layout", "rcmarl_lattice_forget", "rcmarl_fit_partial_size", "rcmarl_lattice_set_f16_mode",  "rcmarl_actor_partial_size", "rcmarl_rows_per_chunk", "rcmarl_lattice_f16_mode",
              "rcmarl_wide_grad_size", "rcmarl_wide_rows_per_chunk", "rcmarl_wide_f16_mode", "rcmarl_wide_set_f16_mode",
-             "rcmarl_consensus_params_circulant_supported", "rcmarl_pk_supported"}
+             "rcmarl_consensus_params_circulant_supported", "rcmarl_pk_supported", "rcmarl_pk_parts"}
 
 ERRORS = {1: "RCMARL_ERR_ARG (bad argument)", 2: "RCMARL_ERR_LAUNCH (HIP launch failed)",
           3: "RCMARL_ERR_UNSUPPORTED (shape outside the compiled kernels)"}

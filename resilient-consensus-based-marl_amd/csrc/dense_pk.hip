@@ -118,6 +118,7 @@ struct PkFwdArgs {
   unsigned char* mask_bj; int mbj_rt;       // [Z][mbj_rt][JK][8 KiB], f16 1.0 / 0, or NULL
   unsigned char* mask_jb; int mjb_kt;       // [Z][JT][mjb_kt][8 KiB], 0xffff / 0, or NULL
   float* vpart;                             // [Z][JT][ldb], or NULL
+  float* npart;                             // [Z][JT][ldb], or NULL: sum_{j in tile} a2[j][b]^2 (|phi|^2 of the projection step)
   int Z, B, hid, ntb;                       // ntb = ceil(B / 128)
 };
 
@@ -138,6 +139,7 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_forward2(const PkFwdArgs a) {
   float* sb = reinterpret_cast<float*>(lds);              // b2, W3 of the tile's units; the row halves' parts of v
   float* sw3 = sb + BM;
   float* sv = sw3 + BM;
+  float* sn = sv + WM * BN;
   const float* __restrict__ th = a.theta + (long)z * a.ldp;
   if (threadIdx.x < BM) {
     sb[threadIdx.x] = th[a.o_b2 + bm * BM + threadIdx.x];
@@ -151,7 +153,7 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_forward2(const PkFwdArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n0 = bn * BN + wn * 32 * NT + 32 * nt, n = n0 + l31;
-    float vp = 0.f;
+    float vp = 0.f, np2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int j0 = wm * 32 * MT + 32 * mt;              // first unit of this 32 x 32 block inside the tile
@@ -170,6 +172,7 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_forward2(const PkFwdArgs a) {
           const float o = fmaxf(zz, RC_LEAK * zz);
           pos[e] = o > 0.f;
           vp = fmaf(o, wq[e], vp);
+          np2 = fmaf(o, o, np2);
           if (a.a2 != nullptr && n < a.B)
             RC_NT_STORE(a.a2 + ((long)z * a.hid + bm * BM + j0 + 8 * qq + 4 * half + e) * a.ldb + n, o);
           m16[0][r] = pos[e] ? (unsigned short)0xffffu : (unsigned short)0u;
@@ -190,6 +193,20 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_forward2(const PkFwdArgs a) {
     if (a.vpart != nullptr) {
       vp += __shfl_xor(vp, 32);
       if (half == 0) sv[wm * BN + wn * 32 * NT + 32 * nt + l31] = vp;
+    }
+    if (a.npart != nullptr) {
+      np2 += __shfl_xor(np2, 32);
+      if (half == 0) sn[wm * BN + wn * 32 * NT + 32 * nt + l31] = np2;
+    }
+  }
+  if (a.npart != nullptr) {
+    __syncthreads();
+    if (threadIdx.x < BN) {
+      const int n = bn * BN + threadIdx.x;
+      float v = sn[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < WM; ++w) v += sn[w * BN + threadIdx.x];
+      if (n < a.ldb) a.npart[((long)z * MTL + bm) * a.ldb + n] = v;
     }
   }
   if (a.vpart != nullptr) {
@@ -592,6 +609,7 @@ template <class T> static int pk_launch_backward_w2(const PkBwArgs& a, void* str
 //   w2t, w2w3:    S*N * (hid/128) * (hid/32) * 2 * 8192 bytes each       s1: S*N*hid * (Bp/32) uint32
 //   dzv: S*N * 4 * Bp uint16     vpart: S*N * (hid/128) * ldb fp32      gw3part: S*N * (hid/128) * hid    gb1part: S*N * ceil(B/128) * hid
 // (the part buffers are used up to hid/T resp. ceil(B/T) entries, T = the block tile side: 256 when hid % 256 == 0, else 128)
+RCMARL_EXPORT int rcmarl_pk_parts(int hid) { return hid > 0 && (hid & 127) == 0 ? hid / pk_tile(hid) : 0; }
 RCMARL_EXPORT int rcmarl_pk_supported(int hid) { return hid > 0 && (hid & 127) == 0 && (rc_lat_f16_mode() & 3) == 3; }
 
 // theta[s][n] -> w2t, w2w3, rs   (o_W2 = in_dim*hid + hid, o_W3 = o_W2 + hid*hid + hid: the Keras row of rcmarl_common.h)
@@ -609,9 +627,9 @@ RCMARL_EXPORT int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, f
 // mask_bj / mask_jb (the fit's LeakyReLU masks, packed), vpart ([S][N][hid/128][ldb], parts of the head's value).
 // Replaces model(x) of the second Dense layer, agents/resilient_CAC_agents.py:95-97,114,118.
 RCMARL_EXPORT int rcmarl_pk_forward2(const void* w2t, const void* a1_bk, int bk_rt, const float* theta, float* a2, void* mask_bj,
-                                     int mbj_rt, void* mask_jb, int mjb_kt, float* vpart, int S, int N, int B, int in_dim, int hid,
-                                     int ldp, int ldb, void* stream) {
-  if (!w2t || !a1_bk || !theta || (!a2 && !mask_bj && !mask_jb && !vpart) || !pk_dims_ok(S, N, B, hid, ldp) || in_dim <= 0 || ldb < B)
+                                     int mbj_rt, void* mask_jb, int mjb_kt, float* vpart, float* npart, int S, int N, int B, int in_dim,
+                                     int hid, int ldp, int ldb, void* stream) {
+  if (!w2t || !a1_bk || !theta || (!a2 && !mask_bj && !mask_jb && !vpart && !npart) || !pk_dims_ok(S, N, B, hid, ldp) || in_dim <= 0 || ldb < B)
     return RCMARL_ERR_ARG;
   if (hid & 127) return RCMARL_ERR_UNSUPPORTED;
   const int T = pk_tile(hid), ntb = rc_ceil_div(B, T), rts = ntb * (T / 128);
@@ -621,7 +639,7 @@ RCMARL_EXPORT int rcmarl_pk_forward2(const void* w2t, const void* a1_bk, int bk_
   a.w2t = (const unsigned char*)w2t; a.a1bk = (const unsigned char*)a1_bk; a.bk_rt = bk_rt;
   a.theta = theta; a.ldp = ldp; a.o_b2 = g.o_b2; a.o_W3 = g.o_W3;
   a.a2 = a2; a.ldb = ldb; a.mask_bj = (unsigned char*)mask_bj; a.mbj_rt = mbj_rt; a.mask_jb = (unsigned char*)mask_jb; a.mjb_kt = mjb_kt;
-  a.vpart = vpart; a.Z = S * N; a.B = B; a.hid = hid; a.ntb = ntb;
+  a.vpart = vpart; a.npart = npart; a.Z = S * N; a.B = B; a.hid = hid; a.ntb = ntb;
   return T == 256 ? pk_launch_forward2<PkBig>(a, stream) : pk_launch_forward2<PkSmall>(a, stream);
 }
 

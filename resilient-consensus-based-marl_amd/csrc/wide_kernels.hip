@@ -566,7 +566,22 @@ __global__ __launch_bounds__(256) void k_wgather_heads(const float* __restrict__
 // (own = m == 0, in_nodes[i][0] == i), residual e[b] = (agg - V_live) / (|phi|^2 + 1).  Order statistics by rank
 // counting with index tie-break (any d, H), as k_consensus_head_generic.
 constexpr int WSEL_ROWS = 128;            // d * 128 floats of LDS per workgroup (d = 66: 33 KiB)
+// |phi|^2 + 1 of replay row b: from the per-tile parts a producer left (nparts > 0: csrc/dense_pk.hip writes sum_j a2[j][b]^2 per tile of
+// units beside the activations) or by a pass over the hid activations of the row
+__device__ __forceinline__ float w_norm1(const float* __restrict__ phi, const float* __restrict__ nparts, int n_parts, long zi, int b,
+                                         int hid, int ldb) {
+  float nrm = 0.f;
+  if (nparts != nullptr) {
+    for (int t = 0; t < n_parts; ++t) nrm += nparts[(zi * n_parts + t) * ldb + b];
+  } else {
+    const float* __restrict__ col = phi + zi * hid * ldb + b;
+    for (int k = 0; k < hid; ++k) { const float p = col[(long)k * ldb]; nrm = fmaf(p, p, nrm); }
+  }
+  return nrm + 1.0f;
+}
+
 __global__ __launch_bounds__(WSEL_ROWS) void k_wselect(const float* __restrict__ est, const float* __restrict__ phi,
+                                                 const float* __restrict__ nparts, int n_parts,
                                                  const int* __restrict__ coop, float* __restrict__ ebuf,
                                                  float* __restrict__ agg_out, int N, int B, int hid, int ldb, int d,
                                                  int H) {
@@ -578,10 +593,7 @@ __global__ __launch_bounds__(WSEL_ROWS) void k_wselect(const float* __restrict__
   if (b >= B) return;                         // no barrier below: every thread works on its own LDS column
   const float* __restrict__ e0 = est + ((long)s * N + i) * (d + 1) * ldb + b;
   for (int k = 0; k < d; ++k) sv[k * WROWS + r] = e0[(long)k * ldb];
-  const float* __restrict__ col = phi + ((long)s * N + i) * hid * ldb + b;
-  float nrm = 0.f;
-  for (int k = 0; k < hid; ++k) { const float p = col[(long)k * ldb]; nrm = fmaf(p, p, nrm); }
-  nrm += 1.0f;
+  const float nrm = w_norm1(phi, nparts, n_parts, (long)s * N + i, b, hid, ldb);
   const float own = sv[r];
   float lo = own, hi = own;
   for (int k = 0; k < d; ++k) {
@@ -607,6 +619,7 @@ __global__ __launch_bounds__(WSEL_ROWS) void k_wselect(const float* __restrict__
 // the same with the generated selection network of (D, H) on registers (selnet_generated.inc) instead of rank counting
 template <int D, int H>
 __global__ __launch_bounds__(WSEL_ROWS) void k_wselect_net(const float* __restrict__ est, const float* __restrict__ phi,
+                                                           const float* __restrict__ nparts, int n_parts,
                                                            const int* __restrict__ coop, float* __restrict__ ebuf,
                                                            float* __restrict__ agg_out, int N, int B, int hid, int ldb) {
   const int s = blockIdx.z, i = blockIdx.y;
@@ -617,10 +630,7 @@ __global__ __launch_bounds__(WSEL_ROWS) void k_wselect_net(const float* __restri
   float v[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) v[k] = e0[(long)k * ldb];
-  const float* __restrict__ col = phi + ((long)s * N + i) * hid * ldb + b;
-  float nrm = 0.f;
-  for (int k = 0; k < hid; ++k) { const float p = col[(long)k * ldb]; nrm = fmaf(p, p, nrm); }
-  nrm += 1.0f;
+  const float nrm = w_norm1(phi, nparts, n_parts, (long)s * N + i, b, hid, ldb);
   float lo, hi;
   SelNet<D, H>::run(v, lo, hi);
   const float lower = fminf(lo, v[0]), upper = fmaxf(hi, v[0]);
@@ -781,10 +791,11 @@ RCMARL_EXPORT int rcmarl_wide_small_sgd(const float* grads, const float* losspar
 // hb [S][N][d+1], est [S][N][d+1][ldb], ebuf [S][N][ldb].  Output: grads[s][n][0..hid] = [sum_b e phi | sum_b e]
 // for cooperative agents; agg_out (optional) [S][N][ldb].  agg_in != NULL: projection toward that aggregate only
 // (K3), nbr/msg/hmat/hb/est unused.
-RCMARL_EXPORT int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float* msg, const int* nbr,
-                                             const int* coop, const float* agg_in, float* hmat, float* hb, float* est,
-                                             float* ebuf, float* grads, float* agg_out, int S, int N, int B, int in_dim,
-                                             int hid, int ldp, int ldb, int d, int H, void* stream) {
+static int wide_consensus_head_impl(const float* phi, const float* nparts, int n_parts, const float* theta, const float* msg, const int* nbr,
+                                    const int* coop, const float* agg_in, float* hmat, float* hb, float* est,
+                                    float* ebuf, float* grads, float* agg_out, int S, int N, int B, int in_dim,
+                                    int hid, int ldp, int ldb, int d, int H, void* stream) {
+  if (nparts != nullptr && n_parts <= 0) return RCMARL_ERR_ARG;
   if (!phi || !theta || !coop || !ebuf || !grads || !w_dims_ok(S, N, B, in_dim, hid, ldp, ldb)) return RCMARL_ERR_ARG;
   const dim3 gc(rc_ceil_div(B, WROWS), N, S), block(256);
   if (agg_in) {
@@ -806,18 +817,36 @@ RCMARL_EXPORT int rcmarl_wide_consensus_head(const float* phi, const float* thet
 #define RC_WSEL_CASE(DD, HH)                                                                                        \
     if (!done && d == DD && H == HH) {                                                                               \
       RCMARL_LAUNCH((k_wselect_net<DD, HH>), dim3(rc_ceil_div(B, WSEL_ROWS), N, S), dim3(WSEL_ROWS), 0, stream,      \
-                    (const float*)est, phi, coop, ebuf, agg_out, N, B, hid, ldb);                                    \
+                    (const float*)est, phi, nparts, n_parts, coop, ebuf, agg_out, N, B, hid, ldb);                  \
       done = true;                                                                                                   \
     }
     RCMARL_SELNET_COMBOS(RC_WSEL_CASE)
 #undef RC_WSEL_CASE
     if (!done)
       RCMARL_LAUNCH(k_wselect, dim3(rc_ceil_div(B, WSEL_ROWS), N, S), dim3(WSEL_ROWS), (size_t)d * WSEL_ROWS * sizeof(float),
-                    stream, (const float*)est, phi, coop, ebuf, agg_out, N, B, hid, ldb, d, H);
+                    stream, (const float*)est, phi, nparts, n_parts, coop, ebuf, agg_out, N, B, hid, ldb, d, H);
   }
   RCMARL_LAUNCH((k_wrows<WROW_DOT>), dim3(rc_ceil_div(hid + 1, 4), N, S), block, 0, stream, const_cast<float*>(phi),
                 (const float*)ebuf, (const float*)nullptr, coop, grads, 0, N, B, in_dim, hid, ldp, ldb);
   return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_wide_consensus_head(const float* phi, const float* theta, const float* msg, const int* nbr,
+                                             const int* coop, const float* agg_in, float* hmat, float* hb, float* est,
+                                             float* ebuf, float* grads, float* agg_out, int S, int N, int B, int in_dim,
+                                             int hid, int ldp, int ldb, int d, int H, void* stream) {
+  return wide_consensus_head_impl(phi, nullptr, 0, theta, msg, nbr, coop, agg_in, hmat, hb, est, ebuf, grads, agg_out, S, N, B, in_dim, hid,
+                                  ldp, ldb, d, H, stream);
+}
+// the same with |phi|^2 of every replay row supplied as n_parts per-tile parts nparts[s][n][n_parts][ldb] (rcmarl_pk_forward2 writes
+// them beside the fp32 activations): the selection pass then reads d + 1 estimates per row instead of d + 1 + hid values
+RCMARL_EXPORT int rcmarl_wide_consensus_head_nrm(const float* phi, const float* nparts, int n_parts, const float* theta, const float* msg,
+                                                 const int* nbr, const int* coop, float* hmat, float* hb, float* est, float* ebuf,
+                                                 float* grads, float* agg_out, int S, int N, int B, int in_dim, int hid, int ldp,
+                                                 int ldb, int d, int H, void* stream) {
+  if (!nparts) return RCMARL_ERR_ARG;
+  return wide_consensus_head_impl(phi, nparts, n_parts, theta, msg, nbr, coop, nullptr, hmat, hb, est, ebuf, grads, agg_out, S, N, B, in_dim,
+                                  hid, ldp, ldb, d, H, stream);
 }
 
 RCMARL_EXPORT int rcmarl_wide_head_apply(const float* grads, float* theta, const int* coop, int S, int N, int B,

@@ -284,7 +284,7 @@ class RPBCACEngine:
         pk.w2t, pk.w2w3 = u8(Z * JT * JK * 2 * LT.PK_BLOCK), u8(Z * JT * JK * 2 * LT.PK_BLOCK)
         pk.rs = torch.zeros(Z, hid, **f32)
         pk.mask_bj, pk.mask_jb = u8(Z * pk.bk_rt * JK * LT.PK_BLOCK), u8(Z * JT * pk.kb_kt * LT.PK_BLOCK)
-        pk.vpart = torch.zeros(Z, JT, self.ldb, **f32)
+        pk.vpart, pk.npart = torch.zeros(Z, JT, self.ldb, **f32), torch.zeros(Z, JT, self.ldb, **f32)
         pk.dzv = torch.zeros(Z, 4, Bp, dtype=torch.int16, device=self.dev)
         pk.gw3part, pk.q = torch.zeros(Z, JT, hid, **f32), torch.zeros(Z, hid, **f32)
         pk.gb1part = torch.zeros(Z, (self.cap + 127) // 128, hid, **f32)
@@ -317,7 +317,7 @@ class RPBCACEngine:
         L.rcmarl_pk_pack_w2(theta.data_ptr(), pk.w2t.data_ptr(), pk.w2w3.data_ptr(), pk.rs.data_ptr(), S, N, in_dim, hid, ldp, st)
         L.rcmarl_pk_forward2(pk.w2t.data_ptr(), a1_bk.data_ptr(), pk.bk_rt, theta.data_ptr(), self.w_a2.data_ptr() if want_a2 else None,
                              pk.mask_bj.data_ptr() if fit else None, pk.bk_rt, pk.mask_jb.data_ptr() if fit else None, pk.kb_kt,
-                             pk.vpart.data_ptr(), S, N, B, in_dim, hid, ldp, self.ldb, st)
+                             pk.vpart.data_ptr(), pk.npart.data_ptr() if want_a2 else None, S, N, B, in_dim, hid, ldp, self.ldb, st)
 
     def _local_fit_wide_pk(self, net, xkey, y, B, mask):
         """_local_fit_wide with every GEMM operand pre-split and packed by its producer (csrc/dense_pk.hip): per step
@@ -428,11 +428,17 @@ class RPBCACEngine:
             self._wide_forward_pk(xkey, self.theta[net], net, B, "net", want_a2=True)
         else:
             self._wide_forward(xkey, self.theta[net], net, B, a1=self.a1net[net])
-        L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), msg_all.data_ptr(),
-                                     self.nbr.data_ptr(), self.coop.data_ptr(), None, self.w_hmat.data_ptr(),
-                                     self.w_hb.data_ptr(), self.w_est.data_ptr(), self.w_ebuf.data_ptr(),
-                                     self.w_grads.data_ptr(), None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb,
-                                     c.d, c.H, self.stream)
+        if pk:      # |phi|^2 per row came out of the forward's epilogue
+            L.rcmarl_wide_consensus_head_nrm(self.w_a2.data_ptr(), self.pk.npart.data_ptr(), L.rcmarl_pk_parts(hid), self.theta[net].data_ptr(),
+                                             msg_all.data_ptr(), self.nbr.data_ptr(), self.coop.data_ptr(), self.w_hmat.data_ptr(),
+                                             self.w_hb.data_ptr(), self.w_est.data_ptr(), self.w_ebuf.data_ptr(), self.w_grads.data_ptr(),
+                                             None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb, c.d, c.H, self.stream)
+        else:
+            L.rcmarl_wide_consensus_head(self.w_a2.data_ptr(), self.theta[net].data_ptr(), msg_all.data_ptr(),
+                                         self.nbr.data_ptr(), self.coop.data_ptr(), None, self.w_hmat.data_ptr(),
+                                         self.w_hb.data_ptr(), self.w_est.data_ptr(), self.w_ebuf.data_ptr(),
+                                         self.w_grads.data_ptr(), None, S, N, B, self.in_dim[net], hid, self.ldp[net], self.ldb,
+                                         c.d, c.H, self.stream)
         self.a1_cached[net] = ("pk" if pk else True) if self.reuse_activations else False
         self.a2_cached = bool(pk and net == "critic" and xkey == "s" and self.reuse_activations)
         L.rcmarl_wide_head_apply(self.w_grads.data_ptr(), self.theta[net].data_ptr(), self.coop.data_ptr(), S, N, B,
@@ -1171,14 +1177,28 @@ class RPBCACEngine:
         return (self.td_shortcut and self.a2_cached and self.wide and self.rows_episode_aligned and ep >= 2
                 and row0 % ep == 0 and nrows % ep == 0)
 
-    def _value_next_cached_wide(self, out, row0, nrows, r_applied, scratch):
+    def _value_cached_wide(self, out, row0, nrows):
+        """out[:, :, 0:nrows] = live head on the cached fp32 layer-2 activations of rows row0..row0+nrows (all agents)"""
+        if self._sharded("critic"):
+            o = self._wv(out)
+            with self._agent_window():
+                self._value_cached_wide(o, row0, nrows)
+            return self._allgather_rows(out, 0, nrows)
+        self.lib.rcmarl_wide_head_value(self.w_a2.data_ptr() + 4 * row0, self.theta["critic"].data_ptr(), None, self.cfg.gamma,
+                                        out.data_ptr(), self.S, self.N, nrows, self.in_c, self.hid["critic"], self.ldp["critic"],
+                                        self.ldb, self.stream)
+
+    def _value_next_cached_wide(self, out, row0, nrows, r_applied, scratch, gather=False):
         """_value_next_cached for a wide critic: inside an episode V(ns[b]) = V(s[b+1]) is the live head on the cached layer-2
         activations of row b+1 (the head moved since they were computed, the hidden layers did not); the last step of every episode
         gets a forward pass of its own on the gathered ns rows."""
-        if self._sharded("critic"):             # this rank's agents only: the targets feed their own local fits
+        if self._sharded("critic"):             # this rank's agents (gather: the actor phase needs everybody's)
             o, r, sc = self._wv(out), self._wv(r_applied), self._wv(scratch)
             with self._agent_window():
-                return self._value_next_cached_wide(o, row0, nrows, r, sc)
+                self._value_next_cached_wide(o, row0, nrows, r, sc)
+            if gather:
+                self._allgather_rows(out, 0, nrows)
+            return
         c, L, S, N = self.cfg, self.lib, self.S, self.N
         ep, th, hid = c.max_ep_len, self.theta["critic"], self.hid["critic"]
         L.rcmarl_wide_head_value(self.w_a2.data_ptr() + 4 * (row0 + 1), th.data_ptr(), self._p(r_applied), c.gamma, out.data_ptr(),
@@ -1404,6 +1424,11 @@ class RPBCACEngine:
         if self._cached_rows_ok("critic", row0, nl):
             self._value_next_cached(self.ybuf["v_next"], row0, nl, None, self.ybuf["delta"])
             self._value_cached("critic", self.ybuf["v_cur"], row0, nl)
+        elif self._a2_rows_ok(row0, nl):
+            # wide critic: both values from the fp32 layer-2 activations the last consensus step left behind (V(s) first: the forward
+            # pass over the episodes' last next-state rows inside _value_next_cached_wide re-uses that buffer)
+            self._value_cached_wide(self.ybuf["v_cur"], row0, nl)
+            self._value_next_cached_wide(self.ybuf["v_next"], row0, nl, None, self.ybuf["delta"], gather=True)
         else:
             self._value("ns", self.theta["critic"], "critic", self.ybuf["v_next"], nl, row0, gather=True)
             self._value("s", self.theta["critic"], "critic", self.ybuf["v_cur"], nl, row0, gather=True)

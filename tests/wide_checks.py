@@ -190,11 +190,24 @@ def check_wide_consensus_head(bk, S, N, B, in_dim, hid, d, H, graph="circ"):
                                  bk.ptr(wb.ebuf), bk.ptr(wb.grads), None, S, N, B, in_dim, hid, ldp, ldb, d, H, bk.stream)
     L.rcmarl_wide_head_apply(bk.ptr(wb.grads), bk.ptr(d_th2), bk.ptr(d_coop), S, N, B, in_dim, hid, ldp, bk.stream)
     th_proj = bk.host(d_th2)
+    # the same step with |phi|^2 per replay row handed over as per-tile parts (rcmarl_wide_consensus_head_nrm: what the packed-operand
+    # forward pass leaves beside its fp32 activations): two parts here, summed in fp64 on the host
+    a2h = bk.host(wb.a2).reshape(S, N, hid, ldb).astype(np.float64)
+    h2 = hid // 2
+    nparts = np.stack([(a2h[:, :, :h2] ** 2).sum(axis=2), (a2h[:, :, h2:] ** 2).sum(axis=2)], axis=2).astype(np.float32)     # [S][N][2][ldb]
+    d_th3, d_np, d_agg3 = bk.dev(theta), bk.dev(nparts), bk.dev(np.zeros((S, N, ldb), np.float32))
+    L.rcmarl_wide_consensus_head_nrm(bk.ptr(wb.a2), bk.ptr(d_np), 2, bk.ptr(d_th3), bk.ptr(d_msg), bk.ptr(d_nbr), bk.ptr(d_coop),
+                                     bk.ptr(wb.hmat), bk.ptr(wb.hb), bk.ptr(wb.est), bk.ptr(wb.ebuf), bk.ptr(wb.grads), bk.ptr(d_agg3), S, N,
+                                     B, in_dim, hid, ldp, ldb, d, H, bk.stream)
+    L.rcmarl_wide_head_apply(bk.ptr(wb.grads), bk.ptr(d_th3), bk.ptr(d_coop), S, N, B, in_dim, hid, ldp, bk.stream)
+    th_nrm, agg3 = bk.host(d_th3), bk.host(d_agg3)
+    np.testing.assert_array_equal(agg3, agg)                              # (the aggregate does not depend on the norm)
     for s in range(S):
         for i in range(N):
             if not coop[i]:
                 np.testing.assert_array_equal(th_new[s, i], theta[s, i])
                 continue
+            rel_close(th_nrm[s, i, :P], th_new[s, i, :P], 2e-6, "projection with |phi|^2 supplied as parts")
             ag = O.CoopAgent(M.init_mlp(rng, in_dim, 20, 5), live[s][i], live[s][i], 0.002, 0.01, 0.9, H)
             want_agg = ag.consensus_estimates_critic(x[s], [msgp[s][j] for j in nbr[i]])
             # fp32 summation order only: a 512-term head on top of two GEMM layers carries ~4x the roundoff of a 128-term one.
@@ -232,7 +245,7 @@ class PkBuffers:
         self.s1 = bk.dev(np.zeros((Z * hid, Bp // 32), np.int32))
         self.w2t, self.w2w3, self.rs = u8(Z * JT * JK * 2 * 8192), u8(Z * JT * JK * 2 * 8192), f32(Z, hid)
         self.mask_bj, self.mask_jb = u8(Z * self.bk_rt * JK * 8192), u8(Z * JT * self.kb_kt * 8192)
-        self.vpart, self.dz3 = f32(Z, JT, ldb), f32(Z, ldb)
+        self.vpart, self.npart, self.dz3 = f32(Z, JT, ldb), f32(Z, JT, ldb), f32(Z, ldb)
         self.dzv = bk.dev(np.zeros((Z, 4, Bp), np.int16))
         self.losspart = f32(Z, (B + 255) // 256)
         self.gw3part, self.q, self.gb1part = f32(Z, JT, hid), f32(Z, hid), f32(Z, (B + 127) // 128, hid)
@@ -256,7 +269,7 @@ def pk_forward(bk, pb, d_alpha, d_theta, S, N, B, in_dim, hid, ldp, ldb, split=T
     L.rcmarl_pk_pack_w2(bk.ptr(d_theta), bk.ptr(pb.w2t), bk.ptr(pb.w2w3), bk.ptr(pb.rs), S, N, in_dim, hid, ldp, bk.stream)
     L.rcmarl_pk_forward2(bk.ptr(pb.w2t), bk.ptr(pb.a1_bk), pb.bk_rt, bk.ptr(d_theta), bk.ptr(pb.a2) if want_a2 else None,
                          bk.ptr(pb.mask_bj) if fit else None, pb.bk_rt, bk.ptr(pb.mask_jb) if fit else None, pb.kb_kt,
-                         bk.ptr(pb.vpart), S, N, B, in_dim, hid, ldp, ldb, bk.stream)
+                         bk.ptr(pb.vpart), bk.ptr(pb.npart) if want_a2 else None, S, N, B, in_dim, hid, ldp, ldb, bk.stream)
 
 
 def pk_fit_step(bk, pb, d_alpha, d_msg, d_y, d_mask, d_loss, S, N, B, in_dim, hid, ldp, ldb, lr, split, emit_wp=True):

@@ -420,18 +420,18 @@ def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2,
             pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
         ("pack W2", 0, lambda: L.rcmarl_pk_pack_w2(p(theta), p(pb.w2t), p(pb.w2w3), p(pb.rs), S, N, in_dim, hid, ldp, st)),
         ("fwd L2 -> masks + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, p(pb.mask_bj),
-                                                                            pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), S, N, B,
+                                                                            pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), None, S, N, B,
                                                                             in_dim, hid, ldp, ldb, st)),
         ("fwd L2 -> mask_bj + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, p(pb.mask_bj),
-                                                                              pb.bk_rt, None, pb.kb_kt, p(pb.vpart), S, N, B,
+                                                                              pb.bk_rt, None, pb.kb_kt, p(pb.vpart), None, S, N, B,
                                                                               in_dim, hid, ldp, ldb, st)),
         ("fwd L2 -> mask_jb + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, None,
-                                                                              pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), S, N, B,
+                                                                              pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), None, S, N, B,
                                                                               in_dim, hid, ldp, ldb, st)),
         ("fwd L2 -> value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, None, pb.bk_rt, None,
-                                                                    pb.kb_kt, p(pb.vpart), S, N, B, in_dim, hid, ldp, ldb, st)),
+                                                                    pb.kb_kt, p(pb.vpart), None, S, N, B, in_dim, hid, ldp, ldb, st)),
         ("fwd L2 -> fp32 a2 (consensus)", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), p(pb.a2), None,
-                                                                            pb.bk_rt, None, pb.kb_kt, p(pb.vpart), S, N, B, in_dim, hid,
+                                                                            pb.bk_rt, None, pb.kb_kt, p(pb.vpart), p(pb.npart), S, N, B, in_dim, hid,
                                                                             ldp, ldb, st)),
         ("head", 0, lambda: L.rcmarl_pk_head(p(pb.vpart), p(theta), p(y), 0.0, 2, p(pb.dz3), p(pb.dzv), p(pb.losspart), S, N, B, in_dim,
                                              hid, ldp, ldb, st)),
