@@ -830,6 +830,207 @@ __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict_
   block_reduce_store<HID + 1>(proj, red, out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2+K3 with layer 2 AND the d + 1 heads on the f16 matrix core (round 6; 20 units, d + 1 <= 32 heads).
+// k_consensus_head above spends ~1270 vector instructions per 64 replay rows, 60 % of them the d + 1 length-20 dot products of the
+// heads and a third the 20 x 20 layer (profiles/r05_sq_k_consensus_head_18_8.json: VALU 100 % busy, SQ_INSTS_MFMA = 0).  Here both
+// run as v_mfma_f32_32x32x16_f16 on two-piece f16 operands in the lane layout of k_mid_fit_v8 (rcmarl_lattice.h: lane (row j, half h)
+// holds ten of the row's 20 units -- the B-operand shape of a contraction over units):
+//   z2[unit][row]  = sum_m W2[m][unit] a1[row][m]     A = 2^10 W2^T (rows / slots permuted as in v8),  B = a1 pieces
+//   est[head][row] = sum_u W3_head[u] phi[row][u]     A = 2^10 [W3 of msg[nbr[i][0..d-1]] | W3 live],  B = phi pieces
+// The estimates come out with the 32 heads of a row spread over its two lanes (lane (j, h): heads 8q + 4h + e).  A wavefront works on
+// TWO blocks of 32 rows; one v_permlane32_swap per accumulator register pair hands lanes 0-31 the other half of block 0's heads and
+// lanes 32-63 the other half of block 1's: afterwards lane l holds ALL heads of replay row l of the wavefront's 64, in registers, and
+// the selection network, the clamp, the mean and the projection residual run one row per lane as before.
+// Range: weights beyond the f16 range of 2^10 w (|w| > 63) or activations beyond 65000 send the wavefront to the fp32 lane code of
+// k_consensus_head for its 64 rows (same launch).
+#define RC_K2MX_RANGE 65000.f
+template <int D, int H>
+__global__ __launch_bounds__(256) void k_consensus_head_mx(const float* __restrict__ a1t, const float* __restrict__ theta,
+                                                           const float* __restrict__ msg, const int* __restrict__ nbr,
+                                                           const int* __restrict__ coop, float* __restrict__ partials,
+                                                           float* __restrict__ agg_out, int N, int B, int in_dim, int ldp, int ldb,
+                                                           int nchunk) {
+  constexpr int HID = 20, LU = 10, NH = D + 1, REC = HID + 2;
+  static_assert(NH <= 32, "the heads of an agent are the 32 rows of one matrix-core operand");
+  __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 2 * 32];      // layer 2: [k-step][piece][k-group][row i] 16-byte A fragments
+  __shared__ __attribute__((aligned(16))) uint4 sHf[2 * 2 * 2 * 32];      // heads:   [k-step][piece][k-group][head]
+  __shared__ float sV[HID + 32];                                          // b2 | b3 of the 32 head rows
+  __shared__ float red[4 * REC];                                          // per wavefront: sum_b e phi (20) | sum_b e (two halves)
+  __shared__ int s_ovf;
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  if (!coop[i]) return;                                                   // workgroup-uniform
+  const int r = threadIdx.x, lane = r & 63, wave = __builtin_amdgcn_readfirstlane(r >> 6), l31 = lane & 31, half = lane >> 5;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* __restrict__ th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  rc_f16_saturate();
+  if (r == 0) s_ovf = 0;
+  __syncthreads();
+  {
+    unsigned short* wf16 = reinterpret_cast<unsigned short*>(sWf);
+    unsigned short* hf16 = reinterpret_cast<unsigned short*>(sHf);
+    bool bad = false;
+    for (int e = r; e < 2 * 32 * 32; e += ROWS) {
+      const int which = e >> 10, ri = (e >> 5) & 31, k = e & 31;
+      const int uk = v8_slot_unit(k);
+      float w = 0.f;
+      if (which == 0) {
+        const int ui = v8_row_unit(ri);
+        if (ui >= 0 && uk >= 0) w = th[g.o_W2 + uk * HID + ui];
+      } else if (ri < NH && uk >= 0) {
+        const float* src = ri < D ? msg + ((long)s * N + nbr[i * D + ri]) * ldp : th;
+        w = src[g.o_W3 + uk];
+      }
+      unsigned ph, pl;
+      rc_split2h_pair(w * RC_V8_S, 0.f, ph, pl);
+      if (!(fabsf(w) * RC_V8_S <= RC_K2MX_RANGE)) bad = true;             // (NaN weights take the fp32 path too)
+      const int ks = k >> 4, kg = (k >> 3) & 1;
+      const int base = ((((ks * 2 + 0) * 2 + kg) * 32 + ri) * 8) + (k & 7);     // in f16 elements; piece stride 2*32*8
+      unsigned short* dst = which ? hf16 : wf16;
+      dst[base] = (unsigned short)ph;
+      dst[base + 2 * 32 * 8] = (unsigned short)pl;
+    }
+    if (bad) s_ovf = 1;
+    if (r < HID) sV[r] = th[g.o_b2 + r];
+    if (r >= 32 && r < 64) {
+      const int hd = r - 32;
+      float b3 = 0.f;
+      if (hd < NH) b3 = hd < D ? msg[((long)s * N + nbr[i * D + hd]) * ldp + g.o_b3] : th[g.o_b3];
+      sV[HID + hd] = b3;
+    }
+  }
+  __syncthreads();
+  const int bw = chunk * ROWS + wave * 64;                                // the wavefront's first replay row
+  const int b = bw + lane;                                                // the row this lane finishes (block `half`, row l31 of it)
+  const bool valid = b < B;
+  float agg = 0.f, e = 0.f, esum_lo = 0.f, esum_hi = 0.f;
+  float usum[LU];                                                         // sum over the half-wave's rows of e * phi[unit v8_unit(half, u)]
+  bool slow = s_ovf != 0;
+  if (!slow) {
+    const uint4* wfA = sWf + half * 32 + l31;
+    const uint4* hfA = sHf + half * 32 + l31;
+    auto loadA = [&](const uint4* base, int ks) {
+      V8Pieces a;
+      a.h = base[((ks * 2 + 0) * 2) * 32];
+      a.l = base[((ks * 2 + 1) * 2) * 32];
+      return a;
+    };
+    uint4 z4;
+    z4.x = z4.y = z4.z = z4.w = 0u;
+    float phi[2][LU], nrmb[2], amax = 0.f;
+    float est[2][16];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int bb = min(bw + 32 * blk + l31, B - 1);                     // (rows beyond B: a clamped read, their e is zero)
+      float a1l[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) a1l[u] = a1t[(row0 + v8_unit(half, u)) * ldb + bb];
+#pragma unroll
+      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1l[u], a1l[u + 1]);
+      V8Pieces p0, p1;
+      {
+        const float x0[8] = {a1l[0], a1l[1], a1l[2], a1l[3], a1l[4], a1l[5], a1l[6], a1l[7]};
+        p0 = v8_split8<false>(x0, 1.f);
+        p1.h = z4; p1.l = z4;
+        rc_split2h_pair(a1l[8], a1l[9], p1.h.x, p1.l.x);
+      }
+      rc_f32x16 zz;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+      zz = v8_mfma4(loadA(wfA, 1), p1, zz);
+      zz = v8_mfma4(loadA(wfA, 0), p0, zz);
+      float np = 0.f;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const float z = fmaf(zz[u], RC_V8_US, sV[v8_unit(half, u)]);
+        phi[blk][u] = fmaxf(z, RC_LEAK * z);
+        np = fmaf(phi[blk][u], phi[blk][u], np);
+      }
+#pragma unroll
+      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, phi[blk][u], phi[blk][u + 1]);
+      float na = np, nb = np;
+      rc_swap32(na, nb);                                                  // na: lanes 32-63 hold the low half's part; nb: lanes 0-31 the high half's
+      nrmb[blk] = (np + (half ? na : nb)) + 1.0f;
+      {
+        const float x0[8] = {phi[blk][0], phi[blk][1], phi[blk][2], phi[blk][3], phi[blk][4], phi[blk][5], phi[blk][6], phi[blk][7]};
+        p0 = v8_split8<false>(x0, 1.f);
+        p1.h = z4; p1.l = z4;
+        rc_split2h_pair(phi[blk][8], phi[blk][9], p1.h.x, p1.l.x);
+      }
+      rc_f32x16 ee;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ee[q] = 0.f;
+      ee = v8_mfma4(loadA(hfA, 1), p1, ee);
+      ee = v8_mfma4(loadA(hfA, 0), p0, ee);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) est[blk][q] = fmaf(ee[q], RC_V8_US, sV[HID + 8 * (q >> 2) + 4 * half + (q & 3)]);
+    }
+    slow = rc_any(!(amax <= RC_K2MX_RANGE));
+    if (!slow) {
+      // register q of est[0] / est[1]: head 8 (q >> 2) + 4 half + (q & 3) of block 0 / 1.  After the swaps est[0][q] is head
+      // 8 (q >> 2) + (q & 3) and est[1][q] head 8 (q >> 2) + 4 + (q & 3) of THIS lane's row (block `half`, row l31).
+      constexpr int NQ = 4 * ((NH + 7) / 8) < 16 ? 4 * ((NH + 7) / 8) : 16;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) rc_swap32(est[0][q], est[1][q]);
+      auto head = [&](int k) { return (k & 4) ? est[1][4 * (k >> 3) + (k & 3)] : est[0][4 * (k >> 3) + (k & 3)]; };
+      float v[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) v[k] = head(k);
+      agg = select_agg<HID, D, H>(v);
+      const float nrm = half ? nrmb[1] : nrmb[0];
+      e = valid ? (agg - head(D)) / nrm : 0.f;
+      const float eo = __shfl_xor(e, 32, 64);                             // the residual of the row the partner lane finishes
+      const float e0 = half ? eo : e, e1 = half ? e : eo;                 // of block 0 / block 1, row l31
+#pragma unroll
+      for (int u = 0; u < LU; ++u) usum[u] = fmaf(e1, phi[1][u], e0 * phi[0][u]);
+      float es = e, dummy = 0.f;
+      static_assert(LU == 10, "ten unit sums + the residual sum, reduced three at a time");
+      rc_half_sum3_lane31(usum[0], usum[1], usum[2]);
+      rc_half_sum3_lane31(usum[3], usum[4], usum[5]);
+      rc_half_sum3_lane31(usum[6], usum[7], usum[8]);
+      rc_half_sum3_lane31(usum[9], es, dummy);
+      if (l31 == 31) {
+#pragma unroll
+        for (int u = 0; u < LU; ++u) red[wave * REC + v8_unit(half, u)] = usum[u];
+        red[wave * REC + HID + half] = es;
+      }
+    }
+  }
+  if (slow) {                                                             // wave-uniform: the fp32 lane code for this wavefront's 64 rows
+    RC_NO_SPECULATE();
+    float a1[HID], phi[HID];
+    load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+    layer2<HID>(th, g, a1, phi);
+    float nrm = 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) nrm = fmaf(phi[k], phi[k], nrm);
+    nrm += 1.0f;
+    float v[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float* mh = msg + ((long)s * N + nbr[i * D + k]) * ldp;
+      v[k] = head1<HID>(mh + g.o_W3, mh[g.o_b3], phi);
+    }
+    agg = select_agg<HID, D, H>(v);
+    e = valid ? (agg - head1<HID>(th + g.o_W3, th[g.o_b3], phi)) / nrm : 0.f;
+#pragma unroll
+    for (int k = 0; k < HID; ++k) {
+      const float t = rc_wave_sum_lane63(e * phi[k]);
+      if (lane == 63) red[wave * REC + k] = t;
+    }
+    const float t = rc_wave_sum_lane63(e);
+    if (lane == 63) { red[wave * REC + HID] = t; red[wave * REC + HID + 1] = 0.f; }
+  }
+  (void)esum_lo; (void)esum_hi;
+  if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
+  __syncthreads();
+  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (HID + 1);
+  if (r < HID) out[r] = (red[r] + red[REC + r]) + (red[2 * REC + r] + red[3 * REC + r]);
+  if (r == HID) out[HID] = ((red[HID] + red[HID + 1]) + (red[REC + HID] + red[REC + HID + 1])) +
+                           ((red[2 * REC + HID] + red[2 * REC + HID + 1]) + (red[3 * REC + HID] + red[3 * REC + HID + 1]));
+}
+
 // runtime (d, H) fallback: neighbour estimates staged in LDS, order statistics by rank counting
 template <int HID>
 __global__ __launch_bounds__(256) void k_consensus_head_generic(
@@ -1235,6 +1436,19 @@ RCMARL_EXPORT int rcmarl_mid_value(const float* a1t, const float* theta, const f
   return rcmarl_check_launch();
 }
 
+template <int DD, int HH>
+static bool launch_consensus_head_mx(dim3 grid, dim3 block, void* stream, const float* a1t, const float* theta, const float* msg,
+                                     const int* nbr, const int* coop, float* partials, float* agg_out, int N, int B, int in_dim,
+                                     int ldp, int ldb, int nchunk) {
+  if constexpr (DD + 1 <= 32) {
+    RCMARL_LAUNCH((k_consensus_head_mx<DD, HH>), grid, block, 0, stream, a1t, theta, msg, nbr, coop, partials, agg_out, N, B, in_dim,
+                  ldp, ldb, nchunk);
+    return true;
+  } else {
+    return false;
+  }
+}
+
 RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, const float* msg, const int* nbr,
                                         const int* coop, float* partials, float* agg_out, int S, int N,
                                         int B, int in_dim, int hid, int ldp, int ldb, int d, int H, void* stream) {
@@ -1244,11 +1458,19 @@ RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, co
   const int nchunk = rc_ceil_div(B, ROWS);
   const dim3 grid(nchunk, N, S), block(ROWS);
   bool done = false;
+  // RCMARL_K2_MX (default 1): layer 2 and the d + 1 heads on the f16 matrix core (k_consensus_head_mx: 20 units, d + 1 <= 32 heads, a
+  // generated selection network); 0: everything on the vector ALUs (k_consensus_head)
+  const char* mxe = getenv("RCMARL_K2_MX");
+  const bool mx = hid == 20 && d + 1 <= 32 && !(mxe && atoi(mxe) == 0);
 #define RC_CASE(DD, HH)                                                                                          \
   if (!done && d == DD && H == HH) {                                                                             \
-    RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_consensus_head<HID_, DD, HH>), grid, block, 0, stream, a1t, theta, msg,  \
-                                     nbr, coop, partials, agg_out, N, B, in_dim, ldp, ldb, nchunk));            \
-    done = true;                                                                                                 \
+    if (mx) done = launch_consensus_head_mx<DD, HH>(grid, block, stream, a1t, theta, msg, nbr, coop, partials, agg_out, N, B, in_dim,  \
+                                                    ldp, ldb, nchunk);                                           \
+    if (!done) {                                                                                                 \
+      RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_consensus_head<HID_, DD, HH>), grid, block, 0, stream, a1t, theta, msg,  \
+                                       nbr, coop, partials, agg_out, N, B, in_dim, ldp, ldb, nchunk));          \
+      done = true;                                                                                               \
+    }                                                                                                            \
   }
   RCMARL_SELNET_COMBOS(RC_CASE)
 #undef RC_CASE

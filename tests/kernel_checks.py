@@ -313,8 +313,8 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
     np.testing.assert_array_equal(bk.host(d_th), theta)           # live weights untouched (rollback)
 
 
-def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
-    """K2+K3: estimate consensus + projection step of the output layer."""
+def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, compare=True):
+    """K2+K3: estimate consensus + projection step of the output layer.  compare=False: only run, return (theta after, aggregate)."""
     rng = np.random.default_rng(S + N * 10 + B + d * 7 + H)
     P, P_hid = geom(in_dim, 1)
     ldp, ldb = pad64(P), pad64(B)
@@ -326,9 +326,9 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
     coop = np.ones(N, np.int32)
     coop[0] = 0
     for s in range(S):                              # an outlier head among the messages
-        msg[s, 1, P_hid:P] *= 50.0
-        msgp[s][1][4] = msgp[s][1][4] * np.float32(50.0)
-        msgp[s][1][5] = msgp[s][1][5] * np.float32(50.0)
+        msg[s, 1, P_hid:P] *= np.float32(outlier)
+        msgp[s][1][4] = msgp[s][1][4] * np.float32(outlier)
+        msgp[s][1][5] = msgp[s][1][5] * np.float32(outlier)
     nchunk = (B + 255) // 256
     d_x, d_th, d_msg, d_nbr, d_coop = bk.dev(x), bk.dev(theta), bk.dev(msg), bk.dev(nbr), bk.dev(coop)
     d_a = bk.dev(np.zeros((S, N * HID, ldb), np.float32))
@@ -340,6 +340,8 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ"):
                             bk.ptr(d_agg), S, N, B, in_dim, HID, ldp, ldb, d, H, bk.stream)
     L.rcmarl_head_apply(bk.ptr(d_part), bk.ptr(d_th), bk.ptr(d_coop), S, N, B, in_dim, HID, ldp, bk.stream)
     th_new, agg = bk.host(d_th), bk.host(d_agg)
+    if not compare:
+        return th_new, agg
     for s in range(S):
         for i in range(N):
             if not coop[i]:

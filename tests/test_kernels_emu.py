@@ -60,8 +60,23 @@ def test_sgd_fit(bk, S, N, B, in_dim, masked):
 
 @pytest.mark.parametrize("S,N,B,in_dim,d,H,graph", [(2, 5, 300, 10, 4, 1, "circ"), (1, 6, 100, 18, 3, 0, "rand"),
                                                     (1, 12, 70, 24, 11, 2, "rand")])
-def test_consensus_head(bk, S, N, B, in_dim, d, H, graph):
+@pytest.mark.parametrize("mx", ["1", "0"])       # layer 2 + heads on the f16 matrix core (k_consensus_head_mx) | everything on the vector ALUs
+def test_consensus_head(bk, S, N, B, in_dim, d, H, graph, mx, monkeypatch):
+    monkeypatch.setenv("RCMARL_K2_MX", mx)
     KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
+
+
+def test_consensus_head_out_of_range_head_takes_the_fp32_lane_code(bk, monkeypatch):
+    """A message head beyond the f16 range of the matrix-core form (2^10 |W3| > 65000): the workgroups that see it run the fp32 lane
+    code inside k_consensus_head_mx: the bits of k_consensus_head (which test_consensus_head holds to the oracle)."""
+    res = {}
+    for mx in ("1", "0"):
+        monkeypatch.setenv("RCMARL_K2_MX", mx)
+        res[mx] = KC.check_consensus_head(bk, 2, 5, 300, 10, 4, 1, "circ", outlier=1e4, compare=False)
+    sees = [1, 3, 4]                             # the agents whose in-neighbourhood [i, i+1, i+2, i+3] holds agent 1, the outlier
+    np.testing.assert_array_equal(res["1"][0][:, sees], res["0"][0][:, sees])
+    np.testing.assert_array_equal(res["1"][1][:, sees], res["0"][1][:, sees])
+    assert not np.array_equal(res["1"][0][:, 2], res["0"][0][:, 2])        # (agent 2 does not: matrix-core form, other last bits)
 
 
 @pytest.mark.parametrize("S,N,B,in_dim", [(2, 3, 300, 6), (1, 5, 100, 10), (1, 8, 70, 32)])
