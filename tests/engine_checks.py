@@ -86,8 +86,96 @@ def snapshot_for_oracle(eng, seed_idx):
             "a": g("a").reshape(B, N, 1)}
 
 
+# ---- the oracle's update block with its per-agent loops spread over worker processes ----------------------------------------
+# oracle.update_block (training/train_agents.py:100-153) walks the agents one after the other; for an all-cooperative team every step
+# of an epoch is independent per agent given the previous step's results (phase I: the local fits; phase II: consensus + projection
+# from the gathered messages; phase III: the actor step).  At 256 agents x 3000 rows one block takes ~4.5 minutes in one process --
+# the GPU boxes have hundreds of cores -- so the SAME agent methods are called per agent in a process pool, epoch by epoch, and the
+# results are those of the serial loop (checked bit for bit in tests/test_engine_emu.py).  Test infrastructure only.
+_POOL_STATE = {}
+
+
+def _set_oracle_mode(mode, seed):
+    from oracle import mlp_np as M_
+    from oracle import rpbcac_oracle as O_
+    if not hasattr(M_, "_pristine_fit_mse"):
+        M_._pristine_fit_mse = M_.fit_mse
+    M_.fit_mse = M_._pristine_fit_mse
+    M_.F32 = O_.F32 = np.float32
+    M_.LEAK = np.float32(0.1)
+    if mode == "f64":
+        # the ARBITER: the same loop nest in float64.  Every array and every scalar the restatement forms through its F32 alias
+        # becomes a double; the inputs are the fp32 snapshot widened.  (Constants such as lr and the LeakyReLU slope are then the
+        # doubles 0.001 / 0.1 rather than their fp32 roundings: a relative 5e-8 on the update.)
+        M_.F32 = O_.F32 = np.float64
+        M_.LEAK = np.float64(0.1)
+    elif mode == "f32_shuffled":
+        # the CONTROL: fp32, the rows of every full-batch local fit in another order per epoch -- what Keras' fit(shuffle=True)
+        # does to the single batch (SURVEY.md 8a): the same sums, taken in another order
+        orig, rng = M_._pristine_fit_mse, np.random.default_rng(seed)
+
+        def fit_shuffled(params, x, y, lr, epochs, batch_size=None, perms=None, sample_weight=None):
+            if batch_size is None and perms is None:
+                B = np.asarray(x).shape[0]
+                perms = np.stack([rng.permutation(B) for _ in range(epochs)])
+            return orig(params, x, y, lr, epochs, batch_size=batch_size, perms=perms, sample_weight=sample_weight)
+        M_.fit_mse = fit_shuffled
+    return M_, O_
+
+
+def _pool_init(root, data_dir, n_snaps, threads):
+    import os
+    import sys
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import threadpoolctl
+        _POOL_STATE["tp"] = threadpoolctl.threadpool_limits(threads)
+    except Exception:
+        pass
+    # per snapshot: s, ns, sa, r, a, r_coop (fp32), memory-mapped from files the parent wrote (one copy in the page cache for all workers)
+    _POOL_STATE["data"] = [{key: np.load(os.path.join(data_dir, "%d_%s.npy" % (k, key)), mmap_mode="r")
+                            for key in ("s", "ns", "sa", "r", "a", "r_coop")} for k in range(n_snaps)]
+
+
+def _pool_task(task):
+    kind, k, mode, i, agent, extra = task
+    M_, O_ = _set_oracle_mode(mode, 12345 + 7919 * k + i)
+    d = _POOL_STATE["data"][k]
+    if kind == "fit":                        # phase I  (train_agents.py:105-121, cooperative branch)
+        r_applied = d["r_coop"] if extra else d["r"][:, i]
+        x, tl = agent.local_fit_tr(d["sa"], r_applied)
+        y, cl = agent.local_fit_critic(d["s"], d["ns"], r_applied)
+        return x, y, tl, cl
+    if kind == "cons":                       # phase II (:125-145)
+        c_in, t_in = extra
+        agent.consensus_hidden_critic(c_in)
+        agent.consensus_hidden_tr(t_in)
+        c_agg = agent.consensus_estimates_critic(d["s"], c_in)
+        t_agg = agent.consensus_estimates_tr(d["sa"], t_in)
+        agent.projection_step_critic(d["s"], c_agg)
+        agent.projection_step_tr(d["sa"], t_agg)
+        return agent
+    n_last = extra                           # phase III (:149-153)
+    agent.actor_step(d["s"][-n_last:], d["ns"][-n_last:], d["sa"][-n_last:], d["a"][-n_last:, i])
+    return agent
+
+
+def _make_agents(args, snap, mode):
+    M_, O_ = _set_oracle_mode(mode, 0)
+    agents = []
+    for i, lab in enumerate(args["agent_label"]):
+        w = snap["W"][i]
+        ag = O_.make_agent(lab, w["actor"], w["critic"], w["tr"], args["slow_lr"], args["fast_lr"], args["gamma"], args["H"])
+        m, v, t = snap["adam"][i]
+        ag.adam.m, ag.adam.v, ag.adam.t = [x.astype(M_.F32).copy() for x in m], [x.astype(M_.F32).copy() for x in v], int(t)
+        agents.append(ag)
+    return agents
+
+
 def _oracle_block_job(payload):
-    """oracle.update_block (training/train_agents.py:100-153) on one snapshot, in a worker process"""
+    """oracle.update_block (training/train_agents.py:100-153) on one snapshot, in a worker process: the serial form"""
     import os
     import sys
     root, args, snap, threads = payload[:4]
@@ -100,58 +188,75 @@ def _oracle_block_job(payload):
         threadpoolctl.threadpool_limits(threads)
     except Exception:
         pass
-    from oracle import mlp_np as M_
-    from oracle import rpbcac_oracle as O_
-    # (a pool worker may serve several jobs: start from the pristine module state every time)
-    if not hasattr(M_, "_pristine_fit_mse"):
-        M_._pristine_fit_mse = M_.fit_mse
-    M_.fit_mse = M_._pristine_fit_mse
-    M_.F32 = O_.F32 = np.float32
-    M_.LEAK = np.float32(0.1)
-    if mode == "f64":
-        # the ARBITER: the same loop nest in float64 (this worker process only).  Every array and every scalar the restatement
-        # forms through its F32 alias becomes a double; the inputs are the fp32 snapshot widened.  (Constants such as lr and the
-        # LeakyReLU slope are then the doubles 0.001 / 0.1 rather than their fp32 roundings: a relative 5e-8 on the update.)
-        M_.F32 = O_.F32 = np.float64
-        M_.LEAK = np.float64(0.1)
-    elif mode == "f32_shuffled":
-        # the CONTROL: fp32, the rows of every full-batch local fit in another order per epoch -- what Keras' fit(shuffle=True)
-        # does to the single batch (SURVEY.md 8a): the same sums, taken in another order
-        orig, rng = M_.fit_mse, np.random.default_rng(12345 + int(args.get("random_seed", 0)))
-
-        def fit_shuffled(params, x, y, lr, epochs, batch_size=None, perms=None, sample_weight=None):
-            if batch_size is None and perms is None:
-                B = np.asarray(x).shape[0]
-                perms = np.stack([rng.permutation(B) for _ in range(epochs)])
-            return orig(params, x, y, lr, epochs, batch_size=batch_size, perms=perms, sample_weight=sample_weight)
-        M_.fit_mse = fit_shuffled
-    agents = []
-    for i, lab in enumerate(args["agent_label"]):
-        w = snap["W"][i]
-        ag = O_.make_agent(lab, w["actor"], w["critic"], w["tr"], args["slow_lr"], args["fast_lr"], args["gamma"], args["H"])
-        m, v, t = snap["adam"][i]
-        ag.adam.m, ag.adam.v, ag.adam.t = [x.astype(M_.F32).copy() for x in m], [x.astype(M_.F32).copy() for x in v], int(t)
-        agents.append(ag)
+    M_, O_ = _set_oracle_mode(mode, 12345 + int(args.get("random_seed", 0)))
+    agents = _make_agents(args, snap, mode)
+    _set_oracle_mode(mode, 12345 + int(args.get("random_seed", 0)))
     O_.update_block(agents, args["agent_label"], args["in_nodes"], snap["s"], snap["ns"], snap["r"], snap["a"], args["n_epochs"],
                     args["common_reward"], args["max_ep_len"], args["n_ep_fixed"], O_.ShuffleStream(args.get("random_seed", 0)))
     return [ag.parameters() for ag in agents]
 
 
-def run_oracle_blocks_parallel(args, snaps, modes=None):
-    """one oracle.update_block per snapshot, one worker process each -> per-snapshot weight lists [agent][actor, critic, tr].
-    modes (per snapshot): "f32" (the oracle), "f64" (the same loop nest in float64), "f32_shuffled" (fp32, local-fit rows reordered)"""
+def run_oracle_blocks_parallel(args, snaps, modes=None, force_serial=False):
+    """one oracle update block per snapshot -> per-snapshot weight lists [agent][actor, critic, tr].
+    modes (per snapshot): "f32" (the oracle), "f64" (the same loop nest in float64), "f32_shuffled" (fp32, local-fit rows reordered).
+    All-cooperative teams on a host with many cores: the per-agent loops of every epoch run in a process pool (see above);
+    otherwise (adversaries draw from a shared shuffle stream in agent order; few cores) one serial oracle.update_block per process."""
     import concurrent.futures as cf
     import multiprocessing as mp
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ncpu = os.cpu_count() or 1
-    workers = max(1, min(len(snaps), ncpu))
-    threads = max(1, min(16, ncpu // workers))
-    jobs = [(root, args, sn, threads, "f32" if modes is None else modes[k]) for k, sn in enumerate(snaps)]
-    if workers == 1:
-        return [_oracle_block_job(j) for j in jobs]
-    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
-        return list(ex.map(_oracle_block_job, jobs))
+    modes = ["f32"] * len(snaps) if modes is None else list(modes)
+    labels = args["agent_label"]
+    n = len(labels)
+    spread = (not force_serial) and all(lab == "Cooperative" for lab in labels) and ncpu >= 8
+    if not spread:
+        workers = max(1, min(len(snaps), ncpu))
+        threads = max(1, min(16, ncpu // workers))
+        jobs = [(root, args, sn, threads, modes[k]) for k, sn in enumerate(snaps)]
+        if workers == 1:
+            return [_oracle_block_job(j) for j in jobs]
+        with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+            return list(ex.map(_oracle_block_job, jobs))
+    import shutil
+    import tempfile
+    data_dir = tempfile.mkdtemp(prefix="rcmarl_oracle_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    for k, sn in enumerate(snaps):
+        s, ns, r, a = (np.asarray(sn[key], np.float32) for key in ("s", "ns", "r", "a"))
+        r_coop = np.zeros((r.shape[0], r.shape[2]), np.float32)
+        for i in range(n):
+            r_coop += r[:, i] / n                                          # train_agents.py:96-98 (all agents cooperative)
+        for key, arr in (("s", s), ("ns", ns), ("sa", np.concatenate([s, a], axis=-1)), ("r", r), ("a", a), ("r_coop", r_coop)):
+            np.save(os.path.join(data_dir, "%d_%s.npy" % (k, key)), np.ascontiguousarray(arr))
+    agents = [_make_agents(args, sn, modes[k]) for k, sn in enumerate(snaps)]
+    _set_oracle_mode("f32", 0)
+    workers = max(1, min(ncpu, 192, len(snaps) * n))
+    in_nodes, common, n_last = args["in_nodes"], bool(args["common_reward"]), args["max_ep_len"] * args["n_ep_fixed"]
+    chunk = max(1, (len(snaps) * n) // (workers * 4))
+    try:
+        return _spread_epochs(cf, mp, workers, root, data_dir, snaps, modes, agents, n, args, in_nodes, common, n_last, chunk)
+    finally:
+        shutil.rmtree(data_dir, ignore_errors=True)
+
+
+def _spread_epochs(cf, mp, workers, root, data_dir, snaps, modes, agents, n, args, in_nodes, common, n_last, chunk):
+    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"), initializer=_pool_init,
+                                initargs=(root, data_dir, len(snaps), 1)) as ex:
+        for _ in range(args["n_epochs"]):
+            fits = list(ex.map(_pool_task, [("fit", k, modes[k], i, agents[k][i], common) for k in range(len(snaps)) for i in range(n)],
+                               chunksize=chunk))
+            tasks = []
+            for k in range(len(snaps)):
+                tr_msgs = [fits[k * n + i][0] for i in range(n)]
+                c_msgs = [fits[k * n + i][1] for i in range(n)]
+                for i in range(n):
+                    tasks.append(("cons", k, modes[k], i, agents[k][i], ([c_msgs[j] for j in in_nodes[i]], [tr_msgs[j] for j in in_nodes[i]])))
+            res = list(ex.map(_pool_task, tasks, chunksize=chunk))
+            for k in range(len(snaps)):
+                agents[k] = res[k * n:(k + 1) * n]
+        res = list(ex.map(_pool_task, [("actor", k, modes[k], i, agents[k][i], n_last) for k in range(len(snaps)) for i in range(n)],
+                           chunksize=chunk))
+    return [[ag.parameters() for ag in res[k * n:(k + 1) * n]] for k in range(len(snaps))]
 
 
 def network_errors(eng, o_weights, nets=("critic", "tr")):

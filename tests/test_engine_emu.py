@@ -81,6 +81,20 @@ def test_update_block_from_injected_state_matches_oracle():
     assert worst <= 1e-5, worst
 
 
+def test_oracle_block_spread_over_processes_equals_the_serial_oracle():
+    """tests/engine_checks.run_oracle_blocks_parallel calls the oracle's per-agent methods from a process pool, epoch by epoch (the
+    256-agent blocks of the GPU suite take minutes in one process): same weights as oracle.update_block's serial loop, bit for bit."""
+    args = EC.make_args(["Cooperative"] * 5, H=1, n_episodes=0, max_ep_len=3, n_ep_fixed=2, n_epochs=2, buffer_size=12, seed=71)
+    eng, snaps = EC.check_block_from_injected_state(args, 5, 5, "cpu", emu_lib(), (71, 72), oracle_later=True)
+    a = EC.run_oracle_blocks_parallel(dict(args), snaps)
+    b = EC.run_oracle_blocks_parallel(dict(args), snaps, force_serial=True)
+    for wa, wb in zip(a, b):
+        for ag_a, ag_b in zip(wa, wb):
+            for net_a, net_b in zip(ag_a, ag_b):
+                for x, y in zip(net_a, net_b):
+                    np.testing.assert_array_equal(x, y)
+
+
 def test_engine_wide_critic_with_faulty_agent_matches_oracle():
     """A Faulty agent (frozen critic / team-reward net, learning actor: adversarial_CAC_agents.py:5-55) beside a wide critic:
     its frozen wide message enters every neighbour's aggregation, its actor takes the mini-batch Adam steps from TD errors

@@ -194,12 +194,17 @@ def mid(L, S=16, N=256, B=3000):
     t = timeit(lambda: L.rcmarl_mid_value(a1t.data_ptr(), theta.data_ptr(), None, 0.9, out.data_ptr(), S, N, B, in_dim, HID, ldp,
                                           ldb, st))
     print("mid_value %8.1f us  (%.2f TB/s on a1t r)" % (t, 4.0 * S * N * HID * B / t / 1e6))
-    for d, H in ((4, 1), (18, 8)):
+    for d, H in ((4, 1), (10, 4), (18, 8)):
         nbr = torch.tensor([[(i + k) % N for k in range(d)] for i in range(N)], dtype=torch.int32, device="cuda")
         coop = torch.ones(N, dtype=torch.int32, device="cuda")
-        t = timeit(lambda: L.rcmarl_consensus_head(a1t.data_ptr(), theta.data_ptr(), theta.data_ptr(), nbr.data_ptr(),
-                                                   coop.data_ptr(), part.data_ptr(), None, S, N, B, in_dim, HID, ldp, ldb, d, H, st))
-        print("cons_head d=%d H=%d %8.1f us" % (d, H, t))
+        for mx in ("1", "0"):        # layer 2 + heads on the f16 matrix core (k_consensus_head_mx) | on the vector ALUs (k_consensus_head)
+            os.environ["RCMARL_K2_MX"] = mx
+            t = timeit(lambda: L.rcmarl_consensus_head(a1t.data_ptr(), theta.data_ptr(), theta.data_ptr(), nbr.data_ptr(),
+                                                       coop.data_ptr(), part.data_ptr(), None, S, N, B, in_dim, HID, ldp, ldb, d, H, st))
+            byts = 4.0 * S * N * B * (HID + 2)
+            print("cons_head d=%d H=%d RCMARL_K2_MX=%s %8.1f us  (%.2f TB/s of 4 B (h + 2) per (agent, row) = %.3f of 8 TB/s)"
+                  % (d, H, mx, t, byts / t / 1e6, byts / t / 1e6 / 8.0))
+        os.environ.pop("RCMARL_K2_MX", None)
 
 
 def lattice(L, S=16, N=256, B=3000):
