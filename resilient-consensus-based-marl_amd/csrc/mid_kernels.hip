@@ -845,12 +845,15 @@ __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict_
 // Range: weights beyond the f16 range of 2^10 w (|w| > 63) or activations beyond 65000 send the wavefront to the fp32 lane code of
 // k_consensus_head for its 64 rows (same launch).
 #define RC_K2MX_RANGE 65000.f
+#ifndef RC_K2MX_WAVES
+#define RC_K2MX_WAVES 3                  // wavefronts per SIMD the register allocation aims at (161 registers; 4 spills, 2 leaves 192 unused)
+#endif
 template <int D, int H>
-__global__ __launch_bounds__(256) void k_consensus_head_mx(const float* __restrict__ a1t, const float* __restrict__ theta,
+__global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const float* __restrict__ a1t, const float* __restrict__ theta,
                                                            const float* __restrict__ msg, const int* __restrict__ nbr,
                                                            const int* __restrict__ coop, float* __restrict__ partials,
                                                            float* __restrict__ agg_out, int N, int B, int in_dim, int ldp, int ldb,
-                                                           int nchunk) {
+                                                           int nchunk, int cpw) {
   constexpr int HID = 20, LU = 10, NH = D + 1, REC = HID + 2;
   static_assert(NH <= 32, "the heads of an agent are the 32 rows of one matrix-core operand");
   __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 2 * 32];      // layer 2: [k-step][piece][k-group][row i] 16-byte A fragments
@@ -901,134 +904,178 @@ __global__ __launch_bounds__(256) void k_consensus_head_mx(const float* __restri
     }
   }
   __syncthreads();
-  const int bw = chunk * ROWS + wave * 64;                                // the wavefront's first replay row
-  const int b = bw + lane;                                                // the row this lane finishes (block `half`, row l31 of it)
-  const bool valid = b < B;
-  float agg = 0.f, e = 0.f, esum_lo = 0.f, esum_hi = 0.f;
-  float usum[LU];                                                         // sum over the half-wave's rows of e * phi[unit v8_unit(half, u)]
-  bool slow = s_ovf != 0;
-  if (!slow) {
-    const uint4* wfA = sWf + half * 32 + l31;
-    const uint4* hfA = sHf + half * 32 + l31;
-    auto loadA = [&](const uint4* base, int ks) {
-      V8Pieces a;
-      a.h = base[((ks * 2 + 0) * 2) * 32];
-      a.l = base[((ks * 2 + 1) * 2) * 32];
-      return a;
-    };
-    uint4 z4;
-    z4.x = z4.y = z4.z = z4.w = 0u;
-    float phi[2][LU], nrmb[2], amax = 0.f;
-    float est[2][16];
+  // The workgroup walks `cpw` chunks of 256 rows (the fragment tables above cost ~300 vector instructions per thread: per chunk
+  // they were a third of the kernel, profiles/r06f_sq_k_consensus_head_mx_per_chunk.json); a wavefront keeps its sums over all its
+  // rows in registers and reduces them ONCE.  The ten activations of the next chunk's two blocks are requested a chunk ahead.
+  const uint4* wfA = sWf + half * 32 + l31;
+  const uint4* hfA = sHf + half * 32 + l31;
+  auto loadA = [&](const uint4* base, int ks) {
+    V8Pieces a;
+    a.h = base[((ks * 2 + 0) * 2) * 32];
+    a.l = base[((ks * 2 + 1) * 2) * 32];
+    return a;
+  };
+  uint4 z4;
+  z4.x = z4.y = z4.z = z4.w = 0u;
+  const bool wg_slow = s_ovf != 0;
+  float usum[LU], es = 0.f;                                               // sums over this lane's rows: e * phi[unit v8_unit(half, u)], e
+#pragma unroll
+  for (int u = 0; u < LU; ++u) usum[u] = 0.f;
+  unsigned slow_mask = 0u;                                                // wave-uniform: bit c - c_begin = that chunk's 64 rows take the fp32 lane code
+  const int c_begin = chunk * cpw, c_end = min(nchunk, c_begin + cpw);
+  float a1n[2][LU];
+  auto fetch = [&](int c) {
+    const int bw = c * ROWS + wave * 64;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const int bb = min(bw + 32 * blk + l31, B - 1);                     // (rows beyond B: a clamped read, their e is zero)
-      float a1l[LU];
 #pragma unroll
-      for (int u = 0; u < LU; ++u) a1l[u] = a1t[(row0 + v8_unit(half, u)) * ldb + bb];
-#pragma unroll
-      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1l[u], a1l[u + 1]);
-      V8Pieces p0, p1;
-      {
-        const float x0[8] = {a1l[0], a1l[1], a1l[2], a1l[3], a1l[4], a1l[5], a1l[6], a1l[7]};
-        p0 = v8_split8<false>(x0, 1.f);
-        p1.h = z4; p1.l = z4;
-        rc_split2h_pair(a1l[8], a1l[9], p1.h.x, p1.l.x);
-      }
-      rc_f32x16 zz;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) zz[q] = 0.f;
-      zz = v8_mfma4(loadA(wfA, 1), p1, zz);
-      zz = v8_mfma4(loadA(wfA, 0), p0, zz);
-      float np = 0.f;
-#pragma unroll
-      for (int u = 0; u < LU; ++u) {
-        const float z = fmaf(zz[u], RC_V8_US, sV[v8_unit(half, u)]);
-        phi[blk][u] = fmaxf(z, RC_LEAK * z);
-        np = fmaf(phi[blk][u], phi[blk][u], np);
-      }
-#pragma unroll
-      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, phi[blk][u], phi[blk][u + 1]);
-      float na = np, nb = np;
-      rc_swap32(na, nb);                                                  // na: lanes 32-63 hold the low half's part; nb: lanes 0-31 the high half's
-      nrmb[blk] = (np + (half ? na : nb)) + 1.0f;
-      {
-        const float x0[8] = {phi[blk][0], phi[blk][1], phi[blk][2], phi[blk][3], phi[blk][4], phi[blk][5], phi[blk][6], phi[blk][7]};
-        p0 = v8_split8<false>(x0, 1.f);
-        p1.h = z4; p1.l = z4;
-        rc_split2h_pair(phi[blk][8], phi[blk][9], p1.h.x, p1.l.x);
-      }
-      rc_f32x16 ee;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) ee[q] = 0.f;
-      ee = v8_mfma4(loadA(hfA, 1), p1, ee);
-      ee = v8_mfma4(loadA(hfA, 0), p0, ee);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) est[blk][q] = fmaf(ee[q], RC_V8_US, sV[HID + 8 * (q >> 2) + 4 * half + (q & 3)]);
+      for (int u = 0; u < LU; ++u) a1n[blk][u] = a1t[(row0 + v8_unit(half, u)) * ldb + bb];
     }
-    slow = rc_any(!(amax <= RC_K2MX_RANGE));
-    if (!slow) {
-      // register q of est[0] / est[1]: head 8 (q >> 2) + 4 half + (q & 3) of block 0 / 1.  After the swaps est[0][q] is head
-      // 8 (q >> 2) + (q & 3) and est[1][q] head 8 (q >> 2) + 4 + (q & 3) of THIS lane's row (block `half`, row l31).
-      constexpr int NQ = 4 * ((NH + 7) / 8) < 16 ? 4 * ((NH + 7) / 8) : 16;
+  };
+  if (!wg_slow) fetch(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    const int bw = c * ROWS + wave * 64;                                  // the wavefront's first replay row of this chunk
+    const int b = bw + lane;                                              // the row this lane finishes (block `half`, row l31 of it)
+    const bool valid = b < B;
+    float agg = 0.f;
+    if (wg_slow) {
+      slow_mask |= 1u << (c - c_begin);
+      continue;
+    }
+    {
+      float a1l[2][LU];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) rc_swap32(est[0][q], est[1][q]);
-      auto head = [&](int k) { return (k & 4) ? est[1][4 * (k >> 3) + (k & 3)] : est[0][4 * (k >> 3) + (k & 3)]; };
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int u = 0; u < LU; ++u) a1l[blk][u] = a1n[blk][u];
+      if (c + 1 < c_end) fetch(c + 1);
+      float phi[2][LU], nrmb[2], amax = 0.f;
+      float est[2][16];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1l[blk][u], a1l[blk][u + 1]);
+        V8Pieces p0, p1;
+        {
+          const float x0[8] = {a1l[blk][0], a1l[blk][1], a1l[blk][2], a1l[blk][3], a1l[blk][4], a1l[blk][5], a1l[blk][6], a1l[blk][7]};
+          p0 = v8_split8<false>(x0, 1.f);
+          p1.h = z4; p1.l = z4;
+          rc_split2h_pair(a1l[blk][8], a1l[blk][9], p1.h.x, p1.l.x);
+        }
+        rc_f32x16 zz;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+        zz = v8_mfma4(loadA(wfA, 1), p1, zz);
+        zz = v8_mfma4(loadA(wfA, 0), p0, zz);
+        float np = 0.f;
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+          const float z = fmaf(zz[u], RC_V8_US, sV[v8_unit(half, u)]);
+          phi[blk][u] = fmaxf(z, RC_LEAK * z);
+          np = fmaf(phi[blk][u], phi[blk][u], np);
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, phi[blk][u], phi[blk][u + 1]);
+        float na = np, nb = np;
+        rc_swap32(na, nb);                                                // na: lanes 32-63 hold the low half's part; nb: lanes 0-31 the high half's
+        nrmb[blk] = (np + (half ? na : nb)) + 1.0f;
+        {
+          const float x0[8] = {phi[blk][0], phi[blk][1], phi[blk][2], phi[blk][3], phi[blk][4], phi[blk][5], phi[blk][6], phi[blk][7]};
+          p0 = v8_split8<false>(x0, 1.f);
+          p1.h = z4; p1.l = z4;
+          rc_split2h_pair(phi[blk][8], phi[blk][9], p1.h.x, p1.l.x);
+        }
+        rc_f32x16 ee;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ee[q] = 0.f;
+        ee = v8_mfma4(loadA(hfA, 1), p1, ee);
+        ee = v8_mfma4(loadA(hfA, 0), p0, ee);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) est[blk][q] = fmaf(ee[q], RC_V8_US, sV[HID + 8 * (q >> 2) + 4 * half + (q & 3)]);
+      }
+      if (rc_any(!(amax <= RC_K2MX_RANGE))) {
+        slow_mask |= 1u << (c - c_begin);
+        continue;
+      }
+      {
+        // register q of est[0] / est[1]: head 8 (q >> 2) + 4 half + (q & 3) of block 0 / 1.  After the swaps est[0][q] is head
+        // 8 (q >> 2) + (q & 3) and est[1][q] head 8 (q >> 2) + 4 + (q & 3) of THIS lane's row (block `half`, row l31).
+        constexpr int NQ = 4 * ((NH + 7) / 8) < 16 ? 4 * ((NH + 7) / 8) : 16;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) rc_swap32(est[0][q], est[1][q]);
+        auto head = [&](int k) { return (k & 4) ? est[1][4 * (k >> 3) + (k & 3)] : est[0][4 * (k >> 3) + (k & 3)]; };
+        float v[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v[k] = head(k);
+        agg = select_agg<HID, D, H>(v);
+        const float nrm = half ? nrmb[1] : nrmb[0];
+        const float e = valid ? (agg - head(D)) / nrm : 0.f;
+        const float eo = __shfl_xor(e, 32, 64);                           // the residual of the row the partner lane finishes
+        const float e0 = half ? eo : e, e1 = half ? e : eo;               // of block 0 / block 1, row l31
+#pragma unroll
+        for (int u = 0; u < LU; ++u) usum[u] = fmaf(e1, phi[1][u], fmaf(e0, phi[0][u], usum[u]));
+        es += e;
+      }
+    }
+    if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
+  }
+  // ---- one reduction per workgroup: the half-wave sums of the matrix-core rows + what the fp32 lane code collected
+  {
+    float dummy = 0.f;
+    static_assert(LU == 10, "ten unit sums + the residual sum, reduced three at a time");
+    rc_half_sum3_lane31(usum[0], usum[1], usum[2]);
+    rc_half_sum3_lane31(usum[3], usum[4], usum[5]);
+    rc_half_sum3_lane31(usum[6], usum[7], usum[8]);
+    rc_half_sum3_lane31(usum[9], es, dummy);
+    if (lane < REC) red[wave * REC + lane] = 0.f;
+    RC_WAVE_SYNC();
+    if (l31 == 31) {
+#pragma unroll
+      for (int u = 0; u < LU; ++u) red[wave * REC + v8_unit(half, u)] = usum[u];
+      red[wave * REC + HID + half] = es;
+    }
+    RC_WAVE_SYNC();
+  }
+  // ---- the chunks whose operands left the f16 range (rare; wave-uniform): the fp32 lane code of k_consensus_head for those 64 rows,
+  // after the matrix-core loop so that the two never hold their registers at the same time
+  if (slow_mask != 0u) {
+    RC_NO_SPECULATE();
+    for (int c = c_begin; c < c_end; ++c) {
+      if (!((slow_mask >> (c - c_begin)) & 1u)) continue;
+      const int b = c * ROWS + wave * 64 + lane;
+      const bool valid = b < B;
+      float a1[HID], phi[HID];
+      load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+      layer2<HID>(th, g, a1, phi);
+      float nrm = 0.f;
+#pragma unroll
+      for (int k = 0; k < HID; ++k) nrm = fmaf(phi[k], phi[k], nrm);
+      nrm += 1.0f;
       float v[D];
 #pragma unroll
-      for (int k = 0; k < D; ++k) v[k] = head(k);
-      agg = select_agg<HID, D, H>(v);
-      const float nrm = half ? nrmb[1] : nrmb[0];
-      e = valid ? (agg - head(D)) / nrm : 0.f;
-      const float eo = __shfl_xor(e, 32, 64);                             // the residual of the row the partner lane finishes
-      const float e0 = half ? eo : e, e1 = half ? e : eo;                 // of block 0 / block 1, row l31
+      for (int k = 0; k < D; ++k) {
+        const float* mh = msg + ((long)s * N + nbr[i * D + k]) * ldp;
+        v[k] = head1<HID>(mh + g.o_W3, mh[g.o_b3], phi);
+      }
+      const float agg = select_agg<HID, D, H>(v);
+      const float e = valid ? (agg - head1<HID>(th + g.o_W3, th[g.o_b3], phi)) / nrm : 0.f;
+      if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
 #pragma unroll
-      for (int u = 0; u < LU; ++u) usum[u] = fmaf(e1, phi[1][u], e0 * phi[0][u]);
-      float es = e, dummy = 0.f;
-      static_assert(LU == 10, "ten unit sums + the residual sum, reduced three at a time");
-      rc_half_sum3_lane31(usum[0], usum[1], usum[2]);
-      rc_half_sum3_lane31(usum[3], usum[4], usum[5]);
-      rc_half_sum3_lane31(usum[6], usum[7], usum[8]);
-      rc_half_sum3_lane31(usum[9], es, dummy);
-      if (l31 == 31) {
-#pragma unroll
-        for (int u = 0; u < LU; ++u) red[wave * REC + v8_unit(half, u)] = usum[u];
-        red[wave * REC + HID + half] = es;
+      for (int k = 0; k <= HID; ++k) {
+        const float t = rc_wave_sum_lane63(k < HID ? e * phi[k] : e);
+        if (lane == 63) red[wave * REC + k] += t;
       }
     }
   }
-  if (slow) {                                                             // wave-uniform: the fp32 lane code for this wavefront's 64 rows
-    RC_NO_SPECULATE();
-    float a1[HID], phi[HID];
-    load_a1<HID>(a1t, row0, ldb, b, valid, a1);
-    layer2<HID>(th, g, a1, phi);
-    float nrm = 0.f;
-#pragma unroll
-    for (int k = 0; k < HID; ++k) nrm = fmaf(phi[k], phi[k], nrm);
-    nrm += 1.0f;
-    float v[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const float* mh = msg + ((long)s * N + nbr[i * D + k]) * ldp;
-      v[k] = head1<HID>(mh + g.o_W3, mh[g.o_b3], phi);
-    }
-    agg = select_agg<HID, D, H>(v);
-    e = valid ? (agg - head1<HID>(th + g.o_W3, th[g.o_b3], phi)) / nrm : 0.f;
-#pragma unroll
-    for (int k = 0; k < HID; ++k) {
-      const float t = rc_wave_sum_lane63(e * phi[k]);
-      if (lane == 63) red[wave * REC + k] = t;
-    }
-    const float t = rc_wave_sum_lane63(e);
-    if (lane == 63) { red[wave * REC + HID] = t; red[wave * REC + HID + 1] = 0.f; }
-  }
-  (void)esum_lo; (void)esum_hi;
-  if (agg_out && valid) agg_out[((long)s * N + i) * ldb + b] = agg;
   __syncthreads();
-  float* out = partials + (((long)s * N + i) * nchunk + chunk) * (HID + 1);
+  // ONE record for the workgroup's chunks (rcmarl_head_apply sums the records of an agent): the first chunk's slot takes it, the
+  // others are zero
+  float* out = partials + (((long)s * N + i) * nchunk + c_begin) * (HID + 1);
   if (r < HID) out[r] = (red[r] + red[REC + r]) + (red[2 * REC + r] + red[3 * REC + r]);
   if (r == HID) out[HID] = ((red[HID] + red[HID + 1]) + (red[REC + HID] + red[REC + HID + 1])) +
                            ((red[2 * REC + HID] + red[2 * REC + HID + 1]) + (red[3 * REC + HID] + red[3 * REC + HID + 1]));
+  for (int e2 = r; e2 < (c_end - c_begin - 1) * (HID + 1); e2 += ROWS) out[(HID + 1) + e2] = 0.f;
 }
 
 // runtime (d, H) fallback: neighbour estimates staged in LDS, order statistics by rank counting
@@ -1441,8 +1488,16 @@ static bool launch_consensus_head_mx(dim3 grid, dim3 block, void* stream, const 
                                      const int* nbr, const int* coop, float* partials, float* agg_out, int N, int B, int in_dim,
                                      int ldp, int ldb, int nchunk) {
   if constexpr (DD + 1 <= 32) {
+    // chunks per workgroup: the whole agent when there are enough (seed, agent) pairs to fill the GPU, else fewer
+    const long pairs = (long)grid.y * grid.z;
+    int wgs = pairs >= 2048 ? 2 : (pairs >= 512 ? 4 : nchunk);
+    if (wgs * 32 < nchunk) wgs = (nchunk + 31) / 32;                      // (a wavefront keeps one bit per chunk)
+    int cpw = (nchunk + wgs - 1) / wgs;
+    const char* ce = getenv("RCMARL_K2_CPW");                             // (tests: chunks per workgroup, 1..32)
+    if (ce && atoi(ce) >= 1 && atoi(ce) <= 32) cpw = atoi(ce);
+    grid.x = (unsigned)((nchunk + cpw - 1) / cpw);
     RCMARL_LAUNCH((k_consensus_head_mx<DD, HH>), grid, block, 0, stream, a1t, theta, msg, nbr, coop, partials, agg_out, N, B, in_dim,
-                  ldp, ldb, nchunk);
+                  ldp, ldb, nchunk, cpw);
     return true;
   } else {
     return false;

@@ -349,7 +349,12 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, 
                 continue
             ag = O.CoopAgent(M.init_mlp(rng, in_dim, HID, 5), live[s][i], live[s][i], 0.002, 0.01, 0.9, H)
             want_agg = ag.consensus_estimates_critic(x[s], [msgp[s][j] for j in nbr[i]])
-            rel_close(agg[s, i, :B], want_agg[:, 0], 5e-6, "estimate aggregate")
+            # fp32 lane code (RCMARL_K2_MX=0): summation order only, 5e-6.  Matrix-core form (the default for 20 units and at most 31
+            # neighbours): layer 2 and the heads carry two-piece f16 operands -- each to 2^-22 of ITS magnitude -- and the test plants
+            # a head 50 times the others' size: where that estimate sits inside the clip window its error, 50 x 2.4e-7 x sum|terms|,
+            # enters the mean; measured 1.6e-5 on the MI355X shapes (profiles/r06f_*) -> 3e-5, i.e. 6e-7 of the planted head
+            mx = os.environ.get("RCMARL_K2_MX", "1") not in ("0",) and d + 1 <= 32
+            rel_close(agg[s, i, :B], want_agg[:, 0], 3e-5 if mx else 5e-6, "estimate aggregate")
             ag.projection_step_critic(x[s], want_agg)
             got = unpack_row(th_new[s, i], in_dim, 1)
             for k in range(4):

@@ -74,6 +74,17 @@ def test_consensus_head(bk, S, N, B, in_dim, d, H, graph, mx, monkeypatch):
     KC.check_consensus_head(bk, S, N, B, in_dim, d, H, graph)
 
 
+@pytest.mark.parametrize("cpw", ["2", "3"])
+def test_consensus_head_matrix_core_form_several_chunks_per_workgroup(bk, cpw, monkeypatch):
+    """k_consensus_head_mx walks several 256-row chunks per workgroup when there are many (seed, agent) pairs: forced here
+    (RCMARL_K2_CPW) on three chunks, the last one ragged -- one record per workgroup, zeros in the other chunks' slots."""
+    monkeypatch.setenv("RCMARL_K2_MX", "1")
+    monkeypatch.setenv("RCMARL_K2_CPW", cpw)
+    KC.check_consensus_head(bk, 1, 5, 600, 10, 4, 1, "circ")
+    monkeypatch.setenv("RCMARL_K2_CPW", "2")
+    KC.check_consensus_head(bk, 1, 5, 600, 10, 4, 1, "circ", outlier=1e4, compare=False)     # (the fp32 lane code behind the loop)
+
+
 def test_consensus_head_out_of_range_head_takes_the_fp32_lane_code(bk, monkeypatch):
     """A message head beyond the f16 range of the matrix-core form (2^10 |W3| > 65000): the workgroups that see it run the fp32 lane
     code inside k_consensus_head_mx: the bits of k_consensus_head (which test_consensus_head holds to the oracle)."""
