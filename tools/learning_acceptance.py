@@ -96,6 +96,10 @@ def main():
                               "n_seeds": len(ref["seeds"])}
             sd = r["phase2"]["team_last%d_std_over_seeds" % a.last]
             r["within_reference_spread"] = bool(ref["team_last500_min"] - sd <= r["phase2"][key] <= ref["team_last500_max"] + sd)
+            # the stricter reading: the standard error of OUR mean over the seeds against the reference's three draws
+            se = sd / max(1.0, float(len(seeds)) ** 0.5)
+            r["mean_standard_error"] = se
+            r["within_reference_range_by_standard_error"] = bool(ref["team_last500_min"] - 2 * se <= r["phase2"][key] <= ref["team_last500_max"] + 2 * se)
             res["scenarios"]["%s/H=%d" % (name, H)] = r
             print("%-10s H=%d  ours %.3f +- %.3f (seed std)   reference %.3f [%.3f, %.3f]   %s   %.1f s" %
                   (name, H, r["phase2"][key], sd, ref["team_last500_mean"], ref["team_last500_min"], ref["team_last500_max"],
@@ -109,8 +113,12 @@ def main():
         rec[name] = {"ours_H1_minus_H0": ours, "reference_H1_minus_H0": refd, "H1_recovers": bool(ours >= 0.5 * refd)}
     res["resilience"] = rec
     res["criterion"] = ("within_reference_spread: our mean over seeds lies in [reference min - s, reference max + s] with s = our "
-                        "seed-to-seed std (each reference seed is one draw from a distribution of that width); H1_recovers: our "
-                        "H=1 minus H=0 gain is at least half the reference's (README.md:31-45)")
+                        "seed-to-seed std (each reference seed is one draw from a distribution of that width) -- a GENEROUS band; "
+                        "within_reference_range_by_standard_error: the same with 2 standard errors of our mean instead of s.  By that "
+                        "reading the adversarial H=1 scenarios sit 0.3-0.7 BELOW the reference's three shipped seeds, and so does the "
+                        "CPU oracle (profiles/learning_r02a_oracle_check.json: -6.26 +- 0.35 over 6 seeds): engine = oracle; both differ "
+                        "from the shipped curves under adversaries (the shipped pickles come from an older revision of the reference).  "
+                        "H1_recovers: our H=1 minus H=0 gain is at least half the reference's (README.md:31-45)")
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
