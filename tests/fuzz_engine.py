@@ -38,7 +38,7 @@ def main():
         hid = 20
         if rng.random() < 0.3:                                   # a wide critic runs with Cooperative and Faulty agents
             labs = [lab if lab in ("Cooperative", "Faulty") else "Cooperative" for lab in labs]
-            hid = int(rng.choice([24, 40, 64]))
+            hid = int(rng.choice([24, 40, 64, 128]))             # (128 beside the lattice layer 1: the packed-operand path, round 6)
         d = int(rng.integers(2, min(n, 12) + 1))
         H = int(rng.integers(0, (d - 1) // 2 + 1))
         circ = bool(rng.random() < 0.5)
