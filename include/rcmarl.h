@@ -381,10 +381,15 @@ int rcmarl_pk_supported(int hid);        /* 1: hid % 128 == 0 and the lattice pa
 /* the layer-1 lattice forward GEMM (rcmarl_layer1_forward_lattice) whose epilogue writes a1_bk / a1_kb / s1 (each optional)
  * INSTEAD of the fp32 activations */
 int rcmarl_layer1_forward_lattice_pk(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt, const float* theta,
-                                     void* a1_bk, int bk_rt, void* a1_kb, int kb_kt, unsigned* s1, int s1_ld, int S, int N, int B,
-                                     int in_dim, int hid, int ldp, void* stream);
-/* W2, W3 of theta[s][n] -> w2t, w2w3, rs[k] = sum_j W2[k][j] W3[j] */
-int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, float* rs, int S, int N, int in_dim, int hid, int ldp, void* stream);
+                                     void* a1_bk, int bk_rt, void* a1_kb, int kb_kt, unsigned* s1, int s1_ld, int* ovf_flag, int S, int N,
+                                     int B, int in_dim, int hid, int ldp, void* stream);
+/* RANGE.  The pieces saturate instead of overflowing (|a1| > 1015, |W2| or |W2 W3| > 63, |dz1| > 254 are carried clipped, finite).  The
+ * three producers of large operands take an optional `ovf_flag` (one int in device memory, never cleared by the library): set to 1 when
+ * a value left the range -- a caller polls it between blocks and switches to the rcmarl_dense_* entry points (which recompute such
+ * tiles in fp32) if it matters to it.
+ * W2, W3 of theta[s][n] -> w2t, w2w3, rs[k] = sum_j W2[k][j] W3[j] */
+int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, float* rs, int* ovf_flag, int S, int N, int in_dim, int hid, int ldp,
+                      void* stream);
 /* layer 2 forward; outputs, each optional: a2 (fp32 feature-major [S][N*hid][ldb]: phi of rcmarl_wide_consensus_head), mask_bj,
  * mask_jb, vpart (per tile of units: sum_j a2[j][b] W3[j]), npart (same shape: sum_j a2[j][b]^2, |phi|^2 of the projection step) */
 int rcmarl_pk_forward2(const void* w2t, const void* a1_bk, int bk_rt, const float* theta, float* a2, void* mask_bj, int mbj_rt,
@@ -398,8 +403,8 @@ int rcmarl_pk_head(const float* vpart, const float* theta, const float* aux, flo
 /* dz1 = lrelu'(a1) W2 dz2 straight into the lattice backward GEMM's operand dzp ([S][dzp_rt][dzp_kt][2][8 KiB], rows = n*hid + unit)
  * + gb1part (sums of dz1 over each tile of 128 replay rows) */
 int rcmarl_pk_backward_data(const void* mask_bj, int mbj_rt, const void* w2w3, const float* rs, const unsigned* s1, int s1_ld,
-                            const float* dz3, void* dzp, int dzp_rt, int dzp_kt, float* gb1part, int S, int N, int B, int hid, int ldb,
-                            void* stream);
+                            const float* dz3, void* dzp, int dzp_rt, int dzp_kt, float* gb1part, int* ovf_flag, int S, int N, int B,
+                            int hid, int ldb, void* stream);
 /* W2 -= lr a1^T dz2 (agents with mask[n] != 0; NULL: all); gw3part and q carry the head's and b2's gradients to rcmarl_pk_small_sgd */
 int rcmarl_pk_backward_w2(const void* a1_kb, int kb_kt, const void* mask_jb, int mjb_kt, const void* dzv, float* theta, const int* mask,
                           float* gw3part, float* q, int S, int N, int B, int in_dim, int hid, int ldp, float lr, void* stream);

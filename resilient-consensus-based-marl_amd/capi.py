@@ -174,11 +174,11 @@ SIGNATURES = {
     "rcmarl_wide_head_apply": [c_f32p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
     # ---- wide networks on pre-split packed operands (csrc/dense_pk.hip) -----------------------------------
     "rcmarl_pk_supported": [c_int],
-    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1_bk, bk_rt, a1_kb, kb_kt, s1, s1_ld, S, N, B, in_dim, hid, ldp, stream
+    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1_bk, bk_rt, a1_kb, kb_kt, s1, s1_ld, ovf_flag, S, N, B, in_dim, hid, ldp, stream
     "rcmarl_layer1_forward_lattice_pk": [c_u8p, c_int, c_int, c_u8p, c_int, c_int, c_f32p, c_u8p, c_int, c_u8p, c_int, c_i32p, c_int,
-                                         c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
-    # theta, w2t, w2w3, rs, S, N, in_dim, hid, ldp, stream
-    "rcmarl_pk_pack_w2": [c_f32p, c_u8p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_stream],
+                                         c_i32p, c_int, c_int, c_int, c_int, c_int, c_int, c_stream],
+    # theta, w2t, w2w3, rs, ovf_flag, S, N, in_dim, hid, ldp, stream
+    "rcmarl_pk_pack_w2": [c_f32p, c_u8p, c_u8p, c_f32p, c_i32p, c_int, c_int, c_int, c_int, c_int, c_stream],
     # w2t, a1_bk, bk_rt, theta, a2, mask_bj, mbj_rt, mask_jb, mjb_kt, vpart, npart, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_pk_forward2": [c_u8p, c_u8p, c_int, c_f32p, c_f32p, c_u8p, c_int, c_u8p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
                            c_int, c_int, c_int, c_stream],
@@ -189,9 +189,9 @@ SIGNATURES = {
     # vpart, theta, aux, gamma, mode, out, dzv, losspart, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_pk_head": [c_f32p, c_f32p, c_f32p, c_float, c_int, c_f32p, c_u8p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                        c_stream],
-    # mask_bj, mbj_rt, w2w3, rs, s1, s1_ld, dz3, dzp, dzp_rt, dzp_kt, gb1part, S, N, B, hid, ldb, stream
-    "rcmarl_pk_backward_data": [c_u8p, c_int, c_u8p, c_f32p, c_i32p, c_int, c_f32p, c_u8p, c_int, c_int, c_f32p, c_int, c_int, c_int,
-                                c_int, c_int, c_stream],
+    # mask_bj, mbj_rt, w2w3, rs, s1, s1_ld, dz3, dzp, dzp_rt, dzp_kt, gb1part, ovf_flag, S, N, B, hid, ldb, stream
+    "rcmarl_pk_backward_data": [c_u8p, c_int, c_u8p, c_f32p, c_i32p, c_int, c_f32p, c_u8p, c_int, c_int, c_f32p, c_i32p, c_int, c_int,
+                                c_int, c_int, c_int, c_stream],
     # a1_kb, kb_kt, mask_jb, mjb_kt, dzv, theta, mask, gw3part, q, S, N, B, in_dim, hid, ldp, lr, stream
     "rcmarl_pk_backward_w2": [c_u8p, c_int, c_u8p, c_int, c_u8p, c_f32p, c_i32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                               c_int, c_float, c_stream],

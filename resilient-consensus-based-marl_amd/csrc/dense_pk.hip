@@ -73,13 +73,14 @@ __device__ __forceinline__ void pk_store8(unsigned char* dst, const float (&w)[8
 // grid (hid / 128, Z): workgroup = 128 rows of BOTH outputs, all k-tiles (a row sum is formed by one thread quad in a fixed order).
 __global__ __launch_bounds__(256) void k_pk_pack_w2(const float* __restrict__ theta, int ldp, int o_W2, int o_W3, int hid,
                                                     unsigned char* __restrict__ w2t, unsigned char* __restrict__ w2w3,
-                                                    float* __restrict__ rs) {
+                                                    float* __restrict__ rs, int* __restrict__ ovf) {
   const int z = blockIdx.y, rt = blockIdx.x, t = threadIdx.x, c4 = t & 3;
   const int JT = hid >> 7, JK = hid >> 5;
   rc_f16_saturate();
   const float* __restrict__ W2 = theta + (long)z * ldp + o_W2;
   const float* __restrict__ W3 = theta + (long)z * ldp + o_W3;
   float acc[2] = {0.f, 0.f};
+  float amax = 0.f;
   for (int kt = 0; kt < JK; ++kt) {
     unsigned char* blk_t = w2t + (((long)z * JT + rt) * JK + kt) * (2 * RC_PK_BLOCK);
     unsigned char* blk_w = w2w3 + (((long)z * JT + rt) * JK + kt) * (2 * RC_PK_BLOCK);
@@ -91,11 +92,13 @@ __global__ __launch_bounds__(256) void k_pk_pack_w2(const float* __restrict__ th
       const float4 w3a = *reinterpret_cast<const float4*>(W3 + c0), w3b = *reinterpret_cast<const float4*>(W3 + c0 + 4);
       const float w[8] = {lo.x * w3a.x, lo.y * w3a.y, lo.z * w3a.z, lo.w * w3a.w, hi.x * w3b.x, hi.y * w3b.y, hi.z * w3b.z, hi.w * w3b.w};
       acc[q] += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      amax = rc_amax3(rc_amax3(rc_amax3(rc_amax3(amax, w[0], w[1]), w[2], w[3]), w[4], w[5]), w[6], w[7]);
       pk_store8(blk_w + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), w, RC_F16_W_SCALE);
       // w2t: row = j, reduction = k (stride hid in memory; the 64 rows of a pass are consecutive j: coalesced per k)
       float u[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) u[e] = W2[(long)(c0 + e) * hid + row];
+      amax = rc_amax3(rc_amax3(rc_amax3(rc_amax3(amax, u[0], u[1]), u[2], u[3]), u[4], u[5]), u[6], u[7]);
       pk_store8(blk_t + r * 64 + ((c4 ^ ((r >> 2) & 3)) << 4), u, RC_F16_W_SCALE);
     }
   }
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(256) void k_pk_pack_w2(const float* __restrict__ th
     v += __shfl_xor(v, 2);
     if (c4 == 0) rs[(long)z * hid + rt * 128 + (t >> 2) + 64 * q] = v;
   }
+  if (ovf != nullptr && !(amax * RC_F16_W_SCALE <= 65000.f)) *ovf = 1;     // (|W2| or |W2 W3| > 63: the pieces saturate; NaN counts)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,6 +276,7 @@ struct PkBdArgs {
   const float* dz3; int ldb;                // [Z][ldb]
   unsigned char* dzp; int dzp_rt, dzp_kt;   // per seed [dzp_rt][dzp_kt][2][8 KiB], rows = agent * hid + unit
   float* gb1part;                           // [Z][ntb][hid]
+  int* ovf;                                 // set when |2^8 dz1| leaves the f16 range
   int Z, N, B, hid, ntb;
 };
 
@@ -306,7 +311,7 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_backward_data(const PkBdArgs a) {
     const int kc = bn * BN + wn * 32 * NT + 32 * nt + l31; // the lane's unit
     const float t01 = RC_LEAK * a.rs[(long)z * a.hid + kc];
     const int prow = agent * a.hid + kc;                  // its row in the packed dz operand
-    float gsum = 0.f;
+    float gsum = 0.f, amax = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int bl = wm * 32 * MT + 32 * mt, b0 = bm * BM + bl;  // first replay row of this 32 x 32 block (a multiple of 32)
@@ -326,6 +331,7 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_backward_data(const PkBdArgs a) {
           gsum += dv;
           x[e] = dv * RC_F16_DZ_SCALE;
         }
+        amax = rc_amax3(rc_amax3(amax, x[0], x[1]), x[2], x[3]);
         rc_split2h_pair(x[0], x[1], pc[0][qq][0], pc[1][qq][0]);
         rc_split2h_pair(x[2], x[3], pc[0][qq][1], pc[1][qq][1]);
       }
@@ -334,6 +340,7 @@ __global__ RC_LAT_OCC(T::THREADS, 2) void k_pk_backward_data(const PkBdArgs a) {
     }
     gsum += __shfl_xor(gsum, 32);
     if (half == 0) sg[wm * BN + wn * 32 * NT + 32 * nt + l31] = gsum;
+    if (a.ovf != nullptr && !(amax <= 65000.f)) *a.ovf = 1;
   }
   __syncthreads();
   if (threadIdx.x < BN) {
@@ -613,13 +620,13 @@ RCMARL_EXPORT int rcmarl_pk_parts(int hid) { return hid > 0 && (hid & 127) == 0 
 RCMARL_EXPORT int rcmarl_pk_supported(int hid) { return hid > 0 && (hid & 127) == 0 && (rc_lat_f16_mode() & 3) == 3; }
 
 // theta[s][n] -> w2t, w2w3, rs   (o_W2 = in_dim*hid + hid, o_W3 = o_W2 + hid*hid + hid: the Keras row of rcmarl_common.h)
-RCMARL_EXPORT int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, float* rs, int S, int N, int in_dim, int hid, int ldp,
-                                    void* stream) {
+RCMARL_EXPORT int rcmarl_pk_pack_w2(const float* theta, void* w2t, void* w2w3, float* rs, int* ovf_flag, int S, int N, int in_dim, int hid,
+                                    int ldp, void* stream) {
   if (!theta || !w2t || !w2w3 || !rs || !pk_dims_ok(S, N, 1, hid, ldp) || in_dim <= 0 || (ldp & 3)) return RCMARL_ERR_ARG;
   if ((hid & 127) || ((in_dim * hid + hid) & 3)) return RCMARL_ERR_UNSUPPORTED;
   const NetGeom g = make_geom(in_dim, hid, 1);
   RCMARL_LAUNCH(k_pk_pack_w2, dim3(hid >> 7, S * N), dim3(256), 0, stream, theta, ldp, g.o_W2, g.o_W3, hid, (unsigned char*)w2t,
-                (unsigned char*)w2w3, rs);
+                (unsigned char*)w2w3, rs, ovf_flag);
   return rcmarl_check_launch();
 }
 
@@ -661,15 +668,15 @@ RCMARL_EXPORT int rcmarl_pk_head(const float* vpart, const float* theta, const f
 // dz1 of every (seed, agent) straight into the lattice backward GEMM's packed operand dzp (two f16 pieces of 2^8 dz1, rows =
 // agent * hid + unit; rcmarl_layer1_backward_sgd_lattice reads it) + gb1part[s][n][tile][unit] (sums of dz1 over the 128 rows of a tile).
 RCMARL_EXPORT int rcmarl_pk_backward_data(const void* mask_bj, int mbj_rt, const void* w2w3, const float* rs, const unsigned* s1,
-                                          int s1_ld, const float* dz3, void* dzp, int dzp_rt, int dzp_kt, float* gb1part, int S, int N,
-                                          int B, int hid, int ldb, void* stream) {
+                                          int s1_ld, const float* dz3, void* dzp, int dzp_rt, int dzp_kt, float* gb1part, int* ovf_flag,
+                                          int S, int N, int B, int hid, int ldb, void* stream) {
   if (!mask_bj || !w2w3 || !rs || !s1 || !dz3 || !dzp || !gb1part || !pk_dims_ok(S, N, B, hid, 1) || ldb < B) return RCMARL_ERR_ARG;
   if ((hid & 127) || !(rc_lat_f16_mode() & 2)) return RCMARL_ERR_UNSUPPORTED;
   const int T = pk_tile(hid), ntb = rc_ceil_div(B, T), rts = ntb * (T / 128);
   if (mbj_rt < rts || s1_ld < 4 * rts || dzp_rt < N * (hid >> 7) || dzp_kt < 4 * rts) return RCMARL_ERR_ARG;
   PkBdArgs a{};
   a.mask_bj = (const unsigned char*)mask_bj; a.mbj_rt = mbj_rt; a.w2w3 = (const unsigned char*)w2w3; a.rs = rs; a.s1 = s1; a.s1_ld = s1_ld;
-  a.dz3 = dz3; a.ldb = ldb; a.dzp = (unsigned char*)dzp; a.dzp_rt = dzp_rt; a.dzp_kt = dzp_kt; a.gb1part = gb1part;
+  a.dz3 = dz3; a.ldb = ldb; a.dzp = (unsigned char*)dzp; a.dzp_rt = dzp_rt; a.dzp_kt = dzp_kt; a.gb1part = gb1part; a.ovf = ovf_flag;
   a.Z = S * N; a.N = N; a.B = B; a.hid = hid; a.ntb = ntb;
   rc_form_set(dzp, 1);
   return T == 256 ? pk_launch_backward_data<PkBig>(a, stream) : pk_launch_backward_data<PkSmall>(a, stream);

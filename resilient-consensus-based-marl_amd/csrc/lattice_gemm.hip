@@ -231,6 +231,7 @@ struct LatPkOut {
   unsigned char* a1_bk; int bk_rt;      // [S][N][bk_rt][hid/32][2][8 KiB]
   unsigned char* a1_kb; int kb_kt;      // [S][N][hid/128][kb_kt][2][8 KiB]
   unsigned* s1; int s1_ld;              // [S][N*hid][s1_ld]
+  int* ovf;                             // set to 1 when an activation leaves the f16 range of 2^6 a1 (|a1| > 1015): the pieces saturate
 };
 
 template <bool W8, bool F16, bool PK = false>
@@ -306,6 +307,7 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
         const int ublk = u0 + wm * 32 * MT + 32 * mt;               // first unit of this 32 x 32 block inside the agent
         unsigned ph[8], pl[8];
         unsigned myw = 0;
+        float amax = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float o[2];
@@ -320,8 +322,10 @@ void k_lat_forward(const unsigned char* __restrict__ wp, int wp_rt, int wp_kt, c
               if (l31 == r) myw = wsel;
             }
           }
+          amax = rc_amax3(amax, o[0], o[1]);
           rc_split2h_pair(o[0] * RC_F16_ACT_SCALE, o[1] * RC_F16_ACT_SCALE, ph[j], pl[j]);
         }
+        if (pk.ovf != nullptr && !(amax * RC_F16_ACT_SCALE <= 65000.f)) *pk.ovf = 1;
         if (pk.s1 != nullptr && l31 < 16) {
           const int col = bm * C::BM + wm * 32 * MT + 32 * mt + 8 * (l31 >> 2) + (l31 & 3) + 4 * half;
           pk.s1[((long)s * ncols + col) * pk.s1_ld + (n0 >> 5)] = myw;
@@ -680,12 +684,13 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice(const void* kp, int kp_rt, int k
 // The same GEMM for a WIDE network (hid a multiple of 128) whose next layers run on packed operands (dense_pk.hip): the epilogue
 // writes the activations as two f16 pieces of 2^6 a1 in packed form -- a1_bk [S][N][bk_rt][hid/32][2][8 KiB] (rows = replay row,
 // reduction = unit), a1_kb [S][N][hid/128][kb_kt][2][8 KiB] (rows = unit, reduction = replay row) -- and their sign bits
-// s1 [S][N*hid][s1_ld] (bit b & 31 of word b >> 5), each optional, INSTEAD of the fp32 activations.  Two-piece f16 form only
+// s1 [S][N*hid][s1_ld] (bit b & 31 of word b >> 5), each optional, INSTEAD of the fp32 activations.  ovf_flag (optional): one int the
+// kernel sets to 1 when an activation leaves the f16 range of the packed form (the pieces saturate).  Two-piece f16 form only
 // (RCMARL_ERR_UNSUPPORTED otherwise).  Replaces model(x) of the first Dense layer, agents/resilient_CAC_agents.py:95-97,114,118.
 RCMARL_EXPORT int rcmarl_layer1_forward_lattice_pk(const void* kp, int kp_rt, int kp_kt, const void* wp, int wp_rt, int wp_kt,
                                                    const float* theta, void* a1_bk, int bk_rt, void* a1_kb, int kb_kt,
-                                                   unsigned* s1, int s1_ld, int S, int N, int B, int in_dim, int hid, int ldp,
-                                                   void* stream) {
+                                                   unsigned* s1, int s1_ld, int* ovf_flag, int S, int N, int B, int in_dim, int hid,
+                                                   int ldp, void* stream) {
   if (!kp || !wp || !theta || (!a1_bk && !a1_kb && !s1) || S <= 0 || N <= 0 || B <= 0 || in_dim <= 0 || hid <= 0 || (ldp & 63) ||
       ldp < in_dim * hid + hid)
     return RCMARL_ERR_ARG;
@@ -698,6 +703,7 @@ RCMARL_EXPORT int rcmarl_layer1_forward_lattice_pk(const void* kp, int kp_rt, in
   const unsigned nb = (unsigned)(S * mtiles * ntiles);
   LatPkOut pk;
   pk.a1_bk = (unsigned char*)a1_bk; pk.bk_rt = bk_rt; pk.a1_kb = (unsigned char*)a1_kb; pk.kb_kt = kb_kt; pk.s1 = s1; pk.s1_ld = s1_ld;
+  pk.ovf = ovf_flag;
   return launch_forward<true, true, true>(nb, stream, (const unsigned char*)wp, wp_rt, wp_kt, (const unsigned char*)kp, kp_rt, kp_kt, theta,
                                           nullptr, S, N, B, in_dim, ldp, 64, mtiles, ntiles, hid, pk);
 }

@@ -288,6 +288,7 @@ class RPBCACEngine:
         pk.dzv = torch.zeros(Z, 4, Bp, dtype=torch.int16, device=self.dev)
         pk.gw3part, pk.q = torch.zeros(Z, JT, hid, **f32), torch.zeros(Z, hid, **f32)
         pk.gb1part = torch.zeros(Z, (self.cap + 127) // 128, hid, **f32)
+        pk.ovf = torch.zeros(1, dtype=torch.int32, device=self.dev)     # set by the kernels when an operand leaves the f16 range
         self.pk = pk
 
     def _pk_ok(self, net, xkey, B, row0=0):
@@ -312,9 +313,10 @@ class RPBCACEngine:
                                   g.wp[1], st)
             L.rcmarl_layer1_forward_lattice_pk(self.lat_kp[xkey].data_ptr(), g.kp[0], g.kp[1], wp.data_ptr(), g.wp[0], g.wp[1],
                                                theta.data_ptr(), a1_bk.data_ptr(), pk.bk_rt, pk.a1_kb.data_ptr() if full else None,
-                                               pk.kb_kt, pk.s1.data_ptr() if full else None, pk.Bp // 32, S, N, B, in_dim, hid, ldp,
-                                               st)
-        L.rcmarl_pk_pack_w2(theta.data_ptr(), pk.w2t.data_ptr(), pk.w2w3.data_ptr(), pk.rs.data_ptr(), S, N, in_dim, hid, ldp, st)
+                                               pk.kb_kt, pk.s1.data_ptr() if full else None, pk.Bp // 32, pk.ovf.data_ptr(), S, N, B,
+                                               in_dim, hid, ldp, st)
+        L.rcmarl_pk_pack_w2(theta.data_ptr(), pk.w2t.data_ptr(), pk.w2w3.data_ptr(), pk.rs.data_ptr(), pk.ovf.data_ptr(), S, N, in_dim,
+                            hid, ldp, st)
         L.rcmarl_pk_forward2(pk.w2t.data_ptr(), a1_bk.data_ptr(), pk.bk_rt, theta.data_ptr(), self.w_a2.data_ptr() if want_a2 else None,
                              pk.mask_bj.data_ptr() if fit else None, pk.bk_rt, pk.mask_jb.data_ptr() if fit else None, pk.kb_kt,
                              pk.vpart.data_ptr(), pk.npart.data_ptr() if want_a2 else None, S, N, B, in_dim, hid, ldp, self.ldb, st)
@@ -334,7 +336,7 @@ class RPBCACEngine:
                              self.w_losspart.data_ptr(), S, N, B, in_dim, hid, ldp, ldb, st)
             L.rcmarl_pk_backward_data(pk.mask_bj.data_ptr(), pk.bk_rt, pk.w2w3.data_ptr(), pk.rs.data_ptr(), pk.s1.data_ptr(),
                                       pk.Bp // 32, self.w_dz3.data_ptr(), dzp.data_ptr(), g.dzp[0], g.dzp[1], pk.gb1part.data_ptr(),
-                                      S, N, B, hid, ldb, st)
+                                      pk.ovf.data_ptr(), S, N, B, hid, ldb, st)
             # every gradient comes from the pre-step weights: the W2 step reads W3, the small step updates it afterwards
             L.rcmarl_pk_backward_w2(pk.a1_kb.data_ptr(), pk.kb_kt, pk.mask_jb.data_ptr(), pk.kb_kt, pk.dzv.data_ptr(), msg.data_ptr(),
                                     mask.data_ptr(), pk.gw3part.data_ptr(), pk.q.data_ptr(), S, N, B, in_dim, hid, ldp, lr, st)
@@ -1528,6 +1530,15 @@ class RPBCACEngine:
         (e.g. 0.01 at N = 256); it would carry on silently.  One warning per engine, one reduction per block.  In an
         agent-sharded instance a rank only sees its own agents' rows: the verdict is all-reduced (MIN) over the shard's
         communicator, so every rank warns (or none) -- a COLLECTIVE there."""
+        if self.pk is not None and int(self.pk.ovf.item()) != 0:
+            # a critic operand left the f16 range of the packed-operand path (|a1| > 1015, |W2| or |W2 W3| > 63, |dz1| > 254: a fit that
+            # is blowing up): its pieces were carried clipped.  From here on this engine takes the rcmarl_dense_* path, whose kernels
+            # recompute such tiles in fp32 -- what the reference's arithmetic would do with the same (diverging) numbers.
+            import warnings
+            warnings.warn("rcmarl_amd: a wide-critic operand left the f16 range of the packed-operand path (training is diverging: "
+                          "lower fast_lr); falling back to the dense path that recomputes out-of-range tiles in fp32", RuntimeWarning)
+            self.pk = None
+            self.a1_cached["critic"] = self.a2_cached = False
         if self._diverged_warned:
             return
         finite = all(bool(torch.isfinite(self.theta[k]).all().item()) for k in ("critic", "tr", "actor"))

@@ -59,12 +59,12 @@ WORK = {
     # in, zs, za, rm, ld, dz, theta, w_off, mask, S, N, B, K, J
     "rcmarl_dense_backward_sgd": lambda a: (2.0 * a[9] * a[10] * a[11] * a[12] * a[13], 0.0),
     # the same layers on pre-split packed operands (csrc/dense_pk.hip): fp32-equivalent 2*S*N*B*hid*hid (layer 1: the lattice GEMM)
-    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1_bk, bk_rt, a1_kb, kb_kt, s1, s1_ld, S, N, B, in_dim, hid
-    "rcmarl_layer1_forward_lattice_pk": lambda a: _gemm_flops(a, 13),
+    # kp, kp_rt, kp_kt, wp, wp_rt, wp_kt, theta, a1_bk, bk_rt, a1_kb, kb_kt, s1, s1_ld, ovf_flag, S, N, B, in_dim, hid
+    "rcmarl_layer1_forward_lattice_pk": lambda a: _gemm_flops(a, 14),
     # w2t, a1_bk, bk_rt, theta, a2, mask_bj, mbj_rt, mask_jb, mjb_kt, vpart, npart, S, N, B, in_dim, hid
     "rcmarl_pk_forward2": lambda a: (2.0 * a[11] * a[12] * a[13] * a[15] * a[15], 0.0),
-    # mask_bj, mbj_rt, w2w3, rs, s1, s1_ld, dz3, dzp, dzp_rt, dzp_kt, gb1part, S, N, B, hid
-    "rcmarl_pk_backward_data": lambda a: (2.0 * a[11] * a[12] * a[13] * a[14] * a[14], 0.0),
+    # mask_bj, mbj_rt, w2w3, rs, s1, s1_ld, dz3, dzp, dzp_rt, dzp_kt, gb1part, ovf_flag, S, N, B, hid
+    "rcmarl_pk_backward_data": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[15], 0.0),
     # a1_kb, kb_kt, mask_jb, mjb_kt, dzv, theta, mask, gw3part, q, S, N, B, in_dim, hid
     "rcmarl_pk_backward_w2": lambda a: (2.0 * a[9] * a[10] * a[11] * a[13] * a[13], 0.0),
 }

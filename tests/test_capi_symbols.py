@@ -85,13 +85,13 @@ def test_argument_validation_needs_no_gpu():
                                         1472, 128, 4, 1, None)),
         ("rcmarl_wide_head_apply", (None, None, None, 1, 5, 100, 10, 32, 1472, None)),
         ("rcmarl_copy3d", (None, 0, 64, None, 0, 64, 1, 5, 40, None, None)),
-        ("rcmarl_layer1_forward_lattice_pk", (None, 0, 0, None, 0, 0, None, None, 0, None, 0, None, 0, 1, 5, 100, 10, 128, 1600, None)),
-        ("rcmarl_pk_pack_w2", (None, None, None, None, 1, 5, 10, 128, 18048, None)),
+        ("rcmarl_layer1_forward_lattice_pk", (None, 0, 0, None, 0, 0, None, None, 0, None, 0, None, 0, None, 1, 5, 100, 10, 128, 1600, None)),
+        ("rcmarl_pk_pack_w2", (None, None, None, None, None, 1, 5, 10, 128, 18048, None)),
         ("rcmarl_pk_forward2", (None, None, 2, None, None, None, 2, None, 8, None, None, 1, 5, 100, 10, 128, 18048, 128, None)),
         ("rcmarl_wide_consensus_head_nrm", (None, None, 1, None, None, None, None, None, None, None, None, None, None, 1, 5, 100, 10, 128, 18048,
                                             128, 4, 1, None)),
         ("rcmarl_pk_head", (None, None, None, 0.9, 2, None, None, None, 1, 5, 100, 10, 128, 18048, 128, None)),
-        ("rcmarl_pk_backward_data", (None, 2, None, None, None, 8, None, None, 5, 8, None, 1, 5, 100, 128, 128, None)),
+        ("rcmarl_pk_backward_data", (None, 2, None, None, None, 8, None, None, 5, 8, None, None, 1, 5, 100, 128, 128, None)),
         ("rcmarl_pk_backward_w2", (None, 8, None, 8, None, None, None, None, None, 1, 5, 100, 10, 128, 18048, 0.01, None)),
         ("rcmarl_pk_small_sgd", (None, None, None, None, None, None, None, None, 1, 5, 100, 10, 128, 18048, 128, 0.01, None)),
     ]

@@ -234,6 +234,10 @@ def test_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps, masked):
     WC.check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=steps, lr=0.05, masked_agent=masked, tol=1e-6)
 
 
+def test_pk_operands_beyond_the_f16_range_raise_the_flag(bk):
+    WC.check_pk_range_flag(bk)
+
+
 @pytest.mark.parametrize("m128", ["0", "1"])
 def test_lattice_backward_both_tile_heights(bk, m128, monkeypatch):
     """Networks of at most 128 inputs take 128-row tiles in the backward GEMM (RCMARL_LAT_M128=0: the 256-row tile of the wide

@@ -291,6 +291,10 @@ def test_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps, masked):
     print("packed-operand fit: worst |w - w_oracle| / max(1, |w|max) = %.2e" % worst)
 
 
+def test_pk_operands_beyond_the_f16_range_raise_the_flag(bk):
+    WC.check_pk_range_flag(bk)
+
+
 @pytest.mark.parametrize("m128", ["0", "1"])
 def test_lattice_backward_both_tile_heights(bk, m128, monkeypatch):
     """Networks of at most 128 inputs take 128-row tiles in the backward GEMM (RCMARL_LAT_M128=0: the 256-row tile of the wide

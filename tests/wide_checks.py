@@ -250,6 +250,7 @@ class PkBuffers:
         self.losspart = f32(Z, (B + 255) // 256)
         self.gw3part, self.q, self.gb1part = f32(Z, JT, hid), f32(Z, hid), f32(Z, (B + 127) // 128, hid)
         self.a2 = f32(S, N * hid, ldb)
+        self.ovf = bk.dev(np.zeros(1, np.int32))
 
 
 def pk_encode(bk, pb, d_x, x_stride, d_alpha, S, B, in_dim):
@@ -265,8 +266,8 @@ def pk_forward(bk, pb, d_alpha, d_theta, S, N, B, in_dim, hid, ldp, ldb, split=T
         L.rcmarl_w1_split(bk.ptr(d_theta), bk.ptr(d_alpha), bk.ptr(pb.wp), S, N, in_dim, hid, ldp, g.wp[0], g.wp[1], bk.stream)
     L.rcmarl_layer1_forward_lattice_pk(bk.ptr(pb.kp), g.kp[0], g.kp[1], bk.ptr(pb.wp), g.wp[0], g.wp[1], bk.ptr(d_theta),
                                        bk.ptr(pb.a1_bk), pb.bk_rt, bk.ptr(pb.a1_kb) if fit else None, pb.kb_kt,
-                                       bk.ptr(pb.s1) if fit else None, pb.Bp // 32, S, N, B, in_dim, hid, ldp, bk.stream)
-    L.rcmarl_pk_pack_w2(bk.ptr(d_theta), bk.ptr(pb.w2t), bk.ptr(pb.w2w3), bk.ptr(pb.rs), S, N, in_dim, hid, ldp, bk.stream)
+                                       bk.ptr(pb.s1) if fit else None, pb.Bp // 32, bk.ptr(pb.ovf), S, N, B, in_dim, hid, ldp, bk.stream)
+    L.rcmarl_pk_pack_w2(bk.ptr(d_theta), bk.ptr(pb.w2t), bk.ptr(pb.w2w3), bk.ptr(pb.rs), bk.ptr(pb.ovf), S, N, in_dim, hid, ldp, bk.stream)
     L.rcmarl_pk_forward2(bk.ptr(pb.w2t), bk.ptr(pb.a1_bk), pb.bk_rt, bk.ptr(d_theta), bk.ptr(pb.a2) if want_a2 else None,
                          bk.ptr(pb.mask_bj) if fit else None, pb.bk_rt, bk.ptr(pb.mask_jb) if fit else None, pb.kb_kt,
                          bk.ptr(pb.vpart), bk.ptr(pb.npart) if want_a2 else None, S, N, B, in_dim, hid, ldp, ldb, bk.stream)
@@ -279,7 +280,7 @@ def pk_fit_step(bk, pb, d_alpha, d_msg, d_y, d_mask, d_loss, S, N, B, in_dim, hi
     L.rcmarl_pk_head(bk.ptr(pb.vpart), bk.ptr(d_msg), bk.ptr(d_y), 0.0, 2, bk.ptr(pb.dz3), bk.ptr(pb.dzv), bk.ptr(pb.losspart), S, N, B,
                      in_dim, hid, ldp, ldb, bk.stream)
     L.rcmarl_pk_backward_data(bk.ptr(pb.mask_bj), pb.bk_rt, bk.ptr(pb.w2w3), bk.ptr(pb.rs), bk.ptr(pb.s1), pb.Bp // 32, bk.ptr(pb.dz3),
-                              bk.ptr(pb.dzp), g.dzp[0], g.dzp[1], bk.ptr(pb.gb1part), S, N, B, hid, ldb, bk.stream)
+                              bk.ptr(pb.dzp), g.dzp[0], g.dzp[1], bk.ptr(pb.gb1part), bk.ptr(pb.ovf), S, N, B, hid, ldb, bk.stream)
     L.rcmarl_pk_backward_w2(bk.ptr(pb.a1_kb), pb.kb_kt, bk.ptr(pb.mask_jb), pb.kb_kt, bk.ptr(pb.dzv), bk.ptr(d_msg), bk.ptr(d_mask),
                             bk.ptr(pb.gw3part), bk.ptr(pb.q), S, N, B, in_dim, hid, ldp, lr, bk.stream)
     L.rcmarl_layer1_backward_sgd_lattice(bk.ptr(pb.ktp), g.ktp[0], g.ktp[1], bk.ptr(pb.dzp), g.dzp[0], g.dzp[1], bk.ptr(d_alpha),
@@ -317,7 +318,7 @@ def check_pk_forward(bk, S, N, B, width, nrow, ncol, hid):
     L.rcmarl_pk_head(bk.ptr(pb.vpart), bk.ptr(d_th), None, 0.0, 0, bk.ptr(d_v), None, None, S, N, B, in_dim, hid, ldp, ldb, bk.stream)
     L.rcmarl_pk_head(bk.ptr(pb.vpart), bk.ptr(d_th), bk.ptr(d_r), 0.9, 1, bk.ptr(d_y), None, None, S, N, B, in_dim, hid, ldp, ldb,
                      bk.stream)
-    assert bk.host(pb.flag)[0] == 0
+    assert bk.host(pb.flag)[0] == 0 and bk.host(pb.ovf)[0] == 0
     a2, v, y = bk.host(pb.a2), bk.host(d_v), bk.host(d_y)
     Bp, JT, JK = pb.Bp, pb.JT, pb.JK
     bk16 = np.asarray(bk.host(pb.a1_bk)).view(np.uint16).reshape(S * N, -1)
@@ -380,7 +381,7 @@ def check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=2, lr=0.01, masked_a
     pk_encode(bk, pb, d_x, B * in_dim, d_al, S, B, in_dim)
     for st in range(steps):
         pk_fit_step(bk, pb, d_al, d_msg, d_y, d_mask, d_loss if st == 0 else None, S, N, B, in_dim, hid, ldp, ldb, lr, split=(st == 0))
-    assert bk.host(pb.flag)[0] == 0
+    assert bk.host(pb.flag)[0] == 0 and bk.host(pb.ovf)[0] == 0
     msg, loss = bk.host(d_msg), bk.host(d_loss)
     worst = 0.0
     for s in range(S):
@@ -401,3 +402,21 @@ def check_pk_fit(bk, S, N, B, width, nrow, ncol, hid, steps=2, lr=0.01, masked_a
                 worst = max(worst, err)
             assert abs(loss[s, n] - hist[0]) <= 1e-5 * max(1.0, abs(hist[0])), (loss[s, n], hist[0])
     return worst
+
+
+def check_pk_range_flag(bk, S=1, N=2, B=150, width=2, nrow=5, ncol=5, hid=128):
+    """Operands beyond the f16 range of the packed form: the pieces saturate (finite outputs) and the producers raise the caller's flag
+    -- W2 of one agent scaled so that 2^10 |W2| > 65000 trips rcmarl_pk_pack_w2, a huge b1 trips the layer-1 epilogue."""
+    rng, in_dim, g, ldp, ldb, params, x, alpha = _wide_lattice_case(S, N, B, width, nrow, ncol, hid, 3)
+    for which in ("w2", "b1"):
+        p2 = [[M.copy_params(p) for p in row] for row in params]
+        if which == "w2":
+            p2[0][1][2] *= np.float32(2000.0)
+        else:
+            p2[0][0][1] += np.float32(5000.0)
+        d_x, d_al, d_th = bk.dev(x), bk.dev(alpha), bk.dev(pack_rows(p2, ldp))
+        pb = PkBuffers(bk, S, N, B, in_dim, hid)
+        pk_encode(bk, pb, d_x, B * in_dim, d_al, S, B, in_dim)
+        pk_forward(bk, pb, d_al, d_th, S, N, B, in_dim, hid, ldp, ldb, want_a2=True)
+        assert bk.host(pb.ovf)[0] == 1, which
+        assert np.isfinite(bk.host(pb.a2)).all() and np.isfinite(bk.host(pb.vpart)).all()

@@ -417,17 +417,17 @@ def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2,
         ("W1 split", 0, lambda: L.rcmarl_w1_split(p(theta), p(d_al), p(pb.wp), S, N, in_dim, hid, ldp, gg.wp[0], gg.wp[1], st)),
         ("fwd L1 lattice -> packed a1 x2 + signs", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
             p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, p(pb.a1_kb), pb.kb_kt, p(pb.s1),
-            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+            pb.Bp // 32, None, S, N, B, in_dim, hid, ldp, st)),
         ("fwd L1 lattice -> packed a1 (values)", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
             p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, None, pb.kb_kt, None,
-            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+            pb.Bp // 32, None, S, N, B, in_dim, hid, ldp, st)),
         ("fwd L1 lattice -> a1_bk + a1_kb", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
             p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, p(pb.a1_kb), pb.kb_kt, None,
-            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
+            pb.Bp // 32, None, S, N, B, in_dim, hid, ldp, st)),
         ("fwd L1 lattice -> a1_bk + signs", f1, lambda: L.rcmarl_layer1_forward_lattice_pk(
             p(pb.kp), gg.kp[0], gg.kp[1], p(pb.wp), gg.wp[0], gg.wp[1], p(theta), p(pb.a1_bk), pb.bk_rt, None, pb.kb_kt, p(pb.s1),
-            pb.Bp // 32, S, N, B, in_dim, hid, ldp, st)),
-        ("pack W2", 0, lambda: L.rcmarl_pk_pack_w2(p(theta), p(pb.w2t), p(pb.w2w3), p(pb.rs), S, N, in_dim, hid, ldp, st)),
+            pb.Bp // 32, None, S, N, B, in_dim, hid, ldp, st)),
+        ("pack W2", 0, lambda: L.rcmarl_pk_pack_w2(p(theta), p(pb.w2t), p(pb.w2w3), p(pb.rs), None, S, N, in_dim, hid, ldp, st)),
         ("fwd L2 -> masks + value parts", f2, lambda: L.rcmarl_pk_forward2(p(pb.w2t), p(pb.a1_bk), pb.bk_rt, p(theta), None, p(pb.mask_bj),
                                                                             pb.bk_rt, p(pb.mask_jb), pb.kb_kt, p(pb.vpart), None, S, N, B,
                                                                             in_dim, hid, ldp, ldb, st)),
@@ -446,7 +446,7 @@ def pk(L, S=1, N=int(os.environ.get("RCMARL_KBENCH_N", "256")), B=3000, width=2,
                                              hid, ldp, ldb, st)),
         ("bwd data L2 -> packed dz1", f2, lambda: L.rcmarl_pk_backward_data(p(pb.mask_bj), pb.bk_rt, p(pb.w2w3), p(pb.rs), p(pb.s1),
                                                                              pb.Bp // 32, p(pb.dz3), p(pb.dzp), gg.dzp[0], gg.dzp[1],
-                                                                             p(pb.gb1part), S, N, B, hid, ldb, st)),
+                                                                             p(pb.gb1part), None, S, N, B, hid, ldb, st)),
         ("bwd W2", f2, lambda: L.rcmarl_pk_backward_w2(p(pb.a1_kb), pb.kb_kt, p(pb.mask_jb), pb.kb_kt, p(pb.dzv), p(theta), p(mask),
                                                         p(pb.gw3part), p(pb.q), S, N, B, in_dim, hid, ldp, lr, st)),
         ("bwd W1 lattice", f1, lambda: L.rcmarl_layer1_backward_sgd_lattice(p(pb.ktp), gg.ktp[0], gg.ktp[1], p(pb.dzp), gg.dzp[0],
