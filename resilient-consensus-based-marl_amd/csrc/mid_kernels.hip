@@ -1515,8 +1515,9 @@ RCMARL_EXPORT int rcmarl_consensus_head(const float* a1t, const float* theta, co
   bool done = false;
   // RCMARL_K2_MX (default 1): layer 2 and the d + 1 heads on the f16 matrix core (k_consensus_head_mx: 20 units, d + 1 <= 32 heads, a
   // generated selection network); 0: everything on the vector ALUs (k_consensus_head)
+  // ... and in the EXACT operand form of the lattice path (RCMARL_LAT_F16 = 0: no operand narrower than fp32 anywhere)
   const char* mxe = getenv("RCMARL_K2_MX");
-  const bool mx = hid == 20 && d + 1 <= 32 && !(mxe && atoi(mxe) == 0);
+  const bool mx = hid == 20 && d + 1 <= 32 && !(mxe && atoi(mxe) == 0) && rc_lat_f16_mode() != 0;
 #define RC_CASE(DD, HH)                                                                                          \
   if (!done && d == DD && H == HH) {                                                                             \
     if (mx) done = launch_consensus_head_mx<DD, HH>(grid, block, stream, a1t, theta, msg, nbr, coop, partials, agg_out, N, B, in_dim,  \

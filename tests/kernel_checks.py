@@ -353,7 +353,7 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, 
             # neighbours): layer 2 and the heads carry two-piece f16 operands -- each to 2^-22 of ITS magnitude -- and the test plants
             # a head 50 times the others' size: where that estimate sits inside the clip window its error, 50 x 2.4e-7 x sum|terms|,
             # enters the mean; measured 1.6e-5 on the MI355X shapes (profiles/r06f_*) -> 3e-5, i.e. 6e-7 of the planted head
-            mx = os.environ.get("RCMARL_K2_MX", "1") not in ("0",) and d + 1 <= 32
+            mx = os.environ.get("RCMARL_K2_MX", "1") not in ("0",) and d + 1 <= 32 and bk.lib.rcmarl_lattice_f16_mode() != 0
             rel_close(agg[s, i, :B], want_agg[:, 0], 3e-5 if mx else 5e-6, "estimate aggregate")
             ag.projection_step_critic(x[s], want_agg)
             got = unpack_row(th_new[s, i], in_dim, 1)
