@@ -288,8 +288,8 @@ def _self_launch(args):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg4_shard", choices=sorted(WORKLOADS))
     ap.add_argument("--seeds-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")

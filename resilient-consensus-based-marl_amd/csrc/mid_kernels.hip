@@ -844,7 +844,16 @@ __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict_
 // the selection network, the clamp, the mean and the projection residual run one row per lane as before.
 // Range: weights beyond the f16 range of 2^10 w (|w| > 63) or activations beyond 65000 send the wavefront to the fp32 lane code of
 // k_consensus_head for its 64 rows (same launch).
+// Scales (round 6, third form): the layer-2 table is 2^6 W2^T and the head table 2^10 W3, the biases ride in two spare contraction
+// slots of the second k-step (units 10 / 11 of half 0: two pieces of the scaled bias + two of what those left; the B operand carries a
+// constant there: 1.0 for layer 2, 2^6 for the heads), so the accumulators ARE 2^6 z2 and 2^16 est and no instruction rescales them:
+// LeakyReLU, the order statistics, the clamp and the mean commute with a power of two (every fp32 operation on 2^k x returns 2^k times
+// its result on x), |phi|^2 is rescaled once per row (2^-12) and the residual twice (2^-16, 2^-6 for the projection sums).
 #define RC_K2MX_RANGE 65000.f
+#define RC_K2MX_S2 64.f
+#define RC_K2MX_S3 1024.f
+#define RC_K2MX_ONE_H2 0x3C003C00u       // f16 (1.0, 1.0): the two bias slots of layer 2
+#define RC_K2MX_ONE_H3 0x54005400u       // f16 (64.0, 64.0): the heads' bias slots (phi arrives as 2^6 phi)
 #ifndef RC_K2MX_WAVES
 #define RC_K2MX_WAVES 3                  // wavefronts per SIMD the register allocation aims at (161 registers; 4 spills, 2 leaves 192 unused)
 #endif
@@ -858,7 +867,6 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
   static_assert(NH <= 32, "the heads of an agent are the 32 rows of one matrix-core operand");
   __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 2 * 32];      // layer 2: [k-step][piece][k-group][row i] 16-byte A fragments
   __shared__ __attribute__((aligned(16))) uint4 sHf[2 * 2 * 2 * 32];      // heads:   [k-step][piece][k-group][head]
-  __shared__ float sV[HID + 32];                                          // b2 | b3 of the 32 head rows
   __shared__ float red[4 * REC];                                          // per wavefront: sum_b e phi (20) | sum_b e (two halves)
   __shared__ int s_ovf;
   const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
@@ -877,17 +885,26 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
     for (int e = r; e < 2 * 32 * 32; e += ROWS) {
       const int which = e >> 10, ri = (e >> 5) & 31, k = e & 31;
       const int uk = v8_slot_unit(k);
+      const bool bias = k == 18 || k == 19;                               // slots of local units 10, 11 of half 0 (second k-step)
+      const float sc = which ? RC_K2MX_S3 : RC_K2MX_S2;
       float w = 0.f;
       if (which == 0) {
         const int ui = v8_row_unit(ri);
         if (ui >= 0 && uk >= 0) w = th[g.o_W2 + uk * HID + ui];
-      } else if (ri < NH && uk >= 0) {
+        if (ui >= 0 && bias) w = th[g.o_b2 + ui];
+      } else if (ri < NH && (uk >= 0 || bias)) {
         const float* src = ri < D ? msg + ((long)s * N + nbr[i * D + ri]) * ldp : th;
-        w = src[g.o_W3 + uk];
+        w = bias ? src[g.o_b3] : src[g.o_W3 + uk];
       }
       unsigned ph, pl;
-      rc_split2h_pair(w * RC_V8_S, 0.f, ph, pl);
-      if (!(fabsf(w) * RC_V8_S <= RC_K2MX_RANGE)) bad = true;             // (NaN weights take the fp32 path too)
+      rc_split2h_pair(w * sc, 0.f, ph, pl);
+      if (!(fabsf(w) * sc <= RC_K2MX_RANGE)) bad = true;                  // (NaN weights take the fp32 path too)
+      if (bias) {                                                         // slot 18: the two pieces of sc*b; slot 19: the pieces of what they left
+        if (k == 19) {
+          const float rest = (w * sc - rc_f16_to_f32(ph & 0xffffu)) - rc_f16_to_f32(pl & 0xffffu);
+          rc_split2h_pair(rest, 0.f, ph, pl);
+        }
+      }
       const int ks = k >> 4, kg = (k >> 3) & 1;
       const int base = ((((ks * 2 + 0) * 2 + kg) * 32 + ri) * 8) + (k & 7);     // in f16 elements; piece stride 2*32*8
       unsigned short* dst = which ? hf16 : wf16;
@@ -895,13 +912,6 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
       dst[base + 2 * 32 * 8] = (unsigned short)pl;
     }
     if (bad) s_ovf = 1;
-    if (r < HID) sV[r] = th[g.o_b2 + r];
-    if (r >= 32 && r < 64) {
-      const int hd = r - 32;
-      float b3 = 0.f;
-      if (hd < NH) b3 = hd < D ? msg[((long)s * N + nbr[i * D + hd]) * ldp + g.o_b3] : th[g.o_b3];
-      sV[HID + hd] = b3;
-    }
   }
   __syncthreads();
   // The workgroup walks `cpw` chunks of 256 rows (the fragment tables above cost ~300 vector instructions per thread: per chunk
@@ -923,14 +933,25 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
   for (int u = 0; u < LU; ++u) usum[u] = 0.f;
   unsigned slow_mask = 0u;                                                // wave-uniform: bit c - c_begin = that chunk's 64 rows take the fp32 lane code
   const int c_begin = chunk * cpw, c_end = min(nchunk, c_begin + cpw);
+  // The twenty activations of a wavefront's two blocks are requested a chunk ahead, straight into the registers the split of the
+  // current chunk has just read (no second register set, no copies).  Addresses as in k_mid_fit_v8: one wave-uniform base per local
+  // unit in scalar registers + one 32-bit byte offset per lane, block and unit group.
+  const unsigned char* ubase[LU];
+#pragma unroll
+  for (int u = 0; u < LU; ++u) ubase[u] = reinterpret_cast<const unsigned char*>(a1t + (row0 + (u < 8 ? u : u + 8)) * ldb);
+  const unsigned hoff8 = (unsigned)(8 * half) * (unsigned)ldb, hoff2 = (unsigned)(2 * half) * (unsigned)ldb;   // v8_unit(half, u) - v8_unit(0, u) rows
   float a1n[2][LU];
   auto fetch = [&](int c) {
     const int bw = c * ROWS + wave * 64;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-      const int bb = min(bw + 32 * blk + l31, B - 1);                     // (rows beyond B: a clamped read, their e is zero)
+      const unsigned bc = (unsigned)min(bw + 32 * blk + l31, B - 1);      // (rows beyond B: a clamped read, their e is zero)
+      const unsigned o8 = (hoff8 + bc) * 4u, o2 = (hoff2 + bc) * 4u;
 #pragma unroll
-      for (int u = 0; u < LU; ++u) a1n[blk][u] = a1t[(row0 + v8_unit(half, u)) * ldb + bb];
+      for (int u = 0; u < LU; ++u) {
+        a1n[blk][u] = *reinterpret_cast<const float*>(ubase[u] + (u < 8 ? o8 : o2));
+        RC_SCHED_FENCE();
+      }
     }
   };
   if (!wg_slow) fetch(c_begin);
@@ -944,47 +965,47 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
       continue;
     }
     {
-      float a1l[2][LU];
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int u = 0; u < LU; ++u) a1l[blk][u] = a1n[blk][u];
-      if (c + 1 < c_end) fetch(c + 1);
-      float phi[2][LU], nrmb[2], amax = 0.f;
-      float est[2][16];
+      float amax = 0.f;
+      V8Pieces pa0[2], pa1[2];
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-        for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1l[blk][u], a1l[blk][u + 1]);
-        V8Pieces p0, p1;
-        {
-          const float x0[8] = {a1l[blk][0], a1l[blk][1], a1l[blk][2], a1l[blk][3], a1l[blk][4], a1l[blk][5], a1l[blk][6], a1l[blk][7]};
-          p0 = v8_split8<false>(x0, 1.f);
-          p1.h = z4; p1.l = z4;
-          rc_split2h_pair(a1l[blk][8], a1l[blk][9], p1.h.x, p1.l.x);
-        }
+        for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1n[blk][u], a1n[blk][u + 1]);
+        const float x0[8] = {a1n[blk][0], a1n[blk][1], a1n[blk][2], a1n[blk][3], a1n[blk][4], a1n[blk][5], a1n[blk][6], a1n[blk][7]};
+        pa0[blk] = v8_split8<false>(x0, 1.f);
+        pa1[blk].h = z4; pa1[blk].l = z4;
+        rc_split2h_pair(a1n[blk][8], a1n[blk][9], pa1[blk].h.x, pa1[blk].l.x);
+        pa1[blk].h.y = RC_K2MX_ONE_H2;                                    // the bias slots: b2 sits in the table
+      }
+      RC_SCHED_FENCE();
+      fetch(min(c + 1, c_end - 1));                                       // (the last chunk once more rather than a branch: lesson (ii) of round 4)
+      float phi[2][LU], nrmb[2];                                          // phi: 2^6 phi
+      float est[2][16];                                                   // 2^16 est
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
         rc_f32x16 zz;
 #pragma unroll
         for (int q = 0; q < 16; ++q) zz[q] = 0.f;
-        zz = v8_mfma4(loadA(wfA, 1), p1, zz);
-        zz = v8_mfma4(loadA(wfA, 0), p0, zz);
+        zz = v8_mfma4(loadA(wfA, 1), pa1[blk], zz);
+        zz = v8_mfma4(loadA(wfA, 0), pa0[blk], zz);
         float np = 0.f;
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
-          const float z = fmaf(zz[u], RC_V8_US, sV[v8_unit(half, u)]);
-          phi[blk][u] = fmaxf(z, RC_LEAK * z);
+          phi[blk][u] = fmaxf(zz[u], RC_LEAK * zz[u]);
           np = fmaf(phi[blk][u], phi[blk][u], np);
         }
 #pragma unroll
         for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, phi[blk][u], phi[blk][u + 1]);
         float na = np, nb = np;
         rc_swap32(na, nb);                                                // na: lanes 32-63 hold the low half's part; nb: lanes 0-31 the high half's
-        nrmb[blk] = (np + (half ? na : nb)) + 1.0f;
+        nrmb[blk] = fmaf(np + (half ? na : nb), 1.0f / (RC_K2MX_S2 * RC_K2MX_S2), 1.0f);
+        V8Pieces p0, p1;
         {
           const float x0[8] = {phi[blk][0], phi[blk][1], phi[blk][2], phi[blk][3], phi[blk][4], phi[blk][5], phi[blk][6], phi[blk][7]};
           p0 = v8_split8<false>(x0, 1.f);
           p1.h = z4; p1.l = z4;
           rc_split2h_pair(phi[blk][8], phi[blk][9], p1.h.x, p1.l.x);
+          p1.h.y = RC_K2MX_ONE_H3;
         }
         rc_f32x16 ee;
 #pragma unroll
@@ -992,7 +1013,7 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
         ee = v8_mfma4(loadA(hfA, 1), p1, ee);
         ee = v8_mfma4(loadA(hfA, 0), p0, ee);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) est[blk][q] = fmaf(ee[q], RC_V8_US, sV[HID + 8 * (q >> 2) + 4 * half + (q & 3)]);
+        for (int q = 0; q < 16; ++q) est[blk][q] = ee[q];
       }
       if (rc_any(!(amax <= RC_K2MX_RANGE))) {
         slow_mask |= 1u << (c - c_begin);
@@ -1008,11 +1029,14 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
         float v[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) v[k] = head(k);
-        agg = select_agg<HID, D, H>(v);
+        constexpr float US23 = 1.0f / (RC_K2MX_S2 * RC_K2MX_S3);
+        const float aggs = select_agg<HID, D, H>(v);                      // 2^16 times the aggregate (every step commutes with the scale)
+        agg = aggs * US23;
         const float nrm = half ? nrmb[1] : nrmb[0];
-        const float e = valid ? (agg - head(D)) / nrm : 0.f;
-        const float eo = __shfl_xor(e, 32, 64);                           // the residual of the row the partner lane finishes
-        const float e0 = half ? eo : e, e1 = half ? e : eo;               // of block 0 / block 1, row l31
+        const float e = valid ? ((aggs - head(D)) * US23) / nrm : 0.f;
+        const float es6 = e * (1.0f / RC_K2MX_S2);                       // phi is carried as 2^6 phi
+        const float eo = __shfl_xor(es6, 32, 64);                         // the residual of the row the partner lane finishes
+        const float e0 = half ? eo : es6, e1 = half ? es6 : eo;           // of block 0 / block 1, row l31
 #pragma unroll
         for (int u = 0; u < LU; ++u) usum[u] = fmaf(e1, phi[1][u], fmaf(e0, phi[0][u], usum[u]));
         es += e;

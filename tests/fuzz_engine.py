@@ -4,6 +4,7 @@ RNG modes, common_reward, and -- for teams without fitting adversaries -- critic
 engine_checks.compare (the bar of the fixed-shape tests).
 
     python tests/fuzz_engine.py SEED COUNT [cuda]        # default: hipemu build on the CPU
+    RCMARL_FUZZ_NMAX=24 RCMARL_FUZZ_ONLY=177 python tests/fuzz_engine.py 606 250   # replay ONE draw of a cuda run on the emulation
 """
 import os
 import sys
@@ -28,9 +29,11 @@ def main():
     else:
         from emu_util import emu_lib
         device, lib, nmax = "cpu", emu_lib(), 8
+    nmax = int(os.environ.get("RCMARL_FUZZ_NMAX", nmax))        # the draws depend on it: set it to 24 to replay a cuda run's stream
+    only = os.environ.get("RCMARL_FUZZ_ONLY")
     rng = np.random.default_rng(seed)
     failed = 0
-    for _ in range(count):
+    for it in range(count):
         n = int(rng.integers(3, nmax))
         labs = [str(rng.choice(POOL)) for _ in range(n)]
         if labs.count("Cooperative") < 2:
@@ -58,10 +61,11 @@ def main():
         desc = dict(n=n, labels="".join(lab[0] for lab in labs), d=d, H=H, circ=circ, ep=(mel, nef, nep, buf, neps), rng=mode,
                     common=common, grid=(nrow, ncol), critic_hid=hid, lattice=lattice)
         t0 = time.time()
+        seeds = (int(rng.integers(100)), int(rng.integers(100, 200)))
+        if only is not None and it != int(only):
+            continue
         try:
-            eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, mode, device, lib,
-                                                 seeds=(int(rng.integers(100)), int(rng.integers(100, 200))), critic_hid=hid,
-                                                 lattice=lattice)
+            eng, logs, o_logs, o_w = EC.run_pair(args, nrow, ncol, mode, device, lib, seeds=seeds, critic_hid=hid, lattice=lattice)
             EC.compare(eng, logs, o_logs, o_w, actor="stat" if n > 12 else "strict")
             print("OK   %5.1fs %s" % (time.time() - t0, desc), flush=True)
         except Exception as e:                                   # noqa: BLE001 -- report and go on
