@@ -12,6 +12,14 @@
 //   k_consensus_head  estimate consensus + projection residual                    (:168-206, :60-84)
 //   k_mid_actor       softmax / TD-weighted sparse CE forward+backward            (:86-101)
 //   k_small_sgd / k_small_adam / k_head_apply   reduce partials, apply updates
+// Round 6 (visit l): the 20-unit layers of this file run THREE of the four piece products (h x h, h x l, l x h); the low x low one is
+// at most 2^-22 of a term -- a quarter of an fp32 rounding step of it -- and leaving it out moves k_mid_fit_v8's gradient records by
+// 0.7-1.5e-7 of their scale, LESS than the fp32 vector-ALU form of the same kernel differs from the four-pass form through its
+// summation order alone (2.2e-7; profiles/r06l_mid_ab_drop_ll.txt), for 5 % of the kernel's time (434-440 -> 410-419 us).
+// -DRC_V8_DROP_LL=0 restores the fourth pass; the adversaries' mini-batch chain (minibatch_fit.hip) keeps all four.
+#ifndef RC_V8_DROP_LL
+#define RC_V8_DROP_LL 1
+#endif
 #include "rcmarl_lattice.h"
 #include <stdlib.h>
 #include "selnet_generated.inc"
@@ -857,6 +865,18 @@ __global__ __launch_bounds__(256) void k_consensus_head(const float* __restrict_
 #ifndef RC_K2MX_WAVES
 #define RC_K2MX_WAVES 3                  // wavefronts per SIMD the register allocation aims at (161 registers; 4 spills, 2 leaves 192 unused)
 #endif
+// The product of the two LOW pieces (<= 2^-22 of a term: a quarter of an fp32 rounding step of it) is left out, as in the packed-operand
+// GEMMs of the wide critic: three matrix-core passes per k-step instead of four (RC_K2MX_DROP_LL=0 restores it).
+#ifndef RC_K2MX_DROP_LL
+#define RC_K2MX_DROP_LL RC_V8_DROP_LL
+#endif
+__device__ __forceinline__ rc_f32x16 k2_mfma(const V8Pieces& a, const V8Pieces& b, rc_f32x16 c) {
+  if (!RC_K2MX_DROP_LL) c = rc_mfma_f16(a.l, b.l, c);
+  c = rc_mfma_f16(a.l, b.h, c);
+  c = rc_mfma_f16(a.h, b.l, c);
+  c = rc_mfma_f16(a.h, b.h, c);
+  return c;
+}
 template <int D, int H>
 __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const float* __restrict__ a1t, const float* __restrict__ theta,
                                                            const float* __restrict__ msg, const int* __restrict__ nbr,
@@ -986,8 +1006,8 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
         rc_f32x16 zz;
 #pragma unroll
         for (int q = 0; q < 16; ++q) zz[q] = 0.f;
-        zz = v8_mfma4(loadA(wfA, 1), pa1[blk], zz);
-        zz = v8_mfma4(loadA(wfA, 0), pa0[blk], zz);
+        zz = k2_mfma(loadA(wfA, 0), pa0[blk], zz);
+        zz = k2_mfma(loadA(wfA, 1), pa1[blk], zz);                        // (the k-step with the bias last: it joins a finished sum)
         float np = 0.f;
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
@@ -1010,8 +1030,8 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
         rc_f32x16 ee;
 #pragma unroll
         for (int q = 0; q < 16; ++q) ee[q] = 0.f;
-        ee = v8_mfma4(loadA(hfA, 1), p1, ee);
-        ee = v8_mfma4(loadA(hfA, 0), p0, ee);
+        ee = k2_mfma(loadA(hfA, 0), p0, ee);
+        ee = k2_mfma(loadA(hfA, 1), p1, ee);
 #pragma unroll
         for (int q = 0; q < 16; ++q) est[blk][q] = ee[q];
       }

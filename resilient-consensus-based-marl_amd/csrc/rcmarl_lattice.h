@@ -266,8 +266,12 @@ __device__ __forceinline__ int v8_slot_unit(int k) {
 }
 
 struct V8Pieces { uint4 h, l; };
+// RC_V8_DROP_LL=1 (set by mid_kernels.hip for its kernels): the low x low pass left out.
+#ifndef RC_V8_DROP_LL
+#define RC_V8_DROP_LL 0
+#endif
 __device__ __forceinline__ rc_f32x16 v8_mfma4(const V8Pieces& a, const V8Pieces& b, rc_f32x16 c) {
-  c = rc_mfma_f16(a.l, b.l, c);
+  if (!RC_V8_DROP_LL) c = rc_mfma_f16(a.l, b.l, c);
   c = rc_mfma_f16(a.l, b.h, c);
   c = rc_mfma_f16(a.h, b.l, c);
   c = rc_mfma_f16(a.h, b.h, c);
