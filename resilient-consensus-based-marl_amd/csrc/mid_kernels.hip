@@ -21,6 +21,13 @@
 #define RC_V8_DROP_LL 1
 #endif
 #include "rcmarl_lattice.h"
+// A/B switch: raise the wavefront's issue priority around its matrix-core groups (so that a group is issued as early as possible and the
+// other wavefronts' vector work runs under it).
+#ifndef RC_MID_SETPRIO
+#define RC_MID_SETPRIO 0
+#endif
+#define RC_MX_BEGIN() do { if (RC_MID_SETPRIO) rc_setprio(RC_MID_SETPRIO); } while (0)
+#define RC_MX_END() do { if (RC_MID_SETPRIO) rc_setprio(0); } while (0)
 #include <stdlib.h>
 #include "selnet_generated.inc"
 
@@ -567,8 +574,10 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
       rc_f32x16 zz;
 #pragma unroll
       for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+      RC_MX_BEGIN();
       zz = v8_mfma4(loadA(0, 1), pa1, zz);
       zz = v8_mfma4(loadA(0, 0), pa0, zz);
+      RC_MX_END();
       RC_SCHED_FENCE();
       // a2 = lrelu(z2 + b2) two units at a time (max(z, leak z): bit for bit the select form), v = a2 . W3 + b3
       rc_f2 a2p[LU / 2], w3p[LU / 2];
@@ -619,8 +628,10 @@ __global__ __launch_bounds__(256, RC_V8_WAVES) void k_mid_fit_v8(float* __restri
       rc_f32x16 dd;
 #pragma unroll
       for (int q = 0; q < 16; ++q) dd[q] = 0.f;
+      RC_MX_BEGIN();
       dd = v8_mfma4(loadA(1, 1), pd1, dd);
       dd = v8_mfma4(loadA(1, 0), pd0, dd);
+      RC_MX_END();
       RC_SCHED_FENCE();
       // dz1 = (dd * scale) * (a1 > 0 ? 1 : leak)   (EMIT: 2^8 dz1, what the packed operand carries)
       float dz1l[LU];
@@ -1006,8 +1017,10 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
         rc_f32x16 zz;
 #pragma unroll
         for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+        RC_MX_BEGIN();
         zz = k2_mfma(loadA(wfA, 0), pa0[blk], zz);
         zz = k2_mfma(loadA(wfA, 1), pa1[blk], zz);                        // (the k-step with the bias last: it joins a finished sum)
+        RC_MX_END();
         float np = 0.f;
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
@@ -1030,8 +1043,10 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
         rc_f32x16 ee;
 #pragma unroll
         for (int q = 0; q < 16; ++q) ee[q] = 0.f;
+        RC_MX_BEGIN();
         ee = k2_mfma(loadA(hfA, 0), p0, ee);
         ee = k2_mfma(loadA(hfA, 1), p1, ee);
+        RC_MX_END();
 #pragma unroll
         for (int q = 0; q < 16; ++q) est[blk][q] = ee[q];
       }

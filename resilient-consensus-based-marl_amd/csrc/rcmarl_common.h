@@ -231,6 +231,7 @@ __device__ __forceinline__ void rc_half_sum3_lane31(float& a, float& b, float& c
 __device__ __forceinline__ void rc_sleep(int) {}
 __device__ __forceinline__ void rc_sleep_short(int) {}
 __device__ __forceinline__ void rc_setprio1() {}
+__device__ __forceinline__ void rc_setprio(int) {}
 #else
 // outstanding vector-memory operations of this wavefront (incl. LDS-DMA issued through inline asm, which hipcc does not see)
 #define RC_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -242,6 +243,7 @@ __device__ __forceinline__ void rc_sleep_short(int n) {   // n x ~0.2 us (64 x 8
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
 }
 __device__ __forceinline__ void rc_setprio1() { __builtin_amdgcn_s_setprio(1); }
+#define rc_setprio(n) __builtin_amdgcn_s_setprio(n)
 #endif
 
 // host side: opt a kernel into more dynamic LDS than the default limit; number of workgroups of a persistent launch

@@ -1,0 +1,34 @@
+#!/bin/bash
+# round 6, visit m: the build with three-pass 20-unit layers -- parity evidence again (steady-state block, fp64 arbiter with the seeds of
+# visit c), GPU suite, kernel stats and the bench line
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
+TAG=${1:-r06m}
+echo "== full GPU suite"
+SECONDS=0
+timeout 2400 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider --durations=6 -rP > gpurun_out/${TAG}_test_gpu.log 2>&1
+echo "suite wall ${SECONDS}s"
+grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_test_gpu.log | tail -20
+grep -E "^E  " gpurun_out/${TAG}_test_gpu.log | head -20
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
+echo "== bench (20 steps)"
+SECONDS=0
+timeout 1200 python bench.py --steps 20 --warmup 5 2> gpurun_out/${TAG}_bench.err > gpurun_out/${TAG}_bench_cfg4_shard.json
+echo "bench.py wall: ${SECONDS}s"
+python - <<PY
+import json
+d=json.loads([l for l in open('gpurun_out/${TAG}_bench_cfg4_shard.json') if l.startswith('{')][-1])
+print({k:d.get(k) for k in ('value','ms_per_step','ms_per_step_exact','exact_steps','steps','n_gpus')})
+print('  ', d.get('summary_ms_per_step'))
+for k,v in list(d['kernels'].items())[:8]: print('  ',k, v)
+PY
+echo "== rocprof cfg4_shard"
+bash tools/gpu_visit.sh ${TAG} prof:cfg4_shard 2>&1 | tail -12 | cut -c1-170
+echo "== steady-state block from identical state"
+SECONDS=0
+timeout 1800 python tools/diag_cfg4_steady.py 2 2> gpurun_out/${TAG}_steady.err | grep -v amdgpu.ids > gpurun_out/${TAG}_cfg4_steady_state_parity.txt
+echo "steady wall ${SECONDS}s"; cat gpurun_out/${TAG}_cfg4_steady_state_parity.txt; tail -3 gpurun_out/${TAG}_steady.err
+echo "== fp64 arbiter, first block, four seeds"
+SECONDS=0
+timeout 1800 python tools/diag_cfg4_fp64_arbiter.py 0 4 2> gpurun_out/${TAG}_arbiter.err | grep -v amdgpu.ids > gpurun_out/${TAG}_cfg4_fp64_arbiter.txt
+echo "arbiter wall ${SECONDS}s"; cat gpurun_out/${TAG}_cfg4_fp64_arbiter.txt; tail -3 gpurun_out/${TAG}_arbiter.err
