@@ -84,8 +84,10 @@ __device__ __forceinline__ void rc_split3_pair(float w0, float w1, unsigned& h, 
 // operand, bit 1 = backward operand in this form; 0 = the exact three-piece bf16 form everywhere.
 #define RC_F16_W_SCALE 1024.f
 #define RC_F16_W_UNSCALE 0.0009765625f
+#ifndef RC_F16_DZ_SCALE                 // (A/B builds: -DRC_F16_DZ_SCALE=65536.f -DRC_F16_DZ_UNSCALE=1.52587890625e-05f in every source)
 #define RC_F16_DZ_SCALE 256.f
 #define RC_F16_DZ_UNSCALE 0.00390625f
+#endif
 // activations of a wide network as two f16 pieces (wide_kernels.hip, dense_pk.hip): full precision from |a| >= 2.0e-3, finite to 1015
 #define RC_F16_ACT_SCALE 64.f
 #define RC_F16_ACT_UNSCALE 0.015625f
