@@ -168,6 +168,11 @@ int rcmarl_small_sgd(const float* partials, float* theta, const int* mask, float
  * (local_TD_target, agents/resilient_CAC_agents.py:114-115).  Also serves r_team, V, nV of :95-97. */
 int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma, float* out, int S,
                      int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
+/* The same on the vector ALUs in fp32 whatever the operand form (rcmarl_mid_value runs layer 2 of 20-unit nets on the f16 matrix core
+ * with two-piece operands: last bits differ).  For callers whose results feed a long sequential chain that amplifies last-bit
+ * differences -- the adversaries' targets ahead of their 32-row mini-batch fits (agents/adversarial_CAC_agents.py:111-117,131-135). */
+int rcmarl_mid_value_f32(const float* a1t, const float* theta, const float* r_applied, float gamma, float* out, int S,
+                         int N, int B, int in_dim, int hid, int ldp, int ldb, void* stream);
 
 /* K2+K3: consensus over estimates + projection residual.
  * Replaces resilient_consensus_critic/_TR (agents/resilient_CAC_agents.py:168-206) and the

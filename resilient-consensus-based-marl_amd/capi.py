@@ -83,6 +83,8 @@ SIGNATURES = {
     # a1t, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream
     "rcmarl_mid_value": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_stream],
+    "rcmarl_mid_value_f32": [c_f32p, c_f32p, c_f32p, c_float, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_stream],
     # a1t, theta, msg, nbr, coop, partials, agg_out, S, N, B, in_dim, hid, ldp, ldb, d, H, stream
     "rcmarl_consensus_head": [c_f32p, c_f32p, c_f32p, c_i32p, c_u8p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_int, c_int, c_stream],

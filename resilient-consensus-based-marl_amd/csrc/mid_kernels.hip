@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
 #pragma unroll
         for (int q = 0; q < 16; ++q) est[blk][q] = ee[q];
       }
-      if (rc_any(!(amax <= RC_K2MX_RANGE))) {
+      if (rc_ballot(!(amax <= RC_K2MX_RANGE)) != 0ull) {           // (a ballot, not rc_any: lane collectives follow, the emulation must decide per WAVE)
         slow_mask |= 1u << (c - c_begin);
         continue;
       }
@@ -1135,6 +1135,153 @@ __global__ __launch_bounds__(256, RC_K2MX_WAVES) void k_consensus_head_mx(const 
   if (r == HID) out[HID] = ((red[HID] + red[HID + 1]) + (red[REC + HID] + red[REC + HID + 1])) +
                            ((red[2 * REC + HID] + red[2 * REC + HID + 1]) + (red[3 * REC + HID] + red[3 * REC + HID + 1]));
   for (int e2 = r; e2 < (c_end - c_begin - 1) * (HID + 1); e2 += ROWS) out[(HID + 1) + e2] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mid_value with layer 2 on the f16 matrix core (round 6, visit t): the value head of a 20-unit net on cached layer-1 activations --
+// the TD target of every epoch and the actor phase's three value rows.  k_mid_value spends ~500 vector instructions per 64 rows on the
+// 20 x 20 layer; here the layer is k_consensus_head_mx's first half (same table, same bias slots, 2^6 z2 in the accumulators), the head
+// is ten FMAs per lane on the scaled activations (W3 pre-divided by 2^6) and one v_permlane32_swap + add joins the two halves of a row.
+// Out-of-range weights / activations: the fp32 lane code for those rows, in the same launch (bit-identical to k_mid_value).
+template <int HID_>
+__global__ __launch_bounds__(256, 4) void k_mid_value_mx(const float* __restrict__ a1t, const float* __restrict__ theta,
+                                                         const float* __restrict__ r_applied, float gamma, float* __restrict__ out,
+                                                         int N, int B, int in_dim, int ldp, int ldb, int nchunk, int cpw) {
+  constexpr int HID = 20, LU = 10;
+  static_assert(HID_ == HID, "compiled for 20 units");
+  __shared__ __attribute__((aligned(16))) uint4 sWf[2 * 2 * 2 * 32];      // layer 2: [k-step][piece][k-group][row i] 16-byte A fragments
+  __shared__ int s_ovf;
+  const int s = blockIdx.z, i = blockIdx.y, chunk = blockIdx.x;
+  const int r = threadIdx.x, lane = r & 63, wave = __builtin_amdgcn_readfirstlane(r >> 6), l31 = lane & 31, half = lane >> 5;
+  const NetGeom g = make_geom(in_dim, HID, 1);
+  const float* __restrict__ th = theta + ((long)s * N + i) * ldp;
+  const long row0 = ((long)s * N + i) * HID;
+  rc_f16_saturate();
+  if (r == 0) s_ovf = 0;
+  __syncthreads();
+  {
+    unsigned short* wf16 = reinterpret_cast<unsigned short*>(sWf);
+    bool bad = false;
+    for (int e = r; e < 32 * 32; e += ROWS) {
+      const int ri = (e >> 5) & 31, k = e & 31;
+      const int uk = v8_slot_unit(k), ui = v8_row_unit(ri);
+      const bool bias = k == 18 || k == 19;
+      float w = 0.f;
+      if (ui >= 0 && uk >= 0) w = th[g.o_W2 + uk * HID + ui];
+      if (ui >= 0 && bias) w = th[g.o_b2 + ui];
+      unsigned ph, pl;
+      rc_split2h_pair(w * RC_K2MX_S2, 0.f, ph, pl);
+      if (!(fabsf(w) * RC_K2MX_S2 <= RC_K2MX_RANGE)) bad = true;
+      if (k == 19) {
+        const float rest = (w * RC_K2MX_S2 - rc_f16_to_f32(ph & 0xffffu)) - rc_f16_to_f32(pl & 0xffffu);
+        rc_split2h_pair(rest, 0.f, ph, pl);
+      }
+      const int ks = k >> 4, kg = (k >> 3) & 1;
+      const int base = ((((ks * 2 + 0) * 2 + kg) * 32 + ri) * 8) + (k & 7);
+      wf16[base] = (unsigned short)ph;
+      wf16[base + 2 * 32 * 8] = (unsigned short)pl;
+    }
+    if (bad) s_ovf = 1;
+  }
+  __syncthreads();
+  const uint4* wfA = sWf + half * 32 + l31;
+  auto loadA = [&](int ks) {
+    V8Pieces a;
+    a.h = wfA[((ks * 2 + 0) * 2) * 32];
+    a.l = wfA[((ks * 2 + 1) * 2) * 32];
+    return a;
+  };
+  uint4 z4;
+  z4.x = z4.y = z4.z = z4.w = 0u;
+  const bool wg_slow = s_ovf != 0;
+  float w3[LU];                                                            // the lane's ten head weights, for activations carried as 2^6 phi
+#pragma unroll
+  for (int u = 0; u < LU; ++u) w3[u] = th[g.o_W3 + v8_unit(half, u)] * (1.0f / RC_K2MX_S2);
+  const float b3 = th[g.o_b3];
+  const int c_begin = chunk * cpw, c_end = min(nchunk, c_begin + cpw);
+  const unsigned char* ubase[LU];
+#pragma unroll
+  for (int u = 0; u < LU; ++u) ubase[u] = reinterpret_cast<const unsigned char*>(a1t + (row0 + (u < 8 ? u : u + 8)) * ldb);
+  const unsigned hoff8 = (unsigned)(8 * half) * (unsigned)ldb, hoff2 = (unsigned)(2 * half) * (unsigned)ldb;
+  float a1n[2][LU];
+  auto fetch = [&](int c) {
+    const int bw = c * ROWS + wave * 64;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const unsigned bc = (unsigned)min(bw + 32 * blk + l31, B - 1);
+      const unsigned o8 = (hoff8 + bc) * 4u, o2 = (hoff2 + bc) * 4u;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        a1n[blk][u] = *reinterpret_cast<const float*>(ubase[u] + (u < 8 ? o8 : o2));
+        RC_SCHED_FENCE();
+      }
+    }
+  };
+  unsigned slow_mask = 0u;
+  if (!wg_slow) fetch(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    const int b = c * ROWS + wave * 64 + lane;                             // the row this lane finishes (block `half`, row l31 of it)
+    if (wg_slow) {
+      slow_mask |= 1u << (c - c_begin);
+      continue;
+    }
+    float amax = 0.f;
+    V8Pieces pa0[2], pa1[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int u = 0; u < LU; u += 2) amax = rc_amax3(amax, a1n[blk][u], a1n[blk][u + 1]);
+      const float x0[8] = {a1n[blk][0], a1n[blk][1], a1n[blk][2], a1n[blk][3], a1n[blk][4], a1n[blk][5], a1n[blk][6], a1n[blk][7]};
+      pa0[blk] = v8_split8<false>(x0, 1.f);
+      pa1[blk].h = z4; pa1[blk].l = z4;
+      rc_split2h_pair(a1n[blk][8], a1n[blk][9], pa1[blk].h.x, pa1[blk].l.x);
+      pa1[blk].h.y = RC_K2MX_ONE_H2;
+    }
+    RC_SCHED_FENCE();
+    fetch(min(c + 1, c_end - 1));
+    float part[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      rc_f32x16 zz;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) zz[q] = 0.f;
+      zz = k2_mfma(loadA(0), pa0[blk], zz);
+      zz = k2_mfma(loadA(1), pa1[blk], zz);
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const float phi = fmaxf(zz[u], RC_LEAK * zz[u]);
+        acc = fmaf(phi, w3[u], acc);
+      }
+      part[blk] = acc;
+    }
+    if (rc_ballot(!(amax <= RC_K2MX_RANGE)) != 0ull) {           // (a ballot, not rc_any: lane collectives follow, the emulation must decide per WAVE)                                // (activations beyond the f16 range; |phi| cannot exceed what the
+      slow_mask |= 1u << (c - c_begin);                                    // saturated pieces of a1 and the in-range table allow)
+      continue;
+    }
+    rc_swap32(part[0], part[1]);          // lanes 0-31: both halves' parts of block 0's row l31; lanes 32-63: of block 1's row l31
+    const float v = (part[0] + part[1]) + b3;
+    if (b < B) {
+      const long o = ((long)s * N + i) * ldb + b;
+      out[o] = r_applied ? r_applied[o] + gamma * v : v;
+    }
+  }
+  if (slow_mask != 0u) {
+    RC_NO_SPECULATE();
+    for (int c = c_begin; c < c_end; ++c) {
+      if (!((slow_mask >> (c - c_begin)) & 1u)) continue;
+      const int b = c * ROWS + wave * 64 + lane;
+      const bool valid = b < B;
+      float a1[HID], a2[HID];
+      load_a1<HID>(a1t, row0, ldb, b, valid, a1);
+      layer2<HID>(th, g, a1, a2);
+      const float v = head1<HID>(th + g.o_W3, th[g.o_b3], a2);
+      if (valid) {
+        const long o = ((long)s * N + i) * ldb + b;
+        out[o] = r_applied ? r_applied[o] + gamma * v : v;
+      }
+    }
+  }
 }
 
 // runtime (d, H) fallback: neighbour estimates staged in LDS, order statistics by rank counting
@@ -1532,14 +1679,37 @@ RCMARL_EXPORT int rcmarl_small_sgd(const float* partials, float* theta, const in
   return rcmarl_check_launch();
 }
 
-RCMARL_EXPORT int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma,
-                                   float* out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
-                                   void* stream) {
+static int mid_value_impl(const float* a1t, const float* theta, const float* r_applied, float gamma, float* out, int S, int N, int B,
+                          int in_dim, int hid, int ldp, int ldb, void* stream, bool f32_only) {
   if (bad_mid(a1t, theta, S, N, B, in_dim, hid, ldp, ldb) || !out) return RCMARL_ERR_ARG;
   const dim3 grid(rc_ceil_div(B, ROWS), N, S), block(ROWS);
+  // RCMARL_MIDVALUE_MX (default 1): layer 2 on the f16 matrix core (k_mid_value_mx; 20 units, a two-piece operand form selected)
+  const char* mxe = getenv("RCMARL_MIDVALUE_MX");
+  if (!f32_only && hid == 20 && !(mxe && atoi(mxe) == 0) && rc_lat_f16_mode() != 0) {
+    const int nchunk = rc_ceil_div(B, ROWS);
+    const long pairs = (long)N * S;
+    int wgs = pairs >= 2048 ? 2 : (pairs >= 512 ? 4 : nchunk);
+    if (wgs * 32 < nchunk) wgs = (nchunk + 31) / 32;                       // (a wavefront keeps one bit per chunk)
+    const int cpw = (nchunk + wgs - 1) / wgs;
+    const dim3 gmx((unsigned)((nchunk + cpw - 1) / cpw), N, S);
+    RCMARL_LAUNCH((k_mid_value_mx<20>), gmx, block, 0, stream, a1t, theta, r_applied, gamma, out, N, B, in_dim, ldp, ldb, nchunk, cpw);
+    return rcmarl_check_launch();
+  }
   RC_HID_SWITCH(hid, RCMARL_LAUNCH((k_mid_value<HID_>), grid, block, 0, stream, a1t, theta, r_applied, gamma, out, N,
                                    B, in_dim, ldp, ldb));
   return rcmarl_check_launch();
+}
+
+RCMARL_EXPORT int rcmarl_mid_value(const float* a1t, const float* theta, const float* r_applied, float gamma,
+                                   float* out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                                   void* stream) {
+  return mid_value_impl(a1t, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream, false);
+}
+
+RCMARL_EXPORT int rcmarl_mid_value_f32(const float* a1t, const float* theta, const float* r_applied, float gamma,
+                                       float* out, int S, int N, int B, int in_dim, int hid, int ldp, int ldb,
+                                       void* stream) {
+  return mid_value_impl(a1t, theta, r_applied, gamma, out, S, N, B, in_dim, hid, ldp, ldb, stream, true);
 }
 
 template <int DD, int HH>

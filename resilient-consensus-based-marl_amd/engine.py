@@ -1080,14 +1080,15 @@ class RPBCACEngine:
             return e not in ("0", "false")
         return self.S * self.n_coop >= 1024
 
-    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None, gather=False):
+    def _value(self, xkey, theta, net, out, B, row0=0, r_applied=None, scratch=None, gather=False, value_f32=False):
         """scratch: private activation buffer of a caller that may run beside the main stream (the adversaries); such a
         caller also stays off the lattice path, whose packed-operand scratch belongs to the main stream.
-        gather (agent-sharded instance only): the caller needs the values of ALL agents, not just this rank's."""
+        gather (agent-sharded instance only): the caller needs the values of ALL agents, not just this rank's.
+        value_f32: layers 2-3 on the fp32 vector-ALU kernel (the adversaries' callers, see below)."""
         if self._sharded(net) and scratch is None:
             th, o, r = self._wv(theta), self._wv(out), self._wv(r_applied)
             with self._agent_window():
-                self._value(xkey, th, net, o, B, row0, r)
+                self._value(xkey, th, net, o, B, row0, r, value_f32=value_f32)
             if gather:
                 self._allgather_rows(out, 0, B)
             return
@@ -1095,8 +1096,11 @@ class RPBCACEngine:
             return self._value_wide(xkey, theta, net, out, B, row0, r_applied)
         buf = self.a1t if scratch is None else scratch
         self._layer1(xkey, theta, net, B, row0, buf=buf, lattice=scratch is None)
-        self.lib.rcmarl_mid_value(buf.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
-                                  self.S, self.N, B, self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
+        # (a caller with a private scratch buffer is an adversary: its values feed a chain of 32-row mini-batch steps that amplifies
+        # last-bit differences -- they stay on the fp32 vector-ALU kernel, as they stay off the lattice path)
+        fn = self.lib.rcmarl_mid_value if (scratch is None and not value_f32) else self.lib.rcmarl_mid_value_f32
+        fn(buf.data_ptr(), theta.data_ptr(), self._p(r_applied), self.cfg.gamma, out.data_ptr(),
+           self.S, self.N, B, self.in_dim[net], HID, self.ldp[net], self.ldb, self.stream)
 
     def _k1(self, net, g_hid):
         """hidden-layer consensus of one network family: msg -> theta (cooperative agents, columns < g_hid)"""

@@ -286,8 +286,8 @@ class AdversaryPath:
                             self.mal_mask.data_ptr(), e.stream)
         rptr, rstride = e._x("r", row0)
         L.rcmarl_gather_agent_major(rptr, rstride, None, None, e.ybuf["r_own"].data_ptr(), S, N, nl, e.ldb, e.stream)
-        e._value("ns", own, "critic", e.ybuf["v_next_adv"], nl, row0)
-        e._value("s", own, "critic", e.ybuf["v_cur_adv"], nl, row0)
+        e._value("ns", own, "critic", e.ybuf["v_next_adv"], nl, row0, value_f32=True)
+        e._value("s", own, "critic", e.ybuf["v_cur_adv"], nl, row0, value_f32=True)
         L.rcmarl_td_error(e.ybuf["r_own"].data_ptr(), e.ybuf["v_next_adv"].data_ptr(), e.ybuf["v_cur_adv"].data_ptr(),
                           e.cfg.gamma, e.ybuf["delta_adv"].data_ptr(), S * N * e.ldb, e.stream)
         sptr, sstride = e._x("s", row0)

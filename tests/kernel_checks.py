@@ -313,7 +313,7 @@ def check_sgd_fit(bk, S, N, B, in_dim, steps=2, lr=0.01, gamma=0.9, masked_agent
     np.testing.assert_array_equal(bk.host(d_th), theta)           # live weights untouched (rollback)
 
 
-def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, compare=True):
+def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, compare=True, big_x_rows=None):
     """K2+K3: estimate consensus + projection step of the output layer.  compare=False: only run, return (theta after, aggregate)."""
     rng = np.random.default_rng(S + N * 10 + B + d * 7 + H)
     P, P_hid = geom(in_dim, 1)
@@ -322,6 +322,8 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, 
     msgp = random_params(rng, S, N, in_dim, 1)
     theta, msg = pack_rows(live, ldp), pack_rows(msgp, ldp)
     x = rng.normal(size=(S, B, in_dim)).astype(np.float32)
+    if big_x_rows is not None:                      # replay rows whose layer-1 activations leave the f16 range of the matrix-core form
+        x[:, big_x_rows] *= np.float32(3.0e6)
     nbr = circulant(N, d) if graph == "circ" else random_regular(N, d, rng)
     coop = np.ones(N, np.int32)
     coop[0] = 0
@@ -361,6 +363,51 @@ def check_consensus_head(bk, S, N, B, in_dim, d, H, graph="circ", outlier=50.0, 
                 np.testing.assert_array_equal(got[k], live[s][i][k])          # hidden layers frozen
             rel_close(got[4], ag.critic[4], 2e-5, "W3 after projection")
             rel_close(got[5], ag.critic[5], 2e-5, "b3 after projection")
+
+
+def _ptr_add(ptr, nbytes):
+    """device pointer (int on the GPU backend, ctypes.c_void_p on the emulation) + a byte offset"""
+    import ctypes
+    return ctypes.c_void_p(ptr.value + nbytes) if isinstance(ptr, ctypes.c_void_p) else ptr + nbytes
+
+
+def check_mid_value(bk, S, N, B, in_dim, row_off=0, big_w2_agent=None, big_a1_rows=None, gamma=0.9, compare=True, entry="rcmarl_mid_value"):
+    """rcmarl_mid_value on cached layer-1 activations: v = head(layer2(a1)) [r + gamma v], against the oracle's layers 2-3 in fp32.
+    row_off: the base pointer the engine passes for shifted rows (a1 + row_off rows, B - row_off rows).  big_w2_agent: that agent's W2
+    beyond the f16 range of the matrix-core form; big_a1_rows: activations beyond it in those rows -> the fp32 lane code, bit for bit."""
+    rng = np.random.default_rng(S * 7 + N * 3 + B + in_dim)
+    P, _ = geom(in_dim, 1)
+    ldp, ldb = pad64(P), pad64(B)
+    params = random_params(rng, S, N, in_dim, 1)
+    if big_w2_agent is not None:
+        for s in range(S):
+            params[s][big_w2_agent][2][3, 5] = np.float32(2000.0)
+    theta = pack_rows(params, ldp)
+    a1 = rng.normal(size=(S, N * HID, ldb)).astype(np.float32)
+    if big_a1_rows is not None:
+        a1[:, 7, big_a1_rows] = np.float32(1.0e5)
+    r_applied = rng.normal(size=(S, N, ldb)).astype(np.float32)
+    d_a, d_th, d_r = bk.dev(a1), bk.dev(theta), bk.dev(r_applied)
+    d_y = bk.dev(np.full((S, N, ldb), np.float32(-7.0)))
+    nrows = B - row_off
+    out = {}
+    for with_r in (True, False):
+        getattr(bk.lib, entry)(_ptr_add(bk.ptr(d_a), 4 * row_off), bk.ptr(d_th), bk.ptr(d_r) if with_r else None, gamma, bk.ptr(d_y), S, N, nrows,
+                                in_dim, HID, ldp, ldb, bk.stream)
+        y = bk.host(d_y)
+        out[with_r] = y.copy()
+        if not compare:
+            continue
+        assert np.all(y[:, :, nrows:] == np.float32(-7.0))            # nothing written beyond the rows asked for
+        for s in range(S):
+            for n in range(N):
+                W1, b1, W2, b2, W3, b3 = params[s][n]
+                a = a1[s, n * HID:(n + 1) * HID, row_off:B].T                                     # [rows][HID]
+                z2 = a @ W2 + b2
+                v = (np.maximum(z2, np.float32(0.1) * z2) @ W3 + b3)[:, 0]
+                want = r_applied[s, n, :nrows] + np.float32(gamma) * v if with_r else v
+                rel_close(y[s, n, :nrows], want, 3e-6, "value on cached activations")
+    return out
 
 
 def check_actor_step(bk, S, N, B, in_dim, steps=2, lr=0.002):

@@ -71,6 +71,8 @@ def test_argument_validation_needs_no_gpu():
         ("rcmarl_mid_fit_lattice", (None, None, None, None, None, 0, 0, 1, 5, 100, 10, 20, 704, 128, None, None)),
         ("rcmarl_shuffle_perms", (None, None, 1, 1, 100, None, 1, None)),
         ("rcmarl_mid_fit", (None, None, None, None, 1, 5, 100, 10, 20, 704, 128, None)),
+        ("rcmarl_mid_value", (None, None, None, 0.9, None, 1, 5, 100, 10, 20, 704, 128, None)),
+        ("rcmarl_mid_value_f32", (None, None, None, 0.9, None, 1, 5, 100, 10, 20, 704, 128, None)),
         ("rcmarl_consensus_params_circulant", (None, None, None, 1, 5, 64, 40, 4, 1, None, None, None)),
         ("rcmarl_lattice_pack_dz", (None, None, 1, 5, 100, 20, 128, 1, 4, None)),
         ("rcmarl_lattice_pack_dz_rowsum", (None, None, None, 61, 41, 1, 5, 100, 20, 128, 1, 4, None)),

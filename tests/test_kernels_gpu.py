@@ -98,6 +98,52 @@ def test_consensus_head_out_of_range_head_takes_the_fp32_lane_code(bk, monkeypat
     assert not np.array_equal(res["1"][0][:, 2], res["0"][0][:, 2])        # (agent 2 does not: matrix-core form, other last bits)
 
 
+def test_consensus_head_out_of_range_activations_take_the_fp32_lane_code(bk, monkeypatch):
+    """layer-1 activations beyond the f16 range in one replay row: the 64 rows of that wavefront (and only those) carry the aggregate of
+    the fp32 lane code, bit for bit (the slow path of k_consensus_head_mx behind its chunk loop, decided per wavefront by a ballot)"""
+    res = {}
+    for mx in ("1", "0"):
+        monkeypatch.setenv("RCMARL_K2_MX", mx)
+        res[mx] = KC.check_consensus_head(bk, 1, 5, 600, 10, 4, 1, "circ", outlier=1.0, compare=False, big_x_rows=[300])
+    a, b = res["1"][1], res["0"][1]                                            # the aggregates [S][N][ldb]
+    np.testing.assert_array_equal(a[:, 1:, 256:320], b[:, 1:, 256:320])
+    assert not np.array_equal(a[:, 1:, :256], b[:, 1:, :256])
+    np.testing.assert_allclose(a[:, 1:, :256], b[:, 1:, :256], rtol=0, atol=3e-5 * max(1.0, float(np.abs(b[:, 1:, :256]).max())))
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=0, atol=2e-5 * max(1.0, float(np.abs(res["0"][0]).max())))
+
+
+@pytest.mark.parametrize("mx", ["1", "0"])       # layer 2 on the f16 matrix core (k_mid_value_mx) | on the vector ALUs (k_mid_value)
+@pytest.mark.parametrize("S,N,B,in_dim,row_off", [(2, 3, 300, 6, 0), (1, 5, 700, 10, 1), (1, 2, 64, 4, 0), (2, 64, 3000, 128, 1)])
+def test_mid_value(bk, S, N, B, in_dim, row_off, mx, monkeypatch):
+    monkeypatch.setenv("RCMARL_MIDVALUE_MX", mx)
+    KC.check_mid_value(bk, S, N, B, in_dim, row_off=row_off)
+
+
+def test_mid_value_f32_entry_is_the_vector_alu_kernel(bk, monkeypatch):
+    """rcmarl_mid_value_f32 (the adversaries' callers): the bits of rcmarl_mid_value with RCMARL_MIDVALUE_MX=0, whatever the knob says"""
+    monkeypatch.setenv("RCMARL_MIDVALUE_MX", "0")
+    want = KC.check_mid_value(bk, 1, 3, 300, 6, compare=False)
+    monkeypatch.setenv("RCMARL_MIDVALUE_MX", "1")
+    got = KC.check_mid_value(bk, 1, 3, 300, 6, compare=False, entry="rcmarl_mid_value_f32")
+    for with_r in (True, False):
+        np.testing.assert_array_equal(got[with_r], want[with_r])
+
+
+def test_mid_value_out_of_range_rows_take_the_fp32_lane_code(bk, monkeypatch):
+    """weights beyond the f16 range of the matrix-core form (a whole agent) or activations beyond it (the 64 rows of one wavefront):
+    the fp32 lane code inside k_mid_value_mx -- the bits of k_mid_value; everything else keeps the matrix-core form's last bits"""
+    res = {}
+    for mx in ("1", "0"):
+        monkeypatch.setenv("RCMARL_MIDVALUE_MX", mx)
+        res[mx] = KC.check_mid_value(bk, 1, 3, 600, 6, big_w2_agent=1, big_a1_rows=[300], compare=False)
+    for with_r in (True, False):
+        a, b = res["1"][with_r], res["0"][with_r]
+        np.testing.assert_array_equal(a[:, 1], b[:, 1])                        # agent 1: W2 out of range
+        np.testing.assert_array_equal(a[:, 0, 256:320], b[:, 0, 256:320])      # agent 0, the wavefront that holds row 300
+        assert not np.array_equal(a[:, 0, :256], b[:, 0, :256])                # the rest of agent 0: matrix-core form
+        np.testing.assert_allclose(a[:, 0, :256], b[:, 0, :256], rtol=0, atol=3e-6 * max(1.0, float(np.abs(b[:, 0, :256]).max())))
+
+
 @pytest.mark.parametrize("S,N,B,in_dim", [(2, 5, 1000, 10), (1, 16, 300, 32), (1, 64, 1000, 128), (1, 256, 1000, 512)])     # last: BASELINE configs[3]
 def test_actor_step(bk, S, N, B, in_dim):
     KC.check_actor_step(bk, S, N, B, in_dim, steps=3)

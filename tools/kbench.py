@@ -193,9 +193,12 @@ def mid(L, S=16, N=256, B=3000):
                                             ldb, st))
         print("mid_fit   %8.1f us  (%.2f TB/s on a1t r+w)" % (t, 8.0 * S * N * HID * B / t / 1e6))
         out = torch.zeros(S, N, ldb, device="cuda")
-        t = timeit(lambda: L.rcmarl_mid_value(a1t.data_ptr(), theta.data_ptr(), None, 0.9, out.data_ptr(), S, N, B, in_dim, HID, ldp,
-                                              ldb, st))
-        print("mid_value %8.1f us  (%.2f TB/s on a1t r)" % (t, 4.0 * S * N * HID * B / t / 1e6))
+        for mx in ("1", "0"):        # layer 2 on the f16 matrix core (k_mid_value_mx) | on the vector ALUs (k_mid_value)
+            os.environ["RCMARL_MIDVALUE_MX"] = mx
+            t = timeit(lambda: L.rcmarl_mid_value(a1t.data_ptr(), theta.data_ptr(), None, 0.9, out.data_ptr(), S, N, B, in_dim, HID, ldp,
+                                                  ldb, st))
+            print("mid_value RCMARL_MIDVALUE_MX=%s %8.1f us  (%.2f TB/s on a1t r)" % (mx, t, 4.0 * S * N * HID * B / t / 1e6))
+        os.environ.pop("RCMARL_MIDVALUE_MX", None)
     for d, H in ((4, 1), (10, 4), (18, 8)):
         if only and d != int(only):
             continue
