@@ -10,9 +10,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "resilient-consensus-based-marl_amd", "csrc")
-OUT = os.path.join(HERE, "librcmarl_emu.so")
+# RCMARL_EMU_SANITIZE=address|undefined|address,undefined: a sanitizer build beside the plain one (own file name, own objects).  Run as
+#   RCMARL_EMU_SANITIZE=address LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
+#       python -m pytest tests/test_kernels_emu.py -q -p no:cacheprovider
+# (the work-items are ucontext fibers on heap-allocated stacks: ASan follows them as heap memory; GPU ASan is not available on this pool)
+SAN = os.environ.get("RCMARL_EMU_SANITIZE", "")
+TAG = ("_" + SAN.replace(",", "_")) if SAN else ""
+OUT = os.path.join(HERE, "librcmarl_emu%s.so" % TAG)
 FLAGS = ["-O1", "-g0", "-std=c++17", "-fPIC", "-DRCMARL_EMU", "-x", "c++", "-Wno-attributes", "-Wno-unknown-pragmas",
          "-ffp-contract=off"]
+if SAN:
+    FLAGS = [f for f in FLAGS if f != "-g0"] + ["-g1", "-fsanitize=" + SAN, "-fno-omit-frame-pointer", "-fno-sanitize-recover=all"]
 
 
 def build_emu(force=False):
@@ -32,7 +40,7 @@ def build_emu(force=False):
     stamp_file = OUT + ".stamp"
     if not force and os.path.exists(OUT) and os.path.exists(stamp_file) and open(stamp_file).read() == h.hexdigest():
         return OUT
-    objdir = os.path.join(HERE, "obj")
+    objdir = os.path.join(HERE, "obj" + TAG)
     os.makedirs(objdir, exist_ok=True)
 
     def cc(src):
@@ -45,7 +53,7 @@ def build_emu(force=False):
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, srcs + [os.path.join(HERE, "hipemu.cpp")]))
-    r = subprocess.run(["g++", "-shared", "-o", OUT] + objs, capture_output=True, text=True)
+    r = subprocess.run(["g++", "-shared", "-o", OUT] + (["-fsanitize=" + SAN] if SAN else []) + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
     with open(stamp_file, "w") as f:
