@@ -40,6 +40,19 @@ def build_emu(force=False):
     stamp_file = OUT + ".stamp"
     if not force and os.path.exists(OUT) and os.path.exists(stamp_file) and open(stamp_file).read() == h.hexdigest():
         return OUT
+    import fcntl
+    lock = open(OUT + ".lock", "w")                   # pytest-xdist workers: one builds, the others wait and find the stamp
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and os.path.exists(OUT) and os.path.exists(stamp_file) and open(stamp_file).read() == h.hexdigest():
+            return OUT
+        return _build_locked(srcs, h, stamp_file)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(srcs, h, stamp_file):
     objdir = os.path.join(HERE, "obj" + TAG)
     os.makedirs(objdir, exist_ok=True)
 
