@@ -15,7 +15,7 @@ python - <<PY
 import csv, glob, collections, json
 names = {"k_lat_forward<true, true, true>": "layer1_forward_lattice_pk", "k_lat_fit": "fit_fused_lattice", "k_lat_forward": "layer1_forward_lattice", "k_lat_backward_sgd": "layer1_backward_sgd_lattice", "k_mid_fit_v3<20, true": "mid_fit_lattice", "k_mid_fit_v8<20, true": "mid_fit_lattice", "k_mid_fit_v5<20, true": "mid_fit_lattice_fixup", "k_mid_fit_v5<20, false": "mid_fit",
          "k_mid_fit_mfma<20, true>": "mid_fit_lattice", "k_w1_split": "w1_split", "k_consensus_params_circ": "consensus_params_circulant", "k_consensus_params": "consensus_params",
-         "k_consensus_head<": "consensus_head", "k_consensus_head_mx<": "consensus_head",
+         "k_consensus_head<": "consensus_head", "k_consensus_head_mx<": "consensus_head", "k_mid_value_mx<": "mid_value",
          "k_lat_forward<true, true, true>": "layer1_forward_lattice_pk", "k_pk_forward2": "pk_forward2", "k_pk_backward_data": "pk_backward_data",
          "k_pk_backward_w2": "pk_backward_w2", "k_pk_pack_w2": "pk_pack_w2", "k_mid_value": "mid_value", "k_lattice_encode": "lattice_encode",
          "fast::k_fwd": "layer1_forward", "fast::k_bwd<1, (anonymous namespace)::fast::ApplySgd>": "layer1_backward_sgd",
