@@ -187,7 +187,12 @@ def mid(L, S=16, N=256, B=3000):
     y = torch.randn(S, N, ldb, device="cuda")
     nchunk = (B + 255) // 256
     part = torch.zeros(S * N * nchunk * L.rcmarl_fit_partial_size(HID), device="cuda")
-    only = os.environ.get("RCMARL_KBENCH_ONLY")       # e.g. "18": just the estimate-consensus kernel at d = 18 (counter runs)
+    only = os.environ.get("RCMARL_KBENCH_ONLY")       # e.g. "18": just the estimate-consensus kernel at d = 18; "value": just mid_value (counter runs)
+    if only == "value":
+        out = torch.zeros(S, N, ldb, device="cuda")
+        t = timeit(lambda: L.rcmarl_mid_value(a1t.data_ptr(), theta.data_ptr(), None, 0.9, out.data_ptr(), S, N, B, in_dim, HID, ldp, ldb, st))
+        print("mid_value %8.1f us  (%.2f TB/s on a1t r)" % (t, 4.0 * S * N * HID * B / t / 1e6))
+        return
     if not only:
         t = timeit(lambda: L.rcmarl_mid_fit(a1t.data_ptr(), theta.data_ptr(), y.data_ptr(), part.data_ptr(), S, N, B, in_dim, HID, ldp,
                                             ldb, st))
