@@ -547,7 +547,7 @@ def main(argv=None):
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if one_instance else "weak",
             "vs_baseline": None,
-            "dtype": "f32 (matrix-core operands as 2 x f16 pieces: each fp32 operand to <= 1 ulp)" if _lat_mode(tlib) else "f32",
+            "dtype": "f32 (matrix-core operands as 2 x f16 pieces: each fp32 operand to <= 1 ulp; the 20-unit layers run 3 of the 4 piece products)" if _lat_mode(tlib) else "f32",
             "dtype_note": "fp32 parameters, activations and accumulation throughout; the matrix-core products of Phase I take their fp32 "
                           "operands as two f16 pieces (the value to one unit in its last place: 22-23 significand bits where fp32 has 24; "
                           "RCMARL_LAT_F16=3, the default; a value below 2^-3 of its fixed scale -- |alpha W1| < 1.2e-4, |dz1| < 4.9e-4 -- is carried to an "
